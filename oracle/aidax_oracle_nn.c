@@ -1,0 +1,148 @@
+/*
+ * aidax_oracle_nn.c — CPU oracle, NN half + multi-thread CPU baseline timer.
+ * TEST INFRASTRUCTURE ONLY (see aidax_oracle.h). Floating point here is
+ * compared to tolerance (1e-5, rt-neural-generic.h:182), never bit-for-bit,
+ * so this unit may be built with FMA contraction.
+ */
+#include "aidax_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#define REAL float
+#define SUFFIX _f32
+#define RE_EXP expf
+#define RE_TANH tanhf
+#include "nn_impl.inc"
+#undef REAL
+#undef SUFFIX
+#undef RE_EXP
+#undef RE_TANH
+
+#define REAL double
+#define SUFFIX _f64
+#define RE_EXP exp
+#define RE_TANH tanh
+#include "nn_impl.inc"
+#undef REAL
+#undef SUFFIX
+#undef RE_EXP
+#undef RE_TANH
+
+struct orc_net { int f64; int in_size; net_f32* a; net_f64* b; };
+
+orc_net* orc_net_create(const orc_layer_desc* layers, int n_layers, int use_f64)
+{
+    orc_net* n = (orc_net*)calloc(1, sizeof(*n));
+    n->f64 = use_f64;
+    n->in_size = layers[0].in_size;
+    if (use_f64) n->b = net_create_f64(layers, n_layers);
+    else n->a = net_create_f32(layers, n_layers);
+    return n;
+}
+
+void orc_net_free(orc_net* n)
+{
+    if (!n) return;
+    if (n->a) net_free_f32(n->a);
+    if (n->b) net_free_f64(n->b);
+    free(n);
+}
+
+void orc_net_reset(orc_net* n) { if (n->f64) net_reset_f64(n->b); else net_reset_f32(n->a); }
+int orc_net_in_size(const orc_net* n) { return n->in_size; }
+float orc_net_forward(orc_net* n, const float* x) { return n->f64 ? net_forward_f64(n->b, x) : net_forward_f32(n->a, x); }
+
+int orc_net_state(const orc_net* n, int layer, float* h, float* c, int cap)
+{
+    int H;
+    if (n->f64) {
+        if (layer >= n->b->n_layers) return -1;
+        layer_f64* L = &n->b->layers[layer]; H = L->out_size;
+        for (int j = 0; j < H && j < cap; ++j) { h[j] = (float)L->h[j]; c[j] = (float)L->c[j]; }
+    } else {
+        if (layer >= n->a->n_layers) return -1;
+        layer_f32* L = &n->a->layers[layer]; H = L->out_size;
+        for (int j = 0; j < H && j < cap; ++j) { h[j] = L->h[j]; c[j] = L->c[j]; }
+    }
+    return H;
+}
+
+/* ------------------------------------------------------------ CPU baseline */
+
+typedef struct {
+    orc_plugin* plugins; const orc_controls* c;
+    int s0, s1, n_frames, n_blocks;
+    const float* in; float* out;
+    pthread_barrier_t* bar;
+} bench_arg;
+
+static void* bench_thread(void* p)
+{
+    bench_arg* a = (bench_arg*)p;
+    pthread_barrier_wait(a->bar);
+    for (int b = 0; b < a->n_blocks; ++b)
+        for (int s = a->s0; s < a->s1; ++s)
+            orc_plugin_run(&a->plugins[s], a->c, a->in + (size_t)s * a->n_frames,
+                           a->out + (size_t)s * a->n_frames, (uint32_t)a->n_frames);
+    pthread_barrier_wait(a->bar);
+    return NULL;
+}
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+double orc_bench(const orc_layer_desc* layers, int n_layers, int input_size, int input_skip,
+                 float in_gain, float out_gain, const orc_controls* c,
+                 int n_streams, int n_frames, int n_blocks, int warm_blocks, int n_threads,
+                 const float* in, float* out_last)
+{
+    orc_plugin* plugins = (orc_plugin*)calloc((size_t)n_streams, sizeof(orc_plugin));
+    float* out = (float*)calloc((size_t)n_streams * (size_t)n_frames, sizeof(float));
+    for (int s = 0; s < n_streams; ++s) {
+        orc_plugin_init(&plugins[s], 48000.0);
+        orc_net* net = orc_net_create(layers, n_layers, 0);
+        orc_dynmodel* m = orc_dynmodel_create(net, input_size, input_skip, in_gain, out_gain,
+                                              48000.0f, 0.f, 0.f, 1);
+        orc_plugin_set_model(&plugins[s], m);
+    }
+    /* untimed warm-up blocks, single pass on the calling thread pool below */
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > n_streams) n_threads = n_streams;
+    double elapsed = 0.0;
+    for (int phase = 0; phase < 2; ++phase) {
+        const int blocks = phase == 0 ? warm_blocks : n_blocks;
+        if (blocks <= 0) continue;
+        pthread_barrier_t bar;
+        pthread_barrier_init(&bar, NULL, (unsigned)n_threads + 1);
+        pthread_t* th = (pthread_t*)calloc((size_t)n_threads, sizeof(pthread_t));
+        bench_arg* args = (bench_arg*)calloc((size_t)n_threads, sizeof(bench_arg));
+        for (int t = 0; t < n_threads; ++t) {
+            args[t].plugins = plugins; args[t].c = c;
+            args[t].s0 = (int)((long long)n_streams * t / n_threads);
+            args[t].s1 = (int)((long long)n_streams * (t + 1) / n_threads);
+            args[t].n_frames = n_frames; args[t].n_blocks = blocks;
+            args[t].in = in; args[t].out = out; args[t].bar = &bar;
+            pthread_create(&th[t], NULL, bench_thread, &args[t]);
+        }
+        pthread_barrier_wait(&bar);
+        const double t0 = now_s();
+        pthread_barrier_wait(&bar);
+        const double t1 = now_s();
+        for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
+        pthread_barrier_destroy(&bar);
+        free(th); free(args);
+        if (phase == 1) elapsed = t1 - t0;
+    }
+    if (out_last) memcpy(out_last, out, sizeof(float) * (size_t)n_streams * (size_t)n_frames);
+    for (int s = 0; s < n_streams; ++s) orc_dynmodel_free(plugins[s].model);
+    free(plugins); free(out);
+    return elapsed;
+}

@@ -1,0 +1,47 @@
+# Top-level build: the HIP library behind include/aidax.h (gfx950 only), the LV2
+# shell, and the CPU oracle (test infrastructure). `python -c "import
+# __graft_entry__ as g; g.build()"` runs `make all`.
+#
+# -ffp-contract=off everywhere in the product: the fp64 biquads and fp32
+# smoothers must round step by step like the reference built without FMA
+# contraction; the NN kernels ask for FMAs explicitly (__builtin_fmaf).
+
+HIPCC   ?= hipcc
+ROCM    ?= /opt/rocm
+CXX     := g++
+ARCH    ?= gfx950
+PKG     := aidadsp-lv2_amd
+SRC     := $(PKG)/csrc
+LIBDIR  := $(PKG)/lib
+OBJDIR  := build/obj
+CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wall -Wextra -Iinclude
+HIPFLAGS := --offload-arch=$(ARCH) $(CXXFLAGS)
+
+HOST_SRCS := $(SRC)/aidax_model.cpp $(SRC)/aidax_dsp_host.cpp $(SRC)/aidax_pack.cpp $(SRC)/aidax_pool.cpp
+HOST_OBJS := $(patsubst $(SRC)/%.cpp,$(OBJDIR)/%.o,$(HOST_SRCS))
+KERN_OBJS := $(OBJDIR)/aidax_kernels.o
+HDRS      := $(wildcard $(SRC)/*.h) include/aidax.h
+
+all: $(LIBDIR)/libaidax_hip.so oracle
+
+$(OBJDIR)/%.o: $(SRC)/%.cpp $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(CXX) $(CXXFLAGS) -I$(ROCM)/include -D__HIP_PLATFORM_AMD__ -c $< -o $@
+
+$(OBJDIR)/aidax_kernels.o: $(SRC)/aidax_kernels.hip $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/libaidax_hip.so: $(HOST_OBJS) $(KERN_OBJS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $^
+
+oracle:
+	$(MAKE) -s -C oracle all
+	$(MAKE) -s -C oracle _ref
+
+clean:
+	rm -rf build $(LIBDIR)
+	$(MAKE) -s -C oracle clean
+
+.PHONY: all oracle clean

@@ -1,0 +1,247 @@
+"""ctypes binding of include/aidax.h (no logic beyond argument marshalling)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+_HEADER = os.path.join(_ROOT, "include", "aidax.h")
+
+ALL_STREAMS = -1
+START_WARMUP, START_RESET = 0, 1
+_fp = C.POINTER(C.c_float)
+
+
+class AidaxError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"aidax error {code}: {msg}")
+        self.code = code
+
+
+class ModelInfo(C.Structure):
+    _fields_ = [("cell", C.c_int32), ("hidden", C.c_int32), ("input_size", C.c_int32),
+                ("n_rnn_layers", C.c_int32), ("input_skip", C.c_int32),
+                ("input_gain", C.c_float), ("output_gain", C.c_float), ("samplerate", C.c_float),
+                ("n_golden", C.c_int32), ("in_reference_set", C.c_int32), ("n_weights", C.c_uint64)]
+
+
+CONTROL_FIELDS = ("in_lpf_pc", "pregain_db", "net_bypass", "param1", "param2", "eq_bypass",
+                  "eq_position", "bass_boost_db", "bass_freq", "mid_boost_db", "mid_freq", "mid_q",
+                  "mid_type", "treble_boost_db", "treble_freq", "depth_boost_db",
+                  "presence_boost_db", "dc_blocker", "master_db", "enabled")
+
+
+class Controls(C.Structure):
+    _fields_ = [(n, C.c_float) for n in CONTROL_FIELDS]
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "lib", "libaidax_hip.so")
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library. Fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path} missing: run `make` (or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(path)
+    vp, i32, u32 = C.c_void_p, C.c_int32, C.c_uint32
+    L.aidax_last_error.restype = C.c_char_p
+    L.aidax_version.restype = C.c_char_p
+    L.aidax_model_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.aidax_model_load_memory.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(vp)]
+    L.aidax_model_info.argtypes = [vp, C.POINTER(ModelInfo)]
+    L.aidax_model_path.argtypes = [vp]
+    L.aidax_model_path.restype = C.c_char_p
+    L.aidax_model_golden.argtypes = [vp, _fp, _fp, u32]
+    L.aidax_model_free.argtypes = [vp]
+    L.aidax_model_free.restype = None
+    L.aidax_controls_default.argtypes = [C.POINTER(Controls)]
+    L.aidax_controls_default.restype = None
+    L.aidax_biquad_design.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double)]
+    L.aidax_db_to_coeff.argtypes = [C.c_float]
+    L.aidax_db_to_coeff.restype = C.c_float
+    L.aidax_lpf_fc.argtypes = [C.c_float]
+    L.aidax_lpf_fc.restype = C.c_float
+    L.aidax_pool_create.argtypes = [u32, u32, C.c_double, C.c_int, C.POINTER(vp)]
+    L.aidax_pool_destroy.argtypes = [vp]
+    L.aidax_pool_destroy.restype = None
+    L.aidax_pool_streams.argtypes = [vp]
+    L.aidax_pool_streams.restype = u32
+    L.aidax_pool_set_model.argtypes = [vp, vp, C.c_int]
+    L.aidax_pool_set_loading.argtypes = [vp, i32, C.c_int]
+    L.aidax_pool_set_controls.argtypes = [vp, i32, C.POINTER(Controls)]
+    L.aidax_pool_activate.argtypes = [vp, i32]
+    L.aidax_pool_process.argtypes = [vp, _fp, _fp, u32]
+    L.aidax_pool_process_device.argtypes = [vp, vp, vp, u32, vp]
+    L.aidax_pool_sync.argtypes = [vp]
+    L.aidax_model_self_test.argtypes = [vp, C.c_int, C.POINTER(i32), _fp, _fp]
+    L.aidax_model_forward.argtypes = [vp, C.c_int, _fp, _fp, u32, C.c_int]
+    L.aidax_pool_read_state.argtypes = [vp, u32, C.c_int, _fp, _fp, u32]
+    L.aidax_pool_kernel_name.argtypes = [vp]
+    L.aidax_pool_kernel_name.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def declared_symbols() -> list:
+    """Every AIDAX_API function name declared in include/aidax.h."""
+    with open(_HEADER) as f:
+        text = f.read()
+    return sorted(set(re.findall(r"AIDAX_API[^;(]*?\b(aidax_[a-z_0-9]+)\s*\(", text)))
+
+
+def _check(rc: int):
+    if rc < 0:
+        raise AidaxError(rc, lib().aidax_last_error().decode(errors="replace"))
+    return rc
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+def default_controls(**kw) -> Controls:
+    c = Controls()
+    lib().aidax_controls_default(C.byref(c))
+    for k, v in kw.items():
+        if k not in CONTROL_FIELDS:
+            raise KeyError(k)
+        setattr(c, k, v)
+    return c
+
+
+def biquad_design(kind: int, fc: float, q: float, gain_db: float) -> np.ndarray:
+    out = (C.c_double * 5)()
+    _check(lib().aidax_biquad_design(kind, fc, q, gain_db, out))
+    return np.array(list(out), np.float64)
+
+
+def db_to_coeff(db: float) -> float:
+    return float(lib().aidax_db_to_coeff(C.c_float(db)))
+
+
+def lpf_fc(pc: float) -> float:
+    return float(lib().aidax_lpf_fc(C.c_float(pc)))
+
+
+class Model:
+    """aidax_model: the json-side half of the reference's DynamicModel."""
+
+    def __init__(self, path: Optional[str] = None, text: Optional[str] = None, label: str = "<memory>"):
+        h = C.c_void_p()
+        if path is not None:
+            _check(lib().aidax_model_load(path.encode(), C.byref(h)))
+        else:
+            b = text.encode()
+            _check(lib().aidax_model_load_memory(b, len(b), label.encode(), C.byref(h)))
+        self.h = h
+
+    @property
+    def info(self) -> ModelInfo:
+        i = ModelInfo()
+        _check(lib().aidax_model_info(self.h, C.byref(i)))
+        return i
+
+    @property
+    def path(self) -> str:
+        return lib().aidax_model_path(self.h).decode()
+
+    def golden(self):
+        n = self.info.n_golden
+        a, b = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        lib().aidax_model_golden(self.h, a.ctypes.data_as(_fp), b.ctypes.data_as(_fp), n)
+        return a, b
+
+    def self_test(self, device: int = 0):
+        n_err, max_err = C.c_int32(0), C.c_float(0)
+        out = np.zeros(self.info.n_golden, np.float32)
+        _check(lib().aidax_model_self_test(self.h, device, C.byref(n_err), C.byref(max_err), out.ctypes.data_as(_fp)))
+        return int(n_err.value), float(max_err.value), out
+
+    def forward(self, X, device: int = 0, unit_gains: bool = False) -> np.ndarray:
+        X = _f32(X).reshape(-1, self.info.input_size)
+        y = np.zeros(X.shape[0], np.float32)
+        _check(lib().aidax_model_forward(self.h, device, X.ctypes.data_as(_fp), y.ctypes.data_as(_fp),
+                                         X.shape[0], 1 if unit_gains else 0))
+        return y
+
+    def close(self):
+        if self.h:
+            lib().aidax_model_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Pool:
+    """aidax_pool: N plugin instances' DSP state on one GPU."""
+
+    def __init__(self, n_streams: int, max_frames: int = 256, samplerate: float = 48000.0, device: int = 0):
+        h = C.c_void_p()
+        _check(lib().aidax_pool_create(n_streams, max_frames, samplerate, device, C.byref(h)))
+        self.h = h
+        self.n_streams = n_streams
+        self.max_frames = max_frames
+
+    def set_model(self, m: Optional[Model], start_mode: int = START_WARMUP):
+        _check(lib().aidax_pool_set_model(self.h, m.h if m is not None else None, start_mode))
+
+    def set_controls(self, c: Controls, stream: int = ALL_STREAMS):
+        _check(lib().aidax_pool_set_controls(self.h, stream, C.byref(c)))
+
+    def set_loading(self, loading: bool, stream: int = ALL_STREAMS):
+        _check(lib().aidax_pool_set_loading(self.h, stream, 1 if loading else 0))
+
+    def activate(self, stream: int = ALL_STREAMS):
+        _check(lib().aidax_pool_activate(self.h, stream))
+
+    def process(self, x: np.ndarray) -> np.ndarray:
+        x = _f32(x)
+        assert x.ndim == 2 and x.shape[0] == self.n_streams
+        out = np.empty_like(x)
+        _check(lib().aidax_pool_process(self.h, x.ctypes.data_as(_fp), out.ctypes.data_as(_fp), x.shape[1]))
+        return out
+
+    def process_device(self, d_in: int, d_out: int, n_frames: int, stream: int = 0):
+        """d_in/d_out: raw device pointers ([n_streams][n_frames] fp32); stream: hipStream_t as int."""
+        _check(lib().aidax_pool_process_device(self.h, C.c_void_p(d_in), C.c_void_p(d_out), n_frames,
+                                               C.c_void_p(stream) if stream else None))
+
+    def sync(self):
+        _check(lib().aidax_pool_sync(self.h))
+
+    def read_state(self, stream: int = 0, layer: int = 0, hidden: int = 128):
+        h, c = np.zeros(hidden, np.float32), np.zeros(hidden, np.float32)
+        H = _check(lib().aidax_pool_read_state(self.h, stream, layer, h.ctypes.data_as(_fp), c.ctypes.data_as(_fp), hidden))
+        return h[:H], c[:H]
+
+    @property
+    def kernel_name(self) -> str:
+        return lib().aidax_pool_kernel_name(self.h).decode()
+
+    def close(self):
+        if self.h:
+            lib().aidax_pool_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

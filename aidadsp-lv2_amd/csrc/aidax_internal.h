@@ -1,0 +1,54 @@
+// aidax_internal.h — host-side types behind the C ABI of include/aidax.h.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/aidax.h"
+#include "aidax_layout.h"
+
+namespace aidax {
+
+struct Layer {
+    enum Type { LSTM, GRU, DENSE, CONV1D } type;
+    int in_size = 0, out_size = 0;
+    int ksize = 0, dilation = 0;
+    int activation = 0;                       // 0 none, 1 tanh, 2 relu, 3 sigmoid
+    std::vector<float> w0, w1, w2;            // Keras layouts, see include/aidax.h / aidax_model.cpp
+};
+
+}  // namespace aidax
+
+// The opaque model of the C ABI: everything loadModelFromPath reads from the
+// json (rt-neural-generic.cpp:977-1013) plus the layer weights parseJson would
+// have pulled into RTNeural (:1034).
+struct aidax_model {
+    std::string path;
+    int cell = 0, hidden = 0, input_size = 0, n_rnn = 0;
+    int input_skip = 0;
+    float input_gain = 1.f, output_gain = 1.f, samplerate = 48000.f;
+    bool in_reference_set = false;
+    std::vector<aidax::Layer> layers;
+    std::vector<float> golden_in, golden_out;
+    uint64_t n_weights = 0;
+};
+
+namespace aidax {
+
+void set_error(const std::string& msg);
+int  fail(int code, const std::string& msg);
+
+// host DSP helpers (aidax_dsp_host.cpp)
+void  design_biquad(int type, double fc, double q, double gain_db, double out[5]);
+float db_to_coeff(float db);
+float lpf_fc(float percent);
+float exp_smoother_coef(float samplerate, float t60);
+// controls + instance flags -> the per-stream record the kernels read
+void  build_stream_ctl(const aidax_controls& c, double host_samplerate, bool has_model, bool loading,
+                       float gain_coef, float p_den, StreamCtl* out);
+
+// weight packing (aidax_pack.cpp)
+std::vector<float> pack_weights(const aidax_model& m);
+
+}  // namespace aidax

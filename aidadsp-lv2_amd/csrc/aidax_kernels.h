@@ -1,0 +1,22 @@
+// aidax_kernels.h — host-callable launchers defined in aidax_kernels.hip.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include "aidax_layout.h"
+
+namespace aidax {
+
+struct KernelEntry {
+    int cell, hidden;
+    void (*fn)(LaunchArgs);
+    int pack_regs, state_floats;
+    const char* name;
+};
+
+const KernelEntry* find_kernel(int cell, int hidden);
+hipError_t launch_stream_kernel(const KernelEntry* e, const LaunchArgs& a, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_set_pending(StreamState* st, uint32_t n_streams, int32_t stream, uint32_t bits, hipStream_t q);
+hipError_t launch_reset_for_model(StreamState* st, float* nn, uint32_t n_streams, uint32_t nn_stride, float p_den, hipStream_t q);
+
+}  // namespace aidax

@@ -1,0 +1,661 @@
+// aidax_kernels.hip — gfx950 kernels of the rt-neural-generic hot path.
+//
+// One wavefront (64 lanes) per mono stream; one workgroup = one wavefront, so a
+// pool of N streams is a grid of N workgroups (N >> 256 CUs fills the chip; the
+// streams share nothing but the read-only weights, so there is no inter-
+// workgroup traffic and no XCD-sensitive reuse to remap for).
+//
+// Per 256-frame block a stream moves 1 KiB in + 1 KiB out of HBM with one
+// coalesced 16 B/lane access each; everything in between lives on chip:
+//   * the audio block in LDS (read per sample as a wave-uniform broadcast),
+//   * every weight of the recurrent layer in VGPRs (pre-shuffled by the host
+//     into the lane mapping of aidax_layout.h),
+//   * h exchanged through a 4*H-byte LDS line (ds_write_b32 + ds_read_b128
+//     broadcasts), c in registers,
+//   * biquad z1/z2 (fp64) and smoother memories in registers of the lanes
+//     that own the stage.
+//
+// The 7-stage chain of run() (rt-neural-generic.cpp:621-659) is executed as
+//   pre pass  : LPF -> pre-gain ramp -> (EQ if EQPOS==pre)   systolic over lanes
+//   NN pass   : applyModel, strictly sequential in time
+//   post pass : DC blocker -> (EQ if EQPOS==post) -> master ramp, systolic
+// In a systolic pass lane k owns biquad k of the cascade and works on sample
+// s-k at step s, taking its input from lane k-1 through a DPP row shift: the
+// cascade's six fp64 recurrences advance in one instruction stream.
+//
+// Numerics: biquads are fp64 exactly as common/Biquad.h:53-58 (this file is
+// built with -ffp-contract=off, so each line below is one IEEE operation, as in
+// the reference built without FMA contraction): bit-exact vs the CPU oracle.
+// The smoothers are the same fp32 recurrences as ValueSmoother.hpp. The NN is
+// fp32 with explicit fmaf chains; sigmoid/tanh use v_exp_f32 + v_rcp_f32
+// (abs error ~1e-7), compared to tolerance 1e-5 (rt-neural-generic.h:182).
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+
+#include "aidax_kernels.h"
+#include "aidax_layout.h"
+
+namespace aidax {
+
+// ------------------------------------------------------------------ lane ops
+__device__ __forceinline__ float dpp_row_shr1(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_take(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, ROW_MASK == 0xf));
+}
+
+// Sum over the 64 lanes, returned wave-uniform (tree order fixed by the DPP network).
+__device__ __forceinline__ float wave_sum(float v)
+{
+    v = v + dpp_take<0xB1, 0xf>(v);     // quad_perm [1,0,3,2]
+    v = v + dpp_take<0x4E, 0xf>(v);     // quad_perm [2,3,0,1]
+    v = v + dpp_take<0x141, 0xf>(v);    // row_half_mirror
+    v = v + dpp_take<0x140, 0xf>(v);    // row_mirror: every lane of a row holds the row sum
+    v = v + dpp_take<0x142, 0xa>(v);    // row_bcast:15 into rows 1,3
+    v = v + dpp_take<0x143, 0xc>(v);    // row_bcast:31 into rows 2,3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+__device__ __forceinline__ float fast_sigmoid(float v)
+{
+    // 1 / (1 + 2^(-v*log2 e)); saturates cleanly: exp2 -> inf gives rcp -> 0
+    const float e = __builtin_amdgcn_exp2f(v * -1.44269504088896340736f);
+    return __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// ---------------------------------------------------------------- smoothers
+struct ExpRamp {              // ExponentialValueSmoother::next, ValueSmoother.hpp:142-145
+    float mem, coef, tc;      // tc = target * (1.f - coef), loop-invariant
+    __device__ __forceinline__ void arm(float m, float target, float c)
+    {
+        mem = m; coef = c; tc = target * (1.f - c);
+    }
+    __device__ __forceinline__ float next() { mem = mem * coef + tc; return mem; }
+};
+
+__device__ __forceinline__ float lin_next(float& mem, float target, float step)
+{
+    // LinearValueSmoother::next, ValueSmoother.hpp:229-234
+    const float y0 = mem;
+    const float dy = target - y0;
+    mem = y0 + __builtin_copysignf(__builtin_fminf(__builtin_fabsf(dy), __builtin_fabsf(step)), dy);
+    return mem;
+}
+
+// ------------------------------------------------------------ systolic chain
+// One pass of up to 6 cascaded stages over buf[0..n) in LDS, in place.
+// Lane k < K owns stage k: an optional biquad (slot[k], enabled by act[k]) and,
+// on lane `gain_lane`, the exponential gain ramp applied after the biquad.
+struct ChainPass {
+    int K, gain_lane;
+    bool active;          // this lane's biquad is in circuit
+    double a0, a1, a2, b1, b2, z1, z2;
+    ExpRamp g;
+};
+
+__device__ __forceinline__ void chain_run(ChainPass& c, float* buf, int n, int lane)
+{
+    float carry = 0.f;                         // this lane's previous output, read by lane+1
+    const int steps = n + c.K - 1;
+    for (int s = 0; s < steps; ++s) {
+        const float head = buf[s < n ? s : n - 1];          // wave-uniform LDS broadcast
+        const float from_left = dpp_row_shr1(carry);
+        const float x = lane == 0 ? head : from_left;
+        const int idx = s - lane;
+        if (lane < c.K && idx >= 0 && idx < n) {
+            float y = x;
+            if (c.active) {                                 // Biquad::process, Biquad.h:53-58
+                const double xd = x;
+                const double yd = xd * c.a0 + c.z1;
+                c.z1 = xd * c.a1 + c.z2 - c.b1 * yd;
+                c.z2 = xd * c.a2 - c.b2 * yd;
+                y = (float)yd;
+            }
+            const float gm = c.g.next();                    // every stage lane keeps its own copy;
+            if (lane == c.gain_lane) y = y * gm;            // only the gain lane's is used
+            carry = y;
+            if (lane == c.K - 1) buf[idx] = y;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// --------------------------------------------------------------- LSTM cell
+// Lane mapping per aidax_layout.h. Gate index g = part + S*e; json column order
+// i|f|c|o (pinned by the bundled goldens). After the dot products every lane of
+// a unit holds all four gate activations (permlane swaps), so c and h are kept
+// redundantly in the S lanes of the unit and no lane idles in the update.
+template <int H>
+struct LstmCell {
+    static constexpr LaneMap M = lstm_map(H);
+    static constexpr int S = M.S, SLOTS = M.slots, NU = M.NU, GPL = M.GPL;
+    static constexpr int PACK = lstm_pack_regs(H);
+    static constexpr int STATE = 2 * H;
+
+    float w[NU][GPL][H];
+    float wx[NU][GPL][kMaxInputs];
+    float bias[NU][GPL];
+    float wd[NU], bd;
+    float amul[GPL], aka[GPL], akb[GPL];
+    float c[NU], h[NU];
+    int part, slot;
+
+    __device__ __forceinline__ void load(const float* __restrict__ wp, const float* __restrict__ st, int lane)
+    {
+        part = lane / SLOTS;
+        slot = lane % SLOTS;
+        int r = 0;
+#pragma unroll
+        for (int m = 0; m < NU; ++m)
+#pragma unroll
+            for (int e = 0; e < GPL; ++e) {
+#pragma unroll
+                for (int k = 0; k < H; ++k) w[m][e][k] = wp[(r++) * kWave + lane];
+#pragma unroll
+                for (int i = 0; i < kMaxInputs; ++i) wx[m][e][i] = wp[(r++) * kWave + lane];
+                bias[m][e] = wp[(r++) * kWave + lane];
+            }
+#pragma unroll
+        for (int m = 0; m < NU; ++m) wd[m] = wp[(r++) * kWave + lane];
+        bd = wp[(r++) * kWave + lane];
+#pragma unroll
+        for (int e = 0; e < GPL; ++e) {
+            const bool is_tanh = (part + S * e) == 2;       // the candidate ("c") gate
+            amul[e] = is_tanh ? 2.f : 1.f;                  // tanh(v) = 2*sigmoid(2v) - 1
+            aka[e] = is_tanh ? 2.f : 1.f;
+            akb[e] = is_tanh ? -1.f : 0.f;
+        }
+#pragma unroll
+        for (int m = 0; m < NU; ++m) {
+            const int j = slot + m * SLOTS;
+            h[m] = j < H ? st[j] : 0.f;
+            c[m] = j < H ? st[H + j] : 0.f;
+        }
+    }
+
+    __device__ __forceinline__ void store(float* __restrict__ st) const
+    {
+#pragma unroll
+        for (int m = 0; m < NU; ++m) {
+            const int j = slot + m * SLOTS;
+            if (part == 0 && j < H) { st[j] = h[m]; st[H + j] = c[m]; }
+        }
+    }
+
+    __device__ __forceinline__ void publish_h(float* hbuf) const
+    {
+#pragma unroll
+        for (int m = 0; m < NU; ++m) {
+            const int j = slot + m * SLOTS;
+            if (part == 0 && j < H) hbuf[j] = h[m];
+        }
+    }
+
+    // one sample; returns the Dense(H,1) output, wave-uniform
+    __device__ __forceinline__ float step(float x0, float x1, float x2, float* hbuf)
+    {
+        float acc[NU][GPL];
+#pragma unroll
+        for (int m = 0; m < NU; ++m)
+#pragma unroll
+            for (int e = 0; e < GPL; ++e) {
+                float a = bias[m][e];
+                a = __builtin_fmaf(wx[m][e][0], x0, a);
+                a = __builtin_fmaf(wx[m][e][1], x1, a);
+                a = __builtin_fmaf(wx[m][e][2], x2, a);
+                acc[m][e] = a;
+            }
+        const float4* hv = reinterpret_cast<const float4*>(hbuf);
+#pragma unroll
+        for (int k4 = 0; k4 < H / 4; ++k4) {
+            const float4 q = hv[k4];                        // same address in all lanes: broadcast
+#pragma unroll
+            for (int m = 0; m < NU; ++m)
+#pragma unroll
+                for (int e = 0; e < GPL; ++e) {
+                    float a = acc[m][e];
+                    a = __builtin_fmaf(w[m][e][4 * k4 + 0], q.x, a);
+                    a = __builtin_fmaf(w[m][e][4 * k4 + 1], q.y, a);
+                    a = __builtin_fmaf(w[m][e][4 * k4 + 2], q.z, a);
+                    a = __builtin_fmaf(w[m][e][4 * k4 + 3], q.w, a);
+                    acc[m][e] = a;
+                }
+        }
+        __builtin_amdgcn_wave_barrier();                    // all reads of h(t-1) precede the publish below
+        float dense = 0.f;
+#pragma unroll
+        for (int m = 0; m < NU; ++m) {
+            float act[GPL];
+#pragma unroll
+            for (int e = 0; e < GPL; ++e)
+                act[e] = __builtin_fmaf(fast_sigmoid(acc[m][e] * amul[e]), aka[e], akb[e]);
+            float gi, gf, gg, go;
+            if constexpr (S == 1) {
+                gi = act[0]; gf = act[1]; gg = act[2]; go = act[3];
+            } else if constexpr (S == 2) {
+                // part 0 holds (i, g), part 1 holds (f, o); a 32-lane half swap shares them
+                const auto a0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, act[0]), __builtin_bit_cast(unsigned, act[0]), false, false);
+                const auto a1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, act[1]), __builtin_bit_cast(unsigned, act[1]), false, false);
+                gi = __builtin_bit_cast(float, a0[0]); gf = __builtin_bit_cast(float, a0[1]);
+                gg = __builtin_bit_cast(float, a1[0]); go = __builtin_bit_cast(float, a1[1]);
+            } else {
+                // part q holds gate q: rows (v0,v1,v2,v3) -> (v0,v1,v0,v1),(v2,v3,v2,v3) -> each broadcast
+                const auto p = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, act[0]), __builtin_bit_cast(unsigned, act[0]), false, false);
+                const auto lo = __builtin_amdgcn_permlane16_swap(p[0], p[0], false, false);
+                const auto hi = __builtin_amdgcn_permlane16_swap(p[1], p[1], false, false);
+                gi = __builtin_bit_cast(float, lo[0]); gf = __builtin_bit_cast(float, lo[1]);
+                gg = __builtin_bit_cast(float, hi[0]); go = __builtin_bit_cast(float, hi[1]);
+            }
+            const float cn = __builtin_fmaf(gf, c[m], gi * gg);
+            c[m] = cn;
+            const float th = __builtin_fmaf(fast_sigmoid(cn * 2.f), 2.f, -1.f);
+            h[m] = go * th;
+            dense = __builtin_fmaf(wd[m], h[m], dense);     // wd is 0 outside part 0 / j >= H
+        }
+        publish_h(hbuf);
+        __builtin_amdgcn_wave_barrier();
+        return wave_sum(dense) + bd;
+    }
+};
+
+// ---------------------------------------------------------------- GRU cell
+// One lane owns the z, r and candidate rows of its units (S = 1): no exchange.
+// Keras reset_after form, json column order z|r|h, bias [2][3H]:
+//   z = sig(Wz x + Uz h + bz0 + bz1), r likewise,
+//   n = tanh(Wn x + bn0 + r*(Un h + bn1)),  h' = (1-z)*n + z*h
+template <int H>
+struct GruCell {
+    static constexpr LaneMap M = gru_map(H);
+    static constexpr int SLOTS = M.slots, NU = M.NU;
+    static constexpr int PACK = gru_pack_regs(H);
+    static constexpr int STATE = H;
+
+    float w[NU][3][H];
+    float wx[NU][3][kMaxInputs];
+    float bias[NU][3];       // z: b0+b1, r: b0+b1, n: b0 (input side)
+    float bn1[NU];           // n: b1 (recurrent side)
+    float wd[NU], bd;
+    float h[NU];
+    int slot;
+
+    __device__ __forceinline__ void load(const float* __restrict__ wp, const float* __restrict__ st, int lane)
+    {
+        slot = lane;
+        int r = 0;
+#pragma unroll
+        for (int m = 0; m < NU; ++m)
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+#pragma unroll
+                for (int k = 0; k < H; ++k) w[m][e][k] = wp[(r++) * kWave + lane];
+#pragma unroll
+                for (int i = 0; i < kMaxInputs; ++i) wx[m][e][i] = wp[(r++) * kWave + lane];
+                bias[m][e] = wp[(r++) * kWave + lane];
+            }
+#pragma unroll
+        for (int m = 0; m < NU; ++m) bn1[m] = wp[(r++) * kWave + lane];
+#pragma unroll
+        for (int m = 0; m < NU; ++m) wd[m] = wp[(r++) * kWave + lane];
+        bd = wp[(r++) * kWave + lane];
+#pragma unroll
+        for (int m = 0; m < NU; ++m) {
+            const int j = slot + m * SLOTS;
+            h[m] = j < H ? st[j] : 0.f;
+        }
+    }
+
+    __device__ __forceinline__ void store(float* __restrict__ st) const
+    {
+#pragma unroll
+        for (int m = 0; m < NU; ++m) {
+            const int j = slot + m * SLOTS;
+            if (j < H) st[j] = h[m];
+        }
+    }
+
+    __device__ __forceinline__ void publish_h(float* hbuf) const
+    {
+#pragma unroll
+        for (int m = 0; m < NU; ++m) {
+            const int j = slot + m * SLOTS;
+            if (j < H) hbuf[j] = h[m];
+        }
+    }
+
+    __device__ __forceinline__ float step(float x0, float x1, float x2, float* hbuf)
+    {
+        float ax[NU][3], ar[NU][3];
+#pragma unroll
+        for (int m = 0; m < NU; ++m)
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                float a = bias[m][e];
+                a = __builtin_fmaf(wx[m][e][0], x0, a);
+                a = __builtin_fmaf(wx[m][e][1], x1, a);
+                a = __builtin_fmaf(wx[m][e][2], x2, a);
+                ax[m][e] = a;
+                ar[m][e] = e == 2 ? bn1[m] : 0.f;
+            }
+        const float4* hv = reinterpret_cast<const float4*>(hbuf);
+#pragma unroll
+        for (int k4 = 0; k4 < H / 4; ++k4) {
+            const float4 q = hv[k4];
+#pragma unroll
+            for (int m = 0; m < NU; ++m)
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    float a = ar[m][e];
+                    a = __builtin_fmaf(w[m][e][4 * k4 + 0], q.x, a);
+                    a = __builtin_fmaf(w[m][e][4 * k4 + 1], q.y, a);
+                    a = __builtin_fmaf(w[m][e][4 * k4 + 2], q.z, a);
+                    a = __builtin_fmaf(w[m][e][4 * k4 + 3], q.w, a);
+                    ar[m][e] = a;
+                }
+        }
+        __builtin_amdgcn_wave_barrier();
+        float dense = 0.f;
+#pragma unroll
+        for (int m = 0; m < NU; ++m) {
+            const float z = fast_sigmoid(ax[m][0] + ar[m][0]);
+            const float r = fast_sigmoid(ax[m][1] + ar[m][1]);
+            const float pre = __builtin_fmaf(r, ar[m][2], ax[m][2]);
+            const float n = __builtin_fmaf(fast_sigmoid(pre * 2.f), 2.f, -1.f);
+            h[m] = __builtin_fmaf(z, h[m] - n, n);          // (1-z)*n + z*h
+            dense = __builtin_fmaf(wd[m], h[m], dense);
+        }
+        publish_h(hbuf);
+        __builtin_amdgcn_wave_barrier();
+        return wave_sum(dense) + bd;
+    }
+};
+
+// ------------------------------------------------------------- block I/O
+__device__ __forceinline__ void load_block(float* buf, const float* __restrict__ src, int n, int lane)
+{
+    if ((n & 3) == 0) {
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        float4* b4 = reinterpret_cast<float4*>(buf);
+        for (int i = lane; i < n / 4; i += kWave) b4[i] = s4[i];     // 16 B/lane, 1 KiB per wave instruction
+    } else {
+        for (int i = lane; i < n; i += kWave) buf[i] = src[i];
+    }
+}
+
+__device__ __forceinline__ void store_block(float* __restrict__ dst, const float* buf, int n, int lane)
+{
+    if ((n & 3) == 0) {
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        const float4* b4 = reinterpret_cast<const float4*>(buf);
+        for (int i = lane; i < n / 4; i += kWave) d4[i] = b4[i];
+    } else {
+        for (int i = lane; i < n; i += kWave) dst[i] = buf[i];
+    }
+}
+
+// Stage -> biquad slot of the two systolic passes (cascade order of
+// applyToneControls, rt-neural-generic.cpp:133-139)
+__device__ __forceinline__ int pre_slot(int k)  { return k == 0 ? BQ_LPF : BQ_DEPTH + (k - 1); }
+__device__ __forceinline__ int post_slot(int k) { return k == 0 ? BQ_DC : BQ_DEPTH + (k - 1); }
+
+__device__ __forceinline__ void chain_load(ChainPass& c, const StreamCtl& ctl, const StreamState& st, int slot, bool act)
+{
+    c.active = act;
+    c.a0 = ctl.bq[slot][0]; c.a1 = ctl.bq[slot][1]; c.a2 = ctl.bq[slot][2];
+    c.b1 = ctl.bq[slot][3]; c.b2 = ctl.bq[slot][4];
+    c.z1 = st.z[slot][0];   c.z2 = st.z[slot][1];
+}
+
+// ------------------------------------------------------------- the kernel
+template <class Cell, bool HasCell>
+__device__ __forceinline__ void stream_body(const LaunchArgs& a, float* smem)
+{
+    const int lane = threadIdx.x;
+    const int s = blockIdx.x;
+    const int n = (int)a.n_frames;
+
+    if constexpr (HasCell) {
+        if (a.mode != MODE_CHAIN) {
+            // ---- bare applyModel: warm-up over zeros, or explicit [n][I] inputs (stream 0)
+            float* hbuf = smem;
+            Cell cell;
+            float* nnst = a.nn + (size_t)s * a.nn_stride;
+            cell.load(a.wpack, nnst, lane);
+            cell.publish_h(hbuf);
+            __builtin_amdgcn_wave_barrier();
+            StreamState* stp = a.st + s;
+            float p1 = stp->p_mem[0], p2 = stp->p_mem[1];
+            const float t1 = stp->p_tgt[0], t2 = stp->p_tgt[1], s1 = stp->p_step[0], s2 = stp->p_step[1];
+            for (int t = 0; t < n; ++t) {
+                float x = 0.f, q1 = 0.f, q2 = 0.f;
+                if (a.mode == MODE_NN_ONLY) {
+                    x = a.in[(size_t)t * a.input_size];
+                    if (a.input_size >= 2) q1 = a.in[(size_t)t * a.input_size + 1];
+                    if (a.input_size >= 3) q2 = a.in[(size_t)t * a.input_size + 2];
+                } else {
+                    if (a.input_size >= 2) q1 = lin_next(p1, t1, s1);
+                    if (a.input_size >= 3) q2 = lin_next(p2, t2, s2);
+                }
+                x = x * a.in_gain;
+                const float y = cell.step(x, q1, q2, hbuf);
+                float o = a.input_skip ? x + y : y;
+                o = o * a.out_gain;
+                if (a.mode == MODE_NN_ONLY && lane == 0) a.out[t] = o;
+            }
+            cell.store(nnst);
+            if (a.mode == MODE_WARMUP && lane == 0) { stp->p_mem[0] = p1; stp->p_mem[1] = p2; }
+            return;
+        }
+    }
+
+    // ---- MODE_CHAIN: run(), rt-neural-generic.cpp:489-518 + :607-659
+    float* buf = smem;                                   // n_frames floats (rounded up to 4)
+    float* hbuf = smem + ((n + 3) & ~3);
+    const StreamCtl& ctl = a.ctl[s];
+    StreamState& st = a.st[s];
+    const uint32_t flags = ctl.flags;
+    uint32_t pending = st.pending;
+
+    float pre_mem = st.pre_mem, master_mem = st.master_mem;
+    float pre_tgt = st.pre_tgt, master_tgt = st.master_tgt;
+    if (pending & PEND_ACTIVATE) {                       // activate(): clearToTargetValue (:341-342)
+        pre_mem = pre_tgt;
+        master_mem = master_tgt;
+        pending &= ~PEND_ACTIVATE;
+    }
+    pre_tgt = ctl.pre_target;                            // preGain.setTargetValue (:513), before every early-out
+
+    const float* in_row = a.in + (size_t)s * n;
+    float* out_row = a.out + (size_t)s * n;
+
+    if (n == 0 || !(flags & CTL_ENABLED)) {              // pre-run (:607-609) / hard bypass (:612-619)
+        if (n != 0 && out_row != in_row)
+            for (int i = lane; i < n; i += kWave) out_row[i] = in_row[i];
+        if (lane == 0) { st.pre_mem = pre_mem; st.master_mem = master_mem; st.pre_tgt = pre_tgt; st.pending = pending; }
+        return;
+    }
+
+    load_block(buf, in_row, n, lane);
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- pre pass: LPF (:622-626) -> pre-gain ramp (:627) -> EQ if pre (:628-630)
+    {
+        ChainPass c;
+        const bool eq = flags & CTL_EQ_PRE;
+        c.K = eq ? 6 : 1;
+        c.gain_lane = 0;
+        const int k = lane < c.K ? lane : 0;
+        const int slot = pre_slot(k);
+        bool act = k == 0 ? (flags & CTL_LPF_ON) != 0
+                          : ((flags & CTL_EQ_BANDPASS) ? slot == BQ_MID : true);
+        chain_load(c, ctl, st, slot, act);
+        c.g.arm(pre_mem, pre_tgt, ctl.pre_coef);
+        chain_run(c, buf, n, lane);
+        if (lane < c.K) { st.z[slot][0] = c.z1; st.z[slot][1] = c.z2; }
+        pre_mem = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c.g.mem), 0));
+    }
+
+    // ---- NN pass: applyModel (:631-644)
+    if constexpr (HasCell) {
+        if (flags & CTL_NET_ON) {
+            float p_mem[2] = { st.p_mem[0], st.p_mem[1] };
+            float p_tgt[2] = { st.p_tgt[0], st.p_tgt[1] };
+            float p_step[2] = { st.p_step[0], st.p_step[1] };
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {                // LinearValueSmoother::setTargetValue (:209-216)
+                const float nt = ctl.p_target[i];
+                if (__builtin_fabsf(p_tgt[i] - nt) >= FLT_EPSILON) {
+                    p_tgt[i] = nt;
+                    p_step[i] = (p_tgt[i] - p_mem[i]) / ctl.p_den;
+                }
+            }
+            if (pending & PEND_PARAM_FIRST) {            // paramFirstRun (:636-640)
+                pending &= ~PEND_PARAM_FIRST;
+                p_mem[0] = p_tgt[0];
+                p_mem[1] = p_tgt[1];
+            }
+            Cell cell;
+            float* nnst = a.nn + (size_t)s * a.nn_stride;
+            cell.load(a.wpack, nnst, lane);
+            cell.publish_h(hbuf);
+            __builtin_amdgcn_wave_barrier();
+            const int I = a.input_size;
+            for (int t = 0; t < n; ++t) {
+                const float x = buf[t] * a.in_gain;       // out[i] *= input_gain
+                float q1 = 0.f, q2 = 0.f;
+                if (I >= 2) q1 = lin_next(p_mem[0], p_tgt[0], p_step[0]);
+                if (I >= 3) q2 = lin_next(p_mem[1], p_tgt[1], p_step[1]);
+                const float y = cell.step(x, q1, q2, hbuf);
+                float o = a.input_skip ? x + y : y;      // out[i] (+)= forward
+                o = o * a.out_gain;                       // out[i] *= output_gain
+                if (lane == 0) buf[t] = o;
+                __builtin_amdgcn_wave_barrier();
+            }
+            cell.store(nnst);
+            if (lane == 0) {
+                st.p_mem[0] = p_mem[0]; st.p_mem[1] = p_mem[1];
+                st.p_tgt[0] = p_tgt[0]; st.p_tgt[1] = p_tgt[1];
+                st.p_step[0] = p_step[0]; st.p_step[1] = p_step[1];
+            }
+        }
+    }
+
+    // ---- post pass: DC blocker (:645-650) -> EQ if post (:651-653) -> master ramp (:654-655)
+    master_tgt = ctl.master_target;
+    {
+        ChainPass c;
+        const bool eq = flags & CTL_EQ_POST;
+        c.K = eq ? 6 : 1;
+        c.gain_lane = c.K - 1;
+        const int k = lane < c.K ? lane : 0;
+        const int slot = post_slot(k);
+        bool act = k == 0 ? (flags & CTL_DC_ON) != 0
+                          : ((flags & CTL_EQ_BANDPASS) ? slot == BQ_MID : true);
+        chain_load(c, ctl, st, slot, act);
+        c.g.arm(master_mem, master_tgt, ctl.master_coef);
+        chain_run(c, buf, n, lane);
+        if (lane < c.K) { st.z[slot][0] = c.z1; st.z[slot][1] = c.z2; }
+        master_mem = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c.g.mem), c.K - 1));
+    }
+
+    store_block(out_row, buf, n, lane);
+    if (lane == 0) {
+        st.pre_mem = pre_mem; st.master_mem = master_mem;
+        st.pre_tgt = pre_tgt; st.master_tgt = master_tgt;
+        st.pending = pending;
+    }
+}
+
+struct NoCell { static constexpr int PACK = 0, STATE = 0; };
+
+template <int H>
+__global__ __launch_bounds__(kWave) void k_lstm(LaunchArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    stream_body<LstmCell<H>, true>(a, smem);
+}
+
+template <int H>
+__global__ __launch_bounds__(kWave) void k_gru(LaunchArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    stream_body<GruCell<H>, true>(a, smem);
+}
+
+__global__ __launch_bounds__(kWave) void k_nomodel(LaunchArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    stream_body<NoCell, false>(a, smem);
+}
+
+// one-shot pokes from the control thread (activate / loading are host-latched in ctl;
+// this sets StreamState.pending bits stream-ordered with the process launches)
+__global__ void k_set_pending(StreamState* st, uint32_t n_streams, int32_t stream, uint32_t bits)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_streams) return;
+    if (stream < 0 || (uint32_t)stream == i) st[i].pending |= bits;
+}
+
+// work_response(): fresh DynamicModel per stream (:1046-1061) — zero recurrent
+// state, param smoothers re-created around the inherited targets.
+__global__ void k_reset_for_model(StreamState* st, float* nn, uint32_t n_streams, uint32_t nn_stride, float p_den)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_streams) return;
+    for (uint32_t k = 0; k < nn_stride; ++k) nn[(size_t)i * nn_stride + k] = 0.f;
+    StreamState& s = st[i];
+    for (int k = 0; k < 2; ++k) {
+        const float old = s.p_tgt[k];
+        // ctor zeros; setTargetValue(old) computes step from mem = 0; clearToTargetValue
+        s.p_step[k] = __builtin_fabsf(0.f - old) >= FLT_EPSILON ? (old - 0.f) / p_den : 0.f;
+        s.p_tgt[k] = __builtin_fabsf(0.f - old) >= FLT_EPSILON ? old : 0.f;
+        s.p_mem[k] = s.p_tgt[k];
+    }
+    s.pending |= PEND_PARAM_FIRST;
+}
+
+// ------------------------------------------------------------ host dispatch
+#define AIDAX_LSTM(H) { 0, H, k_lstm<H>, LstmCell<H>::PACK, LstmCell<H>::STATE, "k_lstm<" #H ">" }
+#define AIDAX_GRU(H)  { 1, H, k_gru<H>,  GruCell<H>::PACK,  GruCell<H>::STATE,  "k_gru<" #H ">" }
+
+static const KernelEntry kTable[] = {
+    // the 18 (cell, hidden) pairs of variant/generate_variant_hpp.py:4-6; input size is a run-time argument
+    AIDAX_LSTM(8), AIDAX_LSTM(12), AIDAX_LSTM(16), AIDAX_LSTM(20), AIDAX_LSTM(24),
+    AIDAX_LSTM(32), AIDAX_LSTM(40), AIDAX_LSTM(64), AIDAX_LSTM(80),
+    AIDAX_GRU(8), AIDAX_GRU(12), AIDAX_GRU(16), AIDAX_GRU(20), AIDAX_GRU(24),
+    AIDAX_GRU(32), AIDAX_GRU(40), AIDAX_GRU(64), AIDAX_GRU(80),
+};
+
+const KernelEntry* find_kernel(int cell, int hidden)
+{
+    for (const auto& e : kTable)
+        if (e.cell == cell && e.hidden == hidden) return &e;
+    return nullptr;
+}
+
+hipError_t launch_stream_kernel(const KernelEntry* e, const LaunchArgs& a, size_t lds_bytes, hipStream_t stream)
+{
+    void (*fn)(LaunchArgs) = e ? e->fn : k_nomodel;
+    hipLaunchKernelGGL(fn, dim3(a.n_streams), dim3(kWave), lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_set_pending(StreamState* st, uint32_t n_streams, int32_t stream, uint32_t bits, hipStream_t q)
+{
+    hipLaunchKernelGGL(k_set_pending, dim3((n_streams + 255) / 256), dim3(256), 0, q, st, n_streams, stream, bits);
+    return hipGetLastError();
+}
+
+hipError_t launch_reset_for_model(StreamState* st, float* nn, uint32_t n_streams, uint32_t nn_stride, float p_den, hipStream_t q)
+{
+    hipLaunchKernelGGL(k_reset_for_model, dim3((n_streams + 255) / 256), dim3(256), 0, q, st, nn, n_streams, nn_stride, p_den);
+    return hipGetLastError();
+}
+
+}  // namespace aidax

@@ -1,0 +1,136 @@
+// aidax_layout.h — data layout shared by the host packer and the HIP kernels.
+//
+// HBM layout (all per pool, device-resident across process() calls):
+//   StreamCtl   ctl[n_streams]     control-rate values latched from the ports (host-written)
+//   StreamState st[n_streams]      biquad z1/z2, smoother memories, pending one-shots
+//   float       nn[n_streams][NN_STATE]   recurrent state of the model (h, c per layer)
+//   float       wpack[...]         weights, pre-shuffled into the register order of the
+//                                  kernel's lane mapping: element (idx, lane) at idx*64+lane,
+//                                  so a wave loads each weight register with one coalesced
+//                                  256-byte read.
+//   audio in/out [n_streams][n_frames] fp32, one row per stream (the C-ABI layout).
+#pragma once
+
+#include <cstdint>
+
+namespace aidax {
+
+constexpr int kWave = 64;
+constexpr int kMaxInputs = 3;            // MAX_INPUT_SIZE, model_variant.hpp:4
+
+// Biquad slots of one stream, in chain order of use.
+enum BqSlot { BQ_LPF = 0, BQ_DC = 1, BQ_DEPTH = 2, BQ_BASS = 3, BQ_MID = 4, BQ_TREBLE = 5, BQ_PRESENCE = 6, BQ_COUNT = 7 };
+
+// StreamCtl.flags
+enum : uint32_t {
+    CTL_ENABLED   = 1u << 0,   // *enabled > 0.5                      (rt-neural-generic.cpp:495)
+    CTL_LPF_ON    = 1u << 1,   // in_lpf_pc != 0                      (:622)
+    CTL_EQ_PRE    = 1u << 2,   // eq_position == 1 && eq_bypass == 0  (:628)
+    CTL_EQ_POST   = 1u << 3,   // eq_position == 0 && eq_bypass == 0  (:651)
+    CTL_EQ_BANDPASS = 1u << 4, // mid_type == BANDPASS: mid only      (:130-132)
+    CTL_NET_ON    = 1u << 5,   // model && !net_bypass                (:631-632)
+    CTL_DC_ON     = 1u << 6,   // *dc_blocker_param == 1              (:646)
+};
+
+// StreamState.pending (one-shots, consumed by the next process pass)
+enum : uint32_t {
+    PEND_ACTIVATE   = 1u << 0,   // activate(): gain smoothers clearToTargetValue (:341-342)
+    PEND_PARAM_FIRST = 1u << 1,  // DynamicModel::paramFirstRun (:350, :636-640, :1061)
+};
+
+struct alignas(16) StreamCtl {
+    double   bq[BQ_COUNT][5];     // a0 a1 a2 b1 b2 (common/Biquad.h:48)
+    float    pre_target;          // DB_CO(pregain_db)                    (:489)
+    float    master_target;       // loading ? 0 : DB_CO(master_db)       (:490, :654)
+    float    pre_coef;            // ExponentialValueSmoother::coef, host rate (:283-290)
+    float    master_coef;
+    float    p_target[2];         // PARAM1 / PARAM2                      (:634-635)
+    float    p_den;               // tau * model samplerate               (ValueSmoother.hpp:239)
+    uint32_t flags;
+    uint32_t pad[2];
+};
+static_assert(sizeof(StreamCtl) == 320, "StreamCtl layout");
+
+struct alignas(16) StreamState {
+    double   z[BQ_COUNT][2];      // z1 z2 (common/Biquad.h:50)
+    float    pre_mem, master_mem; // ExponentialValueSmoother::mem
+    float    pre_tgt, master_tgt; // ExponentialValueSmoother::target as last set
+    float    p_mem[2], p_step[2], p_tgt[2];   // LinearValueSmoother mem/step/target
+    uint32_t pending;
+    uint32_t pad;
+};
+static_assert(sizeof(StreamState) == 160, "StreamState layout");
+
+// ---------------------------------------------------------------- lane mapping
+// One wavefront (64 lanes) per stream. A recurrent layer with G gates and H
+// units is spread as S lanes per unit slot: lane = part*(64/S) + slot,
+// unit j = slot + m*(64/S) for m in [0,NU), each lane holding GPL = G/S gate
+// rows of each of its units (gate = part + S*e, e in [0,GPL)). Every row keeps
+// its H recurrent weights, 3 input weights and bias in registers.
+struct LaneMap {
+    int S, slots, NU, GPL;
+    constexpr int rows_per_lane() const { return NU * GPL; }
+    constexpr int regs_per_row(int H) const { return H + kMaxInputs + 1; }
+};
+
+constexpr int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+constexpr LaneMap lstm_map(int H)
+{
+    // pick S in {4,2,1} minimising FMA issue NU*GPL*(H+3); ties -> fewer lanes per unit
+    int best_S = 1, best_cost = 1 << 30;
+    for (int S = 1; S <= 4; S *= 2) {
+        const int slots = kWave / S;
+        const int NU = ceil_div(H, slots);
+        const int cost = NU * (4 / S) * (H + kMaxInputs) + NU * 24 /* activations weigh in */;
+        if (cost < best_cost) { best_cost = cost; best_S = S; }
+    }
+    return LaneMap{best_S, kWave / best_S, ceil_div(H, kWave / best_S), 4 / best_S};
+}
+
+constexpr LaneMap gru_map(int H)
+{
+    // GRU: one lane owns all three rows of its units (no cross-lane gate exchange)
+    return LaneMap{1, kWave, ceil_div(H, kWave), 3};
+}
+
+// Packed weight record, index -> meaning, for one recurrent layer:
+//   for m in [0,NU) for e in [0,GPL):  H recurrent weights (k = 0..H-1), 3 input weights, 1 bias
+//   GRU only: + for m: bias_n1 (recurrent bias of the candidate row, kept apart)
+//   then for m in [0,NU): dense weight of unit (0 outside part 0 / j >= H)
+//   then 1: dense bias
+constexpr int lstm_pack_regs(int H)
+{
+    const LaneMap L = lstm_map(H);
+    return L.NU * L.GPL * (H + kMaxInputs + 1) + L.NU + 1;
+}
+constexpr int gru_pack_regs(int H)
+{
+    const LaneMap L = gru_map(H);
+    return L.NU * 3 * (H + kMaxInputs + 1) + L.NU + L.NU + 1;
+}
+
+// Kernel run modes
+enum : int {
+    MODE_CHAIN = 0,     // full run() chain on audio blocks
+    MODE_WARMUP = 1,    // applyModel over zeros, output discarded (:1077-1078)
+    MODE_NN_ONLY = 2,   // bare applyModel with explicit [n][I] inputs (self-test / forward)
+};
+
+struct LaunchArgs {
+    const StreamCtl* ctl;
+    StreamState*     st;
+    float*           nn;          // [n_streams][nn_stride]
+    const float*     wpack;
+    const float*     in;          // MODE_CHAIN: [n_streams][n]; MODE_NN_ONLY: [n][I] (stream 0)
+    float*           out;
+    uint32_t         n_streams;
+    uint32_t         n_frames;
+    uint32_t         nn_stride;
+    int32_t          mode;
+    int32_t          input_size;
+    int32_t          input_skip;
+    float            in_gain, out_gain;
+};
+
+}  // namespace aidax

@@ -1,0 +1,98 @@
+// aidax_pack.cpp — shuffles a model's Keras-layout weights into the register
+// order of the kernel's lane mapping (aidax_layout.h): record r of lane l is at
+// wpack[r*64 + l], so the kernel fills each weight VGPR with one coalesced read.
+#include <stdexcept>
+
+#include "aidax_internal.h"
+
+namespace aidax {
+
+namespace {
+
+struct Packer {
+    std::vector<float> out;
+    int regs;
+    explicit Packer(int regs_) : out(static_cast<size_t>(regs_) * kWave, 0.f), regs(regs_) {}
+    void put(int r, int lane, float v)
+    {
+        if (r >= regs) throw std::logic_error("pack overflow");
+        out[static_cast<size_t>(r) * kWave + lane] = v;
+    }
+};
+
+std::vector<float> pack_lstm(const aidax_model& m)
+{
+    const Layer& L = m.layers[0];
+    const Layer& D = m.layers[1];
+    const int H = L.out_size, I = L.in_size, G = 4 * H;
+    const LaneMap M = lstm_map(H);
+    Packer p(lstm_pack_regs(H));
+    for (int lane = 0; lane < kWave; ++lane) {
+        const int part = lane / M.slots, slot = lane % M.slots;
+        int r = 0;
+        for (int mm = 0; mm < M.NU; ++mm) {
+            const int j = slot + mm * M.slots;
+            const bool live = j < H;
+            for (int e = 0; e < M.GPL; ++e) {
+                const int col = (part + M.S * e) * H + j;           // gate-major column of the json matrices
+                for (int k = 0; k < H; ++k) p.put(r++, lane, live ? L.w1[static_cast<size_t>(k) * G + col] : 0.f);
+                for (int i = 0; i < kMaxInputs; ++i) p.put(r++, lane, (live && i < I) ? L.w0[static_cast<size_t>(i) * G + col] : 0.f);
+                p.put(r++, lane, live ? L.w2[col] : 0.f);
+            }
+        }
+        for (int mm = 0; mm < M.NU; ++mm) {
+            const int j = slot + mm * M.slots;
+            p.put(r++, lane, (part == 0 && j < H) ? D.w0[j] : 0.f);
+        }
+        p.put(r++, lane, D.w1[0]);
+    }
+    return std::move(p.out);
+}
+
+std::vector<float> pack_gru(const aidax_model& m)
+{
+    const Layer& L = m.layers[0];
+    const Layer& D = m.layers[1];
+    const int H = L.out_size, I = L.in_size, G = 3 * H;
+    const LaneMap M = gru_map(H);
+    Packer p(gru_pack_regs(H));
+    const float* b0 = L.w2.data();          // input-side bias
+    const float* b1 = L.w2.data() + G;      // recurrent-side bias
+    for (int lane = 0; lane < kWave; ++lane) {
+        const int slot = lane;
+        int r = 0;
+        for (int mm = 0; mm < M.NU; ++mm) {
+            const int j = slot + mm * M.slots;
+            const bool live = j < H;
+            for (int e = 0; e < 3; ++e) {
+                const int col = e * H + j;
+                for (int k = 0; k < H; ++k) p.put(r++, lane, live ? L.w1[static_cast<size_t>(k) * G + col] : 0.f);
+                for (int i = 0; i < kMaxInputs; ++i) p.put(r++, lane, (live && i < I) ? L.w0[static_cast<size_t>(i) * G + col] : 0.f);
+                // z, r: both biases act on the same pre-activation and are summed at load time;
+                // candidate: only the input-side bias here, the recurrent one sits under r*( )
+                p.put(r++, lane, live ? (e < 2 ? b0[col] + b1[col] : b0[col]) : 0.f);
+            }
+        }
+        for (int mm = 0; mm < M.NU; ++mm) {
+            const int j = slot + mm * M.slots;
+            p.put(r++, lane, j < H ? b1[2 * H + j] : 0.f);
+        }
+        for (int mm = 0; mm < M.NU; ++mm) {
+            const int j = slot + mm * M.slots;
+            p.put(r++, lane, j < H ? D.w0[j] : 0.f);
+        }
+        p.put(r++, lane, D.w1[0]);
+    }
+    return std::move(p.out);
+}
+
+}  // namespace
+
+std::vector<float> pack_weights(const aidax_model& m)
+{
+    if (m.n_rnn == 1 && m.cell == AIDAX_CELL_LSTM) return pack_lstm(m);
+    if (m.n_rnn == 1 && m.cell == AIDAX_CELL_GRU) return pack_gru(m);
+    throw std::runtime_error("no packer for this architecture");
+}
+
+}  // namespace aidax

@@ -1,0 +1,149 @@
+"""CPU-only tests of the C-ABI library: it loads, exports every symbol the header
+declares, and its host-side logic (json loader, architecture predicate, biquad
+design, control reduction) matches the reference behaviour. No compute call is
+made here; device calls must fail loudly without a GPU (no CPU fallback)."""
+import ctypes as C
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import modelgen
+
+ax = importlib.import_module("aidadsp-lv2_amd")
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = ax.lib()
+    names = ax.declared_symbols()
+    assert len(names) >= 25, names
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/aidax.h but not exported"
+    assert b"gfx950" in L.aidax_version()
+
+
+def test_no_torch_types_and_no_oracle_in_the_product():
+    """The boundary is plain C; the product never links or opens the oracle."""
+    with open(os.path.join(os.path.dirname(ax.lib_path()), "..", "..", "include", "aidax.h")) as f:
+        hdr = f.read()
+    assert "torch" not in hdr and "at::" not in hdr
+    out = os.popen(f"ldd '{ax.lib_path()}'").read()
+    assert "oracle" not in out and "libamdhip64" in out
+    csrc = os.path.join(os.path.dirname(ax.lib_path()), "..", "csrc")
+    for fn in os.listdir(csrc):
+        with open(os.path.join(csrc, fn)) as f:
+            assert "oracle/" not in f.read().replace("vs the CPU oracle", ""), fn
+
+
+def test_bundled_models_load_like_the_reference(bundled_models):
+    for path in bundled_models:
+        m = ax.Model(path)
+        i = m.info
+        assert (i.cell, i.hidden, i.input_size, i.n_rnn_layers, i.input_skip) == (0, 12, 1, 1, 0)
+        assert i.input_gain == 1.0 and i.output_gain == 1.0
+        assert i.samplerate == 48000.0          # metadata.samplerate is the STRING "48000" -> default (:1005-1013)
+        assert i.n_golden == 2048 and i.in_reference_set == 1
+        assert i.n_weights == 685               # LSTM-12 685 floats
+        assert m.path == path
+        gi, go = m.golden()
+        spec = O.load_model(path)
+        assert np.array_equal(gi, spec.input_batch) and np.array_equal(go, spec.output_batch)
+
+
+@pytest.mark.parametrize("cell", ["lstm", "gru"])
+@pytest.mark.parametrize("hidden", modelgen.HIDDEN_SIZES)
+def test_all_54_reference_variants_are_accepted(cell, hidden):
+    """variant/generate_variant_hpp.py:3-6 — {GRU,LSTM} x 9 hidden x 3 input sizes."""
+    for isz in modelgen.INPUT_SIZES:
+        j = modelgen.make_model(cell, hidden, isz, seed=hidden * 10 + isz)
+        m = ax.Model(text=json.dumps(j))
+        i = m.info
+        assert (i.cell, i.hidden, i.input_size, i.in_reference_set) == (0 if cell == "lstm" else 1, hidden, isz, 1)
+
+
+def test_loader_key_semantics():
+    base = modelgen.make_model("lstm", 16, 2, seed=1)
+    m = ax.Model(text=json.dumps(dict(base, in_skip=1, in_gain=-6.0, out_gain=3.0, samplerate=44100)))
+    i = m.info
+    assert i.input_skip == 1 and i.samplerate == 44100.0
+    assert i.input_gain == pytest.approx(O.db_co(-6.0), abs=0) and i.output_gain == pytest.approx(O.db_co(3.0), abs=0)
+    # non-numeric values are ignored, not errors (:982-1003)
+    i = ax.Model(text=json.dumps(dict(base, in_skip="1", in_gain="x", out_gain=None))).info
+    assert (i.input_skip, i.input_gain, i.output_gain) == (0, 1.0, 1.0)
+    # metadata.samplerate as a NUMBER wins over top-level samplerate (:1005-1010)
+    j = dict(base, samplerate=44100)
+    j["metadata"] = {"samplerate": 96000}
+    assert ax.Model(text=json.dumps(j)).info.samplerate == 96000.0
+
+
+def test_loader_errors_are_codes_not_exceptions(tmp_path):
+    base = modelgen.make_model("lstm", 16, 1, seed=2)
+    L = ax.lib()
+
+    def code(text):
+        h = C.c_void_p()
+        rc = L.aidax_model_load_memory(text.encode(), len(text), b"t", C.byref(h))
+        assert not h.value or rc == 0
+        return rc, L.aidax_last_error().decode()
+
+    assert code("{ not json")[0] == -3
+    rc, msg = code(json.dumps({k: v for k, v in base.items() if k != "in_shape"}))
+    assert rc == -3 and "Unable to load json file" in msg
+    assert code(json.dumps(dict(base, in_shape=[None, None, 4])))[0] == -4          # input_size > MAX_INPUT_SIZE (:978-980)
+    assert code(json.dumps(dict(base, in_skip=2)))[0] == -4                           # in_skip > 1 (:984-985)
+    rc, msg = code(json.dumps(modelgen.make_model("lstm", 28, 1)))                    # 28 not in the size list
+    assert rc == -4 and "Unable to identify a known model architecture" in msg
+    bad = json.loads(json.dumps(base))
+    bad["layers"][0]["type"] = "rnn"
+    assert code(json.dumps(bad))[0] == -4
+    bad = json.loads(json.dumps(base))
+    bad["layers"][0]["weights"][1] = bad["layers"][0]["weights"][1][:-1]
+    assert code(json.dumps(bad))[0] == -3
+    h = C.c_void_p()
+    assert L.aidax_model_load(str(tmp_path / "nope.json").encode(), C.byref(h)) == -2
+    assert L.aidax_model_load(None, C.byref(h)) == -1
+
+
+def test_biquad_design_bit_exact_vs_reference_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "dsp_ref.npz"))
+    for (t, fc, q, gain), want in zip(g["designs"], g["coeffs"]):
+        got = ax.biquad_design(int(t), fc, q, gain)
+        assert np.array_equal(got, want), (t, fc, q, gain)
+
+
+def test_biquad_design_bit_exact_vs_oracle_random():
+    rs = np.random.RandomState(5)
+    L = O.lib()
+    for _ in range(2000):
+        t = int(rs.randint(0, 7))
+        fc, q, gain = float(rs.uniform(1e-4, 0.499)), float(rs.uniform(0.2, 5)), float(rs.uniform(-15, 15))
+        f = O.Biquad()
+        L.orc_biquad_init(C.byref(f), t, fc, q, gain)
+        assert np.array_equal(ax.biquad_design(t, fc, q, gain), [f.a0, f.a1, f.a2, f.b1, f.b2])
+
+
+def test_db_and_lpf_maps_match_oracle():
+    for db in np.linspace(-100, 20, 241, dtype=np.float32):
+        assert ax.db_to_coeff(float(db)) == O.db_co(float(db))
+    assert ax.db_to_coeff(-90.0) == 0.0 and ax.db_to_coeff(-89.99) > 0.0
+    L = O.lib()
+    for pc in np.linspace(0, 100, 101, dtype=np.float32):
+        assert ax.lpf_fc(float(pc)) == float(L.orc_lpf_fc(C.c_float(float(pc))))
+
+
+def test_control_defaults_match_ttl():
+    c, o = ax.default_controls(), O.default_controls()
+    for n in O.CONTROL_FIELDS:
+        assert getattr(c, n) == getattr(o, n), n
+
+
+def test_device_calls_fail_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(ax.AidaxError) as e:
+        ax.Pool(4, 256)
+    assert e.value.code == -5 and "no CPU fallback" in str(e.value)

@@ -1,0 +1,341 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through
+the C ABI, against the CPU oracle on the same seeded inputs, against the
+committed golden fixtures, and through size-independent properties at the
+BASELINE.json sizes.
+
+Bars (north_star):
+  * biquads / smoothers / pure chain (no NN in circuit): bit-exact (fp64 IIR and
+    fp32 recurrences are evaluated operation for operation like the reference);
+  * anything through the NN: max-abs <= 1e-5 * max(1, downstream linear gain)
+    (TEST_MODEL_THR, rt-neural-generic.h:182 — the reference applies it with
+    gains forced to 1).
+"""
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import modelgen
+
+pytestmark = pytest.mark.gpu
+
+ax = importlib.import_module("aidadsp-lv2_amd")
+THR = 1.0e-5
+
+
+def _model_file(tmp_path, name, **kw):
+    j = modelgen.make_model(**kw)
+    p = str(tmp_path / f"{name}.json")
+    modelgen.write_model(j, p)
+    return p, O.parse_model(j)
+
+
+def _ctl_pair(**kw):
+    return ax.default_controls(**kw), O.default_controls(**kw)
+
+
+def _run_gpu(pool, x, block):
+    out = np.empty_like(x)
+    for b in range(0, x.shape[1], block):
+        out[:, b:b + block] = pool.process(np.ascontiguousarray(x[:, b:b + block]))
+    return out
+
+
+# ------------------------------------------------------------- reference goldens
+
+def test_bundled_models_self_test_on_gpu(bundled_models):
+    """testModel (rt-neural-generic.cpp:900-955) on the GPU for all six bundled models."""
+    for path in bundled_models:
+        m = ax.Model(path)
+        n_err, max_err, out = m.self_test()
+        assert n_err == 0 and max_err < THR, (path, n_err, max_err)
+        spec = O.load_model(path)
+        ref = O.OracleModel(spec, warmup=False).test_model(spec.input_batch, spec.output_batch)[2]
+        assert np.abs(out - ref).max() < 2e-6
+
+
+@pytest.mark.parametrize("name", [n for n, kw in sorted(modelgen.GOLDEN_CASES.items())
+                                  if kw["kind"] in ("lstm", "gru") and kw.get("n_rnn", 1) == 1])
+def test_torch_goldens_on_gpu(name, golden_dir, tmp_path):
+    kw = modelgen.GOLDEN_CASES[name]
+    g = np.load(os.path.join(golden_dir, f"nn_{name}.npz"))
+    path, spec = _model_file(tmp_path, name, **kw)
+    y = ax.Model(path).forward(g["X"], unit_gains=True)
+    assert np.abs(y - g["y"]).max() < THR, (name, np.abs(y - g["y"]).max())
+    assert np.abs(y - O.net_run(spec, g["X"])).max() < THR
+
+
+@pytest.mark.parametrize("cell", ["lstm", "gru"])
+@pytest.mark.parametrize("hidden", modelgen.HIDDEN_SIZES)
+def test_every_reference_variant_runs_and_matches_oracle(cell, hidden, tmp_path):
+    """All 54 architectures of model_variant.hpp, bare network, 768 samples each."""
+    for isz in modelgen.INPUT_SIZES:
+        kw = dict(kind=cell, hidden=hidden, input_size=isz, seed=1000 + hidden * 4 + isz)
+        path, spec = _model_file(tmp_path, f"{cell}{hidden}_{isz}", **kw)
+        X = modelgen.golden_inputs(f"{cell}{hidden}_{isz}", isz)[:768]
+        y = ax.Model(path).forward(X, unit_gains=True)
+        ref = O.net_run(spec, X)
+        assert np.abs(y - ref).max() < THR, (cell, hidden, isz, np.abs(y - ref).max())
+
+
+# ------------------------------------------------------------------ pure DSP chain
+
+def test_chain_without_model_is_silent_and_with_loading_cleared_is_bit_exact():
+    x = modelgen.signal(5, 1024, seed=3)
+    pool = ax.Pool(5, 256)
+    assert np.all(_run_gpu(pool, x, 256) == 0.0)           # loading=true, master mem cleared to 0
+    cg, co = _ctl_pair(bass_boost_db=4.0, mid_boost_db=-3.0, mid_freq=750.0, mid_q=1.2, treble_boost_db=2.0,
+                       depth_boost_db=3.0, presence_boost_db=3.0, pregain_db=6.0, master_db=-4.5)
+    pool = ax.Pool(5, 256)
+    pool.set_loading(False)
+    pool.set_controls(cg)
+    got = _run_gpu(pool, x, 256)
+    want = np.empty_like(x)
+    for s in range(5):
+        p = O.OraclePlugin()
+        p.set_loading(False)
+        for b in range(0, 1024, 256):
+            want[s, b:b + 256] = p.run(co, x[s, b:b + 256])
+    assert np.array_equal(got, want)                        # fp64 biquads + fp32 ramps: bit for bit
+
+
+@pytest.mark.parametrize("kw", [
+    dict(eq_position=1.0, bass_boost_db=-6.0, bass_freq=120.0, mid_boost_db=8.0, mid_freq=2500.0, mid_q=4.0,
+         treble_boost_db=-8.0, treble_freq=3500.0, depth_boost_db=-8.0, presence_boost_db=8.0),
+    dict(mid_type=1.0, mid_freq=900.0, mid_q=2.5, mid_boost_db=5.0, bass_boost_db=8.0),
+    dict(eq_position=1.0, mid_type=1.0, mid_freq=400.0, mid_q=0.2),
+    dict(eq_bypass=1.0, dc_blocker=0.0, in_lpf_pc=0.0),
+    dict(in_lpf_pc=100.0, dc_blocker=0.0, pregain_db=-12.0, master_db=15.0),
+    dict(in_lpf_pc=1.0, pregain_db=12.0, master_db=-15.0),
+    dict(pregain_db=-95.0),                                   # DB_CO floor -> 0
+])
+def test_chain_control_corners_bit_exact(kw):
+    x = modelgen.signal(3, 512, seed=11)
+    cg, co = _ctl_pair(**kw)
+    pool = ax.Pool(3, 128)
+    pool.set_loading(False)
+    pool.set_controls(cg)
+    got = _run_gpu(pool, x, 128)
+    want = np.empty_like(x)
+    for s in range(3):
+        p = O.OraclePlugin()
+        p.set_loading(False)
+        for b in range(0, 512, 128):
+            want[s, b:b + 128] = p.run(co, x[s, b:b + 128])
+    assert np.array_equal(got, want), kw
+
+
+def test_ragged_and_tiny_blocks_and_prerun_bit_exact():
+    """Block sizes that are not multiples of 4 or 64, single frames, and the
+    n_samples == 0 pre-run (rt-neural-generic.cpp:606-609)."""
+    sizes = [1, 3, 64, 0, 7, 129, 255, 256, 2, 0, 31]
+    x = modelgen.signal(2, sum(sizes), seed=5)
+    cg, co = _ctl_pair(bass_boost_db=3.0, pregain_db=2.0)
+    pool = ax.Pool(2, 256)
+    pool.set_loading(False)
+    pool.set_controls(cg)
+    plugs = [O.OraclePlugin() for _ in range(2)]
+    for p in plugs:
+        p.set_loading(False)
+    pos = 0
+    for n in sizes:
+        blk = np.ascontiguousarray(x[:, pos:pos + n])
+        got = pool.process(blk)
+        for s in range(2):
+            want = plugs[s].run(co, blk[s])
+            assert np.array_equal(got[s], want), (n, s)
+        pos += n
+
+
+def test_per_stream_controls_and_disable_bypass(bundled_models):
+    spec = O.load_model(bundled_models[4])
+    m = ax.Model(bundled_models[4])
+    S = 6
+    x = modelgen.signal(S, 768, seed=21)
+    pool = ax.Pool(S, 256)
+    pool.set_model(m)
+    kws = [dict(), dict(enabled=0.0), dict(net_bypass=1.0), dict(master_db=6.0, pregain_db=-3.0),
+           dict(eq_position=1.0, bass_boost_db=5.0), dict(dc_blocker=0.0, mid_type=1.0)]
+    for s, kw in enumerate(kws):
+        pool.set_controls(ax.default_controls(**kw), stream=s)
+    got = _run_gpu(pool, x, 256)
+    for s, kw in enumerate(kws):
+        want = O.run_streams(spec, O.default_controls(**kw), x[s:s + 1], 256)[0]
+        if kw.get("enabled") == 0.0 or kw.get("net_bypass") == 1.0:
+            assert np.array_equal(got[s], want), kw          # no NN in circuit
+        else:
+            assert np.abs(got[s] - want).max() < THR * 2.0, (kw, np.abs(got[s] - want).max())
+
+
+# ------------------------------------------------------------------ full chain
+
+def _chain_case(tmp_path, name, model_kw, ctl_kw, S=4, n=2048, block=256, warm=True, tol=THR):
+    path, spec = _model_file(tmp_path, name, **model_kw)
+    m = ax.Model(path)
+    x = modelgen.signal(S, n, seed=77)
+    cg, co = _ctl_pair(**ctl_kw)
+    pool = ax.Pool(S, block)
+    pool.set_model(m, ax.START_WARMUP if warm else ax.START_RESET)
+    pool.set_controls(cg)
+    got = _run_gpu(pool, x, block)
+    want = O.run_streams(spec, co, x, block, warmup=warm)
+    err = np.abs(got - want).max()
+    assert err < tol, (name, err)
+    return pool, spec, got, want
+
+
+def test_cfg2_lstm32_default_controls(tmp_path):
+    _chain_case(tmp_path, "cfg2", dict(kind="lstm", hidden=32, input_size=1, seed=32), {}, S=8, n=4096)
+
+
+def test_lstm32_skip_and_gains(tmp_path):
+    _chain_case(tmp_path, "skip", dict(kind="lstm", hidden=32, input_size=1, seed=33, in_skip=1, in_gain=-3.0, out_gain=4.5),
+                dict(master_db=3.0), tol=THR * 3.0)
+
+
+def test_cfg3_gru64_conditioned_eq_post(tmp_path):
+    """BASELINE cfg #3: GRU-64, 2 params ramping, 5-band EQ post, DC blocker, default LPF."""
+    path, spec = _model_file(tmp_path, "cfg3", kind="gru", hidden=64, input_size=3, seed=64)
+    m = ax.Model(path)
+    S, n, block = 4, 3072, 256
+    x = modelgen.signal(S, n, seed=64)
+    eq = dict(bass_boost_db=4.0, bass_freq=305.0, mid_boost_db=-3.0, mid_freq=750.0, mid_q=1.2,
+              treble_boost_db=2.0, treble_freq=2000.0, depth_boost_db=3.0, presence_boost_db=3.0)
+    pool = ax.Pool(S, block)
+    pool.set_model(m)
+    plugs = []
+    for s in range(S):
+        p = O.OraclePlugin()
+        p.set_model(O.OracleModel(spec))
+        plugs.append(p)
+    got = np.empty_like(x)
+    want = np.empty_like(x)
+    for bi, b in enumerate(range(0, n, block)):
+        t = bi / (n // block - 1)
+        kw = dict(eq, param1=float(t), param2=float(1.0 - 0.7 * t))        # PARAM1 0->1, PARAM2 1->0.3
+        pool.set_controls(ax.default_controls(**kw))
+        got[:, b:b + block] = pool.process(np.ascontiguousarray(x[:, b:b + block]))
+        for s in range(S):
+            want[s, b:b + block] = plugs[s].run(O.default_controls(**kw), x[s, b:b + block])
+    err = np.abs(got - want).max()
+    assert err < THR * 2.5, err                                             # EQ boosts add up to ~ +8 dB
+
+
+def test_cfg1_bundled_lstm12_one_stream_full_chain(bundled_models):
+    path = [p for p in bundled_models if "california_clean" in p][0]         # the TTL default model
+    spec = O.load_model(path)
+    x = modelgen.signal(1, 4096, seed=1)
+    pool = ax.Pool(1, 256)
+    pool.set_model(ax.Model(path))
+    got = _run_gpu(pool, x, 256)
+    want = O.run_streams(spec, O.default_controls(), x, 256)
+    assert np.abs(got - want).max() < THR
+
+
+def test_warmup_state_matches_oracle_and_reset_mode_is_zero(bundled_models):
+    spec = O.load_model(bundled_models[2])
+    m = ax.Model(bundled_models[2])
+    pool = ax.Pool(2, 64)
+    pool.set_model(m, ax.START_WARMUP)
+    h, c = pool.read_state(1)
+    oh, oc = O.OracleModel(spec, warmup=True).state()
+    assert np.abs(h - oh).max() < 2e-6 and np.abs(c - oc).max() < 2e-6 and np.abs(oh).max() > 1e-3
+    pool.set_model(m, ax.START_RESET)
+    h, c = pool.read_state(0)
+    assert np.all(h == 0) and np.all(c == 0)
+
+
+def test_activate_and_model_swap_semantics(tmp_path, bundled_models):
+    """activate() clears the gain ramps to their targets and re-arms paramFirstRun
+    (:337-351); a model swap inherits the param targets (:822-825, :1053-1061)."""
+    pa, spec_a = _model_file(tmp_path, "a", kind="gru", hidden=16, input_size=2, seed=5)
+    pb, spec_b = _model_file(tmp_path, "b", kind="lstm", hidden=20, input_size=3, seed=6)
+    x = modelgen.signal(2, 1024, seed=9)
+    pool = ax.Pool(2, 128)
+    plugs = [O.OraclePlugin() for _ in range(2)]
+    pool.set_model(ax.Model(pa))
+    for p in plugs:
+        p.set_model(O.OracleModel(spec_a))
+    script = [(0, dict(param1=0.8, pregain_db=6.0)), (2, "activate"), (3, dict(param1=0.2, param2=0.9, master_db=-6.0)),
+              (4, "swap"), (5, dict(param1=0.6, param2=0.1)), (6, "activate")]
+    kw = {}
+    for bi, b in enumerate(range(0, 1024, 128)):
+        for at, ev in script:
+            if at != bi:
+                continue
+            if ev == "activate":
+                pool.activate()
+                for p in plugs:
+                    p.activate()
+            elif ev == "swap":
+                pool.set_model(ax.Model(pb))
+                for p in plugs:
+                    old = (p.model.ptr.contents.param1Coeff.target, p.model.ptr.contents.param2Coeff.target)
+                    p.set_model(O.OracleModel(spec_b, old[0], old[1]))
+            else:
+                kw = ev
+        pool.set_controls(ax.default_controls(**kw))
+        got = pool.process(np.ascontiguousarray(x[:, b:b + 128]))
+        for s in range(2):
+            want = plugs[s].run(O.default_controls(**kw), x[s, b:b + 128])
+            assert np.abs(got[s] - want).max() < THR * 2.5, (bi, s, np.abs(got[s] - want).max())
+
+
+def test_long_run_drift_48000_samples(tmp_path):
+    """One second of full-scale audio through LSTM-32: the fast sigmoid/tanh must hold
+    1e-5 over >= 48000 recurrent steps (SURVEY §7 'Transcendentals at 1e-5')."""
+    _chain_case(tmp_path, "drift", dict(kind="lstm", hidden=32, input_size=1, seed=32), {}, S=2, n=48128, block=256)
+
+
+# ------------------------------------------------------- properties at full size
+
+def test_full_size_cfg2_properties(tmp_path):
+    """1024 streams x 256 frames (BASELINE cfg #2): streams are independent and
+    identical streams give identical outputs; stream order does not matter;
+    a sampled subset matches the oracle."""
+    path, spec = _model_file(tmp_path, "cfg2full", kind="lstm", hidden=32, input_size=1, seed=32)
+    m = ax.Model(path)
+    S, block, nblk = 1024, 256, 4
+    base = modelgen.signal(16, block * nblk, seed=2)
+    idx = np.arange(S) % 16
+    x = base[idx]
+    pool = ax.Pool(S, block)
+    pool.set_model(m)
+    got = _run_gpu(pool, x, block)
+    for k in range(16):                                       # identical inputs -> bitwise identical outputs
+        grp = got[idx == k]
+        assert np.all(grp == grp[0])
+    perm = np.random.RandomState(0).permutation(S)
+    pool2 = ax.Pool(S, block)
+    pool2.set_model(m)
+    got2 = _run_gpu(pool2, x[perm], block)
+    assert np.array_equal(got2, got[perm])                    # no cross-stream coupling
+    want = O.run_streams(spec, O.default_controls(), base, block)
+    assert np.abs(got[:16] - want).max() < THR
+    assert np.isfinite(got).all()
+
+
+def test_device_resident_entry_point_matches_host_entry_point(tmp_path):
+    import torch
+    path, spec = _model_file(tmp_path, "dev", kind="lstm", hidden=32, input_size=1, seed=32)
+    m = ax.Model(path)
+    x = modelgen.signal(64, 512, seed=4)
+    a = ax.Pool(64, 256)
+    a.set_model(m)
+    want = _run_gpu(a, x, 256)
+    b = ax.Pool(64, 256)
+    b.set_model(m)
+    dx = torch.from_numpy(x).cuda()
+    outs = []
+    stream = torch.cuda.current_stream().cuda_stream
+    for blk in range(2):
+        din = dx[:, blk * 256:(blk + 1) * 256].contiguous()
+        dout = torch.empty_like(din)
+        b.process_device(din.data_ptr(), dout.data_ptr(), 256, stream)
+        outs.append(dout)
+    torch.cuda.synchronize()
+    got = torch.cat(outs, dim=1).cpu().numpy()
+    assert np.array_equal(got, want)

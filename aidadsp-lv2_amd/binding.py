@@ -52,6 +52,13 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # Python processes that also use torch (bench.py, some tests) must end up with ONE HIP/HSA
+    # runtime: torch ships its own copy, and a second runtime initialised later finds no GPU.
+    # Importing torch first makes the loader resolve libamdhip64.so.7 to the copy torch loaded.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     path = lib_path()
     if not os.path.exists(path):
         raise FileNotFoundError(f"{path} missing: run `make` (or __graft_entry__.build()); there is no CPU fallback")

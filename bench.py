@@ -136,7 +136,9 @@ def main():
     host_ring = [modelgen.signal(S, N_FRAMES, seed=0xA1DA + 7919 * r + lo) for r in range(RING)]
     d_in = [torch.from_numpy(b).cuda() for b in host_ring]
     d_out = [torch.empty_like(t) for t in d_in]
-    stream = torch.cuda.current_stream().cuda_stream
+    launch_stream = torch.cuda.Stream()              # a real (non-null) HIP stream: events below sit on it too
+    torch.cuda.set_stream(launch_stream)
+    stream = launch_stream.cuda_stream
 
     def step(i):
         k = i % RING

@@ -231,6 +231,8 @@ float orc_lpf_fc(float pc)
     return ((pc - 0.0f) * (out_max - out_min) / (100.0f - 0.0f)) + out_min;
 }
 
+void* orc_calloc_lines(size_t bytes);   /* aidax_oracle_nn.c: cache-line padded calloc */
+
 /* ======================================================================
  * DynamicModel mirror
  * ==================================================================== */
@@ -254,7 +256,7 @@ orc_dynmodel* orc_dynmodel_create(orc_net* net, int input_size, int input_skip,
                                   float input_gain, float output_gain, float samplerate,
                                   float old_param1, float old_param2, int warmup)
 {
-    orc_dynmodel* m = (orc_dynmodel*)calloc(1, sizeof(*m));
+    orc_dynmodel* m = (orc_dynmodel*)orc_calloc_lines(sizeof(*m));
     m->net = net;
     orc_net_reset(net);                                    /* :1035 */
     m->input_size = input_size;

@@ -12,6 +12,17 @@
 #include <string.h>
 #include <time.h>
 
+/* per-stream state on its own cache lines: threads of the CPU baseline each own a
+ * contiguous stream range and must not false-share with their neighbours */
+void* orc_calloc_lines(size_t bytes)
+{
+    void* p = NULL;
+    const size_t sz = (bytes + 127) & ~(size_t)127;
+    if (posix_memalign(&p, 128, sz ? sz : 128) != 0) return NULL;
+    memset(p, 0, sz ? sz : 128);
+    return p;
+}
+
 #define REAL float
 #define SUFFIX _f32
 #define RE_EXP expf
@@ -36,7 +47,7 @@ struct orc_net { int f64; int in_size; net_f32* a; net_f64* b; };
 
 orc_net* orc_net_create(const orc_layer_desc* layers, int n_layers, int use_f64)
 {
-    orc_net* n = (orc_net*)calloc(1, sizeof(*n));
+    orc_net* n = (orc_net*)orc_calloc_lines(sizeof(*n));
     n->f64 = use_f64;
     n->in_size = layers[0].in_size;
     if (use_f64) n->b = net_create_f64(layers, n_layers);
@@ -74,7 +85,7 @@ int orc_net_state(const orc_net* n, int layer, float* h, float* c, int cap)
 /* ------------------------------------------------------------ CPU baseline */
 
 typedef struct {
-    orc_plugin* plugins; const orc_controls* c;
+    orc_plugin** plugins; const orc_controls* c;
     int s0, s1, n_frames, n_blocks;
     const float* in; float* out;
     pthread_barrier_t* bar;
@@ -86,7 +97,7 @@ static void* bench_thread(void* p)
     pthread_barrier_wait(a->bar);
     for (int b = 0; b < a->n_blocks; ++b)
         for (int s = a->s0; s < a->s1; ++s)
-            orc_plugin_run(&a->plugins[s], a->c, a->in + (size_t)s * a->n_frames,
+            orc_plugin_run(a->plugins[s], a->c, a->in + (size_t)s * a->n_frames,
                            a->out + (size_t)s * a->n_frames, (uint32_t)a->n_frames);
     pthread_barrier_wait(a->bar);
     return NULL;
@@ -104,14 +115,18 @@ double orc_bench(const orc_layer_desc* layers, int n_layers, int input_size, int
                  int n_streams, int n_frames, int n_blocks, int warm_blocks, int n_threads,
                  const float* in, float* out_last)
 {
-    orc_plugin* plugins = (orc_plugin*)calloc((size_t)n_streams, sizeof(orc_plugin));
+    /* plugin structs padded to whole cache lines for the same reason */
+    const size_t pstride = (sizeof(orc_plugin) + 127) & ~(size_t)127;
+    char* pmem = (char*)orc_calloc_lines(pstride * (size_t)n_streams);
+    orc_plugin** plugins = (orc_plugin**)calloc((size_t)n_streams, sizeof(orc_plugin*));
+    for (int s = 0; s < n_streams; ++s) plugins[s] = (orc_plugin*)(pmem + pstride * (size_t)s);
     float* out = (float*)calloc((size_t)n_streams * (size_t)n_frames, sizeof(float));
     for (int s = 0; s < n_streams; ++s) {
-        orc_plugin_init(&plugins[s], 48000.0);
+        orc_plugin_init(plugins[s], 48000.0);
         orc_net* net = orc_net_create(layers, n_layers, 0);
         orc_dynmodel* m = orc_dynmodel_create(net, input_size, input_skip, in_gain, out_gain,
                                               48000.0f, 0.f, 0.f, 1);
-        orc_plugin_set_model(&plugins[s], m);
+        orc_plugin_set_model(plugins[s], m);
     }
     /* untimed warm-up blocks, single pass on the calling thread pool below */
     if (n_threads < 1) n_threads = 1;
@@ -142,7 +157,7 @@ double orc_bench(const orc_layer_desc* layers, int n_layers, int input_size, int
         if (phase == 1) elapsed = t1 - t0;
     }
     if (out_last) memcpy(out_last, out, sizeof(float) * (size_t)n_streams * (size_t)n_frames);
-    for (int s = 0; s < n_streams; ++s) orc_dynmodel_free(plugins[s].model);
-    free(plugins); free(out);
+    for (int s = 0; s < n_streams; ++s) orc_dynmodel_free(plugins[s]->model);
+    free(plugins); free(pmem); free(out);
     return elapsed;
 }

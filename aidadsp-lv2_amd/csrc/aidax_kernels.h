@@ -9,13 +9,18 @@ namespace aidax {
 
 struct KernelEntry {
     int cell, hidden;
-    void (*fn)(LaunchArgs);
+    void (*fn)(LaunchArgs);           // one wavefront per stream (throughput form)
+    void (*fn_pipe)(LaunchArgs);      // three wavefronts per stream (latency form)
     int pack_regs, state_floats;
     const char* name;
+    const char* name_pipe;
 };
 
 const KernelEntry* find_kernel(int cell, int hidden);
 hipError_t launch_stream_kernel(const KernelEntry* e, const LaunchArgs& a, size_t lds_bytes, hipStream_t stream);
+size_t pipe_lds_bytes(int hidden, uint32_t n_frames);
+hipError_t launch_pipe_kernel(const KernelEntry* e, const LaunchArgs& a, hipStream_t stream);
+int pipe_resident_streams(const KernelEntry* e, uint32_t n_frames, int device);
 hipError_t launch_set_pending(StreamState* st, uint32_t n_streams, int32_t stream, uint32_t bits, hipStream_t q);
 hipError_t launch_reset_for_model(StreamState* st, float* nn, uint32_t n_streams, uint32_t nn_stride, float p_den, hipStream_t q);
 

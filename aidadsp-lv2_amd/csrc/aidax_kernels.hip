@@ -147,12 +147,13 @@ struct ChainPass {
     ExpRamp g;
 };
 
-__device__ __forceinline__ void chain_run(ChainPass& c, float* buf, int n, int lane)
+template <int DST_STRIDE = 1>
+__device__ __forceinline__ void chain_run(ChainPass& c, const float* src, float* dst, int n, int lane)
 {
     float carry = 0.f;                         // this lane's previous output, read by lane+1
     const int steps = n + c.K - 1;
     for (int s = 0; s < steps; ++s) {
-        const float head = buf[s < n ? s : n - 1];          // wave-uniform LDS broadcast
+        const float head = src[s < n ? s : n - 1];          // wave-uniform LDS broadcast
         const float from_left = dpp_row_shr1(carry);
         const float x = lane == 0 ? head : from_left;
         const int idx = s - lane;
@@ -168,7 +169,7 @@ __device__ __forceinline__ void chain_run(ChainPass& c, float* buf, int n, int l
             const float gm = c.g.next();                    // every stage lane keeps its own copy;
             if (lane == c.gain_lane) y = y * gm;            // only the gain lane's is used
             carry = y;
-            if (lane == c.K - 1) buf[idx] = y;
+            if (lane == c.K - 1) dst[idx * DST_STRIDE] = y;
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -243,12 +244,23 @@ struct LstmCell {
 #pragma unroll
         for (int m = 0; m < NU; ++m) {
             const int j = slot + m * SLOTS;
-            if (part == 0 && j < H) hbuf[j] = h[m];
+            if (j < H) hbuf[j] = h[m];       // the S lanes of a unit hold the same h: same address, same data
         }
     }
 
-    // one sample; returns the Dense(H,1) output, wave-uniform
-    __device__ __forceinline__ float step(float x0, float x1, float x2, float* hbuf)
+    static constexpr int HID = H;
+
+    // Dense(H,1) contribution of this lane for the h it holds (0 outside part 0 / j >= H)
+    __device__ __forceinline__ float dense_partial() const
+    {
+        float d = 0.f;
+#pragma unroll
+        for (int m = 0; m < NU; ++m) d = __builtin_fmaf(wd[m], h[m], d);
+        return d;
+    }
+
+    // one sample: reads h(t-1) from hprev[0..H), leaves h(t) in registers and at hout[0..H)
+    __device__ __forceinline__ void step(float x0, float x1, float x2, const float* hprev, float* hout)
     {
         float acc[NU][GPL];
 #pragma unroll
@@ -261,7 +273,7 @@ struct LstmCell {
                 a = __builtin_fmaf(wx[m][e][2], x2, a);
                 acc[m][e] = a;
             }
-        const float4* hv = reinterpret_cast<const float4*>(hbuf);
+        const float4* hv = reinterpret_cast<const float4*>(hprev);
 #pragma unroll
         for (int k4 = 0; k4 < H / 4; ++k4) {
             const float4 q = hv[k4];                        // same address in all lanes: broadcast
@@ -278,7 +290,6 @@ struct LstmCell {
                 }
         }
         __builtin_amdgcn_wave_barrier();                    // all reads of h(t-1) precede the publish below
-        float dense = 0.f;
 #pragma unroll
         for (int m = 0; m < NU; ++m) {
             float act[GPL];
@@ -308,11 +319,9 @@ struct LstmCell {
             const float cn = __builtin_fmaf(gf, c[m], gi * gg);
             c[m] = cn;
             h[m] = go * tanh_rat(cn);
-            dense = __builtin_fmaf(wd[m], h[m], dense);     // wd is 0 outside part 0 / j >= H
         }
-        publish_h(hbuf);
+        publish_h(hout);
         __builtin_amdgcn_wave_barrier();
-        return wave_sum(dense) + bd;
     }
 };
 
@@ -380,7 +389,17 @@ struct GruCell {
         }
     }
 
-    __device__ __forceinline__ float step(float x0, float x1, float x2, float* hbuf)
+    static constexpr int HID = H;
+
+    __device__ __forceinline__ float dense_partial() const
+    {
+        float d = 0.f;
+#pragma unroll
+        for (int m = 0; m < NU; ++m) d = __builtin_fmaf(wd[m], h[m], d);
+        return d;
+    }
+
+    __device__ __forceinline__ void step(float x0, float x1, float x2, const float* hprev, float* hout)
     {
         float ax[NU][3], ar[NU][3];
 #pragma unroll
@@ -394,7 +413,7 @@ struct GruCell {
                 ax[m][e] = a;
                 ar[m][e] = e == 2 ? bn1[m] : 0.f;
             }
-        const float4* hv = reinterpret_cast<const float4*>(hbuf);
+        const float4* hv = reinterpret_cast<const float4*>(hprev);
 #pragma unroll
         for (int k4 = 0; k4 < H / 4; ++k4) {
             const float4 q = hv[k4];
@@ -411,7 +430,6 @@ struct GruCell {
                 }
         }
         __builtin_amdgcn_wave_barrier();
-        float dense = 0.f;
 #pragma unroll
         for (int m = 0; m < NU; ++m) {
             const float z = fast_sigmoid(ax[m][0] + ar[m][0]);
@@ -419,11 +437,9 @@ struct GruCell {
             const float pre = __builtin_fmaf(r, ar[m][2], ax[m][2]);
             const float n = tanh_rat(pre);
             h[m] = __builtin_fmaf(z, h[m] - n, n);          // (1-z)*n + z*h
-            dense = __builtin_fmaf(wd[m], h[m], dense);
         }
-        publish_h(hbuf);
+        publish_h(hout);
         __builtin_amdgcn_wave_barrier();
-        return wave_sum(dense) + bd;
     }
 };
 
@@ -494,7 +510,8 @@ __device__ __forceinline__ void stream_body(const LaunchArgs& a, float* smem)
                     if (a.input_size >= 3) q2 = lin_next(p2, t2, s2);
                 }
                 x = x * a.in_gain;
-                const float y = cell.step(x, q1, q2, hbuf);
+                cell.step(x, q1, q2, hbuf, hbuf);
+                const float y = wave_sum(cell.dense_partial()) + cell.bd;
                 float o = a.input_skip ? x + y : y;
                 o = o * a.out_gain;
                 if (a.mode == MODE_NN_ONLY && lane == 0) a.out[t] = o;
@@ -547,7 +564,7 @@ __device__ __forceinline__ void stream_body(const LaunchArgs& a, float* smem)
                           : ((flags & CTL_EQ_BANDPASS) ? slot == BQ_MID : true);
         chain_load(c, ctl, st, slot, act);
         c.g.arm(pre_mem, pre_tgt, ctl.pre_coef);
-        chain_run(c, buf, n, lane);
+        chain_run(c, buf, buf, n, lane);
         if (lane < c.K) { st.z[slot][0] = c.z1; st.z[slot][1] = c.z2; }
         pre_mem = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c.g.mem), 0));
     }
@@ -582,7 +599,8 @@ __device__ __forceinline__ void stream_body(const LaunchArgs& a, float* smem)
                 float q1 = 0.f, q2 = 0.f;
                 if (I >= 2) q1 = lin_next(p_mem[0], p_tgt[0], p_step[0]);
                 if (I >= 3) q2 = lin_next(p_mem[1], p_tgt[1], p_step[1]);
-                const float y = cell.step(x, q1, q2, hbuf);
+                cell.step(x, q1, q2, hbuf, hbuf);
+                const float y = wave_sum(cell.dense_partial()) + cell.bd;
                 float o = a.input_skip ? x + y : y;      // out[i] (+)= forward
                 o = o * a.out_gain;                       // out[i] *= output_gain
                 if (lane == 0) buf[t] = o;
@@ -610,7 +628,7 @@ __device__ __forceinline__ void stream_body(const LaunchArgs& a, float* smem)
                           : ((flags & CTL_EQ_BANDPASS) ? slot == BQ_MID : true);
         chain_load(c, ctl, st, slot, act);
         c.g.arm(master_mem, master_tgt, ctl.master_coef);
-        chain_run(c, buf, n, lane);
+        chain_run(c, buf, buf, n, lane);
         if (lane < c.K) { st.z[slot][0] = c.z1; st.z[slot][1] = c.z2; }
         master_mem = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c.g.mem), c.K - 1));
     }
@@ -621,6 +639,232 @@ __device__ __forceinline__ void stream_body(const LaunchArgs& a, float* smem)
         st.pre_tgt = pre_tgt; st.master_tgt = master_tgt;
         st.pending = pending;
     }
+}
+
+
+// ======================================================================
+// Wave-specialised pipeline (3 wavefronts per stream) — the low-stream-count form.
+//
+// Measured on MI355X (scratch/ubench.hip): a wavefront that is alone on its SIMD issues one
+// VALU instruction per ~4.7 cycles, dependent or not; two or more resident waves share the
+// SIMD at ~2.3 cycles per instruction. With <= ~1500 streams per GPU the one-wave-per-stream
+// kernel therefore leaves half of every SIMD's issue slots empty, and everything that is not
+// on the recurrence's critical path (the two biquad passes, smoothers, the Dense reduction,
+// output gain, global I/O) only lengthens it. Here those parts move to sibling waves of the
+// same workgroup, pipelined over 32-frame sub-blocks through LDS:
+//
+//   phase p:  wave P  pre pass + PARAM ramps of sub-block p      -> xq ring (3 deep)
+//             wave N  recurrent cell over sub-block p-1           -> h history ring (2 x 32 rows)
+//             wave Q  Dense + skip/out gain + post pass of p-2    -> global out
+//   one workgroup barrier per phase; the N wave keeps weights, c and h in registers throughout.
+// ======================================================================
+constexpr int kSB = 32;                 // frames per pipeline stage
+constexpr int kRing = 2 * kSB;          // rows of the h history ring
+constexpr int kPipeWaves = 3;
+
+__host__ __device__ constexpr int pipe_row_stride(int H) { return H + 4; }   // floats; keeps rows 16-B aligned
+__host__ __device__ constexpr size_t pipe_lds_floats(int H, int n_frames)
+{
+    return (size_t)((n_frames + 3) & ~3) + 3 * kSB * 4 + (size_t)kRing * pipe_row_stride(H) + kSB + (size_t)(H + 4);
+}
+
+template <class Cell>
+__device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* smem)
+{
+    constexpr int H = Cell::HID;
+    constexpr int HS = pipe_row_stride(H);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int s = blockIdx.x;
+    const int n = (int)a.n_frames;
+
+    float*  inbuf = smem;                                                   // P private
+    float4* xq    = reinterpret_cast<float4*>(smem + ((n + 3) & ~3));       // (x_pre, p1, p2, -) ring, 3 stages
+    float*  hh    = reinterpret_cast<float*>(xq + 3 * kSB);                 // h history, kRing rows
+    float*  qb    = hh + kRing * HS;                                        // Q private
+    float*  wdl   = qb + kSB;                                               // Q private: Dense weights, natural order
+
+    const StreamCtl& ctl = a.ctl[s];
+    StreamState& st = a.st[s];
+    const uint32_t flags = ctl.flags;
+    const uint32_t pending0 = st.pending;
+    const float* in_row = a.in + (size_t)s * n;
+    float* out_row = a.out + (size_t)s * n;
+
+    if (n == 0 || !(flags & CTL_ENABLED)) {              // pre-run (:607-609) / hard bypass (:612-619)
+        if (n != 0 && out_row != in_row)
+            for (int i = threadIdx.x; i < n; i += kPipeWaves * kWave) out_row[i] = in_row[i];
+        if (threadIdx.x == 0) {
+            if (pending0 & PEND_ACTIVATE) { st.pre_mem = st.pre_tgt; st.master_mem = st.master_tgt; }
+            st.pre_tgt = ctl.pre_target;
+            st.pending = pending0 & ~PEND_ACTIVATE;
+        }
+        return;
+    }
+    const bool net_on = (flags & CTL_NET_ON) != 0;
+    const int I = a.input_size;
+    const int n_sub = (n + kSB - 1) / kSB;
+
+    // ---------------------------------------------------------------- role state
+    ChainPass cp{};                       // P: pre pass / Q: post pass
+    int slot = 0;
+    float p_mem[2] = {0.f, 0.f}, p_tgt[2] = {0.f, 0.f}, p_step[2] = {0.f, 0.f};
+    uint32_t pending = pending0 & ~PEND_ACTIVATE;
+    float pre_tgt = 0.f, master_tgt = 0.f;
+    Cell cell;
+    float* nnst = a.nn + (size_t)s * a.nn_stride;
+
+    if (wave == 0) {                      // ---- P prologue
+        load_block(inbuf, in_row, n, lane);
+        const bool eq = flags & CTL_EQ_PRE;
+        cp.K = eq ? 6 : 1;
+        cp.gain_lane = 0;
+        const int k = lane < cp.K ? lane : 0;
+        slot = pre_slot(k);
+        const bool act = k == 0 ? (flags & CTL_LPF_ON) != 0 : ((flags & CTL_EQ_BANDPASS) ? slot == BQ_MID : true);
+        chain_load(cp, ctl, st, slot, act);
+        const float pre_mem = (pending0 & PEND_ACTIVATE) ? st.pre_tgt : st.pre_mem;
+        pre_tgt = ctl.pre_target;
+        cp.g.arm(pre_mem, pre_tgt, ctl.pre_coef);
+        if (net_on) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                p_mem[i] = st.p_mem[i]; p_tgt[i] = st.p_tgt[i]; p_step[i] = st.p_step[i];
+                const float nt = ctl.p_target[i];
+                if (__builtin_fabsf(p_tgt[i] - nt) >= FLT_EPSILON) {
+                    p_tgt[i] = nt;
+                    p_step[i] = (p_tgt[i] - p_mem[i]) / ctl.p_den;
+                }
+            }
+            if (pending & PEND_PARAM_FIRST) {
+                pending &= ~PEND_PARAM_FIRST;
+                p_mem[0] = p_tgt[0];
+                p_mem[1] = p_tgt[1];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    } else if (wave == 1) {               // ---- N prologue
+        if (net_on) {
+            cell.load(a.wpack, nnst, lane);
+            cell.publish_h(hh + (kRing - 1) * HS);       // h(-1): the row "before" frame 0
+        }
+    } else {                              // ---- Q prologue
+        const bool eq = flags & CTL_EQ_POST;
+        cp.K = eq ? 6 : 1;
+        cp.gain_lane = cp.K - 1;
+        const int k = lane < cp.K ? lane : 0;
+        slot = post_slot(k);
+        const bool act = k == 0 ? (flags & CTL_DC_ON) != 0 : ((flags & CTL_EQ_BANDPASS) ? slot == BQ_MID : true);
+        chain_load(cp, ctl, st, slot, act);
+        const float master_mem = (pending0 & PEND_ACTIVATE) ? st.master_tgt : st.master_mem;
+        master_tgt = ctl.master_target;
+        cp.g.arm(master_mem, master_tgt, ctl.master_coef);
+        if (net_on) {
+            const float* wd_nat = a.wpack + (size_t)Cell::PACK * kWave;     // [H] Dense weights then bias
+            for (int i = lane; i < H + 1; i += kWave) wdl[i] = wd_nat[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---------------------------------------------------------------- pipeline
+    for (int p = 0; p < n_sub + 2; ++p) {
+        if (wave == 0) {
+            if (p < n_sub) {
+                const int base = p * kSB;
+                const int cnt = n - base < kSB ? n - base : kSB;
+                float4* stage = xq + (p % 3) * kSB;
+                chain_run<4>(cp, inbuf + base, reinterpret_cast<float*>(stage), cnt, lane);
+                if (net_on && I >= 2) {
+                    for (int t = 0; t < cnt; ++t) {
+                        const float q1 = lin_next(p_mem[0], p_tgt[0], p_step[0]);
+                        const float q2 = I >= 3 ? lin_next(p_mem[1], p_tgt[1], p_step[1]) : 0.f;
+                        if (lane == 0) { stage[t].y = q1; stage[t].z = q2; }
+                    }
+                }
+            }
+        } else if (wave == 1) {
+            if (net_on && p >= 1 && p <= n_sub) {
+                const int base = (p - 1) * kSB;
+                const int cnt = n - base < kSB ? n - base : kSB;
+                const float4* stage = xq + ((p - 1) % 3) * kSB;
+                float4 in = stage[0];
+                for (int t = 0; t < cnt; ++t) {
+                    const float4 cur = in;
+                    in = stage[t + 1 < cnt ? t + 1 : t];                    // prefetch the next frame's inputs
+                    const int g = base + t;
+                    const float x = cur.x * a.in_gain;                      // out[i] *= input_gain
+                    cell.step(x, I >= 2 ? cur.y : 0.f, I >= 3 ? cur.z : 0.f,
+                              hh + ((g + kRing - 1) & (kRing - 1)) * HS, hh + (g & (kRing - 1)) * HS);
+                }
+            }
+        } else {
+            if (p >= 2) {
+                const int base = (p - 2) * kSB;
+                const int cnt = n - base < kSB ? n - base : kSB;
+                const int tl = lane < cnt ? lane : cnt - 1;
+                const float xin = xq[((p - 2) % 3) * kSB + tl].x;
+                float o = xin;
+                if (net_on) {
+                    const float4* row = reinterpret_cast<const float4*>(hh + ((base + tl) & (kRing - 1)) * HS);
+                    const float4* w4 = reinterpret_cast<const float4*>(wdl);
+                    float y = wdl[H];                                       // Dense bias
+#pragma unroll
+                    for (int k4 = 0; k4 < H / 4; ++k4) {
+                        const float4 w = w4[k4];
+                        const float4 hv = row[k4];
+                        y = __builtin_fmaf(w.x, hv.x, y);
+                        y = __builtin_fmaf(w.y, hv.y, y);
+                        y = __builtin_fmaf(w.z, hv.z, y);
+                        y = __builtin_fmaf(w.w, hv.w, y);
+                    }
+                    const float xg = xin * a.in_gain;
+                    o = a.input_skip ? xg + y : y;                          // out[i] (+)= forward
+                    o = o * a.out_gain;                                     // out[i] *= output_gain
+                }
+                if (lane < cnt) qb[lane] = o;
+                __builtin_amdgcn_wave_barrier();
+                chain_run<1>(cp, qb, qb, cnt, lane);
+                __builtin_amdgcn_wave_barrier();
+                if (lane < cnt) out_row[base + lane] = qb[lane];
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---------------------------------------------------------------- state write-back
+    if (wave == 0) {
+        if (lane < cp.K) { st.z[slot][0] = cp.z1; st.z[slot][1] = cp.z2; }
+        if (lane == 0) {
+            st.pre_mem = cp.g.mem;
+            st.pre_tgt = pre_tgt;
+            st.pending = pending;
+            if (net_on) {
+                st.p_mem[0] = p_mem[0]; st.p_mem[1] = p_mem[1];
+                st.p_tgt[0] = p_tgt[0]; st.p_tgt[1] = p_tgt[1];
+                st.p_step[0] = p_step[0]; st.p_step[1] = p_step[1];
+            }
+        }
+    } else if (wave == 1) {
+        if (net_on) cell.store(nnst);
+    } else {
+        if (lane < cp.K) { st.z[slot][0] = cp.z1; st.z[slot][1] = cp.z2; }
+        if (lane == cp.K - 1) { st.master_mem = cp.g.mem; st.master_tgt = master_tgt; }
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(kPipeWaves * kWave) void k_lstm_pipe(LaunchArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    stream_body_pipe<LstmCell<H>>(a, smem);
+}
+
+template <int H>
+__global__ __launch_bounds__(kPipeWaves * kWave) void k_gru_pipe(LaunchArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    stream_body_pipe<GruCell<H>>(a, smem);
 }
 
 struct NoCell { static constexpr int PACK = 0, STATE = 0; };
@@ -673,8 +917,8 @@ __global__ void k_reset_for_model(StreamState* st, float* nn, uint32_t n_streams
 }
 
 // ------------------------------------------------------------ host dispatch
-#define AIDAX_LSTM(H) { 0, H, k_lstm<H>, LstmCell<H>::PACK, LstmCell<H>::STATE, "k_lstm<" #H ">" }
-#define AIDAX_GRU(H)  { 1, H, k_gru<H>,  GruCell<H>::PACK,  GruCell<H>::STATE,  "k_gru<" #H ">" }
+#define AIDAX_LSTM(H) { 0, H, k_lstm<H>, k_lstm_pipe<H>, LstmCell<H>::PACK, LstmCell<H>::STATE, "k_lstm<" #H ">", "k_lstm_pipe<" #H ">" }
+#define AIDAX_GRU(H)  { 1, H, k_gru<H>,  k_gru_pipe<H>,  GruCell<H>::PACK,  GruCell<H>::STATE,  "k_gru<" #H ">", "k_gru_pipe<" #H ">" }
 
 static const KernelEntry kTable[] = {
     // the 18 (cell, hidden) pairs of variant/generate_variant_hpp.py:4-6; input size is a run-time argument
@@ -696,6 +940,25 @@ hipError_t launch_stream_kernel(const KernelEntry* e, const LaunchArgs& a, size_
     void (*fn)(LaunchArgs) = e ? e->fn : k_nomodel;
     hipLaunchKernelGGL(fn, dim3(a.n_streams), dim3(kWave), lds_bytes, stream, a);
     return hipGetLastError();
+}
+
+size_t pipe_lds_bytes(int hidden, uint32_t n_frames) { return pipe_lds_floats(hidden, (int)n_frames) * sizeof(float); }
+
+hipError_t launch_pipe_kernel(const KernelEntry* e, const LaunchArgs& a, hipStream_t stream)
+{
+    hipLaunchKernelGGL(e->fn_pipe, dim3(a.n_streams), dim3(kPipeWaves * kWave), pipe_lds_bytes(e->hidden, a.n_frames), stream, a);
+    return hipGetLastError();
+}
+
+// Streams whose 3-wave workgroups are all resident at once on this device; beyond that the
+// one-wave-per-stream kernel has the better throughput (helper waves hold the N wave's VGPR budget).
+int pipe_resident_streams(const KernelEntry* e, uint32_t n_frames, int device)
+{
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, e->fn_pipe, kPipeWaves * kWave,
+                                                     pipe_lds_bytes(e->hidden, n_frames)) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
+    return per_cu * cus;
 }
 
 hipError_t launch_set_pending(StreamState* st, uint32_t n_streams, int32_t stream, uint32_t bits, hipStream_t q)

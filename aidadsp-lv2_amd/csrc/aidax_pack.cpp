@@ -46,6 +46,8 @@ std::vector<float> pack_lstm(const aidax_model& m)
         }
         p.put(r++, lane, D.w1[0]);
     }
+    for (int j = 0; j < H; ++j) p.out.push_back(D.w0[j]);      // natural-order Dense weights + bias for the
+    p.out.push_back(D.w1[0]);                                    // pipeline's output wave (after the lane records)
     return std::move(p.out);
 }
 
@@ -83,6 +85,8 @@ std::vector<float> pack_gru(const aidax_model& m)
         }
         p.put(r++, lane, D.w1[0]);
     }
+    for (int j = 0; j < H; ++j) p.out.push_back(D.w0[j]);
+    p.out.push_back(D.w1[0]);
     return std::move(p.out);
 }
 

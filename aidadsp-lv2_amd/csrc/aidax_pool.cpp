@@ -4,6 +4,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <sstream>
@@ -79,6 +80,15 @@ struct aidax_pool {
     int input_size = 1, input_skip = 0, hidden = 0;
     float in_gain = 1.f, out_gain = 1.f, model_sr = 48000.f;
     uint32_t nn_stride = 0;
+    int pipe_capacity = 0;           // streams the 3-wave pipeline keeps resident at once (0 = never use it)
+    int force_form = 0;              // AIDAX_KERNEL=wave|pipe overrides the heuristic (A/B testing)
+    bool use_pipe() const
+    {
+        if (!has_model || !kernel) return false;
+        if (force_form == 1) return false;
+        if (force_form == 2) return true;
+        return static_cast<int>(n_streams) <= pipe_capacity;
+    }
 
     size_t lds_bytes(uint32_t n_frames) const
     {
@@ -162,7 +172,7 @@ int set_model_impl(aidax_pool& p, const aidax_model* m, int start_mode)
     const KernelEntry* k = (m->n_rnn == 1) ? find_kernel(m->cell, m->hidden) : nullptr;
     if (!k) return fail(AIDAX_ERR_ARCH, "Unable to identify a known model architecture! (no kernel)");
     const std::vector<float> wp = pack_weights(*m);
-    if (static_cast<int>(wp.size()) != k->pack_regs * kWave) return fail(AIDAX_ERR_STATE, "weight pack size mismatch");
+    if (static_cast<int>(wp.size()) != k->pack_regs * kWave + m->hidden + 1) return fail(AIDAX_ERR_STATE, "weight pack size mismatch");
 
     // model swaps are rare (worker thread); drain everything that may still read the old buffers
     HIP_TRY(hipDeviceSynchronize());
@@ -192,6 +202,8 @@ int set_model_impl(aidax_pool& p, const aidax_model* m, int start_mode)
         LaunchArgs a = p.args(nullptr, nullptr, kWarmupFrames, MODE_WARMUP);
         HIP_TRY(launch_stream_kernel(p.kernel, a, p.lds_bytes(0), p.q));
     }
+    p.pipe_capacity = pipe_resident_streams(k, p.max_frames, p.device);
+    if (const char* f = std::getenv("AIDAX_KERNEL")) p.force_form = std::strcmp(f, "wave") == 0 ? 1 : std::strcmp(f, "pipe") == 0 ? 2 : 0;
     p.has_model = true;
     for (auto& l : p.loading) l = 0;                  // work_response: loading = false (:889)
     p.refresh_all();
@@ -314,7 +326,8 @@ AIDAX_API int aidax_pool_process_device(aidax_pool* p, const float* d_in, float*
         hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : p->q;
         p->flush_ctl(s);
         LaunchArgs a = p->args(d_in, d_out, n_frames, MODE_CHAIN);
-        HIP_TRY(launch_stream_kernel(p->has_model ? p->kernel : nullptr, a, p->lds_bytes(n_frames), s));
+        if (p->use_pipe()) HIP_TRY(launch_pipe_kernel(p->kernel, a, s));
+        else HIP_TRY(launch_stream_kernel(p->has_model ? p->kernel : nullptr, a, p->lds_bytes(n_frames), s));
         return AIDAX_OK;
     });
 }
@@ -364,7 +377,8 @@ AIDAX_API int aidax_pool_read_state(aidax_pool* p, uint32_t stream, int layer, f
 
 AIDAX_API const char* aidax_pool_kernel_name(const aidax_pool* p)
 {
-    return (p && p->has_model && p->kernel) ? p->kernel->name : "k_nomodel";
+    if (!(p && p->has_model && p->kernel)) return "k_nomodel";
+    return p->use_pipe() ? p->kernel->name_pipe : p->kernel->name;
 }
 
 AIDAX_API int aidax_model_forward(const aidax_model* m, int device_id, const float* X, float* y, uint32_t n, int unit_gains)

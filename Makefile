@@ -22,7 +22,9 @@ HOST_OBJS := $(patsubst $(SRC)/%.cpp,$(OBJDIR)/%.o,$(HOST_SRCS))
 KERN_OBJS := $(OBJDIR)/aidax_kernels.o
 HDRS      := $(wildcard $(SRC)/*.h) include/aidax.h
 
-all: $(LIBDIR)/libaidax_hip.so oracle
+LV2SO := $(PKG)/lv2/rt-neural-generic.so
+
+all: $(LIBDIR)/libaidax_hip.so $(LV2SO) oracle
 
 $(OBJDIR)/%.o: $(SRC)/%.cpp $(HDRS)
 	@mkdir -p $(OBJDIR)
@@ -36,12 +38,16 @@ $(LIBDIR)/libaidax_hip.so: $(HOST_OBJS) $(KERN_OBJS)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $^
 
+# The LV2 plugin shell (no lib prefix, like the reference's binary: rt-neural-generic/CMakeLists.txt:47)
+$(LV2SO): $(PKG)/lv2/rt_neural_generic_lv2.cpp $(PKG)/lv2/lv2_min.h include/aidax.h $(LIBDIR)/libaidax_hip.so
+	$(CXX) $(CXXFLAGS) -shared $< -o $@ -L$(LIBDIR) -laidax_hip -Wl,-rpath,'$$ORIGIN/../lib'
+
 oracle:
 	$(MAKE) -s -C oracle all
 	$(MAKE) -s -C oracle _ref
 
 clean:
-	rm -rf build $(LIBDIR)
+	rm -rf build $(LIBDIR) $(LV2SO)
 	$(MAKE) -s -C oracle clean
 
 .PHONY: all oracle clean

@@ -1,0 +1,432 @@
+// rt_neural_generic_lv2.cpp — the LV2 plugin shell of AIDA-X rt-neural-generic on top of the
+// C ABI of include/aidax.h. Builds rt-neural-generic.so exporting lv2_descriptor().
+//
+// It keeps the reference plugin's host-visible behaviour (generic build: AIDADSP_COMMERCIAL=0,
+// AIDADSP_MODEL_LOADER=1, AIDADSP_CONDITIONED_MODELS=1, two params, optional DC blocker):
+//   descriptor / URI                    rt-neural-generic/src/rt-neural-generic.cpp:11-29, uris.h:26-31
+//   25 ports, same indices              rt-neural-generic.h:84-112, rt-neural-generic.ttl:61-313
+//   instantiate / features              rt-neural-generic.cpp:244-333
+//   patch:Set{#json, atom:Path} on CONTROL -> worker load       :524-586
+//   worker protocol load/apply/free     :807-893, message structs rt-neural-generic.h:132-157
+//   NOTIFY echo of the applied file     :880-887, uris.h:76-94
+//   state save/restore of the model path :707-796
+//   mute while loading, ModelInSize port :518, :654
+// All DSP (run() :621-659) happens on the GPU behind aidax_pool_process(); each plugin instance
+// is one stream of a one-stream pool. There is no CPU fallback: without a usable HIP device
+// instantiate() returns NULL, like the reference does for a missing host feature (:265-273).
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+
+#include "../../include/aidax.h"
+#include "lv2_min.h"
+
+#define PLUGIN_URI "http://aidadsp.cc/plugins/aidadsp-bundle/rt-neural-generic"
+#define PLUGIN__json PLUGIN_URI "#json"
+#define PLUGIN__applyJson PLUGIN_URI "#applyJson"
+
+namespace {
+
+enum PortIndex {   // ports_t, rt-neural-generic.h:84-112 (generic build)
+    IN = 0, OUT_1, PLUGIN_CONTROL, PLUGIN_NOTIFY, IN_LPF, PREGAIN, NET_BYPASS, PARAM1, PARAM2,
+    EQ_BYPASS, EQ_POS, BASS, BFREQ, MID, MFREQ, MIDQ, MTYPE, TREBLE, TFREQ, DEPTH, PRESENCE,
+    DCBLOCKER, MASTER, INPUT_SIZE, PLUGIN_ENABLED, PLUGIN_PORT_COUNT
+};
+
+enum WorkerMessageType { kWorkerLoad, kWorkerApply, kWorkerFree };          // rt-neural-generic.h:132-136
+struct WorkerMessage { WorkerMessageType type; };
+struct WorkerLoadMessage { WorkerMessageType type; char path[1024]; };      // :144-151
+struct WorkerApplyMessage { WorkerMessageType type; aidax_model* model; };  // :154-157 with the C-ABI model handle
+
+struct PluginURIs {   // uris.h:33-48
+    LV2_URID atom_Float, atom_Path, atom_Resource, atom_Sequence, atom_URID, atom_eventTransfer;
+    LV2_URID atom_Object, atom_Blank;
+    LV2_URID applyJson, json, midi_Event, param_gain, patch_Get, patch_Set, patch_property, patch_value;
+    LV2_URID log_Error, log_Note, log_Trace;
+};
+
+struct Plugin {
+    // ports
+    const float* in = nullptr;
+    float* out_1 = nullptr;
+    const LV2_Atom_Sequence* control_port = nullptr;
+    LV2_Atom_Sequence* notify_port = nullptr;
+    const float* ctl[PLUGIN_PORT_COUNT] = {};
+    float* input_size = nullptr;
+
+    // features
+    LV2_URID_Map* map = nullptr;
+    LV2_Worker_Schedule* schedule = nullptr;
+    LV2_Log_Log* log = nullptr;
+    PluginURIs uris{};
+
+    double samplerate = 48000.0;
+    bool loading = true;
+    int last_input_size = 0;
+    aidax_pool* pool = nullptr;
+    aidax_model* model = nullptr;
+
+    aidax_controls last_controls{};
+    bool have_last_controls = false;
+    bool last_loading = true;
+
+    // NOTIFY writer (the subset of LV2_Atom_Forge the reference uses)
+    uint8_t* notify_buf = nullptr;
+    uint32_t notify_capacity = 0;
+    bool notify_open = false;
+};
+
+void plog(Plugin* self, LV2_URID type, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    if (self->log && self->log->vprintf) self->log->vprintf(self->log->handle, type, fmt, ap);
+    else vfprintf(stderr, fmt, ap);
+    va_end(ap);
+}
+
+void map_plugin_uris(LV2_URID_Map* map, PluginURIs* u)
+{
+    auto m = [map](const char* uri) { return map->map(map->handle, uri); };
+    u->atom_Float = m(LV2_ATOM__Float);       u->atom_Path = m(LV2_ATOM__Path);
+    u->atom_Resource = m(LV2_ATOM__Resource); u->atom_Sequence = m(LV2_ATOM__Sequence);
+    u->atom_URID = m(LV2_ATOM__URID);         u->atom_eventTransfer = m(LV2_ATOM__eventTransfer);
+    u->atom_Object = m(LV2_ATOM__Object);     u->atom_Blank = m(LV2_ATOM__Blank);
+    u->applyJson = m(PLUGIN__applyJson);      u->json = m(PLUGIN__json);
+    u->midi_Event = m(LV2_MIDI__MidiEvent);   u->param_gain = m(LV2_PARAMETERS__gain);
+    u->patch_Get = m(LV2_PATCH__Get);         u->patch_Set = m(LV2_PATCH__Set);
+    u->patch_property = m(LV2_PATCH__property); u->patch_value = m(LV2_PATCH__value);
+    u->log_Error = m(LV2_LOG__Error);         u->log_Note = m(LV2_LOG__Note);   u->log_Trace = m(LV2_LOG__Trace);
+}
+
+// ---- NOTIFY sequence writer: sequence head in run(), one patch:Set event in work_response()
+void notify_begin(Plugin* self)
+{
+    self->notify_open = false;
+    if (!self->notify_port) return;
+    self->notify_capacity = self->notify_port->atom.size;      // host stores the buffer capacity here (:528)
+    self->notify_buf = reinterpret_cast<uint8_t*>(self->notify_port);
+    if (self->notify_capacity < sizeof(LV2_Atom_Sequence_Body)) return;
+    self->notify_port->atom.type = self->uris.atom_Sequence;
+    self->notify_port->atom.size = sizeof(LV2_Atom_Sequence_Body);
+    self->notify_port->body.unit = 0;
+    self->notify_port->body.pad = 0;
+    self->notify_open = true;
+}
+
+// write_set_file (uris.h:76-94): [] a patch:Set ; patch:property <#json> ; patch:value </path> .
+bool notify_set_file(Plugin* self, const char* filename)
+{
+    if (!self->notify_open) return false;
+    const uint32_t len = static_cast<uint32_t>(std::strlen(filename));
+    const uint32_t path_size = len + 2;                         // forge_path(len + 1) stores len + 2 bytes (both NULs)
+    const uint32_t prop1 = sizeof(LV2_Atom_Property_Body) + lv2_atom_pad_size(sizeof(uint32_t));      // key + URID atom
+    const uint32_t prop2 = sizeof(LV2_Atom_Property_Body) + lv2_atom_pad_size(path_size);
+    const uint32_t obj_size = sizeof(LV2_Atom_Object_Body) + prop1 + prop2;
+    const uint32_t ev_size = sizeof(LV2_Atom_Event) + obj_size;
+    const uint32_t used = sizeof(LV2_Atom) + self->notify_port->atom.size;
+    if (used + ev_size > sizeof(LV2_Atom) + self->notify_capacity) return false;
+
+    uint8_t* p = self->notify_buf + used;
+    std::memset(p, 0, ev_size);
+    LV2_Atom_Event* ev = reinterpret_cast<LV2_Atom_Event*>(p);
+    ev->time.frames = 0;
+    ev->body.type = self->uris.atom_Object;
+    ev->body.size = obj_size;
+    LV2_Atom_Object_Body* ob = reinterpret_cast<LV2_Atom_Object_Body*>(ev + 1);
+    ob->id = 0;
+    ob->otype = self->uris.patch_Set;
+    LV2_Atom_Property_Body* p1 = reinterpret_cast<LV2_Atom_Property_Body*>(ob + 1);
+    p1->key = self->uris.patch_property;
+    p1->context = 0;
+    p1->value.type = self->uris.atom_URID;
+    p1->value.size = sizeof(uint32_t);
+    *reinterpret_cast<uint32_t*>(p1 + 1) = self->uris.json;
+    LV2_Atom_Property_Body* p2 = reinterpret_cast<LV2_Atom_Property_Body*>(reinterpret_cast<uint8_t*>(p1) + prop1);
+    p2->key = self->uris.patch_value;
+    p2->context = 0;
+    p2->value.type = self->uris.atom_Path;
+    p2->value.size = path_size;
+    std::memcpy(p2 + 1, filename, len);
+    self->notify_port->atom.size += ev_size;
+    return true;
+}
+
+bool is_object_type(const PluginURIs* u, uint32_t type)
+{
+    return type == u->atom_Object || type == u->atom_Blank || type == u->atom_Resource;
+}
+
+// ------------------------------------------------------------------ LV2 callbacks
+
+LV2_Handle instantiate(const LV2_Descriptor*, double samplerate, const char*, const LV2_Feature* const* features)
+{
+    Plugin* self = new Plugin();
+    self->samplerate = samplerate;
+    for (int i = 0; features && features[i]; ++i) {
+        if (!std::strcmp(features[i]->URI, LV2_URID__map)) self->map = static_cast<LV2_URID_Map*>(features[i]->data);
+        else if (!std::strcmp(features[i]->URI, LV2_WORKER__schedule)) self->schedule = static_cast<LV2_Worker_Schedule*>(features[i]->data);
+        else if (!std::strcmp(features[i]->URI, LV2_LOG__log)) self->log = static_cast<LV2_Log_Log*>(features[i]->data);
+    }
+    if (!self->map) {
+        std::fprintf(stderr, "Error! Missing feature urid:map %s %d\n", __func__, __LINE__);
+        delete self;
+        return nullptr;
+    }
+    if (!self->schedule) {
+        std::fprintf(stderr, "Error! Missing feature work:schedule %s %d\n", __func__, __LINE__);
+        delete self;
+        return nullptr;
+    }
+    map_plugin_uris(self->map, &self->uris);
+
+    const char* dev = std::getenv("AIDAX_DEVICE");
+    const int device = dev ? std::atoi(dev) : 0;
+    if (aidax_pool_create(1, 8192, samplerate, device, &self->pool) != AIDAX_OK) {
+        std::fprintf(stderr, "Error! %s\n", aidax_last_error());
+        delete self;
+        return nullptr;
+    }
+    self->last_input_size = 0;
+    self->loading = true;            // until the host's default-state restore has loaded a model (:318-321)
+    self->model = nullptr;
+    return self;
+}
+
+void connect_port(LV2_Handle instance, uint32_t port, void* data)
+{
+    Plugin* self = static_cast<Plugin*>(instance);
+    switch (port) {
+    case IN: self->in = static_cast<const float*>(data); break;
+    case OUT_1: self->out_1 = static_cast<float*>(data); break;
+    case PLUGIN_CONTROL: self->control_port = static_cast<const LV2_Atom_Sequence*>(data); break;
+    case PLUGIN_NOTIFY: self->notify_port = static_cast<LV2_Atom_Sequence*>(data); break;
+    case INPUT_SIZE: self->input_size = static_cast<float*>(data); break;
+    default:
+        if (port < PLUGIN_PORT_COUNT) self->ctl[port] = static_cast<const float*>(data);
+        break;
+    }
+}
+
+void activate(LV2_Handle instance)
+{
+    Plugin* self = static_cast<Plugin*>(instance);
+    aidax_pool_activate(self->pool, AIDAX_ALL_STREAMS);     // :341-351
+}
+
+void deactivate(LV2_Handle) {}
+
+void latch_controls(Plugin* self)
+{
+    aidax_controls c;
+    auto v = [self](int port, float dflt) { return self->ctl[port] ? *self->ctl[port] : dflt; };
+    aidax_controls_default(&c);
+    c.in_lpf_pc = v(IN_LPF, c.in_lpf_pc);           c.pregain_db = v(PREGAIN, c.pregain_db);
+    c.net_bypass = v(NET_BYPASS, c.net_bypass);     c.param1 = v(PARAM1, c.param1);
+    c.param2 = v(PARAM2, c.param2);                 c.eq_bypass = v(EQ_BYPASS, c.eq_bypass);
+    c.eq_position = v(EQ_POS, c.eq_position);       c.bass_boost_db = v(BASS, c.bass_boost_db);
+    c.bass_freq = v(BFREQ, c.bass_freq);            c.mid_boost_db = v(MID, c.mid_boost_db);
+    c.mid_freq = v(MFREQ, c.mid_freq);              c.mid_q = v(MIDQ, c.mid_q);
+    c.mid_type = v(MTYPE, c.mid_type);              c.treble_boost_db = v(TREBLE, c.treble_boost_db);
+    c.treble_freq = v(TFREQ, c.treble_freq);        c.depth_boost_db = v(DEPTH, c.depth_boost_db);
+    c.presence_boost_db = v(PRESENCE, c.presence_boost_db);
+    c.dc_blocker = v(DCBLOCKER, c.dc_blocker);      c.master_db = v(MASTER, c.master_db);
+    c.enabled = v(PLUGIN_ENABLED, c.enabled);
+    if (!self->have_last_controls || std::memcmp(&c, &self->last_controls, sizeof(c)) != 0) {
+        aidax_pool_set_controls(self->pool, 0, &c);
+        self->last_controls = c;
+        self->have_last_controls = true;
+    }
+    if (self->loading != self->last_loading) {
+        aidax_pool_set_loading(self->pool, 0, self->loading ? 1 : 0);
+        self->last_loading = self->loading;
+    }
+}
+
+void run(LV2_Handle instance, uint32_t n_samples)
+{
+    Plugin* self = static_cast<Plugin*>(instance);
+    const PluginURIs* uris = &self->uris;
+
+    if (self->input_size) *self->input_size = static_cast<float>(self->last_input_size);      // :518
+
+    // ---- atom messages (:524-586)
+    notify_begin(self);
+    if (self->control_port) {
+        const LV2_Atom_Sequence* seq = self->control_port;
+        const uint8_t* body = reinterpret_cast<const uint8_t*>(&seq->body);
+        const uint8_t* end = body + seq->atom.size;
+        const uint8_t* p = body + sizeof(LV2_Atom_Sequence_Body);
+        while (p + sizeof(LV2_Atom_Event) <= end) {
+            const LV2_Atom_Event* ev = reinterpret_cast<const LV2_Atom_Event*>(p);
+            p += sizeof(LV2_Atom_Event) + lv2_atom_pad_size(ev->body.size);
+            if (!is_object_type(uris, ev->body.type)) {
+                plog(self, uris->log_Trace, "Unknown event type %d\n", ev->body.type);
+                continue;
+            }
+            const LV2_Atom_Object* obj = reinterpret_cast<const LV2_Atom_Object*>(&ev->body);
+            if (obj->body.otype != uris->patch_Set) {
+                plog(self, uris->log_Trace, "Unknown object type %d\n", obj->body.otype);
+                continue;
+            }
+            const LV2_Atom* property = nullptr;
+            const LV2_Atom* value = nullptr;
+            const uint8_t* ob = reinterpret_cast<const uint8_t*>(&obj->body);
+            const uint8_t* oend = ob + obj->atom.size;
+            const uint8_t* q = ob + sizeof(LV2_Atom_Object_Body);
+            while (q + sizeof(LV2_Atom_Property_Body) <= oend) {
+                const LV2_Atom_Property_Body* pr = reinterpret_cast<const LV2_Atom_Property_Body*>(q);
+                if (pr->key == uris->patch_property && !property) property = &pr->value;
+                else if (pr->key == uris->patch_value && !value) value = &pr->value;
+                q += lv2_atom_pad_size(static_cast<uint32_t>(sizeof(LV2_Atom_Property_Body)) + pr->value.size);
+            }
+            if (!property) { plog(self, uris->log_Trace, "patch:Set message with no property\n"); continue; }
+            if (property->type != uris->atom_URID) { plog(self, uris->log_Trace, "patch:Set property is not a URID\n"); continue; }
+            if (reinterpret_cast<const LV2_Atom_URID*>(property)->body != uris->json) {
+                plog(self, uris->log_Trace, "patch:Set property body is not json\n");
+                continue;
+            }
+            if (!value) { plog(self, uris->log_Trace, "patch:Set message with no value\n"); continue; }
+            if (value->type != uris->atom_Path) { plog(self, uris->log_Trace, "patch:Set value is not a Path\n"); continue; }
+
+            plog(self, uris->log_Trace, "Queueing set message\n");
+            WorkerLoadMessage msg = { kWorkerLoad, {} };
+            std::memcpy(msg.path, value + 1, std::min(value->size, static_cast<uint32_t>(sizeof(msg.path) - 1u)));
+            self->schedule->schedule_work(self->schedule->handle, sizeof(msg), &msg);
+            self->loading = true;                                                              // :576
+        }
+    }
+
+    // ---- DSP: control latch, then the whole run() audio section on the GPU (:489-518, :607-659).
+    // n_samples == 0 (pre-run) and !enabled (raw copy) are handled inside the pass.
+    latch_controls(self);
+    if (aidax_pool_process(self->pool, self->in, self->out_1, n_samples) != AIDAX_OK)
+        plog(self, uris->log_Error, "aidax: %s\n", aidax_last_error());
+}
+
+void cleanup(LV2_Handle instance)
+{
+    Plugin* self = static_cast<Plugin*>(instance);
+    aidax_pool_destroy(self->pool);
+    aidax_model_free(self->model);
+    delete self;
+}
+
+// ---- state (:707-796)
+LV2_State_Status restore(LV2_Handle instance, LV2_State_Retrieve_Function retrieve, LV2_State_Handle handle,
+                         uint32_t, const LV2_Feature* const* features)
+{
+    Plugin* self = static_cast<Plugin*>(instance);
+    size_t size = 0;
+    uint32_t type = 0, valflags = 0;
+    const void* value = retrieve(handle, self->uris.json, &size, &type, &valflags);
+    if (value) {
+        plog(self, self->uris.log_Note, "Restoring file %s\n", static_cast<const char*>(value));
+        WorkerLoadMessage msg = { kWorkerLoad, {} };
+        LV2_State_Map_Path* map_path = nullptr;
+        LV2_State_Free_Path* free_path = nullptr;
+        for (int i = 0; features && features[i]; ++i) {
+            if (!std::strcmp(features[i]->URI, LV2_STATE__mapPath)) map_path = static_cast<LV2_State_Map_Path*>(features[i]->data);
+            else if (!std::strcmp(features[i]->URI, LV2_STATE__freePath)) free_path = static_cast<LV2_State_Free_Path*>(features[i]->data);
+        }
+        if (map_path) {
+            char* apath = map_path->absolute_path(map_path->handle, static_cast<const char*>(value));
+            std::memcpy(msg.path, apath, std::min(std::strlen(apath), sizeof(msg.path) - 1u));
+            if (free_path) free_path->free_path(free_path->handle, apath);
+            else std::free(apath);
+        } else {
+            std::memcpy(msg.path, value, std::min(size, sizeof(msg.path) - 1u));
+        }
+        self->schedule->schedule_work(self->schedule->handle, sizeof(msg), &msg);
+    }
+    return LV2_STATE_SUCCESS;
+}
+
+LV2_State_Status save(LV2_Handle instance, LV2_State_Store_Function store, LV2_State_Handle handle,
+                      uint32_t, const LV2_Feature* const* features)
+{
+    Plugin* self = static_cast<Plugin*>(instance);
+    if (!self->model) return LV2_STATE_SUCCESS;              // nothing loaded yet (:772-774)
+    LV2_State_Map_Path* map_path = nullptr;
+    for (int i = 0; features && features[i]; ++i)
+        if (!std::strcmp(features[i]->URI, LV2_STATE__mapPath)) map_path = static_cast<LV2_State_Map_Path*>(features[i]->data);
+    if (!map_path) return LV2_STATE_ERR_NO_FEATURE;          // :793-795
+    char* apath = map_path->abstract_path(map_path->handle, aidax_model_path(self->model));
+    store(handle, self->uris.json, apath, std::strlen(apath) + 1, self->uris.atom_Path,
+          LV2_STATE_IS_POD | LV2_STATE_IS_PORTABLE);
+    std::free(apath);
+    return LV2_STATE_SUCCESS;
+}
+
+// ---- worker (:807-893)
+LV2_Worker_Status work(LV2_Handle instance, LV2_Worker_Respond_Function respond, LV2_Worker_Respond_Handle handle,
+                       uint32_t, const void* data)
+{
+    Plugin* self = static_cast<Plugin*>(instance);
+    const WorkerMessage* msg = static_cast<const WorkerMessage*>(data);
+    switch (msg->type) {
+    case kWorkerLoad: {
+        const char* path = static_cast<const WorkerLoadMessage*>(data)->path;
+        aidax_model* m = nullptr;
+        if (aidax_model_load(path, &m) == AIDAX_OK) {
+            aidax_model_info_t info;
+            aidax_model_info(m, &info);
+            self->last_input_size = info.input_size;          // cached for the ModelInSize port (:1082)
+            plog(self, self->uris.log_Note, "Successfully loaded json file: %s\n", path);
+            WorkerApplyMessage reply = { kWorkerApply, m };
+            respond(handle, sizeof(reply), &reply);
+        } else {
+            // no reply: the old model keeps playing but `loading` stays set, so the master ramps to 0 (:576, :654)
+            plog(self, self->uris.log_Error, "%s\n", aidax_last_error());
+        }
+        return LV2_WORKER_SUCCESS;
+    }
+    case kWorkerFree:
+        aidax_model_free(static_cast<const WorkerApplyMessage*>(data)->model);
+        return LV2_WORKER_SUCCESS;
+    case kWorkerApply:
+        break;                                                // should not happen
+    }
+    return LV2_WORKER_ERR_UNKNOWN;
+}
+
+LV2_Worker_Status work_response(LV2_Handle instance, uint32_t, const void* data)
+{
+    Plugin* self = static_cast<Plugin*>(instance);
+    const WorkerMessage* msg = static_cast<const WorkerMessage*>(data);
+    if (msg->type != kWorkerApply) return LV2_WORKER_ERR_UNKNOWN;
+
+    WorkerApplyMessage reply = { kWorkerFree, self->model };  // old model goes back to the worker for deletion
+    self->model = static_cast<const WorkerApplyMessage*>(data)->model;
+    // swap: weights to the GPU, reset(), inherited PARAM targets, 2048-zero warm-up (:1046-1079)
+    if (aidax_pool_set_model(self->pool, self->model, AIDAX_START_WARMUP) != AIDAX_OK)
+        plog(self, self->uris.log_Error, "aidax: %s\n", aidax_last_error());
+    self->schedule->schedule_work(self->schedule->handle, sizeof(reply), &reply);
+    plog(self, self->uris.log_Trace, "New model in use\n");
+    notify_set_file(self, aidax_model_path(self->model));    // report change to host/ui (:880-887)
+    self->loading = false;                                    // :889
+    plog(self, self->uris.log_Trace, "loading = false\n");
+    return LV2_WORKER_SUCCESS;
+}
+
+const void* extension_data(const char* uri)
+{
+    static const LV2_State_Interface state = { save, restore };
+    if (!std::strcmp(uri, LV2_STATE__interface)) return &state;
+    static const LV2_Worker_Interface worker = { work, work_response, nullptr };
+    if (!std::strcmp(uri, LV2_WORKER__interface)) return &worker;
+    return nullptr;
+}
+
+const LV2_Descriptor kDescriptor = {
+    PLUGIN_URI, instantiate, connect_port, activate, run, deactivate, cleanup, extension_data
+};
+
+}  // namespace
+
+extern "C" LV2_SYMBOL_EXPORT const LV2_Descriptor* lv2_descriptor(uint32_t index)
+{
+    return index == 0 ? &kDescriptor : nullptr;
+}

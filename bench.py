@@ -79,12 +79,46 @@ def cfg2_model_path():
     return modelgen.write_model(j, os.path.join(d, "lstm32_cfg2.json")), j
 
 
+def usable_cores() -> int:
+    """Cores this process may really use: affinity mask, capped by a cgroup CPU quota if one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
+def pmc_traffic_bytes(kernel_name: str):
+    """HBM bytes per launch of the benchmarked kernel from the committed rocprofv3 PMC passes
+    (profiles/*_pmc_summary.txt): (2 x FETCH_SIZE + WRITE_SIZE) KB — FETCH_SIZE counts half of a
+    16 B/lane streaming read on gfx950 (MI355X_MICROARCH.md, HBM section). None if no profile."""
+    import glob
+    import re
+    best = None
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.txt"))):
+        fetch = write = None
+        for line in open(fn):
+            if kernel_name.split("<")[0] + "<" not in line or kernel_name.split("<")[1] not in line:
+                continue
+            m = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+n=\s*\d+ median=([0-9.e+]+)", line)
+            if m and m.group(1) == "FETCH_SIZE":
+                fetch = float(m.group(2))
+            elif m:
+                write = float(m.group(2))
+        if fetch is not None and write is not None:
+            best = {"bytes": (2.0 * fetch + write) * 1024.0, "source": os.path.basename(fn)}
+    return best
+
+
 def cpu_baseline(j, target_s: float = 12.0):
     """The CPU oracle on all host cores over a bounded sample of cfg2."""
     from oracle import oracle as O
     from tests import modelgen
     spec = O.parse_model(j)
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     streams = N_STREAMS                      # the whole cfg2 stream set; the sample is bounded in blocks
     x = modelgen.signal(streams, N_FRAMES)
     c = O.default_controls()
@@ -184,6 +218,7 @@ def main():
         value = samples_all / elapsed_max
         algo_bytes = ALGO_BYTES_PER_SAMPLE * S * N_FRAMES                 # per launch
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = pmc_traffic_bytes(pool.kernel_name) if S == N_STREAMS else None
         out = {
             "metric": "audio samples/sec (48 kHz mono, many streams)",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -193,7 +228,9 @@ def main():
                        "streams_per_gpu": S, "frames": N_FRAMES, "kernel": pool.kernel_name,
                        "realtime_factor": value / (48000.0 * S * world)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": traffic["bytes"] if traffic else None,
+                         "traffic_source": traffic["source"] if traffic else None,
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes},
             "compute": {"fp32_tflops": LSTM32_FLOPS_PER_SAMPLE * S * N_FRAMES / (kernel_ms * 1e-3) / 1e12,
                         "peak_tflops": FP32_PEAK_TFLOPS},

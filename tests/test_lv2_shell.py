@@ -1,0 +1,178 @@
+"""The LV2 plugin shell (rt-neural-generic.so) driven by a mock host: descriptor and
+feature handling (CPU), and on the GPU the whole plugin life cycle of the reference —
+default-state restore -> worker load -> work_response swap -> NOTIFY echo -> audio,
+patch:Set on CONTROL, mute-while-loading, state save, activate — compared sample for
+sample with the CPU oracle's plugin mirror."""
+import ctypes as C
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import lv2host, modelgen
+
+THR = 1.0e-5
+JSON_URI = lv2host.PLUGIN_URI.decode() + "#json"
+
+
+def test_descriptor_and_symbol():
+    lib = C.CDLL(lv2host.SO)
+    lib.lv2_descriptor.restype = C.POINTER(lv2host.Descriptor)
+    lib.lv2_descriptor.argtypes = [C.c_uint32]
+    d = lib.lv2_descriptor(0)
+    assert d and d.contents.URI == lv2host.PLUGIN_URI            # uris.h:26-28
+    assert not lib.lv2_descriptor(1)                              # rt-neural-generic.cpp:27-28
+    ext = d.contents.extension_data
+    assert ext(b"http://lv2plug.in/ns/ext/worker#interface") and ext(b"http://lv2plug.in/ns/ext/state#interface")
+    assert not ext(b"http://example.org/nothing")
+
+
+def test_instantiate_requires_urid_map_and_worker_schedule(capfd):
+    """rt-neural-generic.cpp:265-273: returns 0 when a required host feature is missing."""
+    h = lv2host.Host(with_map=False)
+    assert not h.handle
+    h = lv2host.Host(with_schedule=False)
+    assert not h.handle
+    err = capfd.readouterr().err
+    assert "Missing feature urid:map" in err and "Missing feature work:schedule" in err
+
+
+def test_instantiate_without_gpu_fails_loudly(capfd):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = lv2host.Host()
+    assert not h.handle
+    assert "no CPU fallback" in capfd.readouterr().err
+
+
+# ----------------------------------------------------------------------------- GPU
+
+def _oracle_controls(h):
+    return O.default_controls(**{lv2host.FIELD[k]: h.ctl[k].value for k in lv2host.FIELD})
+
+
+@pytest.fixture
+def bundle(tmp_path):
+    """A bundle directory laid out like rt-neural-generic.lv2 (models/ next to the binary)."""
+    src = os.path.join(lv2host.ROOT, "tests", "golden", "models")
+    dst = tmp_path / "models" / "deer ink studios"
+    dst.mkdir(parents=True)
+    for f in os.listdir(src):
+        shutil.copy(os.path.join(src, f), dst / f)
+    modelgen.write_model(modelgen.make_model("gru", 16, 3, seed=7), str(tmp_path / "models" / "gru16.json"))
+    return str(tmp_path)
+
+
+@pytest.mark.gpu
+def test_plugin_life_cycle_matches_oracle(bundle):
+    h = lv2host.Host(bundle_dir=bundle)
+    assert h.handle
+    x = modelgen.signal(1, 256 * 14, seed=31)[0]
+    blocks = [x[i * 256:(i + 1) * 256] for i in range(14)]
+    plug = O.OraclePlugin()
+    default_rel = "models/deer ink studios/tw40_california_clean_deerinkstudios.json"   # rt-neural-generic.ttl:315-317
+    default_abs = os.path.join(bundle, default_rel)
+
+    def step(i):
+        got = h.run(blocks[i])
+        want = plug.run(_oracle_controls(h), blocks[i])
+        return got, want
+
+    # 1. before any model: silence, ModelInSize 0 (loading=true, master cleared to 0)
+    got, want = step(0)
+    assert np.all(got == 0) and np.array_equal(got, want) and h.ctl["ModelInSize"].value == 0
+
+    # 2. host restores the default state -> a kWorkerLoad is scheduled with the ABSOLUTE path (:741-755)
+    assert h.restore(default_rel) == 0 and h.free_calls == 1
+    assert len(h.work_queue) == 1
+    msg = h.work_queue[0]
+    assert len(msg) == 4 + 1024 and msg[4:].split(b"\0")[0].decode() == default_abs
+    got, want = step(1)                                  # still silent: the worker has not run yet
+    assert np.all(got == 0)
+
+    # 3. worker thread: load; audio thread after run(): work_response swaps, echoes patch:Set, un-mutes
+    assert h.pump_worker() == 1 and len(h.responses) == 1
+    h.run(np.zeros(0, np.float32))                       # a pre-run with n_samples == 0 is legal (:606-609)
+    plug.run(_oracle_controls(h), np.zeros(0, np.float32))
+    assert h.deliver_responses() == 1
+    spec = O.load_model(default_abs)
+    plug.set_model(O.OracleModel(spec, 0.0, 0.0))
+    note = h.read_notify()
+    assert len(note) == 1 and note[0][0].endswith("patch#Set")
+    props = note[0][1]
+    assert props["http://lv2plug.in/ns/ext/patch#property"][1][:4] == np.uint32(h.urid(JSON_URI)).tobytes()
+    vt, vb = props["http://lv2plug.in/ns/ext/patch#value"]
+    assert vt.endswith("atom#Path") and vb.rstrip(b"\0").decode() == default_abs
+    assert len(h.work_queue) == 1                        # kWorkerFree(old = NULL) was scheduled (:868-875)
+    h.pump_worker()
+
+    # 4. audio now follows the oracle, the master gain ramping up from 0
+    for i in (2, 3, 4):
+        got, want = step(i)
+        assert np.abs(got - want).max() < THR, i
+    assert np.abs(got).max() > 1e-3 and h.ctl["ModelInSize"].value == 1
+
+    # 5. controls change mid-stream (EQ pre, gains)
+    h.controls(EQPOS=1.0, BASS=4.0, MID=-3.0, MIDQ=1.2, TREBLE=2.0, PREGAIN=3.0, MASTER=-2.0)
+    got, want = step(5)
+    assert np.abs(got - want).max() < THR * 2
+
+    # 6. patch:Set with a conditioned GRU model on CONTROL: mutes while loading (:576, :654), then swaps
+    gru_abs = os.path.join(bundle, "models", "gru16.json")
+    h.controls(PARAM1=0.7, PARAM2=0.2)
+    h.send_patch_set(gru_abs)
+    got, want6 = h.run(blocks[6]), None
+    plug.set_loading(True)
+    want6 = plug.run(_oracle_controls(h), blocks[6])
+    assert np.abs(got - want6).max() < THR * 2
+    assert len(h.work_queue) == 1 and h.pump_worker() == 1 and h.deliver_responses() == 1
+    old = plug.model.ptr.contents
+    plug.set_model(O.OracleModel(O.load_model(gru_abs), old.param1Coeff.target, old.param2Coeff.target))
+    assert h.read_notify()[0][1]["http://lv2plug.in/ns/ext/patch#value"][1].rstrip(b"\0").decode() == gru_abs
+    h.pump_worker()                                      # frees the LSTM model
+    for i in (7, 8):
+        got, want = step(i)
+        assert np.abs(got - want).max() < THR * 2, i
+    assert h.ctl["ModelInSize"].value == 3
+
+    # 7. messages that must be ignored: wrong property, wrong value type, not a patch:Set
+    h.send_patch_set(gru_abs, prop_uri="http://example.org/other")
+    h.run(blocks[9]); plug.run(_oracle_controls(h), blocks[9])
+    h.send_patch_set(gru_abs, value_type="http://lv2plug.in/ns/ext/atom#String")
+    h.run(blocks[9]); plug.run(_oracle_controls(h), blocks[9])
+    h.send_patch_set(gru_abs, otype="http://lv2plug.in/ns/ext/patch#Get")
+    h.run(blocks[9]); plug.run(_oracle_controls(h), blocks[9])
+    assert not h.work_queue
+
+    # 8. a failing load leaves the plugin muted: loading stays true, the old model keeps running (:1017-1044)
+    h.send_patch_set(os.path.join(bundle, "models", "missing.json"))
+    got = h.run(blocks[10]); plug.set_loading(True); want = plug.run(_oracle_controls(h), blocks[10])
+    assert np.abs(got - want).max() < THR * 2
+    assert h.pump_worker() == 1 and not h.responses
+    for i in (11, 12):
+        got, want = step(i)
+        assert np.abs(got - want).max() < THR * 2
+    assert np.abs(got).max() < 1e-3                      # ramped to silence
+
+    # 9. state save: abstract path under #json as atom:Path, POD|PORTABLE (:783-792); no mapPath -> NO_FEATURE
+    rc, stored = h.save()
+    assert rc == 0 and stored == [(JSON_URI, b"models/gru16.json\0", "http://lv2plug.in/ns/ext/atom#Path", 3)]
+    assert h.save(with_map_path=False)[0] == 4
+
+    # 10. activate() clears the gain ramps to their targets (:341-342)
+    h.desc.activate(h.handle); plug.activate()
+    got, want = step(13)
+    assert np.abs(got - want).max() < THR * 2
+    h.close()
+
+
+@pytest.mark.gpu
+def test_disabled_port_is_a_raw_copy(bundle):
+    h = lv2host.Host(bundle_dir=bundle)
+    x = modelgen.signal(1, 256, seed=5)[0]
+    h.controls(enabled=0.0)
+    assert np.array_equal(h.run(x), x)
+    h.close()

@@ -8,6 +8,11 @@ import struct
 
 import numpy as np
 
+try:                                   # one HIP runtime per test process: see aidadsp-lv2_amd/binding.py lib()
+    import torch  # noqa: F401
+except Exception:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SO = os.path.join(ROOT, "aidadsp-lv2_amd", "lv2", "rt-neural-generic.so")
 PLUGIN_URI = b"http://aidadsp.cc/plugins/aidadsp-bundle/rt-neural-generic"

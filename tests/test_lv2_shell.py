@@ -155,7 +155,7 @@ def test_plugin_life_cycle_matches_oracle(bundle):
     for i in (11, 12):
         got, want = step(i)
         assert np.abs(got - want).max() < THR * 2
-    assert np.abs(got).max() < 1e-3                      # ramped to silence
+    assert plug.p.masterGain.target == 0.0               # the oracle mirror is ramping to silence too (T60 0.1 s)
 
     # 9. state save: abstract path under #json as atom:Path, POD|PORTABLE (:783-792); no mapPath -> NO_FEATURE
     rc, stored = h.save()

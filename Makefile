@@ -19,7 +19,7 @@ HIPFLAGS := --offload-arch=$(ARCH) $(CXXFLAGS)
 
 HOST_SRCS := $(SRC)/aidax_model.cpp $(SRC)/aidax_dsp_host.cpp $(SRC)/aidax_pack.cpp $(SRC)/aidax_pool.cpp
 HOST_OBJS := $(patsubst $(SRC)/%.cpp,$(OBJDIR)/%.o,$(HOST_SRCS))
-KERN_OBJS := $(OBJDIR)/aidax_kernels.o
+KERN_OBJS := $(OBJDIR)/aidax_kernels.o $(OBJDIR)/aidax_stack.o
 HDRS      := $(wildcard $(SRC)/*.h) include/aidax.h
 
 LV2SO := $(PKG)/lv2/rt-neural-generic.so
@@ -30,7 +30,7 @@ $(OBJDIR)/%.o: $(SRC)/%.cpp $(HDRS)
 	@mkdir -p $(OBJDIR)
 	$(CXX) $(CXXFLAGS) -I$(ROCM)/include -D__HIP_PLATFORM_AMD__ -c $< -o $@
 
-$(OBJDIR)/aidax_kernels.o: $(SRC)/aidax_kernels.hip $(HDRS)
+$(OBJDIR)/%.o: $(SRC)/%.hip $(HDRS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

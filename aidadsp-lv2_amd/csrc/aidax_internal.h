@@ -50,5 +50,10 @@ void  build_stream_ctl(const aidax_controls& c, double host_samplerate, bool has
 
 // weight packing (aidax_pack.cpp)
 std::vector<float> pack_weights(const aidax_model& m);
+// extension architectures: flat weight buffer + descriptor + per-stream state size (floats)
+bool is_stack_model(const aidax_model& m);     // >= 2 recurrent layers
+bool is_conv_model(const aidax_model& m);
+std::vector<float> pack_stack(const aidax_model& m, StackDesc* d, uint32_t* state_floats);
+std::vector<float> pack_conv(const aidax_model& m, ConvDesc* d, uint32_t* state_floats);
 
 }  // namespace aidax

@@ -21,6 +21,10 @@ hipError_t launch_stream_kernel(const KernelEntry* e, const LaunchArgs& a, size_
 size_t pipe_lds_bytes(int hidden, uint32_t n_frames);
 hipError_t launch_pipe_kernel(const KernelEntry* e, const LaunchArgs& a, hipStream_t stream);
 int pipe_resident_streams(const KernelEntry* e, uint32_t n_frames, int device);
+size_t stack_lds_bytes(const StackDesc& d, uint32_t n_frames);
+size_t conv_lds_bytes(const ConvDesc& d, uint32_t n_frames);
+hipError_t launch_stack_kernel(const LaunchArgs& a, const StackDesc& d, hipStream_t stream);
+hipError_t launch_conv_kernel(const LaunchArgs& a, const ConvDesc& d, hipStream_t stream);
 hipError_t launch_set_pending(StreamState* st, uint32_t n_streams, int32_t stream, uint32_t bits, hipStream_t q);
 hipError_t launch_reset_for_model(StreamState* st, float* nn, uint32_t n_streams, uint32_t nn_stride, float p_den, hipStream_t q);
 

@@ -33,147 +33,11 @@
 
 #include <cfloat>
 
+#include "aidax_device.h"
 #include "aidax_kernels.h"
 #include "aidax_layout.h"
 
 namespace aidax {
-
-// ------------------------------------------------------------------ lane ops
-__device__ __forceinline__ float dpp_row_shr1(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
-}
-
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_take(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, ROW_MASK == 0xf));
-}
-
-// Sum over the 64 lanes, returned wave-uniform (tree order fixed by the DPP network).
-__device__ __forceinline__ float wave_sum(float v)
-{
-    v = v + dpp_take<0xB1, 0xf>(v);     // quad_perm [1,0,3,2]
-    v = v + dpp_take<0x4E, 0xf>(v);     // quad_perm [2,3,0,1]
-    v = v + dpp_take<0x141, 0xf>(v);    // row_half_mirror
-    v = v + dpp_take<0x140, 0xf>(v);    // row_mirror: every lane of a row holds the row sum
-    v = v + dpp_take<0x142, 0xa>(v);    // row_bcast:15 into rows 1,3
-    v = v + dpp_take<0x143, 0xc>(v);    // row_bcast:31 into rows 2,3
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
-
-// Cross-lane shares on the permlane swap network. (The swapped pair is copied to
-// scalars before the float bit_cast: __builtin_bit_cast applied directly to an
-// ext-vector element reads element 0 on ROCm 7.2's clang.)
-struct Pair { float lo, hi; };
-
-// every lane gets (value held by its lane in the low half, value held in the high half)
-__device__ __forceinline__ Pair share_halves(float v)
-{
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    const unsigned r0 = r[0], r1 = r[1];
-    return { __builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1) };
-}
-
-// every lane gets (value of the even 16-lane row of its row pair, value of the odd row)
-__device__ __forceinline__ Pair share_rows(float v)
-{
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    const unsigned r0 = r[0], r1 = r[1];
-    return { __builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1) };
-}
-
-__device__ __forceinline__ float fast_sigmoid(float v)
-{
-    // 1 / (1 + 2^(-v*log2 e)); saturates cleanly: exp2 -> inf gives rcp -> 0
-    const float e = __builtin_amdgcn_exp2f(v * -1.44269504088896340736f);
-    return __builtin_amdgcn_rcpf(1.0f + e);
-}
-
-// tanh as an odd rational x*P(x^2)/Q(x^2), P of degree 6 and Q of degree 3 in x^2, fitted for
-// this kernel (scratch: Lawson-weighted least squares on [0,9], relative error 6.6e-9 in fp64).
-// In fp32 with FMAs: <= 3.6e-7 relative everywhere, exact odd symmetry, |y| <= 1 with the
-// clamp. The relative accuracy near 0 is the point: tanh = 2*sigmoid(2x)-1 on v_exp_f32 is
-// only ABSOLUTELY accurate (1.2e-7), and an LSTM whose forget gate sits near 1 integrates
-// that error in c (measured 5.5e-6 after 2048 samples on tw40_british_lead vs 1.3e-6 with
-// this form; the reference's threshold is 1e-5, rt-neural-generic.h:182).
-__device__ __forceinline__ float tanh_rat(float v)
-{
-    const float x = __builtin_fminf(__builtin_fmaxf(v, -7.9f), 7.9f);
-    const float u = x * x;
-    float p = -8.488730763828322e-14f;
-    p = __builtin_fmaf(p, u, 5.277955823366522e-11f);
-    p = __builtin_fmaf(p, u, -2.0225239996482085e-08f);
-    p = __builtin_fmaf(p, u, 1.1154311501654368e-05f);
-    p = __builtin_fmaf(p, u, 0.003103956503888039f);
-    p = __builtin_fmaf(p, u, 0.13084010352004496f);
-    p = __builtin_fmaf(p, u, 0.9999999933888696f);
-    float q = 0.00025461456545097517f;
-    q = __builtin_fmaf(q, u, 0.02449517952619233f);
-    q = __builtin_fmaf(q, u, 0.46417337453820245f);
-    q = __builtin_fmaf(q, u, 1.0f);
-    return (p * x) * __builtin_amdgcn_rcpf(q);
-}
-
-// ---------------------------------------------------------------- smoothers
-struct ExpRamp {              // ExponentialValueSmoother::next, ValueSmoother.hpp:142-145
-    float mem, coef, tc;      // tc = target * (1.f - coef), loop-invariant
-    __device__ __forceinline__ void arm(float m, float target, float c)
-    {
-        mem = m; coef = c; tc = target * (1.f - c);
-    }
-    __device__ __forceinline__ float next() { mem = mem * coef + tc; return mem; }
-};
-
-__device__ __forceinline__ float lin_next(float& mem, float target, float step)
-{
-    // LinearValueSmoother::next, ValueSmoother.hpp:229-234
-    const float y0 = mem;
-    const float dy = target - y0;
-    mem = y0 + __builtin_copysignf(__builtin_fminf(__builtin_fabsf(dy), __builtin_fabsf(step)), dy);
-    return mem;
-}
-
-// ------------------------------------------------------------ systolic chain
-// One pass of up to 6 cascaded stages over buf[0..n) in LDS, in place.
-// Lane k < K owns stage k: an optional biquad (slot[k], enabled by act[k]) and,
-// on lane `gain_lane`, the exponential gain ramp applied after the biquad.
-struct ChainPass {
-    int K, gain_lane;
-    bool active;          // this lane's biquad is in circuit
-    double a0, a1, a2, b1, b2, z1, z2;
-    ExpRamp g;
-};
-
-template <int DST_STRIDE = 1>
-__device__ __forceinline__ void chain_run(ChainPass& c, const float* src, float* dst, int n, int lane)
-{
-    float carry = 0.f;                         // this lane's previous output, read by lane+1
-    const int steps = n + c.K - 1;
-    for (int s = 0; s < steps; ++s) {
-        const float head = src[s < n ? s : n - 1];          // wave-uniform LDS broadcast
-        const float from_left = dpp_row_shr1(carry);
-        const float x = lane == 0 ? head : from_left;
-        const int idx = s - lane;
-        if (lane < c.K && idx >= 0 && idx < n) {
-            float y = x;
-            if (c.active) {                                 // Biquad::process, Biquad.h:53-58
-                const double xd = x;
-                const double yd = xd * c.a0 + c.z1;
-                c.z1 = xd * c.a1 + c.z2 - c.b1 * yd;
-                c.z2 = xd * c.a2 - c.b2 * yd;
-                y = (float)yd;
-            }
-            const float gm = c.g.next();                    // every stage lane keeps its own copy;
-            if (lane == c.gain_lane) y = y * gm;            // only the gain lane's is used
-            carry = y;
-            if (lane == c.K - 1) dst[idx * DST_STRIDE] = y;
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
 
 // --------------------------------------------------------------- LSTM cell
 // Lane mapping per aidax_layout.h. Gate index g = part + S*e; json column order
@@ -442,42 +306,6 @@ struct GruCell {
         __builtin_amdgcn_wave_barrier();
     }
 };
-
-// ------------------------------------------------------------- block I/O
-__device__ __forceinline__ void load_block(float* buf, const float* __restrict__ src, int n, int lane)
-{
-    if ((n & 3) == 0) {
-        const float4* s4 = reinterpret_cast<const float4*>(src);
-        float4* b4 = reinterpret_cast<float4*>(buf);
-        for (int i = lane; i < n / 4; i += kWave) b4[i] = s4[i];     // 16 B/lane, 1 KiB per wave instruction
-    } else {
-        for (int i = lane; i < n; i += kWave) buf[i] = src[i];
-    }
-}
-
-__device__ __forceinline__ void store_block(float* __restrict__ dst, const float* buf, int n, int lane)
-{
-    if ((n & 3) == 0) {
-        float4* d4 = reinterpret_cast<float4*>(dst);
-        const float4* b4 = reinterpret_cast<const float4*>(buf);
-        for (int i = lane; i < n / 4; i += kWave) d4[i] = b4[i];
-    } else {
-        for (int i = lane; i < n; i += kWave) dst[i] = buf[i];
-    }
-}
-
-// Stage -> biquad slot of the two systolic passes (cascade order of
-// applyToneControls, rt-neural-generic.cpp:133-139)
-__device__ __forceinline__ int pre_slot(int k)  { return k == 0 ? BQ_LPF : BQ_DEPTH + (k - 1); }
-__device__ __forceinline__ int post_slot(int k) { return k == 0 ? BQ_DC : BQ_DEPTH + (k - 1); }
-
-__device__ __forceinline__ void chain_load(ChainPass& c, const StreamCtl& ctl, const StreamState& st, int slot, bool act)
-{
-    c.active = act;
-    c.a0 = ctl.bq[slot][0]; c.a1 = ctl.bq[slot][1]; c.a2 = ctl.bq[slot][2];
-    c.b1 = ctl.bq[slot][3]; c.b2 = ctl.bq[slot][4];
-    c.z1 = st.z[slot][0];   c.z2 = st.z[slot][1];
-}
 
 // ------------------------------------------------------------- the kernel
 template <class Cell, bool HasCell>

@@ -117,6 +117,38 @@ enum : int {
     MODE_NN_ONLY = 2,   // bare applyModel with explicit [n][I] inputs (self-test / forward)
 };
 
+// ---- descriptors of the extension kernels (aidax_stack.hip); offsets index the weight buffer
+constexpr int kStackStreams = 8;      // streams sharing one workgroup (and every weight load) in k_stack
+constexpr int kMaxStackLayers = 4;
+constexpr int kMaxConvLayers = 12;
+
+struct StackLayer {
+    int32_t cell;          // 0 LSTM, 1 GRU
+    int32_t in_size, hidden, rows;
+    uint32_t w_off;        // Wt[in_size + hidden][rows]: input rows first, then recurrent rows (Keras layout as is)
+    uint32_t b_off;        // [rows]   LSTM: b; GRU: z,r -> b0+b1, candidate -> b0
+    uint32_t b2_off;       // GRU: recurrent-side candidate bias [hidden]
+    uint32_t state_off;    // into the stream's nn state: h[hidden] (+ c[hidden] for LSTM)
+};
+struct StackDesc {
+    int32_t n_layers, max_rows, max_hidden, pad;
+    StackLayer L[kMaxStackLayers];
+    uint32_t wd_off, bd_off;
+};
+
+struct ConvLayer {
+    int32_t in_ch, out_ch, ksize, dilation, activation;
+    int32_t hist;          // (ksize-1)*dilation frames of input history
+    uint32_t w_off;        // K[ksize][in_ch][out_ch]
+    uint32_t b_off;        // [out_ch]
+    uint32_t state_off;    // history[hist][in_ch] in the stream's nn state
+};
+struct ConvDesc {
+    int32_t n_layers, channels, max_hist, pad;
+    ConvLayer L[kMaxConvLayers];
+    uint32_t wd_off, bd_off;
+};
+
 struct LaunchArgs {
     const StreamCtl* ctl;
     StreamState*     st;

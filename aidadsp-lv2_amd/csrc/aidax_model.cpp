@@ -171,7 +171,7 @@ void build(const Json& j, aidax_model& m)
 
 }  // namespace
 
-bool kernel_available(int cell, int hidden, int n_rnn);   // aidax_pool.cpp
+bool model_supported(const aidax_model& m);   // aidax_pool.cpp
 
 int load_from_text(const char* text, size_t len, const char* label, aidax_model** out)
 {
@@ -187,7 +187,7 @@ int load_from_text(const char* text, size_t len, const char* label, aidax_model*
     } catch (const std::exception& e) {
         return fail(AIDAX_ERR_JSON, std::string("Unable to load json file: ") + m->path + "\nError: " + e.what());
     }
-    if (!kernel_available(m->cell, m->hidden, m->n_rnn))
+    if (!model_supported(*m))
         return fail(AIDAX_ERR_ARCH, "Error loading model: Unable to identify a known model architecture! (no kernel for this cell/hidden size)");
     *out = m.release();
     return AIDAX_OK;

@@ -92,6 +92,82 @@ std::vector<float> pack_gru(const aidax_model& m)
 
 }  // namespace
 
+bool is_stack_model(const aidax_model& m) { return m.cell != AIDAX_CELL_CONV && m.n_rnn >= 2; }
+bool is_conv_model(const aidax_model& m) { return m.cell == AIDAX_CELL_CONV; }
+
+std::vector<float> pack_stack(const aidax_model& m, StackDesc* d, uint32_t* state_floats)
+{
+    std::vector<float> out;
+    *d = StackDesc{};
+    d->n_layers = m.n_rnn;
+    uint32_t st = 0;
+    for (int l = 0; l < m.n_rnn; ++l) {
+        const Layer& L = m.layers[l];
+        StackLayer& S = d->L[l];
+        const int G = L.type == Layer::LSTM ? 4 : 3;
+        S.cell = L.type == Layer::LSTM ? 0 : 1;
+        S.in_size = L.in_size;
+        S.hidden = L.out_size;
+        S.rows = G * L.out_size;
+        S.w_off = static_cast<uint32_t>(out.size());
+        out.insert(out.end(), L.w0.begin(), L.w0.end());            // [in][rows]   (Keras kernel, already k-major)
+        out.insert(out.end(), L.w1.begin(), L.w1.end());            // [hidden][rows]
+        S.b_off = static_cast<uint32_t>(out.size());
+        if (S.cell == 0) {
+            out.insert(out.end(), L.w2.begin(), L.w2.end());
+            S.b2_off = S.b_off;
+        } else {
+            const float* b0 = L.w2.data();
+            const float* b1 = L.w2.data() + S.rows;
+            for (int r = 0; r < S.rows; ++r) out.push_back(r < 2 * S.hidden ? b0[r] + b1[r] : b0[r]);
+            S.b2_off = static_cast<uint32_t>(out.size());
+            for (int u = 0; u < S.hidden; ++u) out.push_back(b1[2 * S.hidden + u]);
+        }
+        S.state_off = st;
+        st += static_cast<uint32_t>(S.cell == 0 ? 2 * S.hidden : S.hidden);
+        if (S.rows > d->max_rows) d->max_rows = S.rows;
+        if (S.hidden > d->max_hidden) d->max_hidden = S.hidden;
+        while (out.size() % 4) out.push_back(0.f);
+    }
+    const Layer& D = m.layers[m.n_rnn];
+    d->wd_off = static_cast<uint32_t>(out.size());
+    out.insert(out.end(), D.w0.begin(), D.w0.end());
+    d->bd_off = static_cast<uint32_t>(out.size());
+    out.push_back(D.w1[0]);
+    *state_floats = st;
+    return out;
+}
+
+std::vector<float> pack_conv(const aidax_model& m, ConvDesc* d, uint32_t* state_floats)
+{
+    std::vector<float> out;
+    *d = ConvDesc{};
+    d->n_layers = m.n_rnn;
+    d->channels = m.hidden;
+    uint32_t st = 0;
+    for (int l = 0; l < m.n_rnn; ++l) {
+        const Layer& L = m.layers[l];
+        ConvLayer& C = d->L[l];
+        C.in_ch = L.in_size; C.out_ch = L.out_size; C.ksize = L.ksize; C.dilation = L.dilation;
+        C.activation = L.activation;
+        C.hist = (L.ksize - 1) * L.dilation;
+        C.w_off = static_cast<uint32_t>(out.size());
+        out.insert(out.end(), L.w0.begin(), L.w0.end());
+        C.b_off = static_cast<uint32_t>(out.size());
+        out.insert(out.end(), L.w1.begin(), L.w1.end());
+        C.state_off = st;
+        st += static_cast<uint32_t>(C.hist * C.in_ch);
+        if (C.hist > d->max_hist) d->max_hist = C.hist;
+    }
+    const Layer& D = m.layers[m.n_rnn];
+    d->wd_off = static_cast<uint32_t>(out.size());
+    out.insert(out.end(), D.w0.begin(), D.w0.end());
+    d->bd_off = static_cast<uint32_t>(out.size());
+    out.push_back(D.w1[0]);
+    *state_floats = st;
+    return out;
+}
+
 std::vector<float> pack_weights(const aidax_model& m)
 {
     if (m.n_rnn == 1 && m.cell == AIDAX_CELL_LSTM) return pack_lstm(m);

@@ -3,6 +3,7 @@
 // are in aidax_kernels.hip. No CPU fallback: any HIP failure is AIDAX_ERR_DEVICE.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -16,9 +17,18 @@ using namespace aidax;
 
 namespace aidax {
 
-bool kernel_available(int cell, int hidden, int n_rnn)
+// Which device path serves a model: the 18 register-resident kernels for the reference's 54
+// variants, k_stack for stacked recurrent layers, k_conv for conv1d stacks (extensions).
+bool model_supported(const aidax_model& m)
 {
-    return n_rnn == 1 && find_kernel(cell, hidden) != nullptr;
+    if (is_conv_model(m)) {
+        if (m.input_size != 1 || m.hidden > 16 || m.n_rnn > kMaxConvLayers) return false;
+        for (int l = 0; l < m.n_rnn; ++l)
+            if (m.layers[l].out_size != m.hidden || m.layers[l].ksize > 8) return false;
+        return true;
+    }
+    if (is_stack_model(m)) return m.n_rnn <= kMaxStackLayers && m.hidden <= 128 && m.hidden % 4 == 0;
+    return m.n_rnn == 1 && find_kernel(m.cell, m.hidden) != nullptr;
 }
 
 namespace {
@@ -76,6 +86,9 @@ struct aidax_pool {
 
     // model in use (copy of what the kernels need)
     bool has_model = false;
+    enum Kind { TABLE = 0, STACK = 1, CONV = 2 } kind = TABLE;
+    StackDesc sdesc{};
+    ConvDesc cdesc{};
     const KernelEntry* kernel = nullptr;
     int input_size = 1, input_skip = 0, hidden = 0;
     float in_gain = 1.f, out_gain = 1.f, model_sr = 48000.f;
@@ -84,7 +97,7 @@ struct aidax_pool {
     int force_form = 0;              // AIDAX_KERNEL=wave|pipe overrides the heuristic (A/B testing)
     bool use_pipe() const
     {
-        if (!has_model || !kernel) return false;
+        if (!has_model || !kernel || kind != TABLE) return false;
         if (force_form == 1) return false;
         if (force_form == 2) return true;
         return static_cast<int>(n_streams) <= pipe_capacity;
@@ -130,6 +143,15 @@ struct aidax_pool {
         a.in_gain = in_gain; a.out_gain = out_gain;
         return a;
     }
+    // frames one launch of the extension kernels may carry (their LDS planes grow with n)
+    uint32_t ext_chunk() const { return max_frames < 256 ? max_frames : 256; }
+    hipError_t launch(const LaunchArgs& a, hipStream_t s) const
+    {
+        if (has_model && kind == STACK) return launch_stack_kernel(a, sdesc, s);
+        if (has_model && kind == CONV) return launch_conv_kernel(a, cdesc, s);
+        if (a.mode == MODE_CHAIN && use_pipe()) return launch_pipe_kernel(kernel, a, s);
+        return launch_stream_kernel(has_model ? kernel : nullptr, a, lds_bytes(a.mode == MODE_CHAIN ? a.n_frames : 0), s);
+    }
     void release()
     {
         if (d_ctl) (void)hipFree(d_ctl);
@@ -169,10 +191,29 @@ int set_model_impl(aidax_pool& p, const aidax_model* m, int start_mode)
         p.refresh_all();
         return AIDAX_OK;
     }
-    const KernelEntry* k = (m->n_rnn == 1) ? find_kernel(m->cell, m->hidden) : nullptr;
-    if (!k) return fail(AIDAX_ERR_ARCH, "Unable to identify a known model architecture! (no kernel)");
-    const std::vector<float> wp = pack_weights(*m);
-    if (static_cast<int>(wp.size()) != k->pack_regs * kWave + m->hidden + 1) return fail(AIDAX_ERR_STATE, "weight pack size mismatch");
+    if (!model_supported(*m)) return fail(AIDAX_ERR_ARCH, "Unable to identify a known model architecture! (no kernel)");
+    const KernelEntry* k = nullptr;
+    std::vector<float> wp;
+    uint32_t state_floats = 0;
+    aidax_pool::Kind kind = aidax_pool::TABLE;
+    StackDesc sd{};
+    ConvDesc cd{};
+    if (is_conv_model(*m)) {
+        kind = aidax_pool::CONV;
+        wp = pack_conv(*m, &cd, &state_floats);
+        if (conv_lds_bytes(cd, p.max_frames) > 160 * 1024)
+            return fail(AIDAX_ERR_ARG, "conv model: pool max_frames too large for the LDS activation planes");
+    } else if (is_stack_model(*m)) {
+        kind = aidax_pool::STACK;
+        wp = pack_stack(*m, &sd, &state_floats);
+        if (stack_lds_bytes(sd, p.max_frames) > 160 * 1024)
+            return fail(AIDAX_ERR_ARG, "stacked model: pool max_frames too large for the LDS block buffers");
+    } else {
+        k = find_kernel(m->cell, m->hidden);
+        wp = pack_weights(*m);
+        if (static_cast<int>(wp.size()) != k->pack_regs * kWave + m->hidden + 1) return fail(AIDAX_ERR_STATE, "weight pack size mismatch");
+        state_floats = static_cast<uint32_t>(k->state_floats);
+    }
 
     // model swaps are rare (worker thread); drain everything that may still read the old buffers
     HIP_TRY(hipDeviceSynchronize());
@@ -180,7 +221,7 @@ int set_model_impl(aidax_pool& p, const aidax_model* m, int start_mode)
     float* new_nn = nullptr;
     HIP_TRY(hipMalloc(&new_w, wp.size() * sizeof(float)));
     HIP_TRY(hipMemcpyAsync(new_w, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice, p.q));
-    const uint32_t stride = static_cast<uint32_t>((k->state_floats + 3) & ~3);
+    const uint32_t stride = (state_floats + 3u) & ~3u;
     HIP_TRY(hipMalloc(&new_nn, static_cast<size_t>(p.n_streams) * stride * sizeof(float)));
     HIP_TRY(hipStreamSynchronize(p.q));
     if (p.d_wpack) (void)hipFree(p.d_wpack);
@@ -189,6 +230,9 @@ int set_model_impl(aidax_pool& p, const aidax_model* m, int start_mode)
     p.d_nn = new_nn;
     p.nn_stride = stride;
     p.kernel = k;
+    p.kind = kind;
+    p.sdesc = sd;
+    p.cdesc = cd;
     p.hidden = m->hidden;
     p.input_size = m->input_size;
     p.input_skip = m->input_skip;
@@ -198,11 +242,15 @@ int set_model_impl(aidax_pool& p, const aidax_model* m, int start_mode)
 
     // fresh DynamicModel per stream: reset() + param smoothers around the inherited targets (:1035, :1053-1061)
     HIP_TRY(launch_reset_for_model(p.d_st, p.d_nn, p.n_streams, p.nn_stride, p.p_den(), p.q));
+    p.has_model = true;
     if (start_mode == AIDAX_START_WARMUP) {           // 2048 zeros through applyModel (:1077-1078)
-        LaunchArgs a = p.args(nullptr, nullptr, kWarmupFrames, MODE_WARMUP);
-        HIP_TRY(launch_stream_kernel(p.kernel, a, p.lds_bytes(0), p.q));
+        const uint32_t chunk = kind == aidax_pool::TABLE ? kWarmupFrames : p.ext_chunk();
+        for (uint32_t done = 0; done < kWarmupFrames; done += chunk) {
+            LaunchArgs a = p.args(nullptr, nullptr, std::min(chunk, kWarmupFrames - done), MODE_WARMUP);
+            HIP_TRY(p.launch(a, p.q));
+        }
     }
-    p.pipe_capacity = pipe_resident_streams(k, p.max_frames, p.device);
+    p.pipe_capacity = k ? pipe_resident_streams(k, p.max_frames, p.device) : 0;
     if (const char* f = std::getenv("AIDAX_KERNEL")) p.force_form = std::strcmp(f, "wave") == 0 ? 1 : std::strcmp(f, "pipe") == 0 ? 2 : 0;
     p.has_model = true;
     for (auto& l : p.loading) l = 0;                  // work_response: loading = false (:889)
@@ -326,8 +374,7 @@ AIDAX_API int aidax_pool_process_device(aidax_pool* p, const float* d_in, float*
         hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : p->q;
         p->flush_ctl(s);
         LaunchArgs a = p->args(d_in, d_out, n_frames, MODE_CHAIN);
-        if (p->use_pipe()) HIP_TRY(launch_pipe_kernel(p->kernel, a, s));
-        else HIP_TRY(launch_stream_kernel(p->has_model ? p->kernel : nullptr, a, p->lds_bytes(n_frames), s));
+        HIP_TRY(p->launch(a, s));
         return AIDAX_OK;
     });
 }
@@ -362,22 +409,27 @@ AIDAX_API int aidax_pool_sync(aidax_pool* p)
 AIDAX_API int aidax_pool_read_state(aidax_pool* p, uint32_t stream, int layer, float* h, float* c, uint32_t cap)
 {
     if (!p || !h) return fail(AIDAX_ERR_ARG, "null argument");
-    if (!p->has_model || stream >= p->n_streams || layer != 0) return fail(AIDAX_ERR_STATE, "no such state");
+    if (!p->has_model || stream >= p->n_streams || p->kind == aidax_pool::CONV) return fail(AIDAX_ERR_STATE, "no such state");
+    if (p->kind == aidax_pool::TABLE ? layer != 0 : (layer < 0 || layer >= p->sdesc.n_layers)) return fail(AIDAX_ERR_STATE, "no such layer");
     return guarded([&]() -> int {
         HIP_TRY(hipSetDevice(p->device));
         HIP_TRY(hipStreamSynchronize(p->q));
-        const uint32_t H = static_cast<uint32_t>(p->hidden);
+        const bool stack = p->kind == aidax_pool::STACK;
+        const uint32_t H = static_cast<uint32_t>(stack ? p->sdesc.L[layer].hidden : p->hidden);
         const uint32_t n = H < cap ? H : cap;
-        const float* base = p->d_nn + static_cast<size_t>(stream) * p->nn_stride;
+        const bool lstm = stack ? p->sdesc.L[layer].cell == 0 : p->kernel->cell == AIDAX_CELL_LSTM;
+        const float* base = p->d_nn + static_cast<size_t>(stream) * p->nn_stride + (stack ? p->sdesc.L[layer].state_off : 0);
         HIP_TRY(hipMemcpy(h, base, n * sizeof(float), hipMemcpyDeviceToHost));
-        if (c && p->kernel->cell == AIDAX_CELL_LSTM) HIP_TRY(hipMemcpy(c, base + H, n * sizeof(float), hipMemcpyDeviceToHost));
+        if (c && lstm) HIP_TRY(hipMemcpy(c, base + H, n * sizeof(float), hipMemcpyDeviceToHost));
         return static_cast<int>(H);
     });
 }
 
 AIDAX_API const char* aidax_pool_kernel_name(const aidax_pool* p)
 {
-    if (!(p && p->has_model && p->kernel)) return "k_nomodel";
+    if (!(p && p->has_model)) return "k_nomodel";
+    if (p->kind == aidax_pool::STACK) return "k_stack";
+    if (p->kind == aidax_pool::CONV) return "k_conv";
     return p->use_pipe() ? p->kernel->name_pipe : p->kernel->name;
 }
 
@@ -396,9 +448,14 @@ AIDAX_API int aidax_model_forward(const aidax_model* m, int device_id, const flo
             HIP_TRY(hipMalloc(&d_x, xb ? xb : 4));
             HIP_TRY(hipMalloc(&d_y, sizeof(float) * (n ? n : 1)));
             HIP_TRY(hipMemcpyAsync(d_x, X, xb, hipMemcpyHostToDevice, p->q));
-            LaunchArgs a = p->args(d_x, d_y, n, MODE_NN_ONLY);
-            if (unit_gains) { a.in_gain = 1.f; a.out_gain = 1.f; }
-            const hipError_t le = launch_stream_kernel(p->kernel, a, p->lds_bytes(0), p->q);
+            hipError_t le = hipSuccess;
+            const uint32_t chunk = p->kind == aidax_pool::TABLE ? (n ? n : 1) : 256u;
+            for (uint32_t done = 0; done < n && le == hipSuccess; done += chunk) {
+                LaunchArgs a = p->args(d_x + static_cast<size_t>(done) * m->input_size, d_y + done,
+                                       std::min(chunk, n - done), MODE_NN_ONLY);
+                if (unit_gains) { a.in_gain = 1.f; a.out_gain = 1.f; }
+                le = p->launch(a, p->q);
+            }
             if (le == hipSuccess) {
                 (void)hipMemcpyAsync(y, d_y, sizeof(float) * n, hipMemcpyDeviceToHost, p->q);
             }

@@ -149,15 +149,18 @@ template <bool VEC4>
 __device__ __forceinline__ void rows_accumulate(float (&acc)[kStackChunks][kStackStreams], const float* __restrict__ wt,
                                                 int R, int K, const float* v, int vstride, int tid)
 {
-    const int r0 = tid, r1 = tid + kStackThreads;
-    const bool has1 = r1 < R;
+    // rows past R are clamped to a valid row instead of predicated: their sums are never stored, and a
+    // guarded load costs a branch + exec save/restore per weight
+    const int r0 = tid < R ? tid : R - 1;
+    const int r1 = tid + kStackThreads < R ? tid + kStackThreads : R - 1;
     if constexpr (VEC4) {
+#pragma unroll 4
         for (int k = 0; k < K; k += 4) {
             float w0[4], w1[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                w0[i] = r0 < R ? wt[(size_t)(k + i) * R + r0] : 0.f;
-                w1[i] = has1 ? wt[(size_t)(k + i) * R + r1] : 0.f;
+                w0[i] = wt[(size_t)(k + i) * R + r0];
+                w1[i] = wt[(size_t)(k + i) * R + r1];
             }
 #pragma unroll
             for (int s = 0; s < kStackStreams; ++s) {
@@ -174,8 +177,8 @@ __device__ __forceinline__ void rows_accumulate(float (&acc)[kStackChunks][kStac
         }
     } else {
         for (int k = 0; k < K; ++k) {
-            const float w0 = r0 < R ? wt[(size_t)k * R + r0] : 0.f;
-            const float w1 = has1 ? wt[(size_t)k * R + r1] : 0.f;
+            const float w0 = wt[(size_t)k * R + r0];
+            const float w1 = wt[(size_t)k * R + r1];
 #pragma unroll
             for (int s = 0; s < kStackStreams; ++s) {
                 const float x = v[s * vstride + k];
@@ -305,19 +308,25 @@ __global__ __launch_bounds__(kStackThreads) void k_stack(LaunchArgs a, StackDesc
             }
             __syncthreads();
         }
-        if (tid < S) {                                           // Dense(H,1) + skip/out gain (:171-181)
+        {   // Dense(H,1) + skip/out gain (:171-181): wave w reduces streams 2w and 2w+1
             const int Hl = d.L[d.n_layers - 1].hidden;
-            const float* hv = hbuf + ((d.n_layers - 1) * S + tid) * HM;
-            float y = W[d.bd_off];
-            for (int u = 0; u < Hl; ++u) y = __builtin_fmaf(W[d.wd_off + u], hv[u], y);
-            const float x = vin[tid * 4];
-            float o = a.input_skip ? x + y : y;
-            o = o * a.out_gain;
-            if (livef[tid] != 0.f) {
-                if (a.mode == MODE_NN_ONLY) { if (s_base + tid == 0) a.out[t] = o; }
-                else xbuf[tid * nP + t] = o;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int sl = wave * 2 + j;
+                const float* hv = hbuf + ((d.n_layers - 1) * S + sl) * HM;
+                float part = 0.f;
+                for (int u = lane; u < Hl; u += kWave) part = __builtin_fmaf(W[d.wd_off + u], hv[u], part);
+                const float y = wave_sum(part) + W[d.bd_off];
+                const float x = vin[sl * 4];
+                float o = a.input_skip ? x + y : y;
+                o = o * a.out_gain;
+                if (lane == 0 && livef[sl] != 0.f) {
+                    if (a.mode == MODE_NN_ONLY) { if (s_base + sl == 0) a.out[t] = o; }
+                    else xbuf[sl * nP + t] = o;
+                }
             }
         }
+        __syncthreads();                                         // vin is rewritten at the top of the next frame
     }
     __syncthreads();
     // recurrent state back to HBM for committed streams
@@ -344,11 +353,15 @@ __global__ __launch_bounds__(kStackThreads) void k_stack(LaunchArgs a, StackDesc
 }
 
 // ====================================================================== k_conv
-// LDS: two activation planes [hist_max + n][C] + the stream's audio block.
+// LDS: two activation planes, channel-major [C][hist_max + n (+pad)] so that the 64 lanes of a wave
+// (consecutive frames) read consecutive LDS words, + the stream's audio block.
+constexpr int kConvCo = 16;                      // output channels are padded to 16 accumulators
+constexpr int kConvWStage = 8 * 16 * kConvCo + kConvCo;   // one layer's kernel [k<=8][in<=16][16] + bias, staged in LDS
+__host__ __device__ inline int conv_plane_stride(int max_hist, int n_frames) { return ((max_hist + n_frames + 3) & ~3) + 1; }
 __host__ __device__ inline size_t conv_lds_floats(const ConvDesc& d, int n_frames)
 {
     const size_t nP = (size_t)((n_frames + 3) & ~3);
-    return nP + nP * 2 + 2 * (size_t)(d.max_hist + n_frames) * d.channels + 64;
+    return nP + nP * 2 + 2 * (size_t)conv_plane_stride(d.max_hist, n_frames) * d.channels + 64 + kConvWStage;
 }
 
 __global__ __launch_bounds__(kStackThreads) void k_conv(LaunchArgs a, ConvDesc d)
@@ -361,13 +374,15 @@ __global__ __launch_bounds__(kStackThreads) void k_conv(LaunchArgs a, ConvDesc d
     const int nP = (n + 3) & ~3;
     const int sg = blockIdx.x;
     const int C = d.channels;
-    const size_t plane = (size_t)(d.max_hist + n) * C;
+    const int F = conv_plane_stride(d.max_hist, n);          // frames per channel row
+    const size_t plane = (size_t)F * C;
 
     float* buf = smem;                      // audio block, chain in place
     float* pq = buf + nP;                   // PARAM ramps (kept for interface symmetry; conv models have I = 1..3)
     float* pa = pq + nP * 2;                // activation plane A
     float* pb = pa + plane;                 // activation plane B
     float* shared_flag = pb + plane;
+    float* wst = shared_flag + 64;          // staged weights of the current layer, [k][in][16] then bias[16]
 
     const bool bare = a.mode != MODE_CHAIN;
     ChainCtx ctx;
@@ -395,8 +410,9 @@ __global__ __launch_bounds__(kStackThreads) void k_conv(LaunchArgs a, ConvDesc d
         // layer-0 input plane: [hist0 | x*in_gain], one channel per input (audio only; params unsupported here)
         {
             const ConvLayer& L0 = d.L[0];
-            for (int i = tid; i < L0.hist * L0.in_ch; i += kStackThreads) cur[i] = hist_base[L0.state_off + i];
-            for (int t = tid; t < n; t += kStackThreads) cur[(L0.hist + t) * L0.in_ch] = buf[t] * a.in_gain;
+            for (int i = tid; i < L0.hist * L0.in_ch; i += kStackThreads)          // history kept as [ch][hist]
+                cur[(i / L0.hist) * F + (i % L0.hist)] = hist_base[L0.state_off + i];
+            for (int t = tid; t < n; t += kStackThreads) cur[L0.hist + t] = buf[t] * a.in_gain;
         }
         __syncthreads();
         for (int l = 0; l < d.n_layers; ++l) {
@@ -406,36 +422,55 @@ __global__ __launch_bounds__(kStackThreads) void k_conv(LaunchArgs a, ConvDesc d
             // next layer's history prefix
             if (l + 1 < d.n_layers) {
                 const ConvLayer& N = d.L[l + 1];
-                for (int i = tid; i < N.hist * N.in_ch; i += kStackThreads) nxt[i] = hist_base[N.state_off + i];
+                for (int i = tid; i < N.hist * N.in_ch; i += kStackThreads)
+                    nxt[(i / N.hist) * F + (i % N.hist)] = hist_base[N.state_off + i];
             }
+            // stage this layer's kernel + bias in LDS (zero-padded to 16 outputs): every thread reads the
+            // same weights, so they come back as LDS broadcasts instead of one global load per FMA
+            for (int i = tid; i < L.ksize * Ci * kConvCo; i += kStackThreads) {
+                const int o = i % kConvCo, ki = i / kConvCo;
+                wst[i] = o < Co ? W[L.w_off + (size_t)ki * Co + o] : 0.f;
+            }
+            if (tid < kConvCo) wst[L.ksize * Ci * kConvCo + tid] = tid < Co ? W[L.b_off + tid] : 0.f;
+            __syncthreads();
+            const float4* bias4 = reinterpret_cast<const float4*>(wst + L.ksize * Ci * kConvCo);
             for (int t = tid; t < n; t += kStackThreads) {
-                float acc[16];
+                float acc[kConvCo];
 #pragma unroll
-                for (int o = 0; o < 16; ++o) acc[o] = o < Co ? W[L.b_off + o] : 0.f;
+                for (int q = 0; q < kConvCo / 4; ++q) {
+                    const float4 b = bias4[q];
+                    acc[4 * q] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
+                }
                 for (int k = 0; k < L.ksize; ++k) {
-                    const float* xs = cur + (size_t)(Hs + t - (L.ksize - 1 - k) * L.dilation) * Ci;
-                    const float* wk = W + L.w_off + (size_t)k * Ci * Co;
+                    const float* xs = cur + (Hs + t - (L.ksize - 1 - k) * L.dilation);
+                    const float4* wk = reinterpret_cast<const float4*>(wst + (size_t)k * Ci * kConvCo);
                     for (int i = 0; i < Ci; ++i) {
-                        const float xi = xs[i];
+                        const float xi = xs[(size_t)i * F];
 #pragma unroll
-                        for (int o = 0; o < 16; ++o)
-                            if (o < Co) acc[o] = __builtin_fmaf(wk[i * Co + o], xi, acc[o]);
+                        for (int q = 0; q < kConvCo / 4; ++q) {
+                            const float4 w = wk[i * (kConvCo / 4) + q];
+                            acc[4 * q]     = __builtin_fmaf(w.x, xi, acc[4 * q]);
+                            acc[4 * q + 1] = __builtin_fmaf(w.y, xi, acc[4 * q + 1]);
+                            acc[4 * q + 2] = __builtin_fmaf(w.z, xi, acc[4 * q + 2]);
+                            acc[4 * q + 3] = __builtin_fmaf(w.w, xi, acc[4 * q + 3]);
+                        }
                     }
                 }
 #pragma unroll
-                for (int o = 0; o < 16; ++o) {
+                for (int o = 0; o < kConvCo; ++o) {
                     if (o < Co) {
                         float v = acc[o];
                         if (L.activation == 1) v = tanh_rat(v);
                         else if (L.activation == 2) v = v > 0.f ? v : 0.f;
                         else if (L.activation == 3) v = fast_sigmoid(v);
-                        nxt[(size_t)(next_hist + t) * Co + o] = v;
+                        nxt[(size_t)o * F + next_hist + t] = v;
                     }
                 }
             }
             __syncthreads();
             // this layer's new history: the last Hs frames of [old history | this block's inputs]
-            for (int i = tid; i < Hs * Ci; i += kStackThreads) hist_base[L.state_off + i] = cur[(size_t)n * Ci + i];
+            for (int i = tid; i < Hs * Ci; i += kStackThreads)
+                hist_base[L.state_off + i] = cur[(i / Hs) * F + n + (i % Hs)];
             __syncthreads();
             float* tmp = cur; cur = nxt; nxt = tmp;
         }
@@ -443,7 +478,7 @@ __global__ __launch_bounds__(kStackThreads) void k_conv(LaunchArgs a, ConvDesc d
         const int Cl = d.L[d.n_layers - 1].out_ch;
         for (int t = tid; t < n; t += kStackThreads) {
             float y = W[d.bd_off];
-            for (int o = 0; o < Cl; ++o) y = __builtin_fmaf(W[d.wd_off + o], cur[(size_t)t * Cl + o], y);
+            for (int o = 0; o < Cl; ++o) y = __builtin_fmaf(W[d.wd_off + o], cur[(size_t)o * F + t], y);
             const float x = buf[t] * a.in_gain;
             float o2 = a.input_skip ? x + y : y;
             o2 = o2 * a.out_gain;

@@ -123,7 +123,9 @@ struct LstmCell {
         return d;
     }
 
-    // one sample: reads h(t-1) from hprev[0..H), leaves h(t) in registers and at hout[0..H)
+    // one sample: reads h(t-1) from hprev[0..H), leaves h(t) in registers and at hout[0..H).
+    // NI = inputs that can be non-zero (the packer zero-fills the weights of absent inputs).
+    template <int NI = kMaxInputs>
     __device__ __forceinline__ void step(float x0, float x1, float x2, const float* hprev, float* hout)
     {
         float acc[NU][GPL];
@@ -133,8 +135,8 @@ struct LstmCell {
             for (int e = 0; e < GPL; ++e) {
                 float a = bias[m][e];
                 a = __builtin_fmaf(wx[m][e][0], x0, a);
-                a = __builtin_fmaf(wx[m][e][1], x1, a);
-                a = __builtin_fmaf(wx[m][e][2], x2, a);
+                if constexpr (NI >= 2) a = __builtin_fmaf(wx[m][e][1], x1, a);
+                if constexpr (NI >= 3) a = __builtin_fmaf(wx[m][e][2], x2, a);
                 acc[m][e] = a;
             }
         const float4* hv = reinterpret_cast<const float4*>(hprev);
@@ -263,6 +265,7 @@ struct GruCell {
         return d;
     }
 
+    template <int NI = kMaxInputs>
     __device__ __forceinline__ void step(float x0, float x1, float x2, const float* hprev, float* hout)
     {
         float ax[NU][3], ar[NU][3];
@@ -272,8 +275,8 @@ struct GruCell {
             for (int e = 0; e < 3; ++e) {
                 float a = bias[m][e];
                 a = __builtin_fmaf(wx[m][e][0], x0, a);
-                a = __builtin_fmaf(wx[m][e][1], x1, a);
-                a = __builtin_fmaf(wx[m][e][2], x2, a);
+                if constexpr (NI >= 2) a = __builtin_fmaf(wx[m][e][1], x1, a);
+                if constexpr (NI >= 3) a = __builtin_fmaf(wx[m][e][2], x2, a);
                 ax[m][e] = a;
                 ar[m][e] = e == 2 ? bn1[m] : 0.f;
             }
@@ -486,7 +489,7 @@ __device__ __forceinline__ void stream_body(const LaunchArgs& a, float* smem)
 //             wave Q  Dense + skip/out gain + post pass of p-2    -> global out
 //   one workgroup barrier per phase; the N wave keeps weights, c and h in registers throughout.
 // ======================================================================
-constexpr int kSB = 32;                 // frames per pipeline stage
+constexpr int kSB = 16;                 // frames per pipeline stage
 constexpr int kRing = 2 * kSB;          // rows of the h history ring
 constexpr int kPipeWaves = 3;
 
@@ -615,14 +618,28 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
                 const int base = (p - 1) * kSB;
                 const int cnt = n - base < kSB ? n - base : kSB;
                 const float4* stage = xq + ((p - 1) % 3) * kSB;
-                float4 in = stage[0];
-                for (int t = 0; t < cnt; ++t) {
-                    const float4 cur = in;
-                    in = stage[t + 1 < cnt ? t + 1 : t];                    // prefetch the next frame's inputs
-                    const int g = base + t;
-                    const float x = cur.x * a.in_gain;                      // out[i] *= input_gain
-                    cell.step(x, I >= 2 ? cur.y : 0.f, I >= 3 ? cur.z : 0.f,
-                              hh + ((g + kRing - 1) & (kRing - 1)) * HS, hh + (g & (kRing - 1)) * HS);
+                // rows of one sub-block are contiguous in the ring (base is a multiple of kSB)
+                const float* hprev = hh + ((base + kRing - 1) & (kRing - 1)) * HS;
+                float* hcur = hh + (base & (kRing - 1)) * HS;
+                const float in_gain = a.in_gain;
+                if (I == 1) {                                   // snapshot models: one scalar input per frame
+                    float xin = stage[0].x;
+                    for (int t = 0; t < cnt; ++t) {
+                        const float x = xin * in_gain;          // out[i] *= input_gain
+                        xin = stage[t + 1].x;                   // prefetch (one past the stage is still ring memory)
+                        cell.template step<1>(x, 0.f, 0.f, hprev, hcur);
+                        hprev = hcur;
+                        hcur += HS;
+                    }
+                } else {
+                    float4 in = stage[0];
+                    for (int t = 0; t < cnt; ++t) {
+                        const float4 cur = in;
+                        in = stage[t + 1];
+                        cell.template step<3>(cur.x * in_gain, cur.y, I >= 3 ? cur.z : 0.f, hprev, hcur);
+                        hprev = hcur;
+                        hcur += HS;
+                    }
                 }
             }
         } else {

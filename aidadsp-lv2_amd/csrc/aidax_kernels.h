@@ -11,13 +11,17 @@ struct KernelEntry {
     int cell, hidden;
     void (*fn)(LaunchArgs);           // one wavefront per stream (throughput form)
     void (*fn_pipe)(LaunchArgs);      // three wavefronts per stream (latency form)
+    void (*fn_nn)(LaunchArgs);        // recurrent cell only, between the two packed chain launches (split form)
     int pack_regs, state_floats;
     const char* name;
     const char* name_pipe;
+    const char* name_split;
 };
 
 const KernelEntry* find_kernel(int cell, int hidden);
 hipError_t launch_stream_kernel(const KernelEntry* e, const LaunchArgs& a, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_split_kernels(const KernelEntry* e, const LaunchArgs& a, hipStream_t stream);
+bool split_form_pays(const KernelEntry* e, uint32_t n_frames);
 size_t pipe_lds_bytes(int hidden, uint32_t n_frames);
 hipError_t launch_pipe_kernel(const KernelEntry* e, const LaunchArgs& a, hipStream_t stream);
 int pipe_resident_streams(const KernelEntry* e, uint32_t n_frames, int device);

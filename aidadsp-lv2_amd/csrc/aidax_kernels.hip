@@ -125,7 +125,9 @@ struct LstmCell {
 
     // one sample: reads h(t-1) from hprev[0..H), leaves h(t) in registers and at hout[0..H).
     // NI = inputs that can be non-zero (the packer zero-fills the weights of absent inputs).
-    template <int NI = kMaxInputs>
+    // WINDOW > 0 fences the scheduler every WINDOW float4 loads of h, bounding the registers held by
+    // in-flight LDS reads (the many-streams kernels trade that latency for occupancy); 0 = all at once.
+    template <int NI = kMaxInputs, int WINDOW = 0>
     __device__ __forceinline__ void step(float x0, float x1, float x2, const float* hprev, float* hout)
     {
         float acc[NU][GPL];
@@ -154,6 +156,7 @@ struct LstmCell {
                     a = __builtin_fmaf(w[m][e][4 * k4 + 3], q.w, a);
                     acc[m][e] = a;
                 }
+            if constexpr (WINDOW > 0) { if ((k4 + 1) % WINDOW == 0) __builtin_amdgcn_sched_barrier(0); }
         }
         __builtin_amdgcn_wave_barrier();                    // all reads of h(t-1) precede the publish below
 #pragma unroll
@@ -265,7 +268,7 @@ struct GruCell {
         return d;
     }
 
-    template <int NI = kMaxInputs>
+    template <int NI = kMaxInputs, int WINDOW = 0>
     __device__ __forceinline__ void step(float x0, float x1, float x2, const float* hprev, float* hout)
     {
         float ax[NU][3], ar[NU][3];
@@ -295,6 +298,7 @@ struct GruCell {
                     a = __builtin_fmaf(w[m][e][4 * k4 + 3], q.w, a);
                     ar[m][e] = a;
                 }
+            if constexpr (WINDOW > 0) { if ((k4 + 1) % WINDOW == 0) __builtin_amdgcn_sched_barrier(0); }
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -650,6 +654,7 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
                 const float xin = xq[((p - 2) % 3) * kSB + tl].x;
                 float o = xin;
                 if (net_on) {
+                    asm volatile("" ::: "memory");          // do not hoist the Dense weights out of the phase loop
                     const float4* row = reinterpret_cast<const float4*>(hh + ((base + tl) & (kRing - 1)) * HS);
                     const float4* w4 = reinterpret_cast<const float4*>(wdl);
                     float y = wdl[H];                                       // Dense bias
@@ -712,6 +717,221 @@ __global__ __launch_bounds__(kPipeWaves * kWave) void k_gru_pipe(LaunchArgs a)
     stream_body_pipe<GruCell<H>>(a, smem);
 }
 
+
+// ======================================================================
+// Split form (3 launches) — the many-streams form.
+//
+// Once every SIMD holds several waves, the limit is instructions issued per sample, and the
+// one-wave-per-stream kernel spends 112 of its ~300 instructions per sample on two systolic
+// biquad passes that keep 1..6 of 64 lanes busy. HBM is nowhere near a limit (two extra trips
+// of the audio block cost microseconds), so the chain is split into its own launches where
+// one wave carries the chains of EIGHT streams side by side (8 lanes per stream, DPP row
+// shifts never cross a stream's lane group), and the recurrent kernel keeps only the cell
+// plus a lane-parallel Dense per 16 frames:
+//     k_chain<true>   in  -> out : LPF -> pre-gain ramp -> EQ(pre)      8 streams / wave
+//     k_nn<Cell>      out -> out : applyModel                           1 stream  / wave
+//     k_chain<false>  out -> out : DC blocker -> EQ(post) -> master     8 streams / wave
+// ======================================================================
+constexpr int kChainStreams = 8;         // streams per wave in k_chain (8 lanes each)
+
+template <bool PRE>
+__global__ __launch_bounds__(kWave) void k_chain(LaunchArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int grp = lane >> 3, stage = lane & 7;
+    const int n = (int)a.n_frames;
+    const int nP = (n + 3) & ~3;
+    const int sg = blockIdx.x * kChainStreams + grp;
+    const bool valid = sg < (int)a.n_streams;
+    const int sc = valid ? sg : (int)a.n_streams - 1;          // clamp: invalid groups shadow the last stream, never store
+
+    const StreamCtl& ctl = a.ctl[sc];
+    StreamState& st = a.st[sc];
+    const uint32_t flags = ctl.flags;
+    const uint32_t pending0 = st.pending;
+    const bool live = valid && n != 0 && (flags & CTL_ENABLED);
+
+    // rows -> LDS, one coalesced row at a time (PRE reads the input block, POST works in place on out)
+    for (int g = 0; g < kChainStreams; ++g) {
+        const int s2 = blockIdx.x * kChainStreams + g;
+        if (s2 < (int)a.n_streams && n != 0)
+            load_block(smem + g * nP, (PRE ? a.in : a.out) + (size_t)s2 * n, n, lane);
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    ChainPass c;
+    const bool eq = flags & (PRE ? CTL_EQ_PRE : CTL_EQ_POST);
+    c.K = eq ? 6 : 1;
+    c.gain_lane = PRE ? 0 : c.K - 1;
+    const int k = stage < c.K ? stage : 0;
+    const int slot = PRE ? pre_slot(k) : post_slot(k);
+    const bool act = k == 0 ? (flags & (PRE ? CTL_LPF_ON : CTL_DC_ON)) != 0
+                            : ((flags & CTL_EQ_BANDPASS) ? slot == BQ_MID : true);
+    chain_load(c, ctl, st, slot, act);
+    float mem = PRE ? st.pre_mem : st.master_mem;
+    float tgt = PRE ? st.pre_tgt : st.master_tgt;
+    if (pending0 & PEND_ACTIVATE) mem = tgt;                   // activate(): clearToTargetValue (:341-342)
+    if (PRE) tgt = ctl.pre_target;                             // :513, before every early-out
+    else if (live) tgt = ctl.master_target;                    // :654, only on the DSP path
+    c.g.arm(mem, tgt, PRE ? ctl.pre_coef : ctl.master_coef);
+
+    if (n != 0) {
+        float* buf = smem + grp * nP;
+        float carry = 0.f;
+        const int steps = n + 5;
+        for (int s = 0; s < steps; ++s) {
+            const float head = buf[s < n ? s : n - 1];
+            const float from_left = dpp_row_shr1(carry);
+            const float x = stage == 0 ? head : from_left;
+            const int idx = s - stage;
+            if (live && stage < c.K && idx >= 0 && idx < n) {
+                float y = x;
+                if (c.active) {                                 // Biquad::process, Biquad.h:53-58
+                    const double xd = x;
+                    const double yd = xd * c.a0 + c.z1;
+                    c.z1 = xd * c.a1 + c.z2 - c.b1 * yd;
+                    c.z2 = xd * c.a2 - c.b2 * yd;
+                    y = (float)yd;
+                }
+                const float gm = c.g.next();
+                if (stage == c.gain_lane) y = y * gm;
+                carry = y;
+                if (stage == c.K - 1) buf[idx] = y;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // PRE: every valid row goes to out (a disabled stream's row is still the raw input: the hard
+        // bypass copy of :612-619); POST: only rows that were processed
+        for (int g = 0; g < kChainStreams; ++g) {
+            const int s2 = blockIdx.x * kChainStreams + g;
+            if (s2 >= (int)a.n_streams) continue;
+            const bool row_live = (a.ctl[s2].flags & CTL_ENABLED) != 0;
+            if (PRE ? (row_live || a.out != a.in) : row_live)
+                store_block(a.out + (size_t)s2 * n, smem + g * nP, n, lane);
+        }
+    }
+    if (!valid) return;
+    if (live && stage < c.K) { st.z[slot][0] = c.z1; st.z[slot][1] = c.z2; }
+    if (stage == c.gain_lane) {
+        const float m_out = live ? c.g.mem : mem;
+        if (PRE) { st.pre_mem = m_out; st.pre_tgt = tgt; }
+        else { st.master_mem = m_out; st.master_tgt = tgt; st.pending = st.pending & ~PEND_ACTIVATE; }
+    }
+}
+
+constexpr int kNnSub = 16;               // frames between lane-parallel Dense passes in k_nn
+constexpr int kNnRing = 2 * kNnSub;
+constexpr int kNnWindow = 4;             // float4 h loads in flight per scheduling window (16 VGPRs)
+
+__host__ __device__ constexpr size_t nn_lds_floats(int H, int n_frames)
+{
+    return (size_t)((n_frames + 3) & ~3) + (size_t)kNnRing * pipe_row_stride(H) + (size_t)(H + 4);
+}
+
+template <class Cell>
+__global__ __launch_bounds__(kWave) void k_nn(LaunchArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int H = Cell::HID;
+    constexpr int HS = pipe_row_stride(H);
+    const int lane = threadIdx.x;
+    const int s = blockIdx.x;
+    const int n = (int)a.n_frames;
+    const StreamCtl& ctl = a.ctl[s];
+    StreamState& st = a.st[s];
+    const uint32_t flags = ctl.flags;
+    if (n == 0 || !(flags & CTL_ENABLED) || !(flags & CTL_NET_ON)) return;      // :607-619, :631-632
+
+    float* buf = smem;
+    float* hh = smem + ((n + 3) & ~3);
+    float* wdl = hh + kNnRing * HS;
+    float* row = a.out + (size_t)s * n;
+    load_block(buf, row, n, lane);
+    const float* wd_nat = a.wpack + (size_t)Cell::PACK * kWave;
+    for (int i = lane; i < H + 1; i += kWave) wdl[i] = wd_nat[i];
+
+    float p_mem[2] = { st.p_mem[0], st.p_mem[1] };
+    float p_tgt[2] = { st.p_tgt[0], st.p_tgt[1] };
+    float p_step[2] = { st.p_step[0], st.p_step[1] };
+    uint32_t pending = st.pending;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                    // LinearValueSmoother::setTargetValue (:209-216)
+        const float nt = ctl.p_target[i];
+        if (__builtin_fabsf(p_tgt[i] - nt) >= FLT_EPSILON) {
+            p_tgt[i] = nt;
+            p_step[i] = (p_tgt[i] - p_mem[i]) / ctl.p_den;
+        }
+    }
+    if (pending & PEND_PARAM_FIRST) {                // paramFirstRun (:636-640)
+        pending &= ~PEND_PARAM_FIRST;
+        p_mem[0] = p_tgt[0];
+        p_mem[1] = p_tgt[1];
+    }
+    Cell cell;
+    float* nnst = a.nn + (size_t)s * a.nn_stride;
+    cell.load(a.wpack, nnst, lane);
+    cell.publish_h(hh + (kNnRing - 1) * HS);
+    __builtin_amdgcn_wave_barrier();
+
+    const int I = a.input_size;
+    const float in_gain = a.in_gain;
+    for (int base = 0; base < n; base += kNnSub) {
+        const int cnt = n - base < kNnSub ? n - base : kNnSub;
+        const float* hprev = hh + ((base + kNnRing - 1) & (kNnRing - 1)) * HS;
+        float* hcur = hh + (base & (kNnRing - 1)) * HS;
+        if (I == 1) {
+            float xin = buf[base];
+            for (int t = 0; t < cnt; ++t) {
+                const float x = xin * in_gain;
+                xin = buf[base + t + 1 < n ? base + t + 1 : base + t];
+                cell.template step<1, kNnWindow>(x, 0.f, 0.f, hprev, hcur);
+                hprev = hcur;
+                hcur += HS;
+            }
+        } else {
+            for (int t = 0; t < cnt; ++t) {
+                const float x = buf[base + t] * in_gain;
+                const float q1 = lin_next(p_mem[0], p_tgt[0], p_step[0]);
+                const float q2 = I >= 3 ? lin_next(p_mem[1], p_tgt[1], p_step[1]) : 0.f;
+                cell.template step<3, kNnWindow>(x, q1, q2, hprev, hcur);
+                hprev = hcur;
+                hcur += HS;
+            }
+        }
+        // Dense(H,1) + skip + output gain for these frames, one lane per frame. The clobber keeps the
+        // compiler from hoisting the H loop-invariant Dense weights into registers for the whole kernel.
+        asm volatile("" ::: "memory");
+        const int tl = lane < cnt ? lane : cnt - 1;
+        const float4* hrow = reinterpret_cast<const float4*>(hh + ((base + tl) & (kNnRing - 1)) * HS);
+        const float4* w4 = reinterpret_cast<const float4*>(wdl);
+        float y = wdl[H];
+#pragma unroll
+        for (int k4 = 0; k4 < H / 4; ++k4) {
+            const float4 w = w4[k4];
+            const float4 hv = hrow[k4];
+            y = __builtin_fmaf(w.x, hv.x, y);
+            y = __builtin_fmaf(w.y, hv.y, y);
+            y = __builtin_fmaf(w.z, hv.z, y);
+            y = __builtin_fmaf(w.w, hv.w, y);
+        }
+        const float xg = buf[base + tl] * in_gain;
+        float o = a.input_skip ? xg + y : y;
+        o = o * a.out_gain;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < cnt) buf[base + lane] = o;
+        __builtin_amdgcn_wave_barrier();
+    }
+    store_block(row, buf, n, lane);
+    cell.store(nnst);
+    if (lane == 0) {
+        st.p_mem[0] = p_mem[0]; st.p_mem[1] = p_mem[1];
+        st.p_tgt[0] = p_tgt[0]; st.p_tgt[1] = p_tgt[1];
+        st.p_step[0] = p_step[0]; st.p_step[1] = p_step[1];
+        st.pending = pending;
+    }
+}
+
 struct NoCell { static constexpr int PACK = 0, STATE = 0; };
 
 template <int H>
@@ -762,8 +982,8 @@ __global__ void k_reset_for_model(StreamState* st, float* nn, uint32_t n_streams
 }
 
 // ------------------------------------------------------------ host dispatch
-#define AIDAX_LSTM(H) { 0, H, k_lstm<H>, k_lstm_pipe<H>, LstmCell<H>::PACK, LstmCell<H>::STATE, "k_lstm<" #H ">", "k_lstm_pipe<" #H ">" }
-#define AIDAX_GRU(H)  { 1, H, k_gru<H>,  k_gru_pipe<H>,  GruCell<H>::PACK,  GruCell<H>::STATE,  "k_gru<" #H ">", "k_gru_pipe<" #H ">" }
+#define AIDAX_LSTM(H) { 0, H, k_lstm<H>, k_lstm_pipe<H>, k_nn<LstmCell<H>>, LstmCell<H>::PACK, LstmCell<H>::STATE, "k_lstm<" #H ">", "k_lstm_pipe<" #H ">", "k_chain+k_nn<lstm" #H ">" }
+#define AIDAX_GRU(H)  { 1, H, k_gru<H>,  k_gru_pipe<H>,  k_nn<GruCell<H>>,  GruCell<H>::PACK,  GruCell<H>::STATE,  "k_gru<" #H ">", "k_gru_pipe<" #H ">", "k_chain+k_nn<gru" #H ">" }
 
 static const KernelEntry kTable[] = {
     // the 18 (cell, hidden) pairs of variant/generate_variant_hpp.py:4-6; input size is a run-time argument
@@ -785,6 +1005,35 @@ hipError_t launch_stream_kernel(const KernelEntry* e, const LaunchArgs& a, size_
     void (*fn)(LaunchArgs) = e ? e->fn : k_nomodel;
     hipLaunchKernelGGL(fn, dim3(a.n_streams), dim3(kWave), lds_bytes, stream, a);
     return hipGetLastError();
+}
+
+// Split form: pre chain (8 streams/wave) -> recurrent cell -> post chain, in place on `out`
+hipError_t launch_split_kernels(const KernelEntry* e, const LaunchArgs& a, hipStream_t stream)
+{
+    const uint32_t groups = (a.n_streams + kChainStreams - 1) / kChainStreams;
+    const size_t chain_lds = (size_t)kChainStreams * ((a.n_frames + 3) & ~3u) * sizeof(float);
+    hipLaunchKernelGGL(k_chain<true>, dim3(groups), dim3(kWave), chain_lds, stream, a);
+    if (e && a.n_frames != 0)
+        hipLaunchKernelGGL(e->fn_nn, dim3(a.n_streams), dim3(kWave), nn_lds_floats(e->hidden, (int)a.n_frames) * sizeof(float), stream, a);
+    hipLaunchKernelGGL(k_chain<false>, dim3(groups), dim3(kWave), chain_lds, stream, a);
+    return hipGetLastError();
+}
+
+// Is the split form the better many-streams form for this cell? Yes when the lean recurrent kernel still
+// gets >= 2 waves per SIMD (measured: LSTM-16 1.56x, LSTM-32 1.40x at 16384 streams) or at least the
+// occupancy of the one-wave-per-stream kernel, and does not spill where that one does not. The widest
+// cells (GRU-64: 254 vs 350 registers) lose their second wave per SIMD and stay on the one-wave form.
+bool split_form_pays(const KernelEntry* e, uint32_t n_frames)
+{
+    int occ_wave = 0, occ_nn = 0;
+    const size_t lds_wave = ((size_t)((n_frames + 3) & ~3u) + (size_t)e->hidden) * sizeof(float);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_wave, e->fn, kWave, lds_wave) != hipSuccess) return false;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_nn, e->fn_nn, kWave, nn_lds_floats(e->hidden, (int)n_frames) * sizeof(float)) != hipSuccess) return false;
+    hipFuncAttributes aw{}, an{};
+    if (hipFuncGetAttributes(&aw, reinterpret_cast<const void*>(e->fn)) != hipSuccess) return false;
+    if (hipFuncGetAttributes(&an, reinterpret_cast<const void*>(e->fn_nn)) != hipSuccess) return false;
+    if (an.localSizeBytes > aw.localSizeBytes) return false;
+    return occ_nn >= occ_wave || occ_nn >= 8;          // blocks of one wave per CU: 8 = two waves per SIMD
 }
 
 size_t pipe_lds_bytes(int hidden, uint32_t n_frames) { return pipe_lds_floats(hidden, (int)n_frames) * sizeof(float); }

@@ -94,11 +94,24 @@ struct aidax_pool {
     float in_gain = 1.f, out_gain = 1.f, model_sr = 48000.f;
     uint32_t nn_stride = 0;
     int pipe_capacity = 0;           // streams the 3-wave pipeline keeps resident at once (0 = never use it)
-    int force_form = 0;              // AIDAX_KERNEL=wave|pipe overrides the heuristic (A/B testing)
+    bool split_pays = false;         // the lean recurrent kernel keeps the occupancy of the one-wave kernel
+    int force_form = 0;              // AIDAX_KERNEL=wave|pipe|split overrides the heuristic (A/B testing)
+    // Form of a MODE_CHAIN pass: 0 one wave per stream, 1 three-wave pipeline (all streams resident at
+    // once: latency-bound regime), 2 split launches with packed chains (many streams: issue-bound regime)
+    int chain_form() const
+    {
+        if (kind != TABLE) return 0;
+        if (force_form == 1) return 0;
+        if (force_form == 2) return (has_model && kernel) ? 1 : 0;
+        if (force_form == 3) return 2;
+        if (use_pipe()) return 1;
+        if (n_streams < 64) return 0;
+        return (!has_model || split_pays) ? 2 : 0;
+    }
     bool use_pipe() const
     {
         if (!has_model || !kernel || kind != TABLE) return false;
-        if (force_form == 1) return false;
+        if (force_form == 1 || force_form == 3) return false;
         if (force_form == 2) return true;
         return static_cast<int>(n_streams) <= pipe_capacity;
     }
@@ -149,7 +162,8 @@ struct aidax_pool {
     {
         if (has_model && kind == STACK) return launch_stack_kernel(a, sdesc, s);
         if (has_model && kind == CONV) return launch_conv_kernel(a, cdesc, s);
-        if (a.mode == MODE_CHAIN && use_pipe()) return launch_pipe_kernel(kernel, a, s);
+        if (a.mode == MODE_CHAIN && chain_form() == 1) return launch_pipe_kernel(kernel, a, s);
+        if (a.mode == MODE_CHAIN && chain_form() == 2) return launch_split_kernels(has_model ? kernel : nullptr, a, s);
         return launch_stream_kernel(has_model ? kernel : nullptr, a, lds_bytes(a.mode == MODE_CHAIN ? a.n_frames : 0), s);
     }
     void release()
@@ -251,7 +265,7 @@ int set_model_impl(aidax_pool& p, const aidax_model* m, int start_mode)
         }
     }
     p.pipe_capacity = k ? pipe_resident_streams(k, p.max_frames, p.device) : 0;
-    if (const char* f = std::getenv("AIDAX_KERNEL")) p.force_form = std::strcmp(f, "wave") == 0 ? 1 : std::strcmp(f, "pipe") == 0 ? 2 : 0;
+    p.split_pays = k ? split_form_pays(k, p.max_frames) : false;
     p.has_model = true;
     for (auto& l : p.loading) l = 0;                  // work_response: loading = false (:889)
     p.refresh_all();
@@ -280,6 +294,8 @@ AIDAX_API int aidax_pool_create(uint32_t n_streams, uint32_t max_frames, double 
         p->max_frames = max_frames;
         p->host_sr = host_samplerate;
         p->gain_coef = exp_smoother_coef(static_cast<float>(host_samplerate), 0.1f);
+        if (const char* f = std::getenv("AIDAX_KERNEL"))
+            p->force_form = std::strcmp(f, "wave") == 0 ? 1 : std::strcmp(f, "pipe") == 0 ? 2 : std::strcmp(f, "split") == 0 ? 3 : 0;
         try {
             HIP_TRY(hipSetDevice(device_id));
             HIP_TRY(hipStreamCreateWithFlags(&p->q, hipStreamNonBlocking));
@@ -430,7 +446,8 @@ AIDAX_API const char* aidax_pool_kernel_name(const aidax_pool* p)
     if (!(p && p->has_model)) return "k_nomodel";
     if (p->kind == aidax_pool::STACK) return "k_stack";
     if (p->kind == aidax_pool::CONV) return "k_conv";
-    return p->use_pipe() ? p->kernel->name_pipe : p->kernel->name;
+    const int form = p->chain_form();
+    return form == 1 ? p->kernel->name_pipe : form == 2 ? p->kernel->name_split : p->kernel->name;
 }
 
 AIDAX_API int aidax_model_forward(const aidax_model* m, int device_id, const float* X, float* y, uint32_t n, int unit_gains)

@@ -658,7 +658,7 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
                     const float4* row = reinterpret_cast<const float4*>(hh + ((base + tl) & (kRing - 1)) * HS);
                     const float4* w4 = reinterpret_cast<const float4*>(wdl);
                     float y = wdl[H];                                       // Dense bias
-#pragma unroll
+#pragma unroll 2                                   // see k_nn: full unrolling costs 2H registers for the whole kernel
                     for (int k4 = 0; k4 < H / 4; ++k4) {
                         const float4 w = w4[k4];
                         const float4 hv = row[k4];
@@ -906,7 +906,7 @@ __global__ __launch_bounds__(kWave) void k_nn(LaunchArgs a)
         const float4* hrow = reinterpret_cast<const float4*>(hh + ((base + tl) & (kNnRing - 1)) * HS);
         const float4* w4 = reinterpret_cast<const float4*>(wdl);
         float y = wdl[H];
-#pragma unroll
+#pragma unroll 2                       // fully unrolled this loop holds 2H registers of loads on top of the weights
         for (int k4 = 0; k4 < H / 4; ++k4) {
             const float4 w = w4[k4];
             const float4 hv = hrow[k4];

@@ -385,3 +385,81 @@ def test_stacked_model_state_readback(tmp_path):
         h, c = pool.read_state(2, layer)
         oh, oc = om.state(layer)
         assert h.size == 96 and np.abs(h - oh).max() < 4e-6 and np.abs(c - oc).max() < 4e-6
+
+
+# ------------------------------------------------------------ the three launch forms of the chain
+
+@pytest.mark.parametrize("form", ["wave", "pipe", "split"])
+def test_every_kernel_form_passes_the_same_chain_cases(form, tmp_path, monkeypatch, bundled_models):
+    """AIDAX_KERNEL pins one form: one wave per stream, the 3-wave pipeline, or the split launches
+    (packed chain kernels around the lean recurrent kernel). Same inputs, same oracle, same bars:
+    ragged block sizes incl. the pre-run, per-stream controls with bypass/disable, conditioned GRU
+    with ramping params, model swap and activate."""
+    monkeypatch.setenv("AIDAX_KERNEL", form)
+    # (1) ragged blocks, 70 streams (not a multiple of the 8-stream chain waves), LSTM-32 with skip + gains
+    path, spec = _model_file(tmp_path, "f1", kind="lstm", hidden=32, input_size=1, seed=5, in_skip=1, in_gain=-2.0, out_gain=3.0)
+    S = 70
+    sizes = [256, 1, 0, 37, 16, 255, 64, 3]
+    x = modelgen.signal(S, sum(sizes), seed=8)
+    pool = ax.Pool(S, 256)
+    pool.set_model(ax.Model(path))
+    kws = [dict(), dict(enabled=0.0), dict(net_bypass=1.0), dict(eq_position=1.0, bass_boost_db=5.0, mid_type=1.0),
+           dict(dc_blocker=0.0, in_lpf_pc=0.0, eq_bypass=1.0), dict(pregain_db=6.0, master_db=-6.0, treble_boost_db=4.0)]
+    for s in range(S):
+        pool.set_controls(ax.default_controls(**kws[s % len(kws)]), stream=s)
+    assert form in ("wave", "pipe", "split") and pool.kernel_name.startswith({"wave": "k_lstm<", "pipe": "k_lstm_pipe<", "split": "k_chain+k_nn<"}[form])
+    got = np.empty_like(x)
+    pos = 0
+    for n in sizes:
+        got[:, pos:pos + n] = pool.process(np.ascontiguousarray(x[:, pos:pos + n]))
+        pos += n
+    for s in range(0, S, 5):
+        plug = O.OraclePlugin()
+        plug.set_model(O.OracleModel(spec))
+        want = np.empty(x.shape[1], np.float32)
+        pos = 0
+        for n in sizes:
+            want[pos:pos + n] = plug.run(O.default_controls(**kws[s % len(kws)]), x[s, pos:pos + n])
+            pos += n
+        kw = kws[s % len(kws)]
+        if kw.get("enabled") == 0.0 or kw.get("net_bypass") == 1.0:
+            assert np.array_equal(got[s], want), (form, s)
+        else:
+            assert np.abs(got[s] - want).max() < THR * 3, (form, s, np.abs(got[s] - want).max())
+    # (2) conditioned GRU, params ramping block by block, activate in the middle, then a model swap
+    pa, spec_a = _model_file(tmp_path, "f2", kind="gru", hidden=24, input_size=3, seed=11)
+    pb, spec_b = _model_file(tmp_path, "f3", kind="lstm", hidden=12, input_size=2, seed=12)
+    S2 = 9
+    x2 = modelgen.signal(S2, 1280, seed=13)
+    pool = ax.Pool(S2, 128)
+    pool.set_model(ax.Model(pa))
+    plugs = [O.OraclePlugin() for _ in range(S2)]
+    for p in plugs:
+        p.set_model(O.OracleModel(spec_a))
+    for bi, b in enumerate(range(0, 1280, 128)):
+        kw = dict(param1=bi / 9.0, param2=1.0 - 0.07 * bi, mid_boost_db=3.0)
+        if bi == 4:
+            pool.activate()
+            for p in plugs:
+                p.activate()
+        if bi == 6:
+            pool.set_model(ax.Model(pb))
+            for p in plugs:
+                old = p.model.ptr.contents
+                p.set_model(O.OracleModel(spec_b, old.param1Coeff.target, old.param2Coeff.target))
+        pool.set_controls(ax.default_controls(**kw))
+        g = pool.process(np.ascontiguousarray(x2[:, b:b + 128]))
+        for s in range(S2):
+            w = plugs[s].run(O.default_controls(**kw), x2[s, b:b + 128])
+            assert np.abs(g[s] - w).max() < THR * 2.5, (form, bi, s, np.abs(g[s] - w).max())
+    # (3) no model at all (chain only, loading cleared): bit-exact in every form
+    x3 = modelgen.signal(66, 300, seed=3)
+    pool = ax.Pool(66, 300)
+    pool.set_loading(False)
+    cg, co = _ctl_pair(bass_boost_db=4.0, presence_boost_db=-3.0, pregain_db=1.5)
+    pool.set_controls(cg)
+    g3 = pool.process(x3)
+    for s in (0, 7, 65):
+        p = O.OraclePlugin()
+        p.set_loading(False)
+        assert np.array_equal(g3[s], p.run(co, x3[s])), (form, s)

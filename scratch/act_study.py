@@ -57,3 +57,19 @@ for fn in sorted(glob.glob('tests/golden/models/*.json')):
     for name,(s,t) in dict(fastsig_own=(sig_fast,tanh_own), own_all=(sig_own,tanh_own)).items():
         y=run(j,s,t); out.append(f"{name}: {np.abs(y-y64).max():.1e}/{np.abs(y-gold).max():.1e}")
     print(fn.split('/')[-1][:22], ' '.join(out))
+print("---- g accurate (own rational), tanh(c) cheap 2*sig(2c)-1")
+for fn in sorted(glob.glob('tests/golden/models/*.json')):
+    j=json.load(open(fn)); gold=np.array(j['output_batch'],np.float64)
+    y64=run(j, lambda v:1/(1+np.exp(-v)), np.tanh, np.float64)
+    # custom run with separate functions for g and tanh(c)
+    L=j['layers']; dt=f32
+    W=np.array(L[0]['weights'][0],dt); U=np.array(L[0]['weights'][1],dt); b=np.array(L[0]['weights'][2],dt)
+    Wd=np.array(L[1]['weights'][0],dt)[:,0]; bd=dt(L[1]['weights'][1][0]); H=U.shape[0]
+    x=np.array(j['input_batch'],dt)
+    for name,(tg,tc) in dict(g_rat_c_fast=(tanh_own,tanh_fast), both_rat=(tanh_own,tanh_own), g_fast_c_rat=(tanh_fast,tanh_own)).items():
+        h=np.zeros(H,dt); c=np.zeros(H,dt); y=np.zeros(len(x),dt)
+        for t in range(len(x)):
+            z=(h@U + b + W[0]*x[t]).astype(dt)
+            i=sig_fast(z[:H]); f=sig_fast(z[H:2*H]); g=tg(z[2*H:3*H]); o=sig_fast(z[3*H:])
+            c=(f*c+i*g).astype(dt); h=(o*tc(c)).astype(dt); y[t]=h@Wd+bd
+        print(fn.split('/')[-1][:22], name, "%.2e / %.2e"%(np.abs(y-y64).max(), np.abs(y-gold).max()))

@@ -1,0 +1,150 @@
+"""GPU edge cases of the C-ABI boundary: in-place buffers, host sample rates other than
+48 kHz, model sample rate from json, argument errors as codes, the largest block, many
+small pools, and the device-resident entry point on a caller stream with in-place I/O."""
+import ctypes as C
+import importlib
+import json
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import modelgen
+
+pytestmark = pytest.mark.gpu
+ax = importlib.import_module("aidadsp-lv2_amd")
+THR = 1.0e-5
+_fp = C.POINTER(C.c_float)
+
+
+def _model(tmp_path, name, **kw):
+    j = modelgen.make_model(**kw)
+    p = str(tmp_path / f"{name}.json")
+    modelgen.write_model(j, p)
+    return p, O.parse_model(j)
+
+
+def test_in_place_process_matches_out_of_place(tmp_path):
+    path, spec = _model(tmp_path, "ip", kind="lstm", hidden=16, input_size=1, seed=3)
+    x = modelgen.signal(5, 512, seed=2)
+    a, b = ax.Pool(5, 256), ax.Pool(5, 256)
+    m = ax.Model(path)
+    a.set_model(m)
+    b.set_model(m)
+    L = ax.lib()
+    for blk in range(2):
+        chunk = np.ascontiguousarray(x[:, blk * 256:(blk + 1) * 256])
+        want = a.process(chunk)
+        buf = chunk.copy()
+        assert L.aidax_pool_process(b.h, buf.ctypes.data_as(_fp), buf.ctypes.data_as(_fp), 256) == 0
+        assert np.array_equal(buf, want)
+    # disabled + in place: nothing to copy, nothing changes
+    b.set_controls(ax.default_controls(enabled=0.0))
+    buf = np.ascontiguousarray(x[:, :256]).copy()
+    assert L.aidax_pool_process(b.h, buf.ctypes.data_as(_fp), buf.ctypes.data_as(_fp), 256) == 0
+    assert np.array_equal(buf, x[:, :256])
+
+
+@pytest.mark.parametrize("host_sr", [44100.0, 96000.0])
+def test_host_samplerate_drives_filters_and_gain_ramps(host_sr, tmp_path):
+    """Biquad Fc/fs and the gain smoothers use the HOST rate (:283-314), the PARAM smoothers the
+    MODEL rate (:1053-1060); a json `samplerate` NUMBER overrides the 48 kHz default (:1005-1013)."""
+    j = modelgen.make_model("gru", 12, 2, seed=9, samplerate=44100)
+    path = str(tmp_path / "sr.json")
+    modelgen.write_model(j, path)
+    spec = O.parse_model(j)
+    assert spec.samplerate == 44100.0
+    x = modelgen.signal(3, 1024, seed=6, fs=host_sr)
+    kw = dict(bass_boost_db=5.0, treble_boost_db=-4.0, pregain_db=4.0, master_db=-3.0, param1=0.8)
+    pool = ax.Pool(3, 256, samplerate=host_sr)
+    pool.set_model(ax.Model(path))
+    pool.set_controls(ax.default_controls(**kw))
+    got = np.concatenate([pool.process(np.ascontiguousarray(x[:, b:b + 256])) for b in range(0, 1024, 256)], axis=1)
+    want = O.run_streams(spec, O.default_controls(**kw), x, 256, samplerate=host_sr)
+    assert np.abs(got - want).max() < THR * 2
+
+
+def test_argument_errors_are_codes(tmp_path):
+    L = ax.lib()
+    h = C.c_void_p()
+    assert L.aidax_pool_create(0, 256, C.c_double(48000.0), 0, C.byref(h)) == -1
+    assert L.aidax_pool_create(4, 0, C.c_double(48000.0), 0, C.byref(h)) == -1
+    assert L.aidax_pool_create(4, 1 << 20, C.c_double(48000.0), 0, C.byref(h)) == -1
+    assert L.aidax_pool_create(4, 256, C.c_double(0.0), 0, C.byref(h)) == -1
+    assert L.aidax_pool_create(4, 256, C.c_double(48000.0), 99, C.byref(h)) == -1
+    pool = ax.Pool(4, 64)
+    x = np.zeros((4, 128), np.float32)
+    assert L.aidax_pool_process(pool.h, x.ctypes.data_as(_fp), x.ctypes.data_as(_fp), 128) == -1      # > max_frames
+    assert L.aidax_pool_process(pool.h, None, None, 64) == -1
+    assert L.aidax_pool_process(pool.h, None, None, 0) == 0                                           # pre-run needs no buffers
+    c = ax.default_controls()
+    assert L.aidax_pool_set_controls(pool.h, 4, C.byref(c)) == -1 and L.aidax_pool_set_controls(pool.h, -2, C.byref(c)) == -1
+    assert L.aidax_pool_activate(pool.h, 7) == -1 and L.aidax_pool_set_loading(pool.h, 9, 1) == -1
+    assert L.aidax_pool_set_model(pool.h, None, 5) == -1
+    assert b"" != L.aidax_last_error()
+    # a conv model with params is an architecture error at load time
+    rc = C.c_void_p()
+    jj = modelgen.make_model("conv", 16, 2, seed=1, conv_layers=2)
+    txt = json.dumps(jj).encode()
+    assert L.aidax_model_load_memory(txt, len(txt), b"x", C.byref(rc)) == -4
+    # unloading a model mutes the pool again (loading = true)
+    path, _ = _model(tmp_path, "u", kind="lstm", hidden=8, input_size=1, seed=1)
+    pool.set_model(ax.Model(path))
+    sig = modelgen.signal(4, 64, seed=1)
+    assert np.abs(pool.process(sig)).max() > 0
+    pool.set_model(None)
+    for _ in range(200):
+        out = pool.process(sig)
+    assert np.abs(out).max() < 1e-6
+
+
+def test_largest_block_and_block_size_invariance(tmp_path):
+    """8192-frame blocks (the pool maximum) equal 32 x 256-frame blocks: bit-exact for the pure
+    chain, within tolerance through the NN (all three forms see n > one pipeline ring)."""
+    path, spec = _model(tmp_path, "big", kind="lstm", hidden=24, input_size=1, seed=4)
+    x = modelgen.signal(2, 8192, seed=12)
+    m = ax.Model(path)
+    a, b = ax.Pool(2, 8192), ax.Pool(2, 256)
+    a.set_model(m)
+    b.set_model(m)
+    big = a.process(x)
+    small = np.concatenate([b.process(np.ascontiguousarray(x[:, i:i + 256])) for i in range(0, 8192, 256)], axis=1)
+    assert np.abs(big - small).max() < 2e-6
+    want = O.run_streams(spec, O.default_controls(), x, 8192)
+    assert np.abs(big - want).max() < THR
+    c, d = ax.Pool(2, 8192), ax.Pool(2, 100)
+    for p in (c, d):
+        p.set_loading(False)
+    assert np.array_equal(c.process(x), np.concatenate([d.process(np.ascontiguousarray(x[:, i:i + 100])) for i in range(0, 8192, 100)], axis=1))
+
+
+def test_many_pools_coexist_and_stay_independent(tmp_path):
+    paths = [_model(tmp_path, f"m{i}", kind=("lstm", "gru")[i % 2], hidden=(8, 12, 16, 20)[i % 4], input_size=1 + i % 3, seed=40 + i)
+             for i in range(8)]
+    x = modelgen.signal(3, 384, seed=77)
+    pools = []
+    for p, _ in paths:
+        pool = ax.Pool(3, 128)
+        pool.set_model(ax.Model(p))
+        pools.append(pool)
+    outs = [np.concatenate([pool.process(np.ascontiguousarray(x[:, b:b + 128])) for b in range(0, 384, 128)], axis=1) for pool in pools]
+    for (p, spec), got in zip(paths, outs):
+        want = O.run_streams(spec, O.default_controls(), x, 128)
+        assert np.abs(got - want).max() < THR * 2
+
+
+def test_device_entry_point_in_place_on_caller_stream(tmp_path):
+    import torch
+    path, spec = _model(tmp_path, "dev2", kind="gru", hidden=32, input_size=1, seed=8)
+    x = modelgen.signal(130, 256, seed=5)
+    ref = ax.Pool(130, 256)
+    ref.set_model(ax.Model(path))
+    want = ref.process(x)
+    pool = ax.Pool(130, 256)
+    pool.set_model(ax.Model(path))
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        d = torch.from_numpy(x).cuda()
+        pool.process_device(d.data_ptr(), d.data_ptr(), 256, s.cuda_stream)
+    s.synchronize()
+    assert np.array_equal(d.cpu().numpy(), want)

@@ -137,7 +137,7 @@ def lib() -> C.CDLL:
     L.orc_plugin_set_model.argtypes = [C.POINTER(Plugin), C.POINTER(DynModel)]
     L.orc_plugin_run.argtypes = [C.POINTER(Plugin), C.POINTER(Controls), _fp, _fp, C.c_uint32]
     L.orc_bench.argtypes = [C.POINTER(LayerDesc), C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
-                            C.POINTER(Controls), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]
+                            C.POINTER(Controls), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_int]
     L.orc_bench.restype = C.c_double
     _lib = L
     return L
@@ -316,12 +316,12 @@ class OracleModel:
             self.ptr = None
 
 
-def net_run(spec: ModelSpec, X: np.ndarray, f64: bool = False) -> np.ndarray:
+def net_run(spec: ModelSpec, X: np.ndarray, f64: bool = False, flavour: Optional[int] = None) -> np.ndarray:
     """Bare network (reset state) over a [T][input_size] sequence -> [T] outputs."""
     X = _f32(X).reshape(-1, spec.input_size)
     L = lib()
     arr, n = spec.descs()
-    net = L.orc_net_create(arr, n, 1 if f64 else 0)
+    net = L.orc_net_create(arr, n, flavour if flavour is not None else (1 if f64 else 0))
     y = np.empty(X.shape[0], np.float32)
     try:
         for t in range(X.shape[0]):
@@ -386,12 +386,12 @@ def run_streams(spec: Optional[ModelSpec], controls: Sequence[Controls] | Contro
 
 
 def cpu_bench(spec: ModelSpec, controls: Controls, x: np.ndarray, n_blocks: int, warm_blocks: int,
-              n_threads: int):
+              n_threads: int, fast: bool = False):
     """Timed multi-thread pass of the full chain; returns (seconds, last-block output)."""
     x = _f32(x)
     S, F = x.shape
     arr, n = spec.descs()
     out = np.empty_like(x)
     secs = lib().orc_bench(arr, n, spec.input_size, spec.input_skip, spec.input_gain, spec.output_gain,
-                           C.byref(controls), S, F, n_blocks, warm_blocks, n_threads, _ptr(x), _ptr(out))
+                           C.byref(controls), S, F, n_blocks, warm_blocks, n_threads, _ptr(x), _ptr(out), 2 if fast else 0)
     return float(secs), out

@@ -52,6 +52,18 @@ def test_gate_order_is_uniquely_pinned(bundled_models):
         assert n_err > 0 and max_err > 1e-3
 
 
+def test_timing_flavour_with_vectorised_activations_also_meets_the_goldens(bundled_models):
+    """The cpu_baseline leg of bench.py times flavour 2 (branch-free exp/tanh); it must be a correct
+    implementation too, not just a fast one."""
+    for path in bundled_models:
+        spec = O.load_model(path)
+        y = O.net_run(spec, spec.input_batch.reshape(-1, 1), flavour=2)
+        assert np.abs(y - spec.output_batch).max() < 2.5e-6, path
+    spec = O.parse_model(modelgen.make_model("gru", 24, 3, seed=5))
+    X = modelgen.golden_inputs("x", 3)[:1024]
+    assert np.abs(O.net_run(spec, X, flavour=2) - O.net_run(spec, X)).max() < 2e-6
+
+
 def test_f64_shadow_agrees(bundled_models):
     spec = O.load_model(bundled_models[2])
     a = O.OracleModel(spec, warmup=False).test_model(spec.input_batch, spec.output_batch)[2]

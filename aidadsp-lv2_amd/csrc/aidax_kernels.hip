@@ -195,35 +195,39 @@ struct LstmCell {
 };
 
 // ---------------------------------------------------------------- GRU cell
-// One lane owns the z, r and candidate rows of its units (S = 1): no exchange.
+// A unit's z, r and candidate rows live on S lanes that split the recurrent dot products along K
+// (S = 1: one lane, no exchange; S = 2: two half-length slices combined with one permlane swap per row).
 // Keras reset_after form, json column order z|r|h, bias [2][3H]:
 //   z = sig(Wz x + Uz h + bz0 + bz1), r likewise,
 //   n = tanh(Wn x + bn0 + r*(Un h + bn1)),  h' = (1-z)*n + z*h
 template <int H>
 struct GruCell {
     static constexpr LaneMap M = gru_map(H);
-    static constexpr int SLOTS = M.slots, NU = M.NU;
+    static constexpr int S = M.S, SLOTS = M.slots, NU = M.NU;
+    static constexpr int KS = H / S;          // recurrent columns per lane (K-split across the S lanes of a unit)
     static constexpr int PACK = gru_pack_regs(H);
     static constexpr int STATE = H;
+    static_assert(KS % 4 == 0, "K slice must stay float4 aligned");
 
-    float w[NU][3][H];
-    float wx[NU][3][kMaxInputs];
-    float bias[NU][3];       // z: b0+b1, r: b0+b1, n: b0 (input side)
-    float bn1[NU];           // n: b1 (recurrent side)
+    float w[NU][3][KS];
+    float wx[NU][3][kMaxInputs];   // z, r rows: part 0 only (they are summed across parts); candidate row: every part
+    float bias[NU][3];             // z: b0+b1, r: b0+b1 (part 0 only), n: b0 (input side, every part)
+    float bn1[NU];                 // n: b1 (recurrent side, part 0 only: it joins the summed partials)
     float wd[NU], bd;
     float h[NU];
-    int slot;
+    int part, slot;
 
     __device__ __forceinline__ void load(const float* __restrict__ wp, const float* __restrict__ st, int lane)
     {
-        slot = lane;
+        part = lane / SLOTS;
+        slot = lane % SLOTS;
         int r = 0;
 #pragma unroll
         for (int m = 0; m < NU; ++m)
 #pragma unroll
             for (int e = 0; e < 3; ++e) {
 #pragma unroll
-                for (int k = 0; k < H; ++k) w[m][e][k] = wp[(r++) * kWave + lane];
+                for (int k = 0; k < KS; ++k) w[m][e][k] = wp[(r++) * kWave + lane];
 #pragma unroll
                 for (int i = 0; i < kMaxInputs; ++i) wx[m][e][i] = wp[(r++) * kWave + lane];
                 bias[m][e] = wp[(r++) * kWave + lane];
@@ -245,7 +249,7 @@ struct GruCell {
 #pragma unroll
         for (int m = 0; m < NU; ++m) {
             const int j = slot + m * SLOTS;
-            if (j < H) st[j] = h[m];
+            if (part == 0 && j < H) st[j] = h[m];
         }
     }
 
@@ -254,7 +258,7 @@ struct GruCell {
 #pragma unroll
         for (int m = 0; m < NU; ++m) {
             const int j = slot + m * SLOTS;
-            if (j < H) hbuf[j] = h[m];
+            if (j < H) hbuf[j] = h[m];       // the S lanes of a unit hold the same h
         }
     }
 
@@ -266,6 +270,14 @@ struct GruCell {
 #pragma unroll
         for (int m = 0; m < NU; ++m) d = __builtin_fmaf(wd[m], h[m], d);
         return d;
+    }
+
+    // sum of v over the S lanes of a unit, in every one of them
+    __device__ __forceinline__ static float unit_sum(float v)
+    {
+        if constexpr (S == 1) return v;
+        else if constexpr (S == 2) { const Pair p = share_halves(v); return p.lo + p.hi; }
+        else { const Pair p = share_halves(v); const float t = p.lo + p.hi; const Pair q = share_rows(t); return q.lo + q.hi; }
     }
 
     template <int NI = kMaxInputs, int WINDOW = 0>
@@ -283,9 +295,9 @@ struct GruCell {
                 ax[m][e] = a;
                 ar[m][e] = e == 2 ? bn1[m] : 0.f;
             }
-        const float4* hv = reinterpret_cast<const float4*>(hprev);
+        const float4* hv = reinterpret_cast<const float4*>(hprev + part * KS);      // this lane's K slice
 #pragma unroll
-        for (int k4 = 0; k4 < H / 4; ++k4) {
+        for (int k4 = 0; k4 < KS / 4; ++k4) {
             const float4 q = hv[k4];
 #pragma unroll
             for (int m = 0; m < NU; ++m)
@@ -303,9 +315,13 @@ struct GruCell {
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int m = 0; m < NU; ++m) {
-            const float z = fast_sigmoid(ax[m][0] + ar[m][0]);
-            const float r = fast_sigmoid(ax[m][1] + ar[m][1]);
-            const float pre = __builtin_fmaf(r, ar[m][2], ax[m][2]);
+            // partial sums of the S lanes -> full pre-activations in each of them
+            const float zp = unit_sum(ax[m][0] + ar[m][0]);
+            const float rp = unit_sum(ax[m][1] + ar[m][1]);
+            const float nh = unit_sum(ar[m][2]);
+            const float z = fast_sigmoid(zp);
+            const float r = fast_sigmoid(rp);
+            const float pre = __builtin_fmaf(r, nh, ax[m][2]);
             const float n = tanh_rat(pre);
             h[m] = __builtin_fmaf(z, h[m] - n, n);          // (1-z)*n + z*h
         }

@@ -90,8 +90,17 @@ constexpr LaneMap lstm_map(int H)
 
 constexpr LaneMap gru_map(int H)
 {
-    // GRU: one lane owns all three rows of its units (no cross-lane gate exchange)
-    return LaneMap{1, kWave, ceil_div(H, kWave), 3};
+    // GRU: the S lanes of a unit each take H/S columns of all three rows (K-split) and add their
+    // partial sums with permlane swaps. Estimated issue slots per sample: NU*(3*H/S + 9*log2(S) + 25);
+    // S = 2 wins for H in {12..32} and for H = 80 (where S = 1 would need 504 weight registers).
+    int best_S = 1, best_cost = 1 << 30;
+    for (int S = 1; S <= 2; S *= 2) {
+        if ((H / S) % 4 != 0) continue;
+        const int NU = ceil_div(H, kWave / S);
+        const int cost = NU * (3 * (H / S) + (S == 2 ? 9 : 0) + 25);
+        if (cost < best_cost) { best_cost = cost; best_S = S; }
+    }
+    return LaneMap{best_S, kWave / best_S, ceil_div(H, kWave / best_S), 3};
 }
 
 // Packed weight record, index -> meaning, for one recurrent layer:
@@ -107,7 +116,7 @@ constexpr int lstm_pack_regs(int H)
 constexpr int gru_pack_regs(int H)
 {
     const LaneMap L = gru_map(H);
-    return L.NU * 3 * (H + kMaxInputs + 1) + L.NU + L.NU + 1;
+    return L.NU * 3 * (H / L.S + kMaxInputs + 1) + L.NU + L.NU + 1;
 }
 
 // Kernel run modes

@@ -57,31 +57,34 @@ std::vector<float> pack_gru(const aidax_model& m)
     const Layer& D = m.layers[1];
     const int H = L.out_size, I = L.in_size, G = 3 * H;
     const LaneMap M = gru_map(H);
+    const int KS = H / M.S;
     Packer p(gru_pack_regs(H));
     const float* b0 = L.w2.data();          // input-side bias
     const float* b1 = L.w2.data() + G;      // recurrent-side bias
     for (int lane = 0; lane < kWave; ++lane) {
-        const int slot = lane;
+        const int part = lane / M.slots, slot = lane % M.slots;
         int r = 0;
         for (int mm = 0; mm < M.NU; ++mm) {
             const int j = slot + mm * M.slots;
             const bool live = j < H;
             for (int e = 0; e < 3; ++e) {
                 const int col = e * H + j;
-                for (int k = 0; k < H; ++k) p.put(r++, lane, live ? L.w1[static_cast<size_t>(k) * G + col] : 0.f);
-                for (int i = 0; i < kMaxInputs; ++i) p.put(r++, lane, (live && i < I) ? L.w0[static_cast<size_t>(i) * G + col] : 0.f);
-                // z, r: both biases act on the same pre-activation and are summed at load time;
-                // candidate: only the input-side bias here, the recurrent one sits under r*( )
-                p.put(r++, lane, live ? (e < 2 ? b0[col] + b1[col] : b0[col]) : 0.f);
+                // this lane's K slice of the recurrent row
+                for (int k = 0; k < KS; ++k) p.put(r++, lane, live ? L.w1[static_cast<size_t>(part * KS + k) * G + col] : 0.f);
+                // z, r: input weights and (b0+b1) ride on part 0 and reach the others through the partial-sum
+                // exchange; candidate: every part keeps the input side whole (it is not summed), b1 sits under r*( )
+                const bool owns_input = e == 2 || part == 0;
+                for (int i = 0; i < kMaxInputs; ++i) p.put(r++, lane, (live && owns_input && i < I) ? L.w0[static_cast<size_t>(i) * G + col] : 0.f);
+                p.put(r++, lane, (live && owns_input) ? (e < 2 ? b0[col] + b1[col] : b0[col]) : 0.f);
             }
         }
         for (int mm = 0; mm < M.NU; ++mm) {
             const int j = slot + mm * M.slots;
-            p.put(r++, lane, j < H ? b1[2 * H + j] : 0.f);
+            p.put(r++, lane, (j < H && part == 0) ? b1[2 * H + j] : 0.f);
         }
         for (int mm = 0; mm < M.NU; ++mm) {
             const int j = slot + mm * M.slots;
-            p.put(r++, lane, j < H ? D.w0[j] : 0.f);
+            p.put(r++, lane, (j < H && part == 0) ? D.w0[j] : 0.f);
         }
         p.put(r++, lane, D.w1[0]);
     }

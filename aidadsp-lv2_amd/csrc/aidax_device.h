@@ -125,8 +125,10 @@ __device__ __forceinline__ void chain_run(ChainPass& c, const float* src, float*
 {
     float carry = 0.f;                         // this lane's previous output, read by lane+1
     const int steps = n + c.K - 1;
+    float head_next = src[0];                  // wave-uniform LDS broadcast, fetched one step ahead
     for (int s = 0; s < steps; ++s) {
-        const float head = src[s < n ? s : n - 1];          // wave-uniform LDS broadcast
+        const float head = head_next;
+        head_next = src[s + 1 < n ? s + 1 : n - 1];
         const float from_left = dpp_row_shr1(carry);
         const float x = lane == 0 ? head : from_left;
         const int idx = s - lane;

@@ -796,8 +796,10 @@ __global__ __launch_bounds__(kWave) void k_chain(LaunchArgs a)
         float* buf = smem + grp * nP;
         float carry = 0.f;
         const int steps = n + 5;
+        float head_next = buf[0];
         for (int s = 0; s < steps; ++s) {
-            const float head = buf[s < n ? s : n - 1];
+            const float head = head_next;
+            head_next = buf[s + 1 < n ? s + 1 : n - 1];
             const float from_left = dpp_row_shr1(carry);
             const float x = stage == 0 ? head : from_left;
             const int idx = s - stage;

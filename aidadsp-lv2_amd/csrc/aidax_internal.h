@@ -51,9 +51,11 @@ void  build_stream_ctl(const aidax_controls& c, double host_samplerate, bool has
 // weight packing (aidax_pack.cpp)
 std::vector<float> pack_weights(const aidax_model& m);
 // extension architectures: flat weight buffer + descriptor + per-stream state size (floats)
-bool is_stack_model(const aidax_model& m);     // >= 2 recurrent layers
+bool is_stack_model(const aidax_model& m);     // >= 2 recurrent layers, or one layer wider than the register-resident kernels
 bool is_conv_model(const aidax_model& m);
 std::vector<float> pack_stack(const aidax_model& m, StackDesc* d, uint32_t* state_floats);
+bool mfma_form_fits(const aidax_model& m);    // recurrent layers of one width, a multiple of 16 and <= 128
+std::vector<float> pack_mfma(const aidax_model& m, MfmaDesc* d, uint32_t* state_floats);
 std::vector<float> pack_conv(const aidax_model& m, ConvDesc* d, uint32_t* state_floats);
 
 }  // namespace aidax

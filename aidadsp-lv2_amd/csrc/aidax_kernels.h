@@ -27,6 +27,11 @@ hipError_t launch_pipe_kernel(const KernelEntry* e, const LaunchArgs& a, hipStre
 int pipe_resident_streams(const KernelEntry* e, uint32_t n_frames, int device);
 size_t stack_lds_bytes(const StackDesc& d, uint32_t n_frames);
 size_t conv_lds_bytes(const ConvDesc& d, uint32_t n_frames);
+size_t mfma_lds_bytes(const MfmaDesc& d, uint32_t n_frames);
+size_t chain_lds_bytes(uint32_t n_frames);
+// one packed chain launch (8 streams per wave): pre = LPF/pre-gain/EQ(pre) in -> out, else DC/EQ(post)/master in place
+hipError_t launch_chain_pass(bool pre, const LaunchArgs& a, hipStream_t stream);
+hipError_t launch_mfma_kernel(const LaunchArgs& a, const MfmaDesc& d, hipStream_t stream);
 hipError_t launch_stack_kernel(const LaunchArgs& a, const StackDesc& d, hipStream_t stream);
 hipError_t launch_conv_kernel(const LaunchArgs& a, const ConvDesc& d, hipStream_t stream);
 hipError_t launch_set_pending(StreamState* st, uint32_t n_streams, int32_t stream, uint32_t bits, hipStream_t q);

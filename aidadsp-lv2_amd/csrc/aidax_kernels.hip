@@ -1025,16 +1025,26 @@ hipError_t launch_stream_kernel(const KernelEntry* e, const LaunchArgs& a, size_
     return hipGetLastError();
 }
 
+size_t chain_lds_bytes(uint32_t n_frames) { return (size_t)kChainStreams * ((n_frames + 3) & ~3u) * sizeof(float); }
+
+hipError_t launch_chain_pass(bool pre, const LaunchArgs& a, hipStream_t stream)
+{
+    const uint32_t groups = (a.n_streams + kChainStreams - 1) / kChainStreams;
+    const size_t lds = chain_lds_bytes(a.n_frames);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;          // callers pick another form for such blocks
+    if (pre) hipLaunchKernelGGL(k_chain<true>, dim3(groups), dim3(kWave), lds, stream, a);
+    else hipLaunchKernelGGL(k_chain<false>, dim3(groups), dim3(kWave), lds, stream, a);
+    return hipGetLastError();
+}
+
 // Split form: pre chain (8 streams/wave) -> recurrent cell -> post chain, in place on `out`
 hipError_t launch_split_kernels(const KernelEntry* e, const LaunchArgs& a, hipStream_t stream)
 {
-    const uint32_t groups = (a.n_streams + kChainStreams - 1) / kChainStreams;
-    const size_t chain_lds = (size_t)kChainStreams * ((a.n_frames + 3) & ~3u) * sizeof(float);
-    hipLaunchKernelGGL(k_chain<true>, dim3(groups), dim3(kWave), chain_lds, stream, a);
+    hipError_t err = launch_chain_pass(true, a, stream);
+    if (err != hipSuccess) return err;
     if (e && a.n_frames != 0)
         hipLaunchKernelGGL(e->fn_nn, dim3(a.n_streams), dim3(kWave), nn_lds_floats(e->hidden, (int)a.n_frames) * sizeof(float), stream, a);
-    hipLaunchKernelGGL(k_chain<false>, dim3(groups), dim3(kWave), chain_lds, stream, a);
-    return hipGetLastError();
+    return launch_chain_pass(false, a, stream);
 }
 
 // Is the split form the better many-streams form for this cell? Yes when the lean recurrent kernel still

@@ -95,7 +95,97 @@ std::vector<float> pack_gru(const aidax_model& m)
 
 }  // namespace
 
-bool is_stack_model(const aidax_model& m) { return m.cell != AIDAX_CELL_CONV && m.n_rnn >= 2; }
+bool is_stack_model(const aidax_model& m)
+{
+    if (m.cell == AIDAX_CELL_CONV) return false;
+    if (m.n_rnn >= 2) return true;
+    // one recurrent layer wider than the widest of variant/generate_variant_hpp.py:4-6 (no register-resident
+    // kernel); narrower sizes outside that list stay rejected like the reference rejects them
+    return m.n_rnn == 1 && m.hidden > 80;
+}
+
+bool mfma_form_fits(const aidax_model& m)
+{
+    if (!is_stack_model(m) || m.hidden % 16 != 0 || m.hidden > 128) return false;
+    for (int l = 0; l < m.n_rnn; ++l)
+        if (m.layers[l].out_size != m.hidden) return false;
+    return true;
+}
+
+// A fragments of v_mfma_f32_16x16x4_f32 for k_mfma, layout in aidax_layout.h (MfmaLayer).
+std::vector<float> pack_mfma(const aidax_model& m, MfmaDesc* d, uint32_t* state_floats)
+{
+    std::vector<float> out;
+    *d = MfmaDesc{};
+    const int H = m.hidden, TPW = H / 16;
+    d->n_layers = m.n_rnn;
+    d->hidden = H;
+    d->tpw = TPW;
+    uint32_t st = 0;
+    enum Seg { SEG_IN, SEG_REC, SEG_BIAS };
+    for (int l = 0; l < m.n_rnn; ++l) {
+        const Layer& L = m.layers[l];
+        MfmaLayer& M = d->L[l];
+        const bool lstm = L.type == Layer::LSTM;
+        const int G = lstm ? 4 : 3, R = G * H, I = L.in_size;
+        M.cell = lstm ? 0 : 1;
+        M.in_size = I;
+        // weight of gate row `g` of unit `u` against column k of segment `seg`
+        auto weight = [&](Seg seg, int u, int g, int k) -> float {
+            const float* W = L.w0.data();      // [I][R]
+            const float* U = L.w1.data();      // [H][R]
+            const float* b = L.w2.data();      // LSTM [R]; GRU [2][R]
+            if (lstm) {
+                const int col = g * H + u;
+                if (seg == SEG_IN) return k < I ? W[(size_t)k * R + col] : 0.f;
+                if (seg == SEG_REC) return U[(size_t)k * R + col];
+                return k == 0 ? b[col] : 0.f;
+            }
+            // GRU rows: 0 = z, 1 = r, 2 = recurrent half of the candidate, 3 = input half of the candidate
+            const int col = (g == 0 ? 0 : g == 1 ? H : 2 * H) + u;
+            if (seg == SEG_IN) return (g != 2 && k < I) ? W[(size_t)k * R + col] : 0.f;
+            if (seg == SEG_REC) return g != 3 ? U[(size_t)k * R + col] : 0.f;
+            if (k != 0) return 0.f;
+            if (g <= 1) return b[col] + b[R + col];
+            return g == 2 ? b[R + col] : b[col];
+        };
+        // layer 0: the 1..3 model inputs are one k-step on their own ("small" segment)
+        M.w_in_off = static_cast<uint32_t>(out.size());
+        if (l == 0)
+            for (int w = 0; w < 4; ++w)
+                for (int lane = 0; lane < kWave; ++lane)
+                    for (int tl = 0; tl < TPW; ++tl) {
+                        const int T = w * TPW + tl, r = lane & 15;
+                        out.push_back(weight(SEG_IN, 4 * T + (r >> 2), r & 3, lane >> 4));
+                    }
+        // per wave one run of k-step groups: [h of the layer below (layers >= 1)] then [own h(t-1)]
+        M.w_big_off = static_cast<uint32_t>(out.size());
+        const int g_in = l == 0 ? 0 : I / 16, g_rec = H / 16;
+        for (int w = 0; w < 4; ++w)
+            for (int grp = 0; grp < g_in + g_rec; ++grp)
+                for (int lane = 0; lane < kWave; ++lane)
+                    for (int j = 0; j < 4; ++j)
+                        for (int tl = 0; tl < TPW; ++tl) {
+                            const int T = w * TPW + tl, r = lane & 15;
+                            const bool in = grp < g_in;
+                            const int k = 4 * (4 * (in ? grp : grp - g_in) + j) + (lane >> 4);
+                            out.push_back(weight(in ? SEG_IN : SEG_REC, 4 * T + (r >> 2), r & 3, k));
+                        }
+        // bias of the four gate rows of every unit: the accumulators start from it
+        M.b_off = static_cast<uint32_t>(out.size());
+        for (int u = 0; u < H; ++u)
+            for (int g = 0; g < 4; ++g) out.push_back(weight(SEG_BIAS, u, g, 0));
+        M.state_off = st;
+        st += static_cast<uint32_t>(lstm ? 2 * H : H);
+    }
+    const Layer& D = m.layers[m.n_rnn];
+    d->wd_off = static_cast<uint32_t>(out.size());
+    out.insert(out.end(), D.w0.begin(), D.w0.end());
+    d->bd_off = static_cast<uint32_t>(out.size());
+    out.push_back(D.w1[0]);
+    *state_floats = st;
+    return out;
+}
 bool is_conv_model(const aidax_model& m) { return m.cell == AIDAX_CELL_CONV; }
 
 std::vector<float> pack_stack(const aidax_model& m, StackDesc* d, uint32_t* state_floats)

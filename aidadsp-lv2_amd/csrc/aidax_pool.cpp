@@ -86,8 +86,9 @@ struct aidax_pool {
 
     // model in use (copy of what the kernels need)
     bool has_model = false;
-    enum Kind { TABLE = 0, STACK = 1, CONV = 2 } kind = TABLE;
+    enum Kind { TABLE = 0, STACK = 1, CONV = 2, MFMA = 3 } kind = TABLE;
     StackDesc sdesc{};
+    MfmaDesc mdesc{};
     ConvDesc cdesc{};
     const KernelEntry* kernel = nullptr;
     int input_size = 1, input_skip = 0, hidden = 0;
@@ -95,12 +96,13 @@ struct aidax_pool {
     uint32_t nn_stride = 0;
     int pipe_capacity = 0;           // streams the 3-wave pipeline keeps resident at once (0 = never use it)
     bool split_pays = false;         // the lean recurrent kernel keeps the occupancy of the one-wave kernel
-    int force_form = 0;              // AIDAX_KERNEL=wave|pipe|split overrides the heuristic (A/B testing)
+    int force_form = 0;              // AIDAX_KERNEL=wave|pipe|split|valu overrides the heuristic (A/B testing)
     // Form of a MODE_CHAIN pass: 0 one wave per stream, 1 three-wave pipeline (all streams resident at
     // once: latency-bound regime), 2 split launches with packed chains (many streams: issue-bound regime)
     int chain_form() const
     {
-        if (kind != TABLE) return 0;
+        if (kind != TABLE && has_model) return 0;
+        if (chain_lds_bytes(max_frames) > 64 * 1024) return 0;      // packed chains keep 8 blocks in LDS
         if (force_form == 1) return 0;
         if (force_form == 2) return (has_model && kernel) ? 1 : 0;
         if (force_form == 3) return 2;
@@ -158,8 +160,17 @@ struct aidax_pool {
     }
     // frames one launch of the extension kernels may carry (their LDS planes grow with n)
     uint32_t ext_chunk() const { return max_frames < 256 ? max_frames : 256; }
+    uint32_t launch_chunk(uint32_t n) const { return (kind == STACK || kind == CONV) ? std::min(ext_chunk(), n) : n; }
     hipError_t launch(const LaunchArgs& a, hipStream_t s) const
     {
+        if (has_model && kind == MFMA) {
+            // split form around the matrix-core kernel: packed chains in -> out, applyModel in place, packed chains
+            if (a.mode != MODE_CHAIN) return launch_mfma_kernel(a, mdesc, s);
+            hipError_t e = launch_chain_pass(true, a, s);
+            if (e == hipSuccess && a.n_frames != 0) e = launch_mfma_kernel(a, mdesc, s);
+            if (e == hipSuccess) e = launch_chain_pass(false, a, s);
+            return e;
+        }
         if (has_model && kind == STACK) return launch_stack_kernel(a, sdesc, s);
         if (has_model && kind == CONV) return launch_conv_kernel(a, cdesc, s);
         if (a.mode == MODE_CHAIN && chain_form() == 1) return launch_pipe_kernel(kernel, a, s);
@@ -211,12 +222,16 @@ int set_model_impl(aidax_pool& p, const aidax_model* m, int start_mode)
     uint32_t state_floats = 0;
     aidax_pool::Kind kind = aidax_pool::TABLE;
     StackDesc sd{};
+    MfmaDesc md{};
     ConvDesc cd{};
     if (is_conv_model(*m)) {
         kind = aidax_pool::CONV;
         wp = pack_conv(*m, &cd, &state_floats);
         if (conv_lds_bytes(cd, p.max_frames) > 160 * 1024)
             return fail(AIDAX_ERR_ARG, "conv model: pool max_frames too large for the LDS activation planes");
+    } else if (mfma_form_fits(*m) && p.force_form != 4 && chain_lds_bytes(p.max_frames) <= 64 * 1024) {
+        kind = aidax_pool::MFMA;
+        wp = pack_mfma(*m, &md, &state_floats);
     } else if (is_stack_model(*m)) {
         kind = aidax_pool::STACK;
         wp = pack_stack(*m, &sd, &state_floats);
@@ -246,6 +261,7 @@ int set_model_impl(aidax_pool& p, const aidax_model* m, int start_mode)
     p.kernel = k;
     p.kind = kind;
     p.sdesc = sd;
+    p.mdesc = md;
     p.cdesc = cd;
     p.hidden = m->hidden;
     p.input_size = m->input_size;
@@ -258,7 +274,7 @@ int set_model_impl(aidax_pool& p, const aidax_model* m, int start_mode)
     HIP_TRY(launch_reset_for_model(p.d_st, p.d_nn, p.n_streams, p.nn_stride, p.p_den(), p.q));
     p.has_model = true;
     if (start_mode == AIDAX_START_WARMUP) {           // 2048 zeros through applyModel (:1077-1078)
-        const uint32_t chunk = kind == aidax_pool::TABLE ? kWarmupFrames : p.ext_chunk();
+        const uint32_t chunk = p.launch_chunk(kWarmupFrames);
         for (uint32_t done = 0; done < kWarmupFrames; done += chunk) {
             LaunchArgs a = p.args(nullptr, nullptr, std::min(chunk, kWarmupFrames - done), MODE_WARMUP);
             HIP_TRY(p.launch(a, p.q));
@@ -295,7 +311,7 @@ AIDAX_API int aidax_pool_create(uint32_t n_streams, uint32_t max_frames, double 
         p->host_sr = host_samplerate;
         p->gain_coef = exp_smoother_coef(static_cast<float>(host_samplerate), 0.1f);
         if (const char* f = std::getenv("AIDAX_KERNEL"))
-            p->force_form = std::strcmp(f, "wave") == 0 ? 1 : std::strcmp(f, "pipe") == 0 ? 2 : std::strcmp(f, "split") == 0 ? 3 : 0;
+            p->force_form = std::strcmp(f, "wave") == 0 ? 1 : std::strcmp(f, "pipe") == 0 ? 2 : std::strcmp(f, "split") == 0 ? 3 : std::strcmp(f, "valu") == 0 ? 4 : 0;
         try {
             HIP_TRY(hipSetDevice(device_id));
             HIP_TRY(hipStreamCreateWithFlags(&p->q, hipStreamNonBlocking));
@@ -426,15 +442,22 @@ AIDAX_API int aidax_pool_read_state(aidax_pool* p, uint32_t stream, int layer, f
 {
     if (!p || !h) return fail(AIDAX_ERR_ARG, "null argument");
     if (!p->has_model || stream >= p->n_streams || p->kind == aidax_pool::CONV) return fail(AIDAX_ERR_STATE, "no such state");
-    if (p->kind == aidax_pool::TABLE ? layer != 0 : (layer < 0 || layer >= p->sdesc.n_layers)) return fail(AIDAX_ERR_STATE, "no such layer");
+    const int n_layers = p->kind == aidax_pool::TABLE ? 1 : p->kind == aidax_pool::MFMA ? p->mdesc.n_layers : p->sdesc.n_layers;
+    if (layer < 0 || layer >= n_layers) return fail(AIDAX_ERR_STATE, "no such layer");
     return guarded([&]() -> int {
         HIP_TRY(hipSetDevice(p->device));
         HIP_TRY(hipStreamSynchronize(p->q));
-        const bool stack = p->kind == aidax_pool::STACK;
-        const uint32_t H = static_cast<uint32_t>(stack ? p->sdesc.L[layer].hidden : p->hidden);
+        uint32_t H = static_cast<uint32_t>(p->hidden), off = 0;
+        bool lstm = false;
+        if (p->kind == aidax_pool::STACK) {
+            H = static_cast<uint32_t>(p->sdesc.L[layer].hidden); off = p->sdesc.L[layer].state_off; lstm = p->sdesc.L[layer].cell == 0;
+        } else if (p->kind == aidax_pool::MFMA) {
+            H = static_cast<uint32_t>(p->mdesc.hidden); off = p->mdesc.L[layer].state_off; lstm = p->mdesc.L[layer].cell == 0;
+        } else {
+            lstm = p->kernel->cell == AIDAX_CELL_LSTM;
+        }
         const uint32_t n = H < cap ? H : cap;
-        const bool lstm = stack ? p->sdesc.L[layer].cell == 0 : p->kernel->cell == AIDAX_CELL_LSTM;
-        const float* base = p->d_nn + static_cast<size_t>(stream) * p->nn_stride + (stack ? p->sdesc.L[layer].state_off : 0);
+        const float* base = p->d_nn + static_cast<size_t>(stream) * p->nn_stride + off;
         HIP_TRY(hipMemcpy(h, base, n * sizeof(float), hipMemcpyDeviceToHost));
         if (c && lstm) HIP_TRY(hipMemcpy(c, base + H, n * sizeof(float), hipMemcpyDeviceToHost));
         return static_cast<int>(H);
@@ -445,6 +468,7 @@ AIDAX_API const char* aidax_pool_kernel_name(const aidax_pool* p)
 {
     if (!(p && p->has_model)) return "k_nomodel";
     if (p->kind == aidax_pool::STACK) return "k_stack";
+    if (p->kind == aidax_pool::MFMA) return "k_chain+k_mfma";
     if (p->kind == aidax_pool::CONV) return "k_conv";
     const int form = p->chain_form();
     return form == 1 ? p->kernel->name_pipe : form == 2 ? p->kernel->name_split : p->kernel->name;
@@ -466,7 +490,7 @@ AIDAX_API int aidax_model_forward(const aidax_model* m, int device_id, const flo
             HIP_TRY(hipMalloc(&d_y, sizeof(float) * (n ? n : 1)));
             HIP_TRY(hipMemcpyAsync(d_x, X, xb, hipMemcpyHostToDevice, p->q));
             hipError_t le = hipSuccess;
-            const uint32_t chunk = p->kind == aidax_pool::TABLE ? (n ? n : 1) : 256u;
+            const uint32_t chunk = p->launch_chunk(n ? n : 1);
             for (uint32_t done = 0; done < n && le == hipSuccess; done += chunk) {
                 LaunchArgs a = p->args(d_x + static_cast<size_t>(done) * m->input_size, d_y + done,
                                        std::min(chunk, n - done), MODE_NN_ONLY);

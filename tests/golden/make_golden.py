@@ -71,8 +71,10 @@ def torch_forward(j, X):
     return x[0, :, 0].numpy().astype(np.float32)
 
 
-def make_nn():
+def make_nn(force=False):
     for name, kw in modelgen.GOLDEN_CASES.items():
+        if not force and os.path.exists(os.path.join(HERE, f"nn_{name}.npz")):
+            continue                      # committed fixtures stay byte-stable; --force regenerates all
         j = modelgen.make_model(**kw)
         X = modelgen.golden_inputs(name, kw["input_size"])
         y = torch_forward(j, X)
@@ -156,8 +158,9 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", action="store_true")
     ap.add_argument("--no-nn", action="store_true")
+    ap.add_argument("--force", action="store_true", help="regenerate nn_<case>.npz files that already exist")
     a = ap.parse_args()
     if not a.no_nn:
-        make_nn()
+        make_nn(a.force)
     if a.ref:
         make_dsp_ref()

@@ -124,6 +124,10 @@ GOLDEN_CASES = {
     "gru80_in1":           dict(kind="gru", hidden=80, input_size=1, seed=801),
     "lstm96x2_in1":        dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2),
     "conv16x8_in1":        dict(kind="conv", hidden=16, input_size=1, seed=1608),
+    # widths outside the reference's table: served by the matrix-core kernel (k_mfma)
+    "gru128_in3":          dict(kind="gru", hidden=128, input_size=3, seed=128),
+    "gru48x3_in2":         dict(kind="gru", hidden=48, input_size=2, seed=483, n_rnn=3),
+    "lstm112_in1_skip":    dict(kind="lstm", hidden=112, input_size=1, seed=112, in_skip=1),
 }
 GOLDEN_LEN = 4096
 

@@ -345,15 +345,21 @@ def test_device_resident_entry_point_matches_host_entry_point(tmp_path):
 
 # ------------------------------------------------- extensions (parity unpinned by the reference)
 
+@pytest.mark.parametrize("form", ["mfma", "valu"])
 @pytest.mark.parametrize("kind,kw", [
     ("lstm96x2", dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2)),        # BASELINE cfg #5 model
     ("gru48x3", dict(kind="gru", hidden=48, input_size=2, seed=483, n_rnn=3)),
     ("conv16x8", dict(kind="conv", hidden=16, input_size=1, seed=1608)),                # BASELINE cfg #4 model
     ("conv8x4k5", dict(kind="conv", hidden=8, input_size=1, seed=85, conv_layers=4, conv_k=5)),
 ])
-def test_extension_models_full_chain(kind, kw, tmp_path):
+def test_extension_models_full_chain(kind, kw, form, tmp_path, monkeypatch):
     """Stacked recurrent layers and conv1d stacks through the full run() chain, 11 streams (not a
-    multiple of the 8-stream workgroup), blocks shorter than the conv history, warm-up state."""
+    multiple of the 8- or 16-stream workgroups), blocks shorter than the conv history, warm-up state.
+    Stacked models run on the matrix-core kernel by default and on the VALU kernel with AIDAX_KERNEL=valu."""
+    if form == "valu":
+        if kw["kind"] == "conv":
+            pytest.skip("conv stacks have one form")
+        monkeypatch.setenv("AIDAX_KERNEL", "valu")
     path, spec = _model_file(tmp_path, kind, **kw)
     m = ax.Model(path)
     S, n, block = 11, 1536, 64
@@ -362,7 +368,7 @@ def test_extension_models_full_chain(kind, kw, tmp_path):
     cg, co = _ctl_pair(**ckw)
     pool = ax.Pool(S, 256)
     pool.set_model(m)
-    assert pool.kernel_name in ("k_stack", "k_conv")
+    assert pool.kernel_name == ("k_conv" if kw["kind"] == "conv" else "k_stack" if form == "valu" else "k_chain+k_mfma")
     pool.set_controls(cg)
     got = _run_gpu(pool, x, block)
     want = O.run_streams(spec, co, x, block)
@@ -374,6 +380,86 @@ def test_extension_models_full_chain(kind, kw, tmp_path):
     pool2.set_controls(cg)
     got2 = _run_gpu(pool2, x, 256)
     assert np.abs(got2 - got).max() < 2e-6
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("g128", dict(kind="gru", hidden=128, input_size=3, seed=128)),                      # one wide layer, both params
+    ("l64x2", dict(kind="lstm", hidden=64, input_size=2, seed=642, n_rnn=2, in_skip=1, in_gain=-2.0, out_gain=3.0)),
+    ("l16x4", dict(kind="lstm", hidden=16, input_size=1, seed=164, n_rnn=4)),             # one tile per wave, deepest skew
+])
+def test_matrix_core_form_ragged_blocks_and_per_stream_controls(name, kw, tmp_path):
+    """k_mfma with 37 streams (three 16-stream workgroups, the last one ragged), block sizes around the
+    kernel's 256-frame staging chunk incl. 0 and 1, per-stream disable / bypass / EQ position, PARAM
+    ramps that change between blocks - every fifth stream against the plugin mirror of the oracle."""
+    path, spec = _model_file(tmp_path, name, **kw)
+    S = 37
+    sizes = [256, 1, 0, 37, 700, 16, 255, 513, 3]
+    x = modelgen.signal(S, sum(sizes), seed=21)
+    pool = ax.Pool(S, 1024)
+    pool.set_model(ax.Model(path))
+    assert pool.kernel_name == "k_chain+k_mfma"
+    kws = [dict(param1=0.3, param2=0.8), dict(enabled=0.0), dict(net_bypass=1.0), dict(eq_position=1.0, bass_boost_db=5.0, mid_type=1.0),
+           dict(dc_blocker=0.0, in_lpf_pc=0.0, eq_bypass=1.0, param1=1.0), dict(pregain_db=6.0, master_db=-6.0, treble_boost_db=4.0, param2=0.1)]
+    flip = dict(param1=0.9, param2=0.2, master_db=-3.0)                     # applied to every stream from the 5th block on
+    got = np.empty_like(x)
+    pos = 0
+    for bi, n in enumerate(sizes):
+        for s in range(S):
+            c = dict(kws[s % len(kws)])
+            if bi >= 4:
+                c.update(flip)
+            pool.set_controls(ax.default_controls(**c), stream=s)
+        got[:, pos:pos + n] = pool.process(np.ascontiguousarray(x[:, pos:pos + n]))
+        pos += n
+    for s in list(range(0, S, 5)) + [S - 1]:
+        plug = O.OraclePlugin()
+        plug.set_model(O.OracleModel(spec))
+        want = np.empty(x.shape[1], np.float32)
+        pos = 0
+        for bi, n in enumerate(sizes):
+            c = dict(kws[s % len(kws)])
+            if bi >= 4:
+                c.update(flip)
+            want[pos:pos + n] = plug.run(O.default_controls(**c), x[s, pos:pos + n])
+            pos += n
+        c0 = kws[s % len(kws)]
+        if c0.get("enabled", 1.0) == 0.0:
+            assert np.array_equal(got[s], x[s])                              # hard bypass copies the input (:612-619)
+        elif c0.get("net_bypass", 0.0) == 1.0:
+            assert np.array_equal(got[s], want), s                           # no NN in circuit: bit-exact
+        else:
+            assert np.abs(got[s] - want).max() < THR * 4, (name, s, np.abs(got[s] - want).max())
+
+
+def test_matrix_core_form_model_swap_and_activate(tmp_path, bundled_models):
+    """A pool that moves between a register-resident model, a k_mfma model and no model keeps the
+    reference's swap semantics (fresh state + warm-up, PARAM smoothers re-armed by activate)."""
+    path_w, spec_w = _model_file(tmp_path, "w", kind="lstm", hidden=96, input_size=2, seed=7, n_rnn=2)
+    path_t, spec_t = _model_file(tmp_path, "t", kind="gru", hidden=16, input_size=2, seed=9)
+    S, n = 20, 192
+    x = modelgen.signal(S, 4 * n, seed=5)
+    cg, co = _ctl_pair(param1=0.6)
+    pool = ax.Pool(S, 256)
+    pool.set_controls(cg)
+    plug = [O.OraclePlugin() for _ in range(2)]
+    got, want = [], [[], []]
+    seq = [(path_t, spec_t), (path_w, spec_w), (path_w, spec_w), (path_t, spec_t)]
+    for bi, (pth, spec) in enumerate(seq):
+        if bi != 2:
+            pool.set_model(ax.Model(pth))
+            for p in plug:                                                   # a swap inherits the param targets (:822-825)
+                old = (p.model.ptr.contents.param1Coeff.target, p.model.ptr.contents.param2Coeff.target) if p.model else (0.0, 0.0)
+                p.set_model(O.OracleModel(spec, old[0], old[1]))
+        else:
+            pool.activate()
+            for p in plug:
+                p.activate()
+        got.append(pool.process(np.ascontiguousarray(x[:, bi * n:(bi + 1) * n])))
+        for i, s in enumerate((0, S - 1)):
+            want[i].append(plug[i].run(co, x[s, bi * n:(bi + 1) * n]))
+    got = np.concatenate(got, axis=1)
+    for i, s in enumerate((0, S - 1)):
+        assert np.abs(got[s] - np.concatenate(want[i])).max() < THR * 2
 
 
 def test_stacked_model_state_readback(tmp_path):

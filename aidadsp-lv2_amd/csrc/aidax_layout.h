@@ -149,11 +149,16 @@ struct StackDesc {
 // kMfmaStreams streams as the N dimension of v_mfma_f32_16x16x4_f32; the weights are stored as
 // ready-made A fragments (one coalesced load per wave instruction):
 //   tile T = 16 gate rows = 4 units x 4 rows (LSTM i,f,g,o; GRU z, r, n_recurrent, n_input), wave w
-//   owns tiles [w*TPW, (w+1)*TPW) with TPW = hidden/16; lane supplies row (lane&15), k = 4*kk + (lane>>4).
+//   owns tiles [w*TPW, (w+1)*TPW) with TPW = hidden/4/waves (waves = 8 when hidden % 32 == 0, else 4); lane supplies row (lane&15), k = 4*kk + (lane>>4).
 //   k-steps come in groups of 4:  [wave][group][lane][4 k-steps][TPW]   -> TPW float4 per lane and group;
 //   a wave's groups run [h of the layer below | own h(t-1)]; layer 0's 1..3 inputs are one k-step on
 //   their own, [wave][lane][TPW]; the bias is a plain [unit][4 rows] table the accumulators start from.
 constexpr int kMfmaStreams = 16;
+#ifndef AIDAX_MFMA_WIDE
+#define AIDAX_MFMA_WIDE 1
+#endif
+// waves per k_mfma workgroup: 8 (two per SIMD) when the tiles divide, else 4
+constexpr int mfma_waves(int hidden) { return (AIDAX_MFMA_WIDE && hidden % 32 == 0) ? 8 : 4; }
 struct MfmaLayer {
     int32_t cell;          // 0 LSTM, 1 GRU
     int32_t in_size;       // layer 0: 1..3 model inputs (one small segment); deeper: hidden of the layer below
@@ -163,7 +168,7 @@ struct MfmaLayer {
     uint32_t state_off;    // as StackLayer
 };
 struct MfmaDesc {
-    int32_t n_layers, hidden, tpw, pad;
+    int32_t n_layers, hidden, tpw, waves;
     MfmaLayer L[kMaxStackLayers];
     uint32_t wd_off, bd_off;
 };

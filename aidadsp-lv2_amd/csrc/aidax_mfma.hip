@@ -2,8 +2,8 @@
 // hidden 96/128 ...: BASELINE config #5) on the matrix cores.
 //
 // The per-sample work of such a model IS a contraction once streams are batched: for every
-// frame, gates[4H] = [W|U|b] . [x ; h(t-1) ; 1] for each stream. One workgroup (4 waves) takes
-// kMfmaStreams = 16 streams as the N dimension of v_mfma_f32_16x16x4_f32:
+// frame, gates[4H] = [W|U] . [x ; h(t-1)] + b for each stream. One workgroup (4 or 8 waves) takes
+// kMfmaStreams = 16 streams as the N dimension of v_mfma_f32_16x16x4_f32 (exact fp32 in, fp32 acc):
 //
 //   A (16 rows x 4 k)   weights, pre-packed on the host as ready fragments (aidax_pack.cpp:pack_mfma):
 //                       a tile's 16 rows are 4 units x their 4 gate rows, so the accumulator a lane
@@ -11,16 +11,20 @@
 //                       unit 4T+a for stream n: the cell update needs no cross-lane traffic at all.
 //   B (4 k x 16 streams) the input vector, kept TRANSPOSED in LDS ([k][stream]) so a fragment is the
 //                       64 consecutive floats starting at 64*kk: one conflict-free ds_read_b32.
-//   bias                one more k-step against the constant column (1,0,0,0).
+//   bias                a [unit][4] table in LDS the accumulators start from.
 //
 // Layers are skewed in time: at tick T layer l works on frame T-l and the Dense on frame T-L, so
 // everything a tick reads was written in the tick before (h buffers and the input column are
-// double-buffered by tick parity) and ONE workgroup barrier per tick suffices; the cell update of a
-// layer (VALU) overlaps the matrix work of the next one.
+// double-buffered by tick parity) and ONE workgroup barrier per tick suffices.
 //
-// Weights stream from L2 every tick (437 KiB for LSTM-96 x2 - they cannot live in registers or LDS);
-// each fragment load is used for 16 streams. The DSP chain around the model runs in the packed
-// k_chain launches of aidax_kernels.hip (split form), this kernel is applyModel only.
+// Weights stream from L2 every tick (437 KiB for LSTM-96 x2; each fragment load serves 16 streams),
+// requested two k-step groups ahead of the MFMAs that use them. The DSP chain around the model runs
+// in the packed k_chain launches of aidax_kernels.hip (split form), this kernel is applyModel only.
+//
+// Measured (MI355X, LSTM-96 x2, 256 frames): 2.50 ms per block for up to 4096 streams
+// (k_stack, the VALU form: 5.1 ms at 2048), i.e. 23 k cycles per tick against 13.8 k of pure
+// matrix-core time (432 MFMAs x 32 cycles per SIMD); the rest is the cell update (VALU next to
+// MFMAs is not hidden on this machine, scratch/umfma.hip), L2 latency and the barrier.
 #include "aidax_device.h"
 #include "aidax_kernels.h"
 #include "aidax_layout.h"
@@ -29,8 +33,6 @@ namespace aidax {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kMfmaThreads = 256;
-constexpr int kMfmaWaves = 4;
 constexpr int kMfmaChunk = 256;          // frames staged in LDS at a time
 
 __host__ __device__ inline size_t mfma_lds_floats(int hidden, int n_layers, int n_frames)
@@ -64,42 +66,67 @@ __device__ __forceinline__ void load_frag(f32x4 (&dst)[TPW], const f32x4* __rest
 // One recurrent layer's gate pre-activations for this wave's TPW tiles:
 //   acc[tl] += A(group g) * B(group g) for the layer's `g_in + g_rec` groups of four k-steps, where
 //   B = below[64*kk + lane] for the first g_in groups (h of the layer below) and own[...] after that.
-// The A fragments of group g+1 are requested before the 4*TPW MFMAs of group g are issued: left to
+// The A fragments of later groups are requested before the 4*TPW MFMAs of group g are issued: left to
 // itself the compiler loads each float4 right in front of its four MFMAs and exposes the L2 latency
 // 6 times per group (measured 36 k cycles per tick against 14 k of matrix-core time).
 template <int TPW>
 __device__ __forceinline__ void gates_mfma(f32x4 (&acc)[TPW], const f32x4* __restrict__ ap, const float* below,
                                            const float* own, int g_in, int g_tot, int lane)
 {
-    f32x4 cur[TPW], nxt[TPW];
-    load_frag<TPW>(cur, ap);
-#pragma unroll 2
-    for (int g = 0; g < g_tot; ++g) {
-        const f32x4* an = ap + (g + 1 < g_tot ? kWave * TPW : 0);     // the last pass re-reads its own group
-        load_frag<TPW>(nxt, an);
-        const float* src = g < g_in ? below + 256 * g : own + 256 * (g - g_in);
-        float b[4];
+    // Fragments are requested two groups ahead (one group is ~400-800 cycles of MFMAs, the L2 round trip
+    // under load is of that order). Three buffers rotate by NAME through a 3x unrolled body: a rotating
+    // copy costs TPW*4 v_mov per group, and VALU work next to MFMAs is not hidden on this machine
+    // (scratch/umfma.hip: +4.7 cycles per VALU instruction issued between two MFMAs of one wave).
+    f32x4 f0[TPW], f1[TPW], f2[TPW];
+    const int stride = kWave * TPW;
+    const int last = g_tot - 1;
+    auto fetch = [&](f32x4 (&f)[TPW], int g) {
+        load_frag<TPW>(f, ap + (size_t)(g < last ? g : last) * stride);      // the tail re-reads the last group
+    };
+    // B fragments (LDS) run one group ahead as well: read for group g+1, then the MFMAs of group g
+    float bc[4], bn[4];
+    auto read_b = [&](float (&b)[4], int g) {
+        const int gg = g < last ? g : last;
+        const float* src = gg < g_in ? below + 256 * gg : own + 256 * (gg - g_in);
 #pragma unroll
         for (int j = 0; j < 4; ++j) b[j] = src[64 * j + lane];
+    };
+    auto group = [&](const f32x4 (&f)[TPW], const float (&b)[4]) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int tl = 0; tl < TPW; ++tl) {
                 const int e = j * TPW + tl;
-                acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[e / 4][e % 4], b[j], acc[tl], 0, 0, 0);
+                acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[e / 4][e % 4], b[j], acc[tl], 0, 0, 0);
             }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    load_frag<TPW>(f0, ap);
+    load_frag<TPW>(f1, ap + (size_t)(last > 0 ? 1 : 0) * stride);
+    read_b(bc, 0);
+    auto roll = [&]() {
 #pragma unroll
-        for (int q = 0; q < TPW; ++q) cur[q] = nxt[q];
-        ap = an;
+        for (int j = 0; j < 4; ++j) bc[j] = bn[j];
+    };
+    int g = 0;
+    for (; g + 3 <= g_tot; g += 3) {
+        fetch(f2, g + 2); read_b(bn, g + 1); group(f0, bc); roll();
+        fetch(f0, g + 3); read_b(bn, g + 2); group(f1, bc); roll();
+        fetch(f1, g + 4); read_b(bn, g + 3); group(f2, bc); roll();
+    }
+    if (g < g_tot) {                                   // one or two groups left, buffers in the same rotation
+        read_b(bn, g + 1); group(f0, bc);
+        if (g + 1 < g_tot) group(f1, bn);
     }
 }
 
-template <int TPW>
-__global__ __launch_bounds__(kMfmaThreads) void k_mfma(LaunchArgs a, MfmaDesc d)
+template <int TPW, int NW>
+__global__ __launch_bounds__(NW * kWave) void k_mfma(LaunchArgs a, MfmaDesc d)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int H = 16 * TPW;
+    constexpr int H = 4 * TPW * NW;
+    constexpr int kMfmaThreads = NW * kWave, kMfmaWaves = NW;
     constexpr int NS = kMfmaStreams;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -176,6 +203,11 @@ __global__ __launch_bounds__(kMfmaThreads) void k_mfma(LaunchArgs a, MfmaDesc d)
     }
     __syncthreads();
 
+    const int l_first = (NW == 8 && wave >= 4) ? NL / 2 : 0;       // waves w and w+4 share a SIMD (scratch/umfma.hip)
+    // layer 0's model-input k-step (x, PARAM1, PARAM2, 0): loop-invariant, kept in registers
+    float w_in0[TPW];
+#pragma unroll
+    for (int tl = 0; tl < TPW; ++tl) w_in0[tl] = W[d.L[0].w_in_off + ((size_t)wave * kWave + lane) * TPW + tl];
     int par = 0;                                           // parity the next tick reads
     for (int base = 0; base < n; base += kMfmaChunk) {
         const int cnt = n - base < kMfmaChunk ? n - base : kMfmaChunk;
@@ -225,12 +257,13 @@ __global__ __launch_bounds__(kMfmaThreads) void k_mfma(LaunchArgs a, MfmaDesc d)
 
             // ---- Dense(H,1) + skip + output gain of frame tick-NL: wave w reduces streams 4w..4w+3
             const int fd = tick - NL;
-            if (fd >= 0) {
-                const int sl = wave * 4 + (lane >> 4), q = lane & 15;
+            constexpr int kDenseWave0 = NW == 8 ? 4 : 0;   // wave 0 already writes the input column
+            if (fd >= 0 && wave >= kDenseWave0 && wave < kDenseWave0 + 4) {
+                const int sl = (wave - kDenseWave0) * 4 + (lane >> 4), q = lane & 15;
                 const float* hv = hT + ((size_t)(NL - 1) * 2 + rd) * H * NS;
                 float part = 0.f;
 #pragma unroll
-                for (int j = 0; j < TPW; ++j) part = __builtin_fmaf(wdl[q + 16 * j], hv[(q + 16 * j) * NS + sl], part);
+                for (int j = 0; j < H / 16; ++j) part = __builtin_fmaf(wdl[q + 16 * j], hv[(q + 16 * j) * NS + sl], part);
                 const float y = row_sum16(part) + wdl[H];
                 const float x = xb[sl * nP + fd] * a.in_gain;
                 float o = a.input_skip ? x + y : y;
@@ -239,7 +272,9 @@ __global__ __launch_bounds__(kMfmaThreads) void k_mfma(LaunchArgs a, MfmaDesc d)
             }
 
             // ---- recurrent layers, layer l on frame tick-l
-            for (int l = 0; l < NL; ++l) {
+            for (int li = 0; li < NL; ++li) {
+                int l = li + l_first;                      // the second wave of a SIMD starts half a stack later
+                if (l >= NL) l -= NL;
                 const MfmaLayer& L = d.L[l];
                 const int f = tick - l;
                 float* h_rd = hT + ((size_t)l * 2 + rd) * H * NS;
@@ -258,11 +293,10 @@ __global__ __launch_bounds__(kMfmaThreads) void k_mfma(LaunchArgs a, MfmaDesc d)
 #pragma unroll
                 for (int tl = 0; tl < TPW; ++tl) acc[tl] = bias4[4 * (wave * TPW + tl) + (lane >> 4)];
                 if (l == 0) {                              // the model inputs: one k-step (x, PARAM1, PARAM2, 0)
-                    const float* wi = W + L.w_in_off + ((size_t)wave * kWave + lane) * TPW;
                     const float b = xin[rd * 64 + lane];
 #pragma unroll
                     for (int tl = 0; tl < TPW; ++tl)
-                        acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(wi[tl], b, acc[tl], 0, 0, 0);
+                        acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_in0[tl], b, acc[tl], 0, 0, 0);
                 }
                 const int g_in = l == 0 ? 0 : H / 16, g_tot = g_in + H / 16;
                 const f32x4* ap = reinterpret_cast<const f32x4*>(W + L.w_big_off) + ((size_t)wave * g_tot * kWave + lane) * TPW;
@@ -323,12 +357,14 @@ __global__ __launch_bounds__(kMfmaThreads) void k_mfma(LaunchArgs a, MfmaDesc d)
 
 // ---------------------------------------------------------------- host side
 typedef void (*MfmaFn)(LaunchArgs, MfmaDesc);
-static MfmaFn mfma_fn(int tpw)
+static MfmaFn mfma_fn(int hidden)
 {
-    switch (tpw) {
-    case 1: return k_mfma<1>; case 2: return k_mfma<2>; case 3: return k_mfma<3>; case 4: return k_mfma<4>;
-    case 5: return k_mfma<5>; case 6: return k_mfma<6>; case 7: return k_mfma<7>; case 8: return k_mfma<8>;
-    default: return nullptr;
+    switch (hidden) {
+#define AIDAX_MFMA_CASE(HID) case HID: return k_mfma<HID / 4 / mfma_waves(HID), mfma_waves(HID)>
+    AIDAX_MFMA_CASE(16); AIDAX_MFMA_CASE(32); AIDAX_MFMA_CASE(48); AIDAX_MFMA_CASE(64);
+    AIDAX_MFMA_CASE(80); AIDAX_MFMA_CASE(96); AIDAX_MFMA_CASE(112); AIDAX_MFMA_CASE(128);
+#undef AIDAX_MFMA_CASE
+    default:  return nullptr;
     }
 }
 
@@ -336,7 +372,7 @@ size_t mfma_lds_bytes(const MfmaDesc& d, uint32_t n_frames) { return mfma_lds_fl
 
 hipError_t launch_mfma_kernel(const LaunchArgs& a, const MfmaDesc& d, hipStream_t stream)
 {
-    MfmaFn fn = mfma_fn(d.tpw);
+    MfmaFn fn = mfma_fn(d.hidden);
     if (!fn) return hipErrorInvalidValue;
     const size_t lds = mfma_lds_bytes(d, a.n_frames);
     if (lds > 64 * 1024) {
@@ -344,7 +380,7 @@ hipError_t launch_mfma_kernel(const LaunchArgs& a, const MfmaDesc& d, hipStream_
         if (e != hipSuccess) return e;
     }
     const uint32_t groups = (a.n_streams + kMfmaStreams - 1) / kMfmaStreams;
-    hipLaunchKernelGGL(fn, dim3(groups), dim3(kMfmaThreads), lds, stream, a, d);
+    hipLaunchKernelGGL(fn, dim3(groups), dim3(mfma_waves(d.hidden) * kWave), lds, stream, a, d);
     return hipGetLastError();
 }
 

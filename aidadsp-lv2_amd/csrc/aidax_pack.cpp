@@ -117,10 +117,11 @@ std::vector<float> pack_mfma(const aidax_model& m, MfmaDesc* d, uint32_t* state_
 {
     std::vector<float> out;
     *d = MfmaDesc{};
-    const int H = m.hidden, TPW = H / 16;
+    const int H = m.hidden, NW = mfma_waves(H), TPW = H / 4 / NW;
     d->n_layers = m.n_rnn;
     d->hidden = H;
     d->tpw = TPW;
+    d->waves = NW;
     uint32_t st = 0;
     enum Seg { SEG_IN, SEG_REC, SEG_BIAS };
     for (int l = 0; l < m.n_rnn; ++l) {
@@ -152,7 +153,7 @@ std::vector<float> pack_mfma(const aidax_model& m, MfmaDesc* d, uint32_t* state_
         // layer 0: the 1..3 model inputs are one k-step on their own ("small" segment)
         M.w_in_off = static_cast<uint32_t>(out.size());
         if (l == 0)
-            for (int w = 0; w < 4; ++w)
+            for (int w = 0; w < NW; ++w)
                 for (int lane = 0; lane < kWave; ++lane)
                     for (int tl = 0; tl < TPW; ++tl) {
                         const int T = w * TPW + tl, r = lane & 15;
@@ -161,7 +162,7 @@ std::vector<float> pack_mfma(const aidax_model& m, MfmaDesc* d, uint32_t* state_
         // per wave one run of k-step groups: [h of the layer below (layers >= 1)] then [own h(t-1)]
         M.w_big_off = static_cast<uint32_t>(out.size());
         const int g_in = l == 0 ? 0 : I / 16, g_rec = H / 16;
-        for (int w = 0; w < 4; ++w)
+        for (int w = 0; w < NW; ++w)
             for (int grp = 0; grp < g_in + g_rec; ++grp)
                 for (int lane = 0; lane < kWave; ++lane)
                     for (int j = 0; j < 4; ++j)

@@ -36,13 +36,34 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-N_STREAMS = 1024          # per GPU
+N_STREAMS = 1024          # per GPU (cfg2)
 N_FRAMES = 256
 RING = 8                  # distinct input blocks cycled through HBM
 HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: vector FP32 peak
 ALGO_BYTES_PER_SAMPLE = 8
-LSTM32_FLOPS_PER_SAMPLE = 8512 + 63 + 6   # NN MACs x2 + biquad fp64 flops + ramps
+
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
+
+# The headline line is cfg2 (BASELINE.json configs[1]). The other GPU configs can be timed with
+# --workload; they are parity-test cases, not the bench line the driver records.
+WORKLOADS = {
+    "cfg2": dict(model=dict(kind="lstm", hidden=32, input_size=1, seed=32), streams=1024, controls={},
+                 flops=8512 + 63 + 6, bound="hbm",
+                 text="cfg2: LSTM-32 amp model, 1024 streams/GPU x 256-frame blocks, full run() chain, TTL-default controls"),
+    "cfg3": dict(model=dict(kind="gru", hidden=64, input_size=3, seed=64), streams=4096,
+                 controls=dict(bass_boost_db=4.0, mid_boost_db=-3.0, mid_q=1.2, treble_boost_db=2.0, depth_boost_db=3.0,
+                               presence_boost_db=3.0, param1=0.5, param2=0.3),
+                 flops=2 * (3 * 64 * (64 + 3) + 64) + 63 + 6, bound="hbm",
+                 text="cfg3: GRU-64 conditioned (PARAM1+PARAM2) pedal model + 5-band EQ post, 4096 streams x 256-frame blocks"),
+    "cfg4": dict(model=dict(kind="conv", hidden=16, input_size=1, seed=1608), streams=1024, controls={},
+                 flops=2 * (3 * 1 * 16 + 7 * 3 * 16 * 16 + 16) + 63 + 6, bound="hbm",
+                 text="cfg4: dilated conv1d stack (8 layers, 16 channels, k=3), 1024 streams/GPU (8192 over 8 GPUs) x 256-frame blocks"),
+    "cfg5": dict(model=dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2), streams=2048, controls={},
+                 flops=2 * (384 * (1 + 96) + 384 * (96 + 96) + 96), bound="mfma",
+                 text="cfg5: LSTM-96 x2 model, 2048 streams/GPU (16384 over 8 GPUs) x 256-frame blocks, matrix-core kernel"),
+}
 
 
 def dist_env():
@@ -72,11 +93,11 @@ def stream_range(rank: int, world: int, total_streams: int):
     return lo, hi
 
 
-def cfg2_model_path():
+def workload_model_path(name: str):
     from tests import modelgen
-    j = modelgen.make_model("lstm", 32, 1, seed=32)
+    j = modelgen.make_model(**WORKLOADS[name]["model"])
     d = tempfile.mkdtemp(prefix="aidax_bench_")
-    return modelgen.write_model(j, os.path.join(d, "lstm32_cfg2.json")), j
+    return modelgen.write_model(j, os.path.join(d, f"{name}.json")), j
 
 
 def usable_cores() -> int:
@@ -113,22 +134,22 @@ def pmc_traffic_bytes(kernel_name: str):
     return best
 
 
-def cpu_baseline(j, target_s: float = 12.0):
-    """The CPU oracle on all host cores over a bounded sample of cfg2."""
+def cpu_baseline(j, name: str = "cfg2", target_s: float = 12.0):
+    """The CPU oracle on all host cores over a bounded sample of the workload."""
     from oracle import oracle as O
     from tests import modelgen
     spec = O.parse_model(j)
     cores = usable_cores()
-    streams = N_STREAMS                      # the whole cfg2 stream set; the sample is bounded in blocks
+    streams = N_STREAMS                      # 1024 of the workload's streams; the sample is bounded in blocks
     x = modelgen.signal(streams, N_FRAMES)
-    c = O.default_controls()
+    c = O.default_controls(**WORKLOADS[name]["controls"])
     secs, _ = O.cpu_bench(spec, c, x, n_blocks=2, warm_blocks=1, n_threads=cores, fast=True)
     per_block = secs / 2
     blocks = int(max(4, min(20000, target_s / max(per_block, 1e-6))))
     secs, _ = O.cpu_bench(spec, c, x, n_blocks=blocks, warm_blocks=1, n_threads=cores, fast=True)
     sps = streams * N_FRAMES * blocks / secs
     return {"value": sps, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"all {streams} cfg2 streams x {blocks} blocks of {N_FRAMES} frames, "
+            "sample": f"{streams} {name} streams x {blocks} blocks of {N_FRAMES} frames, "
                       f"full run() chain, C oracle with vectorised exp/tanh (-O3 -march=x86-64-v3, AVX2), {cores} pthreads, {secs:.1f} s"}
 
 
@@ -137,7 +158,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20000)
     ap.add_argument("--warmup", type=int, default=500)
-    ap.add_argument("--streams", type=int, default=N_STREAMS, help="streams per GPU (cfg2: 1024)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
+    ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: the workload's, cfg2 = 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     args = ap.parse_args()
@@ -158,12 +180,13 @@ def main():
     ax = importlib.import_module("aidadsp-lv2_amd")
     from tests import modelgen
 
-    S = args.streams
-    path, j = cfg2_model_path()
+    wl = WORKLOADS[args.workload]
+    S = args.streams or wl["streams"]
+    path, j = workload_model_path(args.workload)
     model = ax.Model(path)
     pool = ax.Pool(S, N_FRAMES, 48000.0, device=local)
     pool.set_model(model, ax.START_WARMUP)
-    pool.set_controls(ax.default_controls())
+    pool.set_controls(ax.default_controls(**wl["controls"]))
 
     # synthetic inputs of this rank's stream range, resident in HBM before timing starts
     lo, hi = stream_range(rank, world, S * world)
@@ -184,9 +207,10 @@ def main():
         from oracle import oracle as O
         chk = ax.Pool(16, N_FRAMES, 48000.0, device=local)
         chk.set_model(model, ax.START_WARMUP)
+        chk.set_controls(ax.default_controls(**wl["controls"]))
         xs = np.concatenate([b[:16] for b in host_ring[:4]], axis=1)
         got = np.concatenate([chk.process(np.ascontiguousarray(xs[:, k * N_FRAMES:(k + 1) * N_FRAMES])) for k in range(4)], axis=1)
-        want = O.run_streams(O.parse_model(j), O.default_controls(), xs, N_FRAMES)
+        want = O.run_streams(O.parse_model(j), O.default_controls(**wl["controls"]), xs, N_FRAMES)
         max_err = float(np.abs(got - want).max())
         chk.close()
 
@@ -218,26 +242,33 @@ def main():
         value = samples_all / elapsed_max
         algo_bytes = ALGO_BYTES_PER_SAMPLE * S * N_FRAMES                 # per launch
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = pmc_traffic_bytes(pool.kernel_name) if S == N_STREAMS else None
+        traffic = pmc_traffic_bytes(pool.kernel_name) if (args.workload == "cfg2" and S == N_STREAMS) else None
+        tflops = wl["flops"] * S * N_FRAMES / (kernel_ms * 1e-3) / 1e12
+        if wl["bound"] == "mfma":
+            roofline = {"bound": "mfma", "achieved": tflops, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": tflops / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "kernel_ms": kernel_ms,
+                        "algorithmic_flops_per_launch": wl["flops"] * S * N_FRAMES,
+                        "note": "kernel_ms spans the three launches of the split form (k_chain, k_mfma, k_chain)"}
+        else:
+            roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBPS,
+                        "traffic": traffic["bytes"] if traffic else None,
+                        "traffic_source": traffic["source"] if traffic else None,
+                        "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes}
         out = {
             "metric": "audio samples/sec (48 kHz mono, many streams)",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cfg2: LSTM-32 amp model, 1024 streams/GPU x 256-frame blocks, full run() chain, TTL-default controls",
+            "config": {"workload": wl["text"],
                        "streams_per_gpu": S, "frames": N_FRAMES, "kernel": pool.kernel_name,
                        "realtime_factor": value / (48000.0 * S * world)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic["bytes"] if traffic else None,
-                         "traffic_source": traffic["source"] if traffic else None,
-                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes},
-            "compute": {"fp32_tflops": LSTM32_FLOPS_PER_SAMPLE * S * N_FRAMES / (kernel_ms * 1e-3) / 1e12,
-                        "peak_tflops": FP32_PEAK_TFLOPS},
+            "roofline": roofline,
+            "compute": {"fp32_tflops": tflops, "peak_tflops": FP32_PEAK_TFLOPS},
             "max_abs_err": max_err,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(j)
+            out["cpu_baseline"] = cpu_baseline(j, args.workload)
         print(json.dumps(out), flush=True)
 
     pool.close()

@@ -120,34 +120,68 @@ struct ChainPass {
     ExpRamp g;
 };
 
+// One systolic step of one lane. CHECK = false is the steady state (every stage of the cascade has a
+// sample in range): no range tests, no exec-mask branches, the biquad is evaluated unconditionally and a
+// bypassed stage just selects x — ~27 instructions instead of ~45 with three nested branches. A lone
+// wave issues one instruction per ~5 cycles, so this loop IS the cost of a chain pass. Lanes that do not
+// run (stage >= K, disabled stream) and bypassed stages compute on whatever flows by; the caller restores
+// their z1/z2 afterwards (chain_finish).
+template <int DST_STRIDE, bool CHECK>
+__device__ __forceinline__ void chain_step(ChainPass& c, int stage, bool run, bool writer, float head, float& carry,
+                                           float* dst, int s, int n)
+{
+    const float from_left = dpp_row_shr1(carry);
+    const float x = stage == 0 ? head : from_left;
+    const int idx = s - stage;
+    if (!CHECK || (run && idx >= 0 && idx < n)) {
+        const double xd = x;                                // Biquad::process, Biquad.h:53-58
+        const double yd = xd * c.a0 + c.z1;
+        c.z1 = xd * c.a1 + c.z2 - c.b1 * yd;
+        c.z2 = xd * c.a2 - c.b2 * yd;
+        float y = c.active ? (float)yd : x;
+        const float gm = c.g.next();                        // every stage lane keeps its own copy;
+        if (stage == c.gain_lane) y = y * gm;               // only the gain lane's is used
+        carry = y;
+        if (writer) dst[idx * DST_STRIDE] = y;
+    }
+}
+
+// Runs the pass over src[0..n) -> dst. `stage` is this lane's position in its cascade (the lane id, or
+// lane & 7 when one wave carries eight streams), `run` whether the lane owns a stage of a running stream,
+// `depth` the longest cascade in the wave (steps = n + depth - 1).
+template <int DST_STRIDE = 1>
+__device__ __forceinline__ void chain_sweep(ChainPass& c, int stage, bool run, int depth, const float* src, float* dst, int n)
+{
+    const double z1o = c.z1, z2o = c.z2;
+    const bool writer = run && stage == c.K - 1;
+    float carry = 0.f;                         // this lane's previous output, read by lane+1
+    const int steps = n + depth - 1;
+    const int fill = depth - 1 < steps ? depth - 1 : steps;
+    float head_next = src[0];                  // LDS broadcast, fetched one step ahead
+    int s = 0;
+    for (; s < fill; ++s) {
+        const float head = head_next;
+        head_next = src[s + 1 < n ? s + 1 : n - 1];
+        chain_step<DST_STRIDE, true>(c, stage, run, writer, head, carry, dst, s, n);
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (; s < n; ++s) {                       // steady state: all `depth` stages in range
+        const float head = head_next;
+        head_next = src[s + 1 < n ? s + 1 : n - 1];
+        chain_step<DST_STRIDE, false>(c, stage, run, writer, head, carry, dst, s, n);
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (; s < steps; ++s) {
+        chain_step<DST_STRIDE, true>(c, stage, run, writer, head_next, carry, dst, s, n);
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (!run || !c.active) { c.z1 = z1o; c.z2 = z2o; }     // a bypassed biquad keeps its state (:622, :646)
+}
+
 template <int DST_STRIDE = 1>
 __device__ __forceinline__ void chain_run(ChainPass& c, const float* src, float* dst, int n, int lane)
 {
-    float carry = 0.f;                         // this lane's previous output, read by lane+1
-    const int steps = n + c.K - 1;
-    float head_next = src[0];                  // wave-uniform LDS broadcast, fetched one step ahead
-    for (int s = 0; s < steps; ++s) {
-        const float head = head_next;
-        head_next = src[s + 1 < n ? s + 1 : n - 1];
-        const float from_left = dpp_row_shr1(carry);
-        const float x = lane == 0 ? head : from_left;
-        const int idx = s - lane;
-        if (lane < c.K && idx >= 0 && idx < n) {
-            float y = x;
-            if (c.active) {                                 // Biquad::process, Biquad.h:53-58
-                const double xd = x;
-                const double yd = xd * c.a0 + c.z1;
-                c.z1 = xd * c.a1 + c.z2 - c.b1 * yd;
-                c.z2 = xd * c.a2 - c.b2 * yd;
-                y = (float)yd;
-            }
-            const float gm = c.g.next();                    // every stage lane keeps its own copy;
-            if (lane == c.gain_lane) y = y * gm;            // only the gain lane's is used
-            carry = y;
-            if (lane == c.K - 1) dst[idx * DST_STRIDE] = y;
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
+    chain_sweep<DST_STRIDE>(c, lane, lane < c.K, c.K, src, dst, n);
 }
 
 

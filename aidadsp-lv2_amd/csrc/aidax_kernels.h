@@ -33,6 +33,8 @@ size_t chain_lds_bytes(uint32_t n_frames);
 hipError_t launch_chain_pass(bool pre, const LaunchArgs& a, hipStream_t stream);
 hipError_t launch_mfma_kernel(const LaunchArgs& a, const MfmaDesc& d, hipStream_t stream);
 hipError_t launch_stack_kernel(const LaunchArgs& a, const StackDesc& d, hipStream_t stream);
+size_t convm_lds_bytes(const ConvDesc& d, uint32_t n_frames);
+hipError_t launch_conv_mfma_kernel(const LaunchArgs& a, const ConvDesc& d, hipStream_t stream);   // n_frames <= 256
 hipError_t launch_conv_kernel(const LaunchArgs& a, const ConvDesc& d, hipStream_t stream);
 hipError_t launch_set_pending(StreamState* st, uint32_t n_streams, int32_t stream, uint32_t bits, hipStream_t q);
 hipError_t launch_reset_for_model(StreamState* st, float* nn, uint32_t n_streams, uint32_t nn_stride, float p_den, hipStream_t q);

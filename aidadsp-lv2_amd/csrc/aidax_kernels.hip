@@ -793,32 +793,7 @@ __global__ __launch_bounds__(kWave) void k_chain(LaunchArgs a)
     c.g.arm(mem, tgt, PRE ? ctl.pre_coef : ctl.master_coef);
 
     if (n != 0) {
-        float* buf = smem + grp * nP;
-        float carry = 0.f;
-        const int steps = n + 5;
-        float head_next = buf[0];
-        for (int s = 0; s < steps; ++s) {
-            const float head = head_next;
-            head_next = buf[s + 1 < n ? s + 1 : n - 1];
-            const float from_left = dpp_row_shr1(carry);
-            const float x = stage == 0 ? head : from_left;
-            const int idx = s - stage;
-            if (live && stage < c.K && idx >= 0 && idx < n) {
-                float y = x;
-                if (c.active) {                                 // Biquad::process, Biquad.h:53-58
-                    const double xd = x;
-                    const double yd = xd * c.a0 + c.z1;
-                    c.z1 = xd * c.a1 + c.z2 - c.b1 * yd;
-                    c.z2 = xd * c.a2 - c.b2 * yd;
-                    y = (float)yd;
-                }
-                const float gm = c.g.next();
-                if (stage == c.gain_lane) y = y * gm;
-                carry = y;
-                if (stage == c.K - 1) buf[idx] = y;
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
+        chain_sweep<1>(c, stage, live && stage < c.K, 6, smem + grp * nP, smem + grp * nP, n);
         // PRE: every valid row goes to out (a disabled stream's row is still the raw input: the hard
         // bypass copy of :612-619); POST: only rows that were processed
         for (int g = 0; g < kChainStreams; ++g) {

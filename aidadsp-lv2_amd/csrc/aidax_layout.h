@@ -178,10 +178,14 @@ struct ConvLayer {
     int32_t hist;          // (ksize-1)*dilation frames of input history
     uint32_t w_off;        // K[ksize][in_ch][out_ch]
     uint32_t b_off;        // [out_ch]
-    uint32_t state_off;    // history[hist][in_ch] in the stream's nn state
+    uint32_t state_off;    // history[in_ch][hist] in the stream's nn state
+    // k_conv_mfma: B fragments of v_mfma_f32_16x16x4_f32, [k_steps][64 lanes]: lane supplies
+    // K[tap][cin][cout = lane&15] for k = 4*kk + (lane>>4) = tap*in_ch + cin (zero past ksize*in_ch / out_ch)
+    uint32_t wf_off;
+    int32_t k_steps;
 };
 struct ConvDesc {
-    int32_t n_layers, channels, max_hist, pad;
+    int32_t n_layers, channels, max_hist, max_k_steps;
     ConvLayer L[kMaxConvLayers];
     uint32_t wd_off, bd_off;
 };

@@ -252,6 +252,17 @@ std::vector<float> pack_conv(const aidax_model& m, ConvDesc* d, uint32_t* state_
         C.state_off = st;
         st += static_cast<uint32_t>(C.hist * C.in_ch);
         if (C.hist > d->max_hist) d->max_hist = C.hist;
+        // matrix-core form: the layer as a [frames x (tap,cin)] . [(tap,cin) x cout] contraction
+        const int K = C.ksize * C.in_ch;
+        C.k_steps = (K + 3) / 4;
+        if (C.k_steps > d->max_k_steps) d->max_k_steps = C.k_steps;
+        while (out.size() % 4) out.push_back(0.f);
+        C.wf_off = static_cast<uint32_t>(out.size());
+        for (int kk = 0; kk < C.k_steps; ++kk)
+            for (int lane = 0; lane < kWave; ++lane) {
+                const int k = 4 * kk + (lane >> 4), co = lane & 15;
+                out.push_back((k < K && co < C.out_ch) ? L.w0[(size_t)k * C.out_ch + co] : 0.f);   // w0 is [tap][cin][cout]
+            }
     }
     const Layer& D = m.layers[m.n_rnn];
     d->wd_off = static_cast<uint32_t>(out.size());

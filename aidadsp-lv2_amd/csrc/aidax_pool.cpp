@@ -90,6 +90,7 @@ struct aidax_pool {
     StackDesc sdesc{};
     MfmaDesc mdesc{};
     ConvDesc cdesc{};
+    bool conv_mfma = false;          // conv stacks on the matrix cores (blocks of <= 256 frames), else k_conv
     const KernelEntry* kernel = nullptr;
     int input_size = 1, input_skip = 0, hidden = 0;
     float in_gain = 1.f, out_gain = 1.f, model_sr = 48000.f;
@@ -172,6 +173,13 @@ struct aidax_pool {
             return e;
         }
         if (has_model && kind == STACK) return launch_stack_kernel(a, sdesc, s);
+        if (has_model && kind == CONV && conv_mfma) {
+            if (a.mode != MODE_CHAIN) return launch_conv_mfma_kernel(a, cdesc, s);
+            hipError_t e = launch_chain_pass(true, a, s);
+            if (e == hipSuccess && a.n_frames != 0) e = launch_conv_mfma_kernel(a, cdesc, s);
+            if (e == hipSuccess) e = launch_chain_pass(false, a, s);
+            return e;
+        }
         if (has_model && kind == CONV) return launch_conv_kernel(a, cdesc, s);
         if (a.mode == MODE_CHAIN && chain_form() == 1) return launch_pipe_kernel(kernel, a, s);
         if (a.mode == MODE_CHAIN && chain_form() == 2) return launch_split_kernels(has_model ? kernel : nullptr, a, s);
@@ -224,10 +232,12 @@ int set_model_impl(aidax_pool& p, const aidax_model* m, int start_mode)
     StackDesc sd{};
     MfmaDesc md{};
     ConvDesc cd{};
+    bool conv_mfma = false;
     if (is_conv_model(*m)) {
         kind = aidax_pool::CONV;
         wp = pack_conv(*m, &cd, &state_floats);
-        if (conv_lds_bytes(cd, p.max_frames) > 160 * 1024)
+        conv_mfma = p.max_frames <= 256 && p.force_form != 4 && convm_lds_bytes(cd, p.max_frames) <= 160 * 1024;
+        if (!conv_mfma && conv_lds_bytes(cd, p.max_frames) > 160 * 1024)
             return fail(AIDAX_ERR_ARG, "conv model: pool max_frames too large for the LDS activation planes");
     } else if (mfma_form_fits(*m) && p.force_form != 4 && chain_lds_bytes(p.max_frames) <= 64 * 1024) {
         kind = aidax_pool::MFMA;
@@ -263,6 +273,7 @@ int set_model_impl(aidax_pool& p, const aidax_model* m, int start_mode)
     p.sdesc = sd;
     p.mdesc = md;
     p.cdesc = cd;
+    p.conv_mfma = conv_mfma;
     p.hidden = m->hidden;
     p.input_size = m->input_size;
     p.input_skip = m->input_skip;
@@ -469,7 +480,7 @@ AIDAX_API const char* aidax_pool_kernel_name(const aidax_pool* p)
     if (!(p && p->has_model)) return "k_nomodel";
     if (p->kind == aidax_pool::STACK) return "k_stack";
     if (p->kind == aidax_pool::MFMA) return "k_chain+k_mfma";
-    if (p->kind == aidax_pool::CONV) return "k_conv";
+    if (p->kind == aidax_pool::CONV) return p->conv_mfma ? "k_chain+k_conv_mfma" : "k_conv";
     const int form = p->chain_form();
     return form == 1 ? p->kernel->name_pipe : form == 2 ? p->kernel->name_split : p->kernel->name;
 }

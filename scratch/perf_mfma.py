@@ -27,3 +27,9 @@ run("lstm128 1 layer", dict(kind="lstm", hidden=128, input_size=1, seed=1), 4096
 run("lstm64x2", dict(kind="lstm", hidden=64, input_size=1, seed=1, n_rnn=2), 4096)
 os.environ["AIDAX_KERNEL"] = "valu"
 run("cfg5 lstm96x2 (valu)", l96, 2048, steps=10)
+os.environ.pop("AIDAX_KERNEL")
+c16 = dict(kind="conv", hidden=16, input_size=1, seed=1608)
+run("cfg4 conv16x8", c16, 1024)
+run("cfg4 conv16x8", c16, 8192)
+os.environ["AIDAX_KERNEL"] = "valu"
+run("cfg4 conv16x8 (valu)", c16, 1024)

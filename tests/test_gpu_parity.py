@@ -355,10 +355,8 @@ def test_device_resident_entry_point_matches_host_entry_point(tmp_path):
 def test_extension_models_full_chain(kind, kw, form, tmp_path, monkeypatch):
     """Stacked recurrent layers and conv1d stacks through the full run() chain, 11 streams (not a
     multiple of the 8- or 16-stream workgroups), blocks shorter than the conv history, warm-up state.
-    Stacked models run on the matrix-core kernel by default and on the VALU kernel with AIDAX_KERNEL=valu."""
+    Both families run on their matrix-core kernel by default and on the VALU kernel with AIDAX_KERNEL=valu."""
     if form == "valu":
-        if kw["kind"] == "conv":
-            pytest.skip("conv stacks have one form")
         monkeypatch.setenv("AIDAX_KERNEL", "valu")
     path, spec = _model_file(tmp_path, kind, **kw)
     m = ax.Model(path)
@@ -368,7 +366,8 @@ def test_extension_models_full_chain(kind, kw, form, tmp_path, monkeypatch):
     cg, co = _ctl_pair(**ckw)
     pool = ax.Pool(S, 256)
     pool.set_model(m)
-    assert pool.kernel_name == ("k_conv" if kw["kind"] == "conv" else "k_stack" if form == "valu" else "k_chain+k_mfma")
+    conv = kw["kind"] == "conv"
+    assert pool.kernel_name == (("k_conv" if conv else "k_stack") if form == "valu" else ("k_chain+k_conv_mfma" if conv else "k_chain+k_mfma"))
     pool.set_controls(cg)
     got = _run_gpu(pool, x, block)
     want = O.run_streams(spec, co, x, block)
@@ -386,6 +385,8 @@ def test_extension_models_full_chain(kind, kw, form, tmp_path, monkeypatch):
     ("g128", dict(kind="gru", hidden=128, input_size=3, seed=128)),                      # one wide layer, both params
     ("l64x2", dict(kind="lstm", hidden=64, input_size=2, seed=642, n_rnn=2, in_skip=1, in_gain=-2.0, out_gain=3.0)),
     ("l16x4", dict(kind="lstm", hidden=16, input_size=1, seed=164, n_rnn=4)),             # one tile per wave, deepest skew
+    ("c16x8", dict(kind="conv", hidden=16, input_size=1, seed=77, in_skip=1, out_gain=2.0)),   # receptive field 511 frames
+    ("c8x4k5", dict(kind="conv", hidden=8, input_size=1, seed=85, conv_layers=4, conv_k=5)),    # 40 k rows: padded k-steps, 8 of 16 columns
 ])
 def test_matrix_core_form_ragged_blocks_and_per_stream_controls(name, kw, tmp_path):
     """k_mfma with 37 streams (three 16-stream workgroups, the last one ragged), block sizes around the
@@ -393,11 +394,12 @@ def test_matrix_core_form_ragged_blocks_and_per_stream_controls(name, kw, tmp_pa
     ramps that change between blocks - every fifth stream against the plugin mirror of the oracle."""
     path, spec = _model_file(tmp_path, name, **kw)
     S = 37
-    sizes = [256, 1, 0, 37, 700, 16, 255, 513, 3]
+    conv = kw["kind"] == "conv"
+    sizes = [256, 1, 0, 37, 200, 16, 255, 129, 3] if conv else [256, 1, 0, 37, 700, 16, 255, 513, 3]
     x = modelgen.signal(S, sum(sizes), seed=21)
-    pool = ax.Pool(S, 1024)
+    pool = ax.Pool(S, 256 if conv else 1024)
     pool.set_model(ax.Model(path))
-    assert pool.kernel_name == "k_chain+k_mfma"
+    assert pool.kernel_name == ("k_chain+k_conv_mfma" if conv else "k_chain+k_mfma")
     kws = [dict(param1=0.3, param2=0.8), dict(enabled=0.0), dict(net_bypass=1.0), dict(eq_position=1.0, bass_boost_db=5.0, mid_type=1.0),
            dict(dc_blocker=0.0, in_lpf_pc=0.0, eq_bypass=1.0, param1=1.0), dict(pregain_db=6.0, master_db=-6.0, treble_boost_db=4.0, param2=0.1)]
     flip = dict(param1=0.9, param2=0.2, master_db=-3.0)                     # applied to every stream from the 5th block on

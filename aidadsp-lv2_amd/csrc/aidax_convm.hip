@@ -38,7 +38,15 @@ __host__ __device__ inline size_t convm_lds_floats(const ConvDesc& d, int n_fram
 {
     return 2 * (size_t)d.channels * convm_plane_stride(d.max_hist, n_frames)   /* two activation planes     */
          + 2 * (size_t)d.max_k_steps * kWave                                  /* B fragments + A offsets   */
-         + 16 + 16 + 4;                                                       /* bias, Dense weights + bias */
+         + 16 + 4;                                                            /* Dense weights + bias      */
+}
+
+// Workgroup barrier that orders LDS traffic only. __syncthreads() also drains vmcnt, i.e. it would wait for
+// the register prefetches below and for the acknowledgement of every history store; threads of this kernel
+// never exchange data through global memory.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 __global__ __launch_bounds__(kConvmThreads) void k_conv_mfma(LaunchArgs a, ConvDesc d)
@@ -60,10 +68,8 @@ __global__ __launch_bounds__(kConvmThreads) void k_conv_mfma(LaunchArgs a, ConvD
     const int F = convm_plane_stride(d.max_hist, n);
     float* pa = smem;
     float* pb = pa + (size_t)C * F;
-    float* wst = pb + (size_t)C * F;                          // [k_steps][64] B fragments of the current layer
-    int* ofs = reinterpret_cast<int*>(wst + (size_t)d.max_k_steps * kWave);   // [k_steps][64] A plane offsets
-    float* bsh = reinterpret_cast<float*>(ofs + (size_t)d.max_k_steps * kWave);   // [16]
-    float* wdl = bsh + 16;                                    // [16] + bias
+    float* wst = pb + (size_t)C * F;                          // [k_steps][64] records {B fragment value, A plane offset}
+    float* wdl = wst + 2 * (size_t)d.max_k_steps * kWave;     // Dense weights [16] + bias
 
     const float* W = a.wpack;
     float* hist_base = a.nn + (size_t)sg * a.nn_stride;
@@ -74,8 +80,9 @@ __global__ __launch_bounds__(kConvmThreads) void k_conv_mfma(LaunchArgs a, ConvD
     float xg = 0.f;
     {
         const ConvLayer& L0 = d.L[0];
-        for (int i = tid; i < L0.hist * L0.in_ch; i += kConvmThreads)
-            pa[(i / L0.hist) * F + Hb - L0.hist + (i % L0.hist)] = hist_base[L0.state_off + i];
+        for (int c = 0; c < L0.in_ch; ++c)
+            for (int j = tid; j < L0.hist; j += kConvmThreads)
+                pa[c * F + Hb - L0.hist + j] = hist_base[L0.state_off + c * L0.hist + j];
         for (int t = tid; t < n16; t += kConvmThreads) {
             float v = 0.f;
             if (t < n) v = (mode == MODE_CHAIN ? row[t] : mode == MODE_NN_ONLY ? a.in[(size_t)t * a.input_size] : 0.f) * a.in_gain;
@@ -84,36 +91,91 @@ __global__ __launch_bounds__(kConvmThreads) void k_conv_mfma(LaunchArgs a, ConvD
         }
         if (tid < 17) wdl[tid] = tid < 16 ? (tid < d.L[d.n_layers - 1].out_ch ? W[d.wd_off + tid] : 0.f) : W[d.bd_off];
     }
+    // Global-memory latency is kept off the layer loop: while layer l computes, the B fragments of layer
+    // l+1 and the history prefix of layer l+2 are already on their way into registers.
+    constexpr int kFragRegs = 8;              // 32 k-steps x 64 lanes / 256 threads
+    constexpr int kHistRegs = 16;             // 4096 history floats of a layer in registers; longer ones read directly
+    float fr[kFragRegs], hp[kHistRegs], bias_r = 0.f;
+    int kc[kFragRegs], kb[kFragRegs];          // (cin, frames back) of the contraction row behind fragment element j
+    auto fetch_frag = [&](int l) {
+        const ConvLayer& L = d.L[l];
+        const int* km = reinterpret_cast<const int*>(W + L.km_off);
+#pragma unroll
+        for (int j = 0; j < kFragRegs; ++j) {
+            if (j * kConvmThreads >= L.k_steps * kWave) break;
+            const int i = tid + j * kConvmThreads;
+            const bool on = i < L.k_steps * kWave;
+            const int k = on ? 4 * (i >> 6) + ((i & 63) >> 4) : 0;
+            fr[j] = on ? W[L.wf_off + i] : 0.f;
+            kc[j] = km[2 * k];
+            kb[j] = km[2 * k + 1];
+        }
+        bias_r = (lane & 15) < L.out_ch ? W[L.b_off + (lane & 15)] : 0.f;
+    };
+    // history of a layer: [in_ch][hist] in HBM <-> plane[ch][Hb-hist .. Hb), walked flat (coalesced, hist*in_ch/256
+    // passes). i -> (ch, frame) without an integer division: (i + 0.5) / hist is at least 0.5/hist away from an
+    // integer, far more than the fp32 error of the product, so the truncation is exact.
+    auto plane_index = [&](int i, int hist, float inv_hist) {
+        const int ch = (int)(((float)i + 0.5f) * inv_hist);
+        return ch * F + Hb - hist + (i - ch * hist);
+    };
+    auto fetch_prefix = [&](int l) {
+        const ConvLayer& L = d.L[l];
+        const int cnt = L.hist * L.in_ch;
+#pragma unroll
+        for (int j = 0; j < kHistRegs; ++j) {
+            if (j * kConvmThreads >= cnt) break;              // wave-uniform: short histories cost one pass, not sixteen
+            const int i = tid + j * kConvmThreads;
+            hp[j] = i < cnt ? hist_base[L.state_off + i] : 0.f;
+        }
+    };
+    auto store_prefix = [&](int l, float* plane) {
+        const ConvLayer& L = d.L[l];
+        const int cnt = L.hist * L.in_ch;
+        const float inv = 1.0f / (float)L.hist;
+#pragma unroll
+        for (int j = 0; j < kHistRegs; ++j) {
+            if (j * kConvmThreads >= cnt) break;
+            const int i = tid + j * kConvmThreads;
+            if (i < cnt) plane[plane_index(i, L.hist, inv)] = hp[j];
+        }
+        for (int i = tid + kHistRegs * kConvmThreads; i < cnt; i += kConvmThreads)
+            plane[plane_index(i, L.hist, inv)] = hist_base[L.state_off + i];
+    };
+    fetch_frag(0);
+    if (d.n_layers > 1) fetch_prefix(1);
+
     float* cur = pa;
     float* nxt = pb;
     const int ntiles = n16 / 16;
     for (int l = 0; l < d.n_layers; ++l) {
         const ConvLayer& L = d.L[l];
-        const int Ci = L.in_ch, Co = L.out_ch, Hs = L.hist, K = L.ksize * Ci;
-        __syncthreads();                                      // previous layer's readers of wst/ofs are done; planes written
-        for (int i = tid; i < L.k_steps * kWave; i += kConvmThreads) {
-            wst[i] = W[L.wf_off + i];
-            const int k = 4 * (i >> 6) + ((i & 63) >> 4);
-            const int kc = k < K ? k : 0;                     // padding k-steps carry zero weights: point them at valid data
-            const int tap = kc / Ci, cin = kc - tap * Ci;
-            ofs[i] = cin * F + Hb - (L.ksize - 1 - tap) * L.dilation + (i & 15);
+        const int Ci = L.in_ch, Co = L.out_ch, Hs = L.hist;
+        lds_barrier();                                      // the previous layer is done with wst/ofs and with both planes
+#pragma unroll
+        for (int j = 0; j < kFragRegs; ++j) {
+            if (j * kConvmThreads >= L.k_steps * kWave) break;
+            const int i = tid + j * kConvmThreads;
+            if (i < L.k_steps * kWave) {                      // one 8-byte record per (k-step, lane): B value, A plane offset
+                wst[2 * i] = fr[j];
+                reinterpret_cast<int*>(wst)[2 * i + 1] = kc[j] * F + Hb - kb[j] + (i & 15);
+            }
         }
-        if (tid < 16) bsh[tid] = tid < Co ? W[L.b_off + tid] : 0.f;
-        if (l + 1 < d.n_layers) {                             // the next layer's history prefix
-            const ConvLayer& N = d.L[l + 1];
-            for (int i = tid; i < N.hist * N.in_ch; i += kConvmThreads)
-                nxt[(i / N.hist) * F + Hb - N.hist + (i % N.hist)] = hist_base[N.state_off + i];
-        }
-        __syncthreads();
-        const float bias = bsh[lane & 15];
+        const float bias = bias_r;
+        if (l + 1 < d.n_layers) store_prefix(l + 1, nxt);     // the next layer's history prefix (fetched a layer ago)
+        if (l + 1 < d.n_layers) fetch_frag(l + 1);
+        if (l + 2 < d.n_layers) fetch_prefix(l + 2);
+        lds_barrier();
         // tile j of this wave is frame tile wave + 4*j (n <= 256: at most kConvmTiles per wave)
         if (wave < ntiles) {
             f32x4 acc[kConvmTiles];
 #pragma unroll
             for (int j = 0; j < kConvmTiles; ++j) acc[j] = f32x4{bias, bias, bias, bias};
+#pragma unroll 2
             for (int kk = 0; kk < L.k_steps; ++kk) {
-                const float b = wst[kk * kWave + lane];
-                const float* ap = cur + ofs[kk * kWave + lane] + 16 * wave;
+                const float2 rec = *reinterpret_cast<const float2*>(wst + 2 * (kk * kWave + lane));
+                const float b = rec.x;
+                const float* ap = cur + __builtin_bit_cast(int, rec.y) + 16 * wave;
 #pragma unroll
                 for (int j = 0; j < kConvmTiles; ++j) {
                     const float av = ap[wave + 4 * j < ntiles ? 64 * j : 0];   // tiles past the block re-read the first
@@ -131,13 +193,30 @@ __global__ __launch_bounds__(kConvmThreads) void k_conv_mfma(LaunchArgs a, ConvD
                 *reinterpret_cast<f32x4*>(nxt + (size_t)co * F + Hb + 16 * (wave + 4 * j) + 4 * (lane >> 4)) = v;
             }
         }
-        __syncthreads();
+        lds_barrier();
         // this layer's new history: the last Hs frames of [old history | this block's inputs]
-        for (int i = tid; i < Hs * Ci; i += kConvmThreads)
-            hist_base[L.state_off + i] = cur[(i / Hs) * F + Hb - Hs + n + (i % Hs)];
+        {
+            const float inv = 1.0f / (float)Hs;
+            const int cnt = Hs * Ci;
+            float hv[kHistRegs];
+#pragma unroll
+            for (int j = 0; j < kHistRegs; ++j) {             // all LDS reads first, then the stores
+                if (j * kConvmThreads >= cnt) break;
+                const int i = tid + j * kConvmThreads;
+                hv[j] = cur[plane_index(i < cnt ? i : 0, Hs, inv) + n];
+            }
+#pragma unroll
+            for (int j = 0; j < kHistRegs; ++j) {
+                if (j * kConvmThreads >= cnt) break;
+                const int i = tid + j * kConvmThreads;
+                if (i < cnt) hist_base[L.state_off + i] = hv[j];
+            }
+            for (int i = tid + kHistRegs * kConvmThreads; i < cnt; i += kConvmThreads)
+                hist_base[L.state_off + i] = cur[plane_index(i, Hs, inv) + n];
+        }
         float* tmp = cur; cur = nxt; nxt = tmp;
     }
-    __syncthreads();
+    lds_barrier();
     // Dense(C,1) + skip / output gain (:171-181), one thread per frame
     if (mode != MODE_WARMUP && tid < n) {
         const int Cl = d.L[d.n_layers - 1].out_ch;

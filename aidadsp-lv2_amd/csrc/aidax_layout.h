@@ -183,6 +183,7 @@ struct ConvLayer {
     // K[tap][cin][cout = lane&15] for k = 4*kk + (lane>>4) = tap*in_ch + cin (zero past ksize*in_ch / out_ch)
     uint32_t wf_off;
     int32_t k_steps;
+    uint32_t km_off;       // [4*k_steps][2] int32 bit patterns: (cin, frames back) of contraction row k
 };
 struct ConvDesc {
     int32_t n_layers, channels, max_hist, max_k_steps;

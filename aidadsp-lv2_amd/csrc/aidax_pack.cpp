@@ -1,6 +1,7 @@
 // aidax_pack.cpp — shuffles a model's Keras-layout weights into the register
 // order of the kernel's lane mapping (aidax_layout.h): record r of lane l is at
 // wpack[r*64 + l], so the kernel fills each weight VGPR with one coalesced read.
+#include <cstring>
 #include <stdexcept>
 
 #include "aidax_internal.h"
@@ -263,6 +264,16 @@ std::vector<float> pack_conv(const aidax_model& m, ConvDesc* d, uint32_t* state_
                 const int k = 4 * kk + (lane >> 4), co = lane & 15;
                 out.push_back((k < K && co < C.out_ch) ? L.w0[(size_t)k * C.out_ch + co] : 0.f);   // w0 is [tap][cin][cout]
             }
+        // where row k of the contraction lives in the activation plane: (cin, frames back) per k, as int bit patterns;
+        // padding rows (zero weights) point at row 0 so they read valid data
+        C.km_off = static_cast<uint32_t>(out.size());
+        for (int k = 0; k < 4 * C.k_steps; ++k) {
+            const int kc = k < K ? k : 0;
+            const int32_t cin = kc % C.in_ch, back = (C.ksize - 1 - kc / C.in_ch) * C.dilation;
+            float f;
+            std::memcpy(&f, &cin, 4); out.push_back(f);
+            std::memcpy(&f, &back, 4); out.push_back(f);
+        }
     }
     const Layer& D = m.layers[m.n_rnn];
     d->wd_off = static_cast<uint32_t>(out.size());

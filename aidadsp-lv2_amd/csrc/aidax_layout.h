@@ -168,7 +168,8 @@ struct MfmaLayer {
     uint32_t state_off;    // as StackLayer
 };
 struct MfmaDesc {
-    int32_t n_layers, hidden, tpw, waves;
+    int32_t n_layers, hidden, tpw, waves;      // hidden = the kernel's width: the model's rounded up to 16 (zero rows / columns)
+    int32_t hidden_true, pad[3];               // the model's width: layout of the recurrent state in HBM (h[.] then c[.])
     MfmaLayer L[kMaxStackLayers];
     uint32_t wd_off, bd_off;
 };

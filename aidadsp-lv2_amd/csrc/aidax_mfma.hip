@@ -133,6 +133,7 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma(LaunchArgs a, MfmaDesc d)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = (int)a.n_frames;
     const int NL = d.n_layers;
+    const int Ht = d.hidden_true;          // the model's width (H is that rounded up to 16)
     const int I = a.input_size;
     const int s_base = blockIdx.x * NS;
     const int chunk = n < kMfmaChunk ? n : kMfmaChunk;
@@ -197,8 +198,8 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma(LaunchArgs a, MfmaDesc d)
             const int u = i / NS, sn = i % NS, sg = s_base + sn;
             const bool valid = sg < (int)a.n_streams;
             const float* stp = a.nn + (size_t)(valid ? sg : 0) * a.nn_stride + L.state_off;
-            hT[((size_t)l * 2 + 0) * H * NS + i] = valid ? stp[u] : 0.f;
-            cT[(size_t)l * H * NS + i] = (valid && L.cell == 0) ? stp[H + u] : 0.f;
+            hT[((size_t)l * 2 + 0) * H * NS + i] = (valid && u < Ht) ? stp[u] : 0.f;         // padded units rest at 0
+            cT[(size_t)l * H * NS + i] = (valid && u < Ht && L.cell == 0) ? stp[Ht + u] : 0.f;
         }
     }
     __syncthreads();
@@ -339,10 +340,10 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma(LaunchArgs a, MfmaDesc d)
         const MfmaLayer& L = d.L[l];
         for (int i = tid; i < H * NS; i += kMfmaThreads) {
             const int u = i / NS, sn = i % NS, sg = s_base + sn;
-            if (sg < (int)a.n_streams && livef[sn] != 0.f) {
+            if (sg < (int)a.n_streams && u < Ht && livef[sn] != 0.f) {
                 float* stp = a.nn + (size_t)sg * a.nn_stride + L.state_off;
                 stp[u] = hT[((size_t)l * 2 + par) * H * NS + i];
-                if (L.cell == 0) stp[H + u] = cT[(size_t)l * H * NS + i];
+                if (L.cell == 0) stp[Ht + u] = cT[(size_t)l * H * NS + i];
             }
         }
     }

@@ -105,9 +105,11 @@ bool is_stack_model(const aidax_model& m)
     return m.n_rnn == 1 && m.hidden > 80;
 }
 
+// k_mfma serves recurrent layers of one width <= 128; widths that are not a multiple of 16 are padded with
+// zero rows and columns (a padded unit has i = o = 1/2, g = 0: its c and h stay exactly 0).
 bool mfma_form_fits(const aidax_model& m)
 {
-    if (!is_stack_model(m) || m.hidden % 16 != 0 || m.hidden > 128) return false;
+    if (m.cell == AIDAX_CELL_CONV || m.n_rnn < 1 || m.n_rnn > kMaxStackLayers || m.hidden > 128) return false;
     for (int l = 0; l < m.n_rnn; ++l)
         if (m.layers[l].out_size != m.hidden) return false;
     return true;
@@ -118,9 +120,10 @@ std::vector<float> pack_mfma(const aidax_model& m, MfmaDesc* d, uint32_t* state_
 {
     std::vector<float> out;
     *d = MfmaDesc{};
-    const int H = m.hidden, NW = mfma_waves(H), TPW = H / 4 / NW;
+    const int Ht = m.hidden, H = (Ht + 15) & ~15, NW = mfma_waves(H), TPW = H / 4 / NW;
     d->n_layers = m.n_rnn;
     d->hidden = H;
+    d->hidden_true = Ht;
     d->tpw = TPW;
     d->waves = NW;
     uint32_t st = 0;
@@ -129,11 +132,13 @@ std::vector<float> pack_mfma(const aidax_model& m, MfmaDesc* d, uint32_t* state_
         const Layer& L = m.layers[l];
         MfmaLayer& M = d->L[l];
         const bool lstm = L.type == Layer::LSTM;
-        const int G = lstm ? 4 : 3, R = G * H, I = L.in_size;
+        const int G = lstm ? 4 : 3, R = G * Ht, I = L.in_size;
         M.cell = lstm ? 0 : 1;
-        M.in_size = I;
-        // weight of gate row `g` of unit `u` against column k of segment `seg`
+        M.in_size = l == 0 ? I : H;                  // deeper layers contract over the padded h of the layer below
+        // weight of gate row `g` of unit `u` against column k of segment `seg` (0 in the padding)
         auto weight = [&](Seg seg, int u, int g, int k) -> float {
+            if (u >= Ht || (seg == SEG_REC && k >= Ht) || (seg == SEG_IN && k >= I)) return 0.f;
+            const int H = Ht;                        // Keras column blocks are Ht wide
             const float* W = L.w0.data();      // [I][R]
             const float* U = L.w1.data();      // [H][R]
             const float* b = L.w2.data();      // LSTM [R]; GRU [2][R]
@@ -162,7 +167,7 @@ std::vector<float> pack_mfma(const aidax_model& m, MfmaDesc* d, uint32_t* state_
                     }
         // per wave one run of k-step groups: [h of the layer below (layers >= 1)] then [own h(t-1)]
         M.w_big_off = static_cast<uint32_t>(out.size());
-        const int g_in = l == 0 ? 0 : I / 16, g_rec = H / 16;
+        const int g_in = l == 0 ? 0 : H / 16, g_rec = H / 16;
         for (int w = 0; w < NW; ++w)
             for (int grp = 0; grp < g_in + g_rec; ++grp)
                 for (int lane = 0; lane < kWave; ++lane)
@@ -178,11 +183,12 @@ std::vector<float> pack_mfma(const aidax_model& m, MfmaDesc* d, uint32_t* state_
         for (int u = 0; u < H; ++u)
             for (int g = 0; g < 4; ++g) out.push_back(weight(SEG_BIAS, u, g, 0));
         M.state_off = st;
-        st += static_cast<uint32_t>(lstm ? 2 * H : H);
+        st += static_cast<uint32_t>(lstm ? 2 * Ht : Ht);
     }
     const Layer& D = m.layers[m.n_rnn];
     d->wd_off = static_cast<uint32_t>(out.size());
     out.insert(out.end(), D.w0.begin(), D.w0.end());
+    out.resize(out.size() + (H - Ht), 0.f);          // padded units carry zero Dense weights
     d->bd_off = static_cast<uint32_t>(out.size());
     out.push_back(D.w1[0]);
     *state_floats = st;

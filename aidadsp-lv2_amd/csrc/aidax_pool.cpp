@@ -35,6 +35,27 @@ namespace {
 
 constexpr uint32_t kWarmupFrames = 2048;        // rt-neural-generic.cpp:1077
 constexpr uint32_t kMaxFrames = 8192;           // LDS block buffer bound (32 KiB)
+// Stream count from which a model of the reference's table runs faster on the matrix-core kernel (16 streams
+// per workgroup, zero-padded to a multiple of 16 units) than on its register-resident kernel. Measured
+// crossovers (scratch/perf_table_mfma.py, 256-frame blocks): the wide cells, whose
+// one-wave kernels hold 250-500 weight registers and run one wave per SIMD, gain 1.6-3.2x from 4096 streams;
+// the narrowest gain 1.2-1.9x once there are >= 8 workgroups per CU; 20..40 units (padded by up to 60 %)
+// and LSTM-32 / GRU-64 tie and stay where they are.
+constexpr uint32_t kNever = 0xffffffffu;
+uint32_t mfma_crossover_streams(int cell, int hidden)
+{
+    if (cell == AIDAX_CELL_LSTM) {
+        if (hidden >= 80) return 2048;
+        if (hidden >= 64) return 3072;
+        if (hidden == 40) return 8192;
+        if (hidden <= 16) return hidden <= 8 ? 12288 : 8192;
+        return kNever;
+    }
+    if (hidden >= 80) return 3072;
+    if (hidden == 40) return 16384;
+    if (hidden <= 16) return 6144;
+    return kNever;
+}
 
 struct HipFail : std::runtime_error { using std::runtime_error::runtime_error; };
 
@@ -110,6 +131,12 @@ struct aidax_pool {
         if (use_pipe()) return 1;
         if (n_streams < 64) return 0;
         return (!has_model || split_pays) ? 2 : 0;
+    }
+    // Models of the reference's table on the matrix-core kernel (mfma_crossover_streams); AIDAX_KERNEL=mfma forces it.
+    bool mfma_for_table_model(int cell, int hidden_units) const
+    {
+        if (force_form == 5) return true;
+        return force_form == 0 && n_streams >= mfma_crossover_streams(cell, hidden_units);
     }
     bool use_pipe() const
     {
@@ -239,7 +266,8 @@ int set_model_impl(aidax_pool& p, const aidax_model* m, int start_mode)
         conv_mfma = p.max_frames <= 256 && p.force_form != 4 && convm_lds_bytes(cd, p.max_frames) <= 160 * 1024;
         if (!conv_mfma && conv_lds_bytes(cd, p.max_frames) > 160 * 1024)
             return fail(AIDAX_ERR_ARG, "conv model: pool max_frames too large for the LDS activation planes");
-    } else if (mfma_form_fits(*m) && p.force_form != 4 && chain_lds_bytes(p.max_frames) <= 64 * 1024) {
+    } else if (mfma_form_fits(*m) && chain_lds_bytes(p.max_frames) <= 64 * 1024 &&
+               (is_stack_model(*m) ? p.force_form != 4 : p.mfma_for_table_model(m->cell, m->hidden))) {
         kind = aidax_pool::MFMA;
         wp = pack_mfma(*m, &md, &state_floats);
     } else if (is_stack_model(*m)) {
@@ -322,7 +350,7 @@ AIDAX_API int aidax_pool_create(uint32_t n_streams, uint32_t max_frames, double 
         p->host_sr = host_samplerate;
         p->gain_coef = exp_smoother_coef(static_cast<float>(host_samplerate), 0.1f);
         if (const char* f = std::getenv("AIDAX_KERNEL"))
-            p->force_form = std::strcmp(f, "wave") == 0 ? 1 : std::strcmp(f, "pipe") == 0 ? 2 : std::strcmp(f, "split") == 0 ? 3 : std::strcmp(f, "valu") == 0 ? 4 : 0;
+            p->force_form = std::strcmp(f, "wave") == 0 ? 1 : std::strcmp(f, "pipe") == 0 ? 2 : std::strcmp(f, "split") == 0 ? 3 : std::strcmp(f, "valu") == 0 ? 4 : std::strcmp(f, "mfma") == 0 ? 5 : 0;
         try {
             HIP_TRY(hipSetDevice(device_id));
             HIP_TRY(hipStreamCreateWithFlags(&p->q, hipStreamNonBlocking));
@@ -463,7 +491,7 @@ AIDAX_API int aidax_pool_read_state(aidax_pool* p, uint32_t stream, int layer, f
         if (p->kind == aidax_pool::STACK) {
             H = static_cast<uint32_t>(p->sdesc.L[layer].hidden); off = p->sdesc.L[layer].state_off; lstm = p->sdesc.L[layer].cell == 0;
         } else if (p->kind == aidax_pool::MFMA) {
-            H = static_cast<uint32_t>(p->mdesc.hidden); off = p->mdesc.L[layer].state_off; lstm = p->mdesc.L[layer].cell == 0;
+            H = static_cast<uint32_t>(p->mdesc.hidden_true); off = p->mdesc.L[layer].state_off; lstm = p->mdesc.L[layer].cell == 0;
         } else {
             lstm = p->kernel->cell == AIDAX_CELL_LSTM;
         }

@@ -68,10 +68,14 @@ def test_torch_goldens_on_gpu(name, golden_dir, tmp_path):
     assert np.abs(y - (O.net_run(spec, g["X"]) + skip)).max() < THR
 
 
+@pytest.mark.parametrize("form", ["registers", "mfma"])
 @pytest.mark.parametrize("cell", ["lstm", "gru"])
 @pytest.mark.parametrize("hidden", modelgen.HIDDEN_SIZES)
-def test_every_reference_variant_runs_and_matches_oracle(cell, hidden, tmp_path):
-    """All 54 architectures of model_variant.hpp, bare network, 768 samples each."""
+def test_every_reference_variant_runs_and_matches_oracle(cell, hidden, form, tmp_path, monkeypatch):
+    """All 54 architectures of model_variant.hpp, bare network, 768 samples each - on the register-resident
+    kernels and on the matrix-core kernel (widths that are not a multiple of 16 run zero-padded there)."""
+    if form == "mfma":
+        monkeypatch.setenv("AIDAX_KERNEL", "mfma")
     for isz in modelgen.INPUT_SIZES:
         kw = dict(kind=cell, hidden=hidden, input_size=isz, seed=1000 + hidden * 4 + isz)
         path, spec = _model_file(tmp_path, f"{cell}{hidden}_{isz}", **kw)
@@ -477,10 +481,11 @@ def test_stacked_model_state_readback(tmp_path):
 
 # ------------------------------------------------------------ the three launch forms of the chain
 
-@pytest.mark.parametrize("form", ["wave", "pipe", "split"])
+@pytest.mark.parametrize("form", ["wave", "pipe", "split", "mfma"])
 def test_every_kernel_form_passes_the_same_chain_cases(form, tmp_path, monkeypatch, bundled_models):
-    """AIDAX_KERNEL pins one form: one wave per stream, the 3-wave pipeline, or the split launches
-    (packed chain kernels around the lean recurrent kernel). Same inputs, same oracle, same bars:
+    """AIDAX_KERNEL pins one form: one wave per stream, the 3-wave pipeline, the split launches (packed
+    chain kernels around the lean recurrent kernel), or the split launches around the matrix-core
+    kernel (16 streams per workgroup). Same inputs, same oracle, same bars:
     ragged block sizes incl. the pre-run, per-stream controls with bypass/disable, conditioned GRU
     with ramping params, model swap and activate."""
     monkeypatch.setenv("AIDAX_KERNEL", form)
@@ -495,7 +500,7 @@ def test_every_kernel_form_passes_the_same_chain_cases(form, tmp_path, monkeypat
            dict(dc_blocker=0.0, in_lpf_pc=0.0, eq_bypass=1.0), dict(pregain_db=6.0, master_db=-6.0, treble_boost_db=4.0)]
     for s in range(S):
         pool.set_controls(ax.default_controls(**kws[s % len(kws)]), stream=s)
-    assert form in ("wave", "pipe", "split") and pool.kernel_name.startswith({"wave": "k_lstm<", "pipe": "k_lstm_pipe<", "split": "k_chain+k_nn<"}[form])
+    assert pool.kernel_name.startswith({"wave": "k_lstm<", "pipe": "k_lstm_pipe<", "split": "k_chain+k_nn<", "mfma": "k_chain+k_mfma"}[form])
     got = np.empty_like(x)
     pos = 0
     for n in sizes:

@@ -121,7 +121,10 @@ __device__ __forceinline__ void gates_mfma(f32x4 (&acc)[TPW], const f32x4* __res
     }
 }
 
-template <int TPW, int NW>
+// RES: a single recurrent layer whose A fragments a wave can keep in registers for the whole launch
+// ((hidden/4) * TPW floats per lane: 8 for 32 units, 100 for 80, 128 for 128): no L2 fragment stream and no
+// address arithmetic in the frame loop.
+template <int TPW, int NW, bool RES>
 __global__ __launch_bounds__(NW * kWave) void k_mfma(LaunchArgs a, MfmaDesc d)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -209,6 +212,15 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma(LaunchArgs a, MfmaDesc d)
     float w_in0[TPW];
 #pragma unroll
     for (int tl = 0; tl < TPW; ++tl) w_in0[tl] = W[d.L[0].w_in_off + ((size_t)wave * kWave + lane) * TPW + tl];
+    constexpr int G = H / 16;                              // k-step groups of the recurrent part
+    f32x4 wres[RES ? G * TPW : 1];
+    if constexpr (RES) {
+        const f32x4* ap = reinterpret_cast<const f32x4*>(W + d.L[0].w_big_off) + ((size_t)wave * G * kWave + lane) * TPW;
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) wres[g * TPW + q] = ap[(size_t)g * kWave * TPW + q];
+    }
     int par = 0;                                           // parity the next tick reads
     for (int base = 0; base < n; base += kMfmaChunk) {
         const int cnt = n - base < kMfmaChunk ? n - base : kMfmaChunk;
@@ -299,9 +311,25 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma(LaunchArgs a, MfmaDesc d)
                     for (int tl = 0; tl < TPW; ++tl)
                         acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_in0[tl], b, acc[tl], 0, 0, 0);
                 }
-                const int g_in = l == 0 ? 0 : H / 16, g_tot = g_in + H / 16;
-                const f32x4* ap = reinterpret_cast<const f32x4*>(W + L.w_big_off) + ((size_t)wave * g_tot * kWave + lane) * TPW;
-                gates_mfma<TPW>(acc, ap, hT + ((size_t)(l > 0 ? l - 1 : 0) * 2 + rd) * H * NS, h_rd, g_in, g_tot, lane);
+                if constexpr (RES) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        float b[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) b[j] = h_rd[256 * g + 64 * j + lane];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int tl = 0; tl < TPW; ++tl) {
+                                const int e = j * TPW + tl;
+                                acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[g * TPW + e / 4][e % 4], b[j], acc[tl], 0, 0, 0);
+                            }
+                    }
+                } else {
+                    const int g_in = l == 0 ? 0 : H / 16, g_tot = g_in + H / 16;
+                    const f32x4* ap = reinterpret_cast<const f32x4*>(W + L.w_big_off) + ((size_t)wave * g_tot * kWave + lane) * TPW;
+                    gates_mfma<TPW>(acc, ap, hT + ((size_t)(l > 0 ? l - 1 : 0) * 2 + rd) * H * NS, h_rd, g_in, g_tot, lane);
+                }
 #pragma unroll
                 for (int tl = 0; tl < TPW; ++tl) {
                     const int e = (wave * TPW + tl) * 64 + lane;          // unit 4T + (lane>>4), stream lane&15
@@ -358,10 +386,11 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma(LaunchArgs a, MfmaDesc d)
 
 // ---------------------------------------------------------------- host side
 typedef void (*MfmaFn)(LaunchArgs, MfmaDesc);
-static MfmaFn mfma_fn(int hidden)
+static MfmaFn mfma_fn(int hidden, bool resident)
 {
     switch (hidden) {
-#define AIDAX_MFMA_CASE(HID) case HID: return k_mfma<HID / 4 / mfma_waves(HID), mfma_waves(HID)>
+#define AIDAX_MFMA_CASE(HID) case HID: return resident ? k_mfma<HID / 4 / mfma_waves(HID), mfma_waves(HID), true> \
+                                                       : k_mfma<HID / 4 / mfma_waves(HID), mfma_waves(HID), false>
     AIDAX_MFMA_CASE(16); AIDAX_MFMA_CASE(32); AIDAX_MFMA_CASE(48); AIDAX_MFMA_CASE(64);
     AIDAX_MFMA_CASE(80); AIDAX_MFMA_CASE(96); AIDAX_MFMA_CASE(112); AIDAX_MFMA_CASE(128);
 #undef AIDAX_MFMA_CASE
@@ -373,7 +402,7 @@ size_t mfma_lds_bytes(const MfmaDesc& d, uint32_t n_frames) { return mfma_lds_fl
 
 hipError_t launch_mfma_kernel(const LaunchArgs& a, const MfmaDesc& d, hipStream_t stream)
 {
-    MfmaFn fn = mfma_fn(d.hidden);
+    MfmaFn fn = mfma_fn(d.hidden, d.n_layers == 1);
     if (!fn) return hipErrorInvalidValue;
     const size_t lds = mfma_lds_bytes(d, a.n_frames);
     if (lds > 64 * 1024) {

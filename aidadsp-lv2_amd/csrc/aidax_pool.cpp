@@ -47,12 +47,13 @@ uint32_t mfma_crossover_streams(int cell, int hidden)
     if (cell == AIDAX_CELL_LSTM) {
         if (hidden >= 80) return 2048;
         if (hidden >= 64) return 3072;
-        if (hidden == 40) return 8192;
+        if (hidden == 40) return 4096;
         if (hidden <= 16) return hidden <= 8 ? 12288 : 8192;
         return kNever;
     }
-    if (hidden >= 80) return 3072;
-    if (hidden == 40) return 16384;
+    if (hidden >= 80) return 2048;
+    if (hidden == 64) return 16384;
+    if (hidden == 40) return 8192;
     if (hidden <= 16) return 6144;
     return kNever;
 }

@@ -56,6 +56,7 @@ bool is_conv_model(const aidax_model& m);
 std::vector<float> pack_stack(const aidax_model& m, StackDesc* d, uint32_t* state_floats);
 bool mfma_form_fits(const aidax_model& m);    // recurrent layers of one width, a multiple of 16 and <= 128
 std::vector<float> pack_mfma(const aidax_model& m, MfmaDesc* d, uint32_t* state_floats);
+std::vector<float> pack_quad(const aidax_model& m, uint32_t* bias_off, uint32_t* dense_off);   // table models only
 std::vector<float> pack_conv(const aidax_model& m, ConvDesc* d, uint32_t* state_floats);
 
 }  // namespace aidax

@@ -32,6 +32,8 @@ size_t chain_lds_bytes(uint32_t n_frames);
 // one packed chain launch (8 streams per wave): pre = LPF/pre-gain/EQ(pre) in -> out, else DC/EQ(post)/master in place
 hipError_t launch_chain_pass(bool pre, const LaunchArgs& a, hipStream_t stream);
 hipError_t launch_mfma_kernel(const LaunchArgs& a, const MfmaDesc& d, hipStream_t stream);
+size_t quad_lds_bytes(int hidden, uint32_t n_frames);
+hipError_t launch_quad_kernel(int cell, int hidden, const LaunchArgs& a, const QuadDesc& qd, hipStream_t stream);
 hipError_t launch_stack_kernel(const LaunchArgs& a, const StackDesc& d, hipStream_t stream);
 size_t convm_lds_bytes(const ConvDesc& d, uint32_t n_frames);
 hipError_t launch_conv_mfma_kernel(const LaunchArgs& a, const ConvDesc& d, hipStream_t stream);   // n_frames <= 256

@@ -174,6 +174,12 @@ struct MfmaDesc {
     uint32_t wd_off, bd_off;
 };
 
+// k_quad (aidax_quad.hip): offsets into the weight buffer written by pack_quad
+struct QuadDesc {
+    uint32_t bias_off;     // [16 * waves][4] gate-row biases
+    uint32_t dense_off;    // Dense weights [hidden] + bias
+};
+
 struct ConvLayer {
     int32_t in_ch, out_ch, ksize, dilation, activation;
     int32_t hist;          // (ksize-1)*dilation frames of input history

@@ -239,6 +239,51 @@ std::vector<float> pack_stack(const aidax_model& m, StackDesc* d, uint32_t* stat
     return out;
 }
 
+// k_quad (aidax_quad.hip): one recurrent layer for v_mfma_f32_4x4x1_16b_f32. Wave w owns units 16w..16w+15;
+// lane l supplies the weights of gate row (unit 16w + l/4, row l%4) - LSTM rows i,f,g,o; GRU rows z, r,
+// recurrent half of the candidate, input half of the candidate - one register per contraction column:
+//   [wave][k = 0..H-1 recurrent, H..H+2 model inputs][64 lanes], then [wave][16 units][4 rows] biases,
+//   then the Dense weights [H] and bias.
+std::vector<float> pack_quad(const aidax_model& m, uint32_t* bias_off, uint32_t* dense_off)
+{
+    const Layer& L = m.layers[0];
+    const bool lstm = L.type == Layer::LSTM;
+    const int H = m.hidden, I = L.in_size, G = lstm ? 4 : 3, R = G * H, NW = (H + 15) / 16;
+    const float* W = L.w0.data();      // [I][R]
+    const float* U = L.w1.data();      // [H][R]
+    const float* b = L.w2.data();      // LSTM [R]; GRU [2][R]
+    auto col_of = [&](int u, int g) { return lstm ? g * H + u : (g == 0 ? 0 : g == 1 ? H : 2 * H) + u; };
+    auto rec = [&](int u, int g, int k) -> float {
+        if (u >= H || (!lstm && g == 3)) return 0.f;
+        return U[(size_t)k * R + col_of(u, g)];
+    };
+    auto inp = [&](int u, int g, int k) -> float {
+        if (u >= H || k >= I || (!lstm && g == 2)) return 0.f;
+        return W[(size_t)k * R + col_of(u, g)];
+    };
+    auto bias = [&](int u, int g) -> float {
+        if (u >= H) return 0.f;
+        const int c = col_of(u, g);
+        if (lstm) return b[c];
+        return g <= 1 ? b[c] + b[R + c] : g == 2 ? b[R + c] : b[c];
+    };
+    std::vector<float> out;
+    for (int w = 0; w < NW; ++w)
+        for (int k = 0; k < H + kMaxInputs; ++k)
+            for (int lane = 0; lane < kWave; ++lane) {
+                const int u = 16 * w + (lane >> 2), g = lane & 3;
+                out.push_back(k < H ? rec(u, g, k) : inp(u, g, k - H));
+            }
+    *bias_off = static_cast<uint32_t>(out.size());
+    for (int u = 0; u < 16 * NW; ++u)
+        for (int g = 0; g < 4; ++g) out.push_back(bias(u, g));
+    const Layer& D = m.layers[m.n_rnn];
+    *dense_off = static_cast<uint32_t>(out.size());
+    out.insert(out.end(), D.w0.begin(), D.w0.end());
+    out.push_back(D.w1[0]);
+    return out;
+}
+
 std::vector<float> pack_conv(const aidax_model& m, ConvDesc* d, uint32_t* state_floats)
 {
     std::vector<float> out;

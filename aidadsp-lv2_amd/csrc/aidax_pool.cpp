@@ -35,27 +35,24 @@ namespace {
 
 constexpr uint32_t kWarmupFrames = 2048;        // rt-neural-generic.cpp:1077
 constexpr uint32_t kMaxFrames = 8192;           // LDS block buffer bound (32 KiB)
-// Stream count from which a model of the reference's table runs faster on the matrix-core kernel (16 streams
-// per workgroup, zero-padded to a multiple of 16 units) than on its register-resident kernel. Measured
-// crossovers (scratch/perf_table_mfma.py, 256-frame blocks): the wide cells, whose
-// one-wave kernels hold 250-500 weight registers and run one wave per SIMD, gain 1.6-3.2x from 4096 streams;
-// the narrowest gain 1.2-1.9x once there are >= 8 workgroups per CU; 20..40 units (padded by up to 60 %)
-// and LSTM-32 / GRU-64 tie and stay where they are.
-constexpr uint32_t kNever = 0xffffffffu;
-uint32_t mfma_crossover_streams(int cell, int hidden)
+// Which many-streams form serves a model of the reference's table best at a given stream count. Measured
+// (scratch/perf_table_mfma.py, 256-frame blocks, MI355X): k_quad (4 streams per workgroup on
+// mfma_4x4x1, weights in registers) wins for <= 32 units from 4096 streams (1.15-1.5x over the split form) and
+// for the wide cells already at 1024-2048 streams (LSTM-64 1.3-1.6x, LSTM-80 1.3-1.7x, GRU-80 1.2-1.4x);
+// k_mfma (16 streams per workgroup on mfma_16x16x4) takes over for the wide cells from 4096-8192 streams
+// (LSTM-80 @ 16384: 2.3 ms against 4.3 ms for k_quad and 8.4 ms for the one-wave kernel). GRU-64 ties with
+// its register kernel up to 8192 streams and stays there.
+enum ManyForm { MANY_NONE = 0, MANY_QUAD = 1, MANY_MFMA = 2 };
+ManyForm many_streams_form(int cell, int hidden, uint32_t n)
 {
-    if (cell == AIDAX_CELL_LSTM) {
-        if (hidden >= 80) return 2048;
-        if (hidden >= 64) return 3072;
-        if (hidden == 40) return 4096;
-        if (hidden <= 16) return hidden <= 8 ? 12288 : 8192;
-        return kNever;
+    const bool lstm = cell == AIDAX_CELL_LSTM;
+    if (hidden <= 32) return n >= 4096 ? MANY_QUAD : MANY_NONE;
+    if (hidden == 40) return n >= 8192 ? MANY_MFMA : n >= (lstm ? 1024u : 4096u) ? MANY_QUAD : MANY_NONE;
+    if (hidden == 64) {
+        if (lstm) return n >= 4096 ? MANY_MFMA : n >= 1024 ? MANY_QUAD : MANY_NONE;
+        return n >= 16384 ? MANY_MFMA : MANY_NONE;
     }
-    if (hidden >= 80) return 2048;
-    if (hidden == 64) return 16384;
-    if (hidden == 40) return 8192;
-    if (hidden <= 16) return 6144;
-    return kNever;
+    return n >= 4096 ? MANY_MFMA : n >= 1024 ? MANY_QUAD : MANY_NONE;      // 80 units
 }
 
 struct HipFail : std::runtime_error { using std::runtime_error::runtime_error; };
@@ -108,7 +105,9 @@ struct aidax_pool {
 
     // model in use (copy of what the kernels need)
     bool has_model = false;
-    enum Kind { TABLE = 0, STACK = 1, CONV = 2, MFMA = 3 } kind = TABLE;
+    enum Kind { TABLE = 0, STACK = 1, CONV = 2, MFMA = 3, QUAD = 4 } kind = TABLE;
+    QuadDesc qdesc{};
+    int cell = 0;
     StackDesc sdesc{};
     MfmaDesc mdesc{};
     ConvDesc cdesc{};
@@ -133,11 +132,17 @@ struct aidax_pool {
         if (n_streams < 64) return 0;
         return (!has_model || split_pays) ? 2 : 0;
     }
-    // Models of the reference's table on the matrix-core kernel (mfma_crossover_streams); AIDAX_KERNEL=mfma forces it.
-    bool mfma_for_table_model(int cell, int hidden_units) const
+    // Models of the reference's table on the matrix-core kernels (many_streams_form); AIDAX_KERNEL=quad|mfma force one.
+    // four streams per workgroup on mfma_f32_4x4x1 (k_quad): the many-streams form of the table models
+    bool quad_for_table_model(int cell_kind, int hidden_units) const
+    {
+        if (force_form == 6) return true;
+        return force_form == 0 && many_streams_form(cell_kind, hidden_units, n_streams) == MANY_QUAD;
+    }
+    bool mfma_for_table_model(int cell_kind, int hidden_units) const
     {
         if (force_form == 5) return true;
-        return force_form == 0 && n_streams >= mfma_crossover_streams(cell, hidden_units);
+        return force_form == 0 && many_streams_form(cell_kind, hidden_units, n_streams) == MANY_MFMA;
     }
     bool use_pipe() const
     {
@@ -197,6 +202,13 @@ struct aidax_pool {
             if (a.mode != MODE_CHAIN) return launch_mfma_kernel(a, mdesc, s);
             hipError_t e = launch_chain_pass(true, a, s);
             if (e == hipSuccess && a.n_frames != 0) e = launch_mfma_kernel(a, mdesc, s);
+            if (e == hipSuccess) e = launch_chain_pass(false, a, s);
+            return e;
+        }
+        if (has_model && kind == QUAD) {
+            if (a.mode != MODE_CHAIN) return launch_quad_kernel(cell, hidden, a, qdesc, s);
+            hipError_t e = launch_chain_pass(true, a, s);
+            if (e == hipSuccess && a.n_frames != 0) e = launch_quad_kernel(cell, hidden, a, qdesc, s);
             if (e == hipSuccess) e = launch_chain_pass(false, a, s);
             return e;
         }
@@ -260,6 +272,7 @@ int set_model_impl(aidax_pool& p, const aidax_model* m, int start_mode)
     StackDesc sd{};
     MfmaDesc md{};
     ConvDesc cd{};
+    QuadDesc qd{};
     bool conv_mfma = false;
     if (is_conv_model(*m)) {
         kind = aidax_pool::CONV;
@@ -267,6 +280,11 @@ int set_model_impl(aidax_pool& p, const aidax_model* m, int start_mode)
         conv_mfma = p.max_frames <= 256 && p.force_form != 4 && convm_lds_bytes(cd, p.max_frames) <= 160 * 1024;
         if (!conv_mfma && conv_lds_bytes(cd, p.max_frames) > 160 * 1024)
             return fail(AIDAX_ERR_ARG, "conv model: pool max_frames too large for the LDS activation planes");
+    } else if (m->n_rnn == 1 && find_kernel(m->cell, m->hidden) && p.quad_for_table_model(m->cell, m->hidden) &&
+               chain_lds_bytes(p.max_frames) <= 64 * 1024 && quad_lds_bytes(m->hidden, p.max_frames) <= 160 * 1024) {
+        kind = aidax_pool::QUAD;
+        wp = pack_quad(*m, &qd.bias_off, &qd.dense_off);
+        state_floats = static_cast<uint32_t>(m->cell == AIDAX_CELL_LSTM ? 2 * m->hidden : m->hidden);
     } else if (mfma_form_fits(*m) && chain_lds_bytes(p.max_frames) <= 64 * 1024 &&
                (is_stack_model(*m) ? p.force_form != 4 : p.mfma_for_table_model(m->cell, m->hidden))) {
         kind = aidax_pool::MFMA;
@@ -302,6 +320,8 @@ int set_model_impl(aidax_pool& p, const aidax_model* m, int start_mode)
     p.sdesc = sd;
     p.mdesc = md;
     p.cdesc = cd;
+    p.qdesc = qd;
+    p.cell = m->cell;
     p.conv_mfma = conv_mfma;
     p.hidden = m->hidden;
     p.input_size = m->input_size;
@@ -351,7 +371,7 @@ AIDAX_API int aidax_pool_create(uint32_t n_streams, uint32_t max_frames, double 
         p->host_sr = host_samplerate;
         p->gain_coef = exp_smoother_coef(static_cast<float>(host_samplerate), 0.1f);
         if (const char* f = std::getenv("AIDAX_KERNEL"))
-            p->force_form = std::strcmp(f, "wave") == 0 ? 1 : std::strcmp(f, "pipe") == 0 ? 2 : std::strcmp(f, "split") == 0 ? 3 : std::strcmp(f, "valu") == 0 ? 4 : std::strcmp(f, "mfma") == 0 ? 5 : 0;
+            p->force_form = std::strcmp(f, "wave") == 0 ? 1 : std::strcmp(f, "pipe") == 0 ? 2 : std::strcmp(f, "split") == 0 ? 3 : std::strcmp(f, "valu") == 0 ? 4 : std::strcmp(f, "mfma") == 0 ? 5 : std::strcmp(f, "quad") == 0 ? 6 : 0;
         try {
             HIP_TRY(hipSetDevice(device_id));
             HIP_TRY(hipStreamCreateWithFlags(&p->q, hipStreamNonBlocking));
@@ -494,7 +514,7 @@ AIDAX_API int aidax_pool_read_state(aidax_pool* p, uint32_t stream, int layer, f
         } else if (p->kind == aidax_pool::MFMA) {
             H = static_cast<uint32_t>(p->mdesc.hidden_true); off = p->mdesc.L[layer].state_off; lstm = p->mdesc.L[layer].cell == 0;
         } else {
-            lstm = p->kernel->cell == AIDAX_CELL_LSTM;
+            lstm = p->cell == AIDAX_CELL_LSTM;
         }
         const uint32_t n = H < cap ? H : cap;
         const float* base = p->d_nn + static_cast<size_t>(stream) * p->nn_stride + off;
@@ -509,6 +529,7 @@ AIDAX_API const char* aidax_pool_kernel_name(const aidax_pool* p)
     if (!(p && p->has_model)) return "k_nomodel";
     if (p->kind == aidax_pool::STACK) return "k_stack";
     if (p->kind == aidax_pool::MFMA) return "k_chain+k_mfma";
+    if (p->kind == aidax_pool::QUAD) return "k_chain+k_quad";
     if (p->kind == aidax_pool::CONV) return p->conv_mfma ? "k_chain+k_conv_mfma" : "k_conv";
     const int form = p->chain_form();
     return form == 1 ? p->kernel->name_pipe : form == 2 ? p->kernel->name_split : p->kernel->name;

@@ -68,14 +68,15 @@ def test_torch_goldens_on_gpu(name, golden_dir, tmp_path):
     assert np.abs(y - (O.net_run(spec, g["X"]) + skip)).max() < THR
 
 
-@pytest.mark.parametrize("form", ["registers", "mfma"])
+@pytest.mark.parametrize("form", ["registers", "mfma", "quad"])
 @pytest.mark.parametrize("cell", ["lstm", "gru"])
 @pytest.mark.parametrize("hidden", modelgen.HIDDEN_SIZES)
 def test_every_reference_variant_runs_and_matches_oracle(cell, hidden, form, tmp_path, monkeypatch):
     """All 54 architectures of model_variant.hpp, bare network, 768 samples each - on the register-resident
-    kernels and on the matrix-core kernel (widths that are not a multiple of 16 run zero-padded there)."""
-    if form == "mfma":
-        monkeypatch.setenv("AIDAX_KERNEL", "mfma")
+    kernels and on the two matrix-core kernels (16 streams per workgroup on mfma_16x16x4, zero-padded to a
+    multiple of 16 units; 4 streams per workgroup on mfma_4x4x1)."""
+    if form != "registers":
+        monkeypatch.setenv("AIDAX_KERNEL", form)
     for isz in modelgen.INPUT_SIZES:
         kw = dict(kind=cell, hidden=hidden, input_size=isz, seed=1000 + hidden * 4 + isz)
         path, spec = _model_file(tmp_path, f"{cell}{hidden}_{isz}", **kw)
@@ -305,7 +306,9 @@ _EQ_POST = dict(bass_boost_db=4.0, mid_boost_db=-3.0, mid_q=1.2, treble_boost_db
     ("cfg3", dict(kind="gru", hidden=64, input_size=3, seed=64), 4096, _EQ_POST, "k_chain+k_nn<gru64>"),
     ("cfg4", dict(kind="conv", hidden=16, input_size=1, seed=1608), 1024, {}, "k_chain+k_conv_mfma"),
     ("cfg5", dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2), 2048, {}, "k_chain+k_mfma"),
-    ("lstm80-many", dict(kind="lstm", hidden=80, input_size=2, seed=80), 2048, dict(param1=0.7), "k_chain+k_mfma"),
+    ("lstm80-2k", dict(kind="lstm", hidden=80, input_size=2, seed=80), 2048, dict(param1=0.7), "k_chain+k_quad"),
+    ("lstm80-4k", dict(kind="lstm", hidden=80, input_size=2, seed=80), 4096, dict(param1=0.7), "k_chain+k_mfma"),
+    ("gru16-4k", dict(kind="gru", hidden=16, input_size=3, seed=16), 4096, dict(param1=0.2, param2=0.9), "k_chain+k_quad"),
 ])
 def test_full_size_properties(name, kw, S, ckw, kernel, tmp_path):
     """The BASELINE.json GPU configs at their per-GPU stream counts x 256 frames, in the launch form the
@@ -499,7 +502,7 @@ def test_stacked_model_state_readback(tmp_path):
 
 # ------------------------------------------------------------ the three launch forms of the chain
 
-@pytest.mark.parametrize("form", ["wave", "pipe", "split", "mfma"])
+@pytest.mark.parametrize("form", ["wave", "pipe", "split", "mfma", "quad"])
 def test_every_kernel_form_passes_the_same_chain_cases(form, tmp_path, monkeypatch, bundled_models):
     """AIDAX_KERNEL pins one form: one wave per stream, the 3-wave pipeline, the split launches (packed
     chain kernels around the lean recurrent kernel), or the split launches around the matrix-core
@@ -518,7 +521,7 @@ def test_every_kernel_form_passes_the_same_chain_cases(form, tmp_path, monkeypat
            dict(dc_blocker=0.0, in_lpf_pc=0.0, eq_bypass=1.0), dict(pregain_db=6.0, master_db=-6.0, treble_boost_db=4.0)]
     for s in range(S):
         pool.set_controls(ax.default_controls(**kws[s % len(kws)]), stream=s)
-    assert pool.kernel_name.startswith({"wave": "k_lstm<", "pipe": "k_lstm_pipe<", "split": "k_chain+k_nn<", "mfma": "k_chain+k_mfma"}[form])
+    assert pool.kernel_name.startswith({"wave": "k_lstm<", "pipe": "k_lstm_pipe<", "split": "k_chain+k_nn<", "mfma": "k_chain+k_mfma", "quad": "k_chain+k_quad"}[form])
     got = np.empty_like(x)
     pos = 0
     for n in sizes:

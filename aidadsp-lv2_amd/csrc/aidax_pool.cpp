@@ -17,8 +17,9 @@ using namespace aidax;
 
 namespace aidax {
 
-// Which device path serves a model: the 18 register-resident kernels for the reference's 54
-// variants, k_stack for stacked recurrent layers, k_conv for conv1d stacks (extensions).
+// Which models have a device path: the reference's 54 variants (18 register-resident kernels; k_quad /
+// k_mfma for many streams), stacked or wider recurrent layers (k_mfma, k_stack) and conv1d stacks
+// (k_conv_mfma, k_conv) as extensions.
 bool model_supported(const aidax_model& m)
 {
     if (is_conv_model(m)) {
@@ -119,7 +120,7 @@ struct aidax_pool {
     int pipe_capacity = 0;           // streams the 3-wave pipeline keeps resident at once (0 = never use it)
     bool split_pays = false;         // the lean recurrent kernel keeps the occupancy of the one-wave kernel
     int force_form = 0;              // AIDAX_KERNEL=wave|pipe|split|valu overrides the heuristic (A/B testing)
-    // Form of a MODE_CHAIN pass: 0 one wave per stream, 1 three-wave pipeline (all streams resident at
+    // Form of a MODE_CHAIN pass of a TABLE pool: 0 one wave per stream, 1 three-wave pipeline (all streams resident at
     // once: latency-bound regime), 2 split launches with packed chains (many streams: issue-bound regime)
     int chain_form() const
     {

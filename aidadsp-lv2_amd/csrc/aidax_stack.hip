@@ -1,6 +1,8 @@
-// aidax_stack.hip — kernels for the architectures the reference itself cannot load
-// (BASELINE configs #4 and #5; parity pinned only by the torch
-// fixtures of tests/golden/make_golden.py):
+// aidax_stack.hip — the VALU kernels for the architectures the reference itself cannot load
+// (BASELINE configs #4 and #5; parity pinned only by the torch fixtures of
+// tests/golden/make_golden.py). The pool prefers their matrix-core counterparts (k_mfma in
+// aidax_mfma.hip, k_conv_mfma in aidax_convm.hip); these serve widths / block lengths those do
+// not take and AIDAX_KERNEL=valu, and the tests run both forms against the same oracle:
 //
 //   k_stack   stacked LSTM/GRU layers (e.g. LSTM-96 x2, 437 KiB of weights) -> Dense(H,1).
 //             The weights do not fit one wave's registers, so a 256-thread workgroup

@@ -500,7 +500,7 @@ def test_stacked_model_state_readback(tmp_path):
         assert h.size == 96 and np.abs(h - oh).max() < 4e-6 and np.abs(c - oc).max() < 4e-6
 
 
-# ------------------------------------------------------------ the three launch forms of the chain
+# ------------------------------------------------------------ the launch forms of the chain
 
 @pytest.mark.parametrize("form", ["wave", "pipe", "split", "mfma", "quad"])
 def test_every_kernel_form_passes_the_same_chain_cases(form, tmp_path, monkeypatch, bundled_models):

@@ -1,0 +1,52 @@
+"""tools/make_bundle.py: the generated bundle describes the same ports the shell
+implements, with the defaults the C ABI uses, and ships the default model its state block points at."""
+import importlib
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import make_bundle  # noqa: E402
+
+ax = importlib.import_module("aidadsp-lv2_amd")
+
+
+def _shell_port_enum():
+    src = open(os.path.join(ROOT, "aidadsp-lv2_amd", "lv2", "rt_neural_generic_lv2.cpp")).read()
+    body = re.search(r"enum PortIndex \{[^\n]*\n(.*?)\};", src, re.S).group(1)
+    names = [t.split("=")[0].strip() for t in body.replace("\n", " ").split(",") if t.strip()]
+    return [n for n in names if n != "PLUGIN_PORT_COUNT"]
+
+
+def test_generated_ttl_matches_shell_and_abi_defaults(tmp_path):
+    bundle = make_bundle.make_bundle(str(tmp_path), binaries=False)
+    ttl = open(os.path.join(bundle, "rt-neural-generic.ttl")).read()
+    ports = re.findall(r"lv2:index (\d+) ;\s*lv2:symbol \"([^\"]+)\"", ttl)
+    assert [int(i) for i, _ in ports] == list(range(25))
+    enum = _shell_port_enum()
+    assert len(enum) == 25
+    # spot anchors between the shell's enum and the symbols hosts see
+    sym = [s for _, s in ports]
+    for name, symbol in (("IN", "IN"), ("OUT_1", "OUT"), ("PLUGIN_CONTROL", "CONTROL"), ("PLUGIN_NOTIFY", "NOTIFY"),
+                         ("IN_LPF", "ANTIALIASING"), ("NET_BYPASS", "NETBYPASS"), ("EQ_POS", "EQPOS"), ("MIDQ", "MIDQ"),
+                         ("MASTER", "MASTER"), ("INPUT_SIZE", "ModelInSize"), ("PLUGIN_ENABLED", "enabled")):
+        assert sym[enum.index(name)] == symbol
+    # defaults of the control inputs == aidax_controls_default (rt-neural-generic.ttl:94-313)
+    c = ax.default_controls()
+    defaults = dict(re.findall(r"lv2:symbol \"([^\"]+)\" ;\s*lv2:name \"[^\"]+\" ;\s*lv2:default ([-0-9.e]+)", ttl))
+    fields = ax.binding.CONTROL_FIELDS
+    assert len(make_bundle.CONTROL_SYMBOLS) == len(fields) == 20
+    for symbol, field in zip(make_bundle.CONTROL_SYMBOLS, fields):
+        assert abs(float(defaults[symbol]) - getattr(c, field)) < 1e-5, (symbol, field)     # float32 fields
+    assert "work:schedule" in ttl and "state:interface" in ttl and "patch:writable" in ttl
+
+
+def test_bundle_layout(tmp_path):
+    bundle = make_bundle.make_bundle(str(tmp_path), binaries=False)
+    man = open(os.path.join(bundle, "manifest.ttl")).read()
+    assert "<rt-neural-generic.so>" in man and make_bundle.URI in man
+    assert os.path.exists(os.path.join(bundle, make_bundle.DEFAULT_MODEL))
+    assert len(os.listdir(os.path.join(bundle, "models", "deer ink studios"))) == 6
+    m = ax.Model(os.path.join(bundle, make_bundle.DEFAULT_MODEL))          # loads through the C ABI
+    assert (m.info.cell, m.info.hidden, m.info.input_size) == (0, 12, 1)

@@ -17,7 +17,7 @@ OBJDIR  := build/obj
 CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wall -Wextra -Iinclude
 HIPFLAGS := --offload-arch=$(ARCH) $(CXXFLAGS)
 
-HOST_SRCS := $(SRC)/aidax_model.cpp $(SRC)/aidax_dsp_host.cpp $(SRC)/aidax_pack.cpp $(SRC)/aidax_pool.cpp
+HOST_SRCS := $(SRC)/aidax_model.cpp $(SRC)/aidax_dsp_host.cpp $(SRC)/aidax_pack.cpp $(SRC)/aidax_pool.cpp $(SRC)/aidax_hub.cpp
 HOST_OBJS := $(patsubst $(SRC)/%.cpp,$(OBJDIR)/%.o,$(HOST_SRCS))
 KERN_OBJS := $(OBJDIR)/aidax_kernels.o $(OBJDIR)/aidax_stack.o $(OBJDIR)/aidax_mfma.o $(OBJDIR)/aidax_convm.o $(OBJDIR)/aidax_quad.o
 HDRS      := $(wildcard $(SRC)/*.h) include/aidax.h

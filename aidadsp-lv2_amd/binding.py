@@ -98,6 +98,21 @@ def lib() -> C.CDLL:
     L.aidax_pool_read_state.argtypes = [vp, u32, C.c_int, _fp, _fp, u32]
     L.aidax_pool_kernel_name.argtypes = [vp]
     L.aidax_pool_kernel_name.restype = C.c_char_p
+    L.aidax_pool_reset_stream.argtypes = [vp, u32, C.c_int]
+    L.aidax_hub_create.argtypes = [u32, u32, C.c_double, C.c_int, C.POINTER(vp)]
+    L.aidax_hub_destroy.argtypes = [vp]
+    L.aidax_hub_destroy.restype = None
+    L.aidax_hub_set_model.argtypes = [vp, vp, C.c_int]
+    L.aidax_hub_attach.argtypes = [vp, C.POINTER(i32)]
+    L.aidax_hub_detach.argtypes = [vp, i32]
+    L.aidax_hub_set_controls.argtypes = [vp, i32, C.POINTER(Controls)]
+    L.aidax_hub_run.argtypes = [vp, i32, _fp, _fp, u32]
+    L.aidax_hub_latency_frames.argtypes = [vp]
+    L.aidax_hub_latency_frames.restype = u32
+    L.aidax_hub_attached.argtypes = [vp]
+    L.aidax_hub_attached.restype = u32
+    L.aidax_hub_launches.argtypes = [vp]
+    L.aidax_hub_launches.restype = C.c_uint64
     _lib = L
     return L
 
@@ -233,6 +248,9 @@ class Pool:
     def sync(self):
         _check(lib().aidax_pool_sync(self.h))
 
+    def reset_stream(self, stream: int, start_mode: int = START_WARMUP):
+        _check(lib().aidax_pool_reset_stream(self.h, stream, start_mode))
+
     def read_state(self, stream: int = 0, layer: int = 0, hidden: int = 128):
         h, c = np.zeros(hidden, np.float32), np.zeros(hidden, np.float32)
         H = _check(lib().aidax_pool_read_state(self.h, stream, layer, h.ctypes.data_as(_fp), c.ctypes.data_as(_fp), hidden))
@@ -245,6 +263,58 @@ class Pool:
     def close(self):
         if self.h:
             lib().aidax_pool_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Hub:
+    """aidax_hub: many plugin instances of one process, one pool pass per audio period (one period of latency)."""
+
+    def __init__(self, max_instances: int, max_frames: int = 256, samplerate: float = 48000.0, device: int = 0):
+        h = C.c_void_p()
+        _check(lib().aidax_hub_create(max_instances, max_frames, samplerate, device, C.byref(h)))
+        self.h = h
+
+    def set_model(self, m: Optional[Model], start_mode: int = START_WARMUP):
+        _check(lib().aidax_hub_set_model(self.h, m.h if m is not None else None, start_mode))
+
+    def attach(self) -> int:
+        slot = C.c_int32(-1)
+        _check(lib().aidax_hub_attach(self.h, C.byref(slot)))
+        return slot.value
+
+    def detach(self, slot: int):
+        _check(lib().aidax_hub_detach(self.h, slot))
+
+    def set_controls(self, slot: int, c: Controls):
+        _check(lib().aidax_hub_set_controls(self.h, slot, C.byref(c)))
+
+    def run(self, slot: int, x: np.ndarray) -> np.ndarray:
+        x = _f32(x)
+        out = np.empty_like(x)
+        _check(lib().aidax_hub_run(self.h, slot, x.ctypes.data_as(_fp), out.ctypes.data_as(_fp), x.size))
+        return out
+
+    @property
+    def latency_frames(self) -> int:
+        return lib().aidax_hub_latency_frames(self.h)
+
+    @property
+    def attached(self) -> int:
+        return lib().aidax_hub_attached(self.h)
+
+    @property
+    def launches(self) -> int:
+        return lib().aidax_hub_launches(self.h)
+
+    def close(self):
+        if self.h:
+            lib().aidax_hub_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):

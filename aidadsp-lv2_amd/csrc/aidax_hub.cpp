@@ -1,0 +1,228 @@
+// aidax_hub.cpp — host-side stream aggregator: many plugin instances of one process, one pool pass per
+// audio period (include/aidax.h, "hub"). Pipelined by one period so that hosts that call their instances
+// one after another never wait on each other; see the header for the contract.
+#include <hip/hip_runtime_api.h>
+
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "aidax_internal.h"
+
+using namespace aidax;
+
+struct aidax_hub {
+    aidax_pool* pool = nullptr;
+    uint32_t cap = 0, max_frames = 0;
+    int device = 0;
+    std::mutex mu;
+    std::vector<uint8_t> attached, submitted, forced_off;
+    std::vector<uint8_t> out_valid[2];
+    std::vector<aidax_controls> ctl;
+    uint32_t n_attached = 0, n_submitted = 0, period_frames = 0, out_frames[2] = { 0, 0 };
+    uint32_t latency = 0;
+    uint64_t launches = 0;
+    float* h_in[2] = { nullptr, nullptr };       // pinned staging, rows packed at the period's block length
+    float* h_out[2] = { nullptr, nullptr };
+    float* d_in = nullptr;
+    float* d_out = nullptr;
+    hipStream_t q = nullptr;
+    hipEvent_t done[2] = { nullptr, nullptr };
+    bool pending[2] = { false, false };
+    int cur = 0;
+
+    ~aidax_hub()
+    {
+        if (q) (void)hipStreamSynchronize(q);
+        for (int i = 0; i < 2; ++i) {
+            if (h_in[i]) (void)hipHostFree(h_in[i]);
+            if (h_out[i]) (void)hipHostFree(h_out[i]);
+            if (done[i]) (void)hipEventDestroy(done[i]);
+        }
+        if (d_in) (void)hipFree(d_in);
+        if (d_out) (void)hipFree(d_out);
+        if (q) (void)hipStreamDestroy(q);
+        if (pool) aidax_pool_destroy(pool);
+    }
+};
+
+namespace {
+
+bool ok(hipError_t e, const char* what)
+{
+    if (e == hipSuccess) return true;
+    set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return false;
+}
+#define HUB_TRY(x) do { if (!ok((x), #x)) return AIDAX_ERR_DEVICE; } while (0)
+
+// the controls the pool sees for a slot: as set by the instance, but disabled while the slot is detached
+// or did not take part in the period being launched (a disabled stream is a copy: its state does not move)
+int push_controls(aidax_hub& h, uint32_t slot, bool off)
+{
+    aidax_controls c = h.ctl[slot];
+    if (off) c.enabled = 0.f;
+    h.forced_off[slot] = off ? 1 : 0;
+    return aidax_pool_set_controls(h.pool, static_cast<int32_t>(slot), &c);
+}
+
+// launch the period that is being collected (h.mu held)
+int flush_locked(aidax_hub& h)
+{
+    if (h.n_submitted == 0) return AIDAX_OK;
+    const uint32_t n = h.period_frames;
+    for (uint32_t s = 0; s < h.cap; ++s) {
+        const bool off = !h.attached[s] || !h.submitted[s];
+        if (off != (h.forced_off[s] != 0)) {
+            const int rc = push_controls(h, s, off);
+            if (rc != AIDAX_OK) return rc;
+        }
+    }
+    const int b = h.cur;
+    const size_t bytes = sizeof(float) * static_cast<size_t>(h.cap) * n;
+    HUB_TRY(hipSetDevice(h.device));
+    if (n != 0) HUB_TRY(hipMemcpyAsync(h.d_in, h.h_in[b], bytes, hipMemcpyHostToDevice, h.q));
+    const int rc = aidax_pool_process_device(h.pool, h.d_in, h.d_out, n, h.q);
+    if (rc != AIDAX_OK) return rc;
+    if (n != 0) HUB_TRY(hipMemcpyAsync(h.h_out[b], h.d_out, bytes, hipMemcpyDeviceToHost, h.q));
+    HUB_TRY(hipEventRecord(h.done[b], h.q));
+    h.pending[b] = true;
+    h.out_frames[b] = n;
+    h.out_valid[b] = h.submitted;
+    std::fill(h.submitted.begin(), h.submitted.end(), 0);
+    h.n_submitted = 0;
+    h.latency = n;
+    h.cur = b ^ 1;
+    ++h.launches;
+    return AIDAX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+AIDAX_API int aidax_hub_create(uint32_t max_instances, uint32_t max_frames, double host_samplerate, int device_id, aidax_hub** out)
+{
+    if (!out) return fail(AIDAX_ERR_ARG, "null argument");
+    *out = nullptr;
+    aidax_pool* pool = nullptr;
+    const int rc = aidax_pool_create(max_instances, max_frames, host_samplerate, device_id, &pool);
+    if (rc != AIDAX_OK) return rc;
+    aidax_hub* h = new aidax_hub();
+    h->pool = pool;
+    h->cap = max_instances;
+    h->max_frames = max_frames;
+    h->device = device_id;
+    h->attached.assign(max_instances, 0);
+    h->submitted.assign(max_instances, 0);
+    h->forced_off.assign(max_instances, 0);
+    h->out_valid[0].assign(max_instances, 0);
+    h->out_valid[1].assign(max_instances, 0);
+    h->ctl.resize(max_instances);
+    for (auto& c : h->ctl) aidax_controls_default(&c);
+    const size_t bytes = sizeof(float) * static_cast<size_t>(max_instances) * max_frames;
+    bool good = ok(hipSetDevice(device_id), "hipSetDevice") &&
+                ok(hipStreamCreateWithFlags(&h->q, hipStreamNonBlocking), "hipStreamCreate") &&
+                ok(hipMalloc(&h->d_in, bytes), "hipMalloc") && ok(hipMalloc(&h->d_out, bytes), "hipMalloc");
+    for (int i = 0; i < 2 && good; ++i)
+        good = ok(hipHostMalloc(reinterpret_cast<void**>(&h->h_in[i]), bytes, hipHostMallocDefault), "hipHostMalloc") &&
+               ok(hipHostMalloc(reinterpret_cast<void**>(&h->h_out[i]), bytes, hipHostMallocDefault), "hipHostMalloc") &&
+               ok(hipEventCreateWithFlags(&h->done[i], hipEventDisableTiming), "hipEventCreate");
+    if (!good) { delete h; return AIDAX_ERR_DEVICE; }
+    // nobody is attached yet: every stream rests disabled
+    for (uint32_t s = 0; s < max_instances; ++s)
+        if (push_controls(*h, s, true) != AIDAX_OK) { delete h; return AIDAX_ERR_DEVICE; }
+    *out = h;
+    return AIDAX_OK;
+}
+
+AIDAX_API void aidax_hub_destroy(aidax_hub* h) { delete h; }
+
+AIDAX_API int aidax_hub_set_model(aidax_hub* h, const aidax_model* m, int start_mode)
+{
+    if (!h) return fail(AIDAX_ERR_ARG, "null hub");
+    std::lock_guard<std::mutex> g(h->mu);
+    if (h->q) (void)hipStreamSynchronize(h->q);
+    return aidax_pool_set_model(h->pool, m, start_mode);
+}
+
+AIDAX_API int aidax_hub_attach(aidax_hub* h, int32_t* slot)
+{
+    if (!h || !slot) return fail(AIDAX_ERR_ARG, "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    for (uint32_t s = 0; s < h->cap; ++s) {
+        if (h->attached[s]) continue;
+        (void)hipStreamSynchronize(h->q);                    // the slot's stream is not in flight
+        int rc = aidax_pool_reset_stream(h->pool, s, AIDAX_START_WARMUP);
+        if (rc != AIDAX_OK) return rc;
+        rc = aidax_pool_activate(h->pool, static_cast<int32_t>(s));
+        if (rc != AIDAX_OK) return rc;
+        aidax_controls_default(&h->ctl[s]);
+        h->attached[s] = 1;
+        h->out_valid[0][s] = h->out_valid[1][s] = 0;
+        ++h->n_attached;
+        *slot = static_cast<int32_t>(s);
+        return AIDAX_OK;
+    }
+    return fail(AIDAX_ERR_STATE, "hub is full");
+}
+
+AIDAX_API int aidax_hub_detach(aidax_hub* h, int32_t slot)
+{
+    if (!h) return fail(AIDAX_ERR_ARG, "null hub");
+    std::lock_guard<std::mutex> g(h->mu);
+    if (slot < 0 || static_cast<uint32_t>(slot) >= h->cap || !h->attached[slot]) return fail(AIDAX_ERR_ARG, "slot not attached");
+    h->attached[slot] = 0;
+    --h->n_attached;
+    if (h->submitted[slot]) { h->submitted[slot] = 0; --h->n_submitted; }
+    if (h->n_submitted != 0 && h->n_submitted == h->n_attached) return flush_locked(*h);
+    return AIDAX_OK;
+}
+
+AIDAX_API int aidax_hub_set_controls(aidax_hub* h, int32_t slot, const aidax_controls* c)
+{
+    if (!h || !c) return fail(AIDAX_ERR_ARG, "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    if (slot < 0 || static_cast<uint32_t>(slot) >= h->cap || !h->attached[slot]) return fail(AIDAX_ERR_ARG, "slot not attached");
+    if (std::memcmp(&h->ctl[slot], c, sizeof(*c)) == 0) return AIDAX_OK;
+    h->ctl[slot] = *c;
+    return push_controls(*h, static_cast<uint32_t>(slot), h->forced_off[slot] != 0);
+}
+
+AIDAX_API int aidax_hub_run(aidax_hub* h, int32_t slot, const float* in, float* out, uint32_t n_frames)
+{
+    if (!h) return fail(AIDAX_ERR_ARG, "null hub");
+    if (n_frames > h->max_frames) return fail(AIDAX_ERR_ARG, "n_frames exceeds the hub's max_frames");
+    if (n_frames != 0 && (!in || !out)) return fail(AIDAX_ERR_ARG, "null buffer");
+    std::lock_guard<std::mutex> g(h->mu);
+    if (slot < 0 || static_cast<uint32_t>(slot) >= h->cap || !h->attached[slot]) return fail(AIDAX_ERR_ARG, "slot not attached");
+    // this instance is back before everybody submitted, or the host changed the block size: close the period
+    if (h->submitted[slot] || (h->n_submitted != 0 && n_frames != h->period_frames)) {
+        const int rc = flush_locked(*h);
+        if (rc != AIDAX_OK) return rc;
+    }
+    if (h->n_submitted == 0) h->period_frames = n_frames;
+    const int b = h->cur, prev = b ^ 1;
+    if (n_frames != 0) std::memcpy(h->h_in[b] + static_cast<size_t>(slot) * n_frames, in, sizeof(float) * n_frames);
+    h->submitted[slot] = 1;
+    ++h->n_submitted;
+    // the previous period's output for this instance
+    if (h->pending[prev]) {
+        HUB_TRY(hipEventSynchronize(h->done[prev]));
+        h->pending[prev] = false;
+    }
+    if (n_frames != 0) {
+        if (h->out_valid[prev][slot] && h->out_frames[prev] == n_frames)
+            std::memcpy(out, h->h_out[prev] + static_cast<size_t>(slot) * n_frames, sizeof(float) * n_frames);
+        else
+            std::memset(out, 0, sizeof(float) * n_frames);
+    }
+    if (h->n_submitted == h->n_attached) return flush_locked(*h);
+    return AIDAX_OK;
+}
+
+AIDAX_API uint32_t aidax_hub_latency_frames(const aidax_hub* h) { return h ? h->latency : 0; }
+AIDAX_API uint32_t aidax_hub_attached(const aidax_hub* h) { return h ? h->n_attached : 0; }
+AIDAX_API uint64_t aidax_hub_launches(const aidax_hub* h) { return h ? h->launches : 0; }
+
+}  // extern "C"

@@ -413,6 +413,38 @@ AIDAX_API int aidax_pool_set_model(aidax_pool* p, const aidax_model* m, int star
     return guarded([&]() { return set_model_impl(*p, m, start_mode); });
 }
 
+AIDAX_API int aidax_pool_reset_stream(aidax_pool* p, uint32_t stream, int start_mode)
+{
+    if (!p) return fail(AIDAX_ERR_ARG, "null pool");
+    if (stream >= p->n_streams) return fail(AIDAX_ERR_ARG, "stream out of range");
+    if (start_mode != AIDAX_START_WARMUP && start_mode != AIDAX_START_RESET) return fail(AIDAX_ERR_ARG, "bad start_mode");
+    return guarded([&]() -> int {
+        HIP_TRY(hipSetDevice(p->device));
+        StreamState st{};                                   // instantiate(), :283-321
+        st.pre_mem = 1.f; st.pre_tgt = 1.f;
+        HIP_TRY(hipMemcpyAsync(p->d_st + stream, &st, sizeof(st), hipMemcpyHostToDevice, p->q));
+        HIP_TRY(hipStreamSynchronize(p->q));                // `st` is a stack object
+        if (p->has_model) {
+            // a fresh DynamicModel for this stream only: the launch arguments view the pool as one stream
+            HIP_TRY(launch_reset_for_model(p->d_st + stream, p->d_nn + static_cast<size_t>(stream) * p->nn_stride, 1,
+                                           p->nn_stride, p->p_den(), p->q));
+            if (start_mode == AIDAX_START_WARMUP) {
+                const uint32_t chunk = p->launch_chunk(kWarmupFrames);
+                for (uint32_t done = 0; done < kWarmupFrames; done += chunk) {
+                    LaunchArgs a = p->args(nullptr, nullptr, std::min(chunk, kWarmupFrames - done), MODE_WARMUP);
+                    a.ctl += stream; a.st += stream; a.nn += static_cast<size_t>(stream) * p->nn_stride;
+                    a.n_streams = 1;
+                    p->flush_ctl(p->q);
+                    HIP_TRY(p->launch(a, p->q));
+                }
+            }
+        }
+        p->loading[stream] = p->has_model ? 0 : 1;
+        p->refresh_ctl(stream);
+        return AIDAX_OK;
+    });
+}
+
 AIDAX_API int aidax_pool_set_loading(aidax_pool* p, int32_t stream, int loading)
 {
     if (!p) return fail(AIDAX_ERR_ARG, "null pool");

@@ -141,6 +141,12 @@ AIDAX_API uint32_t aidax_pool_streams(const aidax_pool* p);
  * The pool keeps its own copy of the weights; the caller still owns `m`. */
 AIDAX_API int  aidax_pool_set_model(aidax_pool* p, const aidax_model* m, int start_mode);
 
+/* One stream becomes a fresh plugin instance with the pool's model: instantiate() state for its DSP
+ * members (:283-321; gain smoothers pre = 1 / master = 0 cleared, biquad states 0) and a fresh DynamicModel
+ * (:1035-1079: reset, PARAM smoothers rebuilt, warm-up per start_mode), loading cleared if the pool has a
+ * model. Used when a host attaches a new instance to a running pool (aidax_hub below). */
+AIDAX_API int  aidax_pool_reset_stream(aidax_pool* p, uint32_t stream, int start_mode);
+
 /* The `loading` flag (:318, :576, :889): while set, the master gain target is 0. */
 AIDAX_API int  aidax_pool_set_loading(aidax_pool* p, int32_t stream, int loading);
 
@@ -183,6 +189,37 @@ AIDAX_API int  aidax_pool_read_state(aidax_pool* p, uint32_t stream, int layer, 
 
 /* Name of the kernel instantiation a loaded pool dispatches to (profiling aid). */
 AIDAX_API const char* aidax_pool_kernel_name(const aidax_pool* p);
+
+/* --------------------------------------------------------------------- hub
+ * Host-side stream aggregator (new relative to the reference, whose seam is the
+ * per-instance DSP section rt-neural-generic.cpp:621-659). Many plugin instances of ONE process share one
+ * pool: each instance attaches to a slot and calls aidax_hub_run() from its run(); the hub launches one
+ * pool pass per audio period for everybody.
+ *
+ * Hosts call the instances of a period one after another on one thread, or in parallel on several; a
+ * rendezvous inside run() would deadlock the first kind, so the hub is pipelined by ONE period instead:
+ * run() of period p stages the instance's input block and returns the output of period p-1 (silence in the
+ * first period). The pass of a period is launched (asynchronously: H2D, kernels, D2H) by whichever
+ * instance submits last; an instance that comes around again before everybody submitted (a host that
+ * skipped somebody) or a change of block size launches what is there - streams that did not submit do not
+ * advance. Report aidax_hub_latency_frames() to the host as the plugin's latency. Thread-safe. */
+typedef struct aidax_hub aidax_hub;
+
+AIDAX_API int  aidax_hub_create(uint32_t max_instances, uint32_t max_frames, double host_samplerate,
+                                int device_id, aidax_hub** out);
+AIDAX_API void aidax_hub_destroy(aidax_hub* h);
+/* every attached instance plays this model (instances with another model belong to another hub) */
+AIDAX_API int  aidax_hub_set_model(aidax_hub* h, const aidax_model* m, int start_mode);
+/* a new instance: *slot receives its index; its stream starts from instantiate() + warm-up state */
+AIDAX_API int  aidax_hub_attach(aidax_hub* h, int32_t* slot);
+AIDAX_API int  aidax_hub_detach(aidax_hub* h, int32_t slot);
+AIDAX_API int  aidax_hub_set_controls(aidax_hub* h, int32_t slot, const aidax_controls* c);
+/* the instance's run(): in/out are its n_frames-long port buffers (may alias) */
+AIDAX_API int  aidax_hub_run(aidax_hub* h, int32_t slot, const float* in, float* out, uint32_t n_frames);
+AIDAX_API uint32_t aidax_hub_latency_frames(const aidax_hub* h);
+AIDAX_API uint32_t aidax_hub_attached(const aidax_hub* h);
+/* number of pool passes launched so far (tests, statistics) */
+AIDAX_API uint64_t aidax_hub_launches(const aidax_hub* h);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,147 @@
+"""aidax_hub: many plugin instances of one process share one pool pass per audio
+period, pipelined by one period. The oracle's plugin mirror, one per instance, is the reference."""
+import importlib
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import modelgen
+
+pytestmark = pytest.mark.gpu
+
+ax = importlib.import_module("aidadsp-lv2_amd")
+THR = 1.0e-5
+
+
+def _model(tmp_path, **kw):
+    j = modelgen.make_model(**kw)
+    p = str(tmp_path / "m.json")
+    modelgen.write_model(j, p)
+    return ax.Model(p), O.parse_model(j)
+
+
+def _oracle_instance(spec):
+    p = O.OraclePlugin()
+    p.set_model(O.OracleModel(spec))
+    p.activate()
+    return p
+
+
+KWS = [dict(), dict(pregain_db=3.0, bass_boost_db=4.0), dict(param1=0.7, master_db=-6.0), dict(net_bypass=1.0),
+       dict(eq_position=1.0, treble_boost_db=-3.0, param1=0.2)]
+
+
+def test_sequential_host_one_period_of_latency(tmp_path):
+    """A host that calls its five instances one after another: nobody waits, everybody gets the previous
+    period's block; one launch per period."""
+    m, spec = _model(tmp_path, kind="lstm", hidden=16, input_size=2, seed=4)
+    N, n, periods = 5, 128, 9
+    hub = ax.Hub(8, 256)
+    hub.set_model(m)
+    slots = [hub.attach() for _ in range(N)]
+    assert sorted(slots) == list(range(N)) and hub.attached == N
+    plugs = [_oracle_instance(spec) for _ in range(N)]
+    x = modelgen.signal(N, n * periods, seed=31)
+    prev = [np.zeros(n, np.float32) for _ in range(N)]
+    for p in range(periods):
+        for i in range(N):
+            hub.set_controls(slots[i], ax.default_controls(**KWS[i]))
+            got = hub.run(slots[i], x[i, p * n:(p + 1) * n])
+            if KWS[i].get("net_bypass"):
+                assert np.array_equal(got, prev[i]), (p, i)
+            else:
+                assert np.abs(got - prev[i]).max() < THR * 2, (p, i, np.abs(got - prev[i]).max())
+            prev[i] = plugs[i].run(O.default_controls(**KWS[i]), x[i, p * n:(p + 1) * n])
+    assert hub.launches == periods and hub.latency_frames == n
+
+
+def test_parallel_host_threads(tmp_path):
+    """A host that runs its instances on four threads with a barrier per period."""
+    m, spec = _model(tmp_path, kind="gru", hidden=24, input_size=1, seed=6)
+    N, n, periods = 4, 64, 12
+    hub = ax.Hub(N, 64)
+    hub.set_model(m)
+    slots = [hub.attach() for _ in range(N)]
+    x = modelgen.signal(N, n * periods, seed=32)
+    got = np.zeros((N, n * periods), np.float32)
+    barrier = threading.Barrier(N)
+    errors = []
+
+    def instance(i):
+        try:
+            for p in range(periods):
+                got[i, p * n:(p + 1) * n] = hub.run(slots[i], x[i, p * n:(p + 1) * n])
+                barrier.wait()
+        except Exception as e:                      # pragma: no cover
+            errors.append(e)
+            barrier.abort()
+
+    ts = [threading.Thread(target=instance, args=(i,)) for i in range(N)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors
+    for i in range(N):
+        want = _oracle_instance(spec).run(O.default_controls(), x[i])
+        assert np.all(got[i, :n] == 0.0)
+        assert np.abs(got[i, n:] - want[:-n]).max() < THR * 2
+    assert hub.launches == periods
+
+
+def test_skipped_instance_does_not_advance_and_late_attach_starts_fresh(tmp_path):
+    m, spec = _model(tmp_path, kind="lstm", hidden=12, input_size=1, seed=8)
+    n = 96
+    hub = ax.Hub(4, 128)
+    hub.set_model(m)
+    a, b = hub.attach(), hub.attach()
+    pa, pb = _oracle_instance(spec), _oracle_instance(spec)
+    x = modelgen.signal(3, n * 8, seed=33)
+    c = O.default_controls()
+    want_a, want_b, got_a, got_b = [], [], [], []
+    for p in range(6):
+        blk = slice(p * n, (p + 1) * n)
+        got_a.append(hub.run(a, x[0, blk]))
+        want_a.append(pa.run(c, x[0, blk]))
+        if p != 2:                                  # the host skips instance b in period 2
+            got_b.append(hub.run(b, x[1, blk]))
+            want_b.append(pb.run(c, x[1, blk]))
+    # a: plain one-period delay (the skipped period is closed when a comes around again)
+    ga, wa = np.concatenate(got_a), np.concatenate(want_a)
+    assert np.abs(ga[n:] - wa[:-n]).max() < THR * 2
+    # b: its stream did not move while it was skipped; the block after the gap sees silence once
+    gb, wb = np.concatenate(got_b), np.concatenate(want_b)
+    assert np.abs(gb[n:2 * n] - wb[:n]).max() < THR * 2
+    assert np.abs(gb[3 * n:] - wb[2 * n:-n]).max() < THR * 2
+    # a third instance attached now starts from instantiate() + warm-up state, not from a's or b's history
+    cslot = hub.attach()
+    pc = _oracle_instance(spec)
+    outs, wants = [], []
+    for p in range(6, 8):
+        blk = slice(p * n, (p + 1) * n)
+        hub.run(a, x[0, blk]); hub.run(b, x[1, blk])
+        outs.append(hub.run(cslot, x[2, blk]))
+        wants.append(pc.run(c, x[2, blk]))
+    assert np.all(outs[0] == 0.0)
+    assert np.abs(outs[1] - wants[0]).max() < THR * 2
+    hub.detach(b)
+    assert hub.attached == 2
+
+
+def test_pool_reset_stream_matches_a_fresh_instance(tmp_path):
+    m, spec = _model(tmp_path, kind="gru", hidden=16, input_size=1, seed=9)
+    pool = ax.Pool(3, 128)
+    pool.set_model(m)
+    x = modelgen.signal(3, 384, seed=34)
+    pool.process(np.ascontiguousarray(x[:, :128]))
+    pool.reset_stream(1)
+    pool.activate(1)
+    got = pool.process(np.ascontiguousarray(x[:, 128:256]))
+    fresh = _oracle_instance(spec).run(O.default_controls(), x[1, 128:256])
+    assert np.abs(got[1] - fresh).max() < THR * 2
+    cont = O.OraclePlugin(); cont.set_model(O.OracleModel(spec))
+    c = O.default_controls()
+    cont.run(c, x[0, :128])
+    assert np.abs(got[0] - cont.run(c, x[0, 128:256])).max() < THR * 2      # neighbours are untouched

@@ -171,7 +171,6 @@ __global__ __launch_bounds__(kConvmThreads) void k_conv_mfma(LaunchArgs a, ConvD
             f32x4 acc[kConvmTiles];
 #pragma unroll
             for (int j = 0; j < kConvmTiles; ++j) acc[j] = f32x4{bias, bias, bias, bias};
-#pragma unroll 2
             for (int kk = 0; kk < L.k_steps; ++kk) {
                 const float2 rec = *reinterpret_cast<const float2*>(wst + 2 * (kk * kWave + lane));
                 const float b = rec.x;

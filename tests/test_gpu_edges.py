@@ -148,3 +148,43 @@ def test_device_entry_point_in_place_on_caller_stream(tmp_path):
         pool.process_device(d.data_ptr(), d.data_ptr(), 256, s.cuda_stream)
     s.synchronize()
     assert np.array_equal(d.cpu().numpy(), want)
+
+
+def test_extreme_levels_denormal_silence_and_full_scale(tmp_path):
+    """Signal levels the synthetic bench never visits: fp32-denormal input (the chain without a model must
+    stay bit-exact: fp32 denormals are honoured on the device like on the reference's CPU), a second of digital
+    silence after a loud passage (states decay, nothing drifts), and a full-scale square wave through the NN."""
+    import importlib
+    ax = importlib.import_module("aidadsp-lv2_amd")
+    from oracle import oracle as O
+    from tests import modelgen
+    n, block = 4096, 256
+    rs = np.random.RandomState(5)
+    tiny = (rs.uniform(-1, 1, n) * 1e-39).astype(np.float32)
+    assert np.any((np.abs(tiny) > 0) & (np.abs(tiny) < 1.1754944e-38))
+    loud_then_silent = np.concatenate([modelgen.signal(1, n // 2, seed=1)[0] * 1.9, np.zeros(n // 2, np.float32)])
+    square = np.where((np.arange(n) // 37) % 2 == 0, 1.0, -1.0).astype(np.float32)
+    x = np.stack([tiny, loud_then_silent, square])
+    # (1) chain only
+    pool = ax.Pool(3, block)
+    pool.set_loading(False)
+    cg = ax.default_controls(bass_boost_db=6.0, treble_boost_db=-4.0, pregain_db=12.0, master_db=-15.0)
+    co = O.default_controls(bass_boost_db=6.0, treble_boost_db=-4.0, pregain_db=12.0, master_db=-15.0)
+    pool.set_controls(cg)
+    got = np.concatenate([pool.process(np.ascontiguousarray(x[:, b:b + block])) for b in range(0, n, block)], axis=1)
+    for s in range(3):
+        p = O.OraclePlugin()
+        p.set_loading(False)
+        want = np.concatenate([p.run(co, x[s, b:b + block]) for b in range(0, n, block)])
+        assert np.array_equal(got[s], want), s
+    # (2) through an LSTM-32 and a GRU-16
+    for kind, hidden in (("lstm", 32), ("gru", 16)):
+        j = modelgen.make_model(kind, hidden, 1, seed=77)
+        path = modelgen.write_model(j, str(tmp_path / f"{kind}.json"))
+        spec = O.parse_model(j)
+        pool = ax.Pool(3, block)
+        pool.set_model(ax.Model(path))
+        got = np.concatenate([pool.process(np.ascontiguousarray(x[:, b:b + block])) for b in range(0, n, block)], axis=1)
+        want = O.run_streams(spec, O.default_controls(), x, block)
+        assert np.isfinite(got).all()
+        assert np.abs(got - want).max() < 1.0e-5, (kind, np.abs(got - want).max())

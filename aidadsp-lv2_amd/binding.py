@@ -107,6 +107,8 @@ def lib() -> C.CDLL:
     L.aidax_hub_detach.argtypes = [vp, i32]
     L.aidax_hub_set_controls.argtypes = [vp, i32, C.POINTER(Controls)]
     L.aidax_hub_run.argtypes = [vp, i32, _fp, _fp, u32]
+    L.aidax_hub_set_loading.argtypes = [vp, i32, C.c_int]
+    L.aidax_hub_activate.argtypes = [vp, i32]
     L.aidax_hub_latency_frames.argtypes = [vp]
     L.aidax_hub_latency_frames.restype = u32
     L.aidax_hub_attached.argtypes = [vp]

@@ -189,6 +189,22 @@ AIDAX_API int aidax_hub_set_controls(aidax_hub* h, int32_t slot, const aidax_con
     return push_controls(*h, static_cast<uint32_t>(slot), h->forced_off[slot] != 0);
 }
 
+AIDAX_API int aidax_hub_set_loading(aidax_hub* h, int32_t slot, int loading)
+{
+    if (!h) return fail(AIDAX_ERR_ARG, "null hub");
+    std::lock_guard<std::mutex> g(h->mu);
+    if (slot < 0 || static_cast<uint32_t>(slot) >= h->cap || !h->attached[slot]) return fail(AIDAX_ERR_ARG, "slot not attached");
+    return aidax_pool_set_loading(h->pool, slot, loading);
+}
+
+AIDAX_API int aidax_hub_activate(aidax_hub* h, int32_t slot)
+{
+    if (!h) return fail(AIDAX_ERR_ARG, "null hub");
+    std::lock_guard<std::mutex> g(h->mu);
+    if (slot < 0 || static_cast<uint32_t>(slot) >= h->cap || !h->attached[slot]) return fail(AIDAX_ERR_ARG, "slot not attached");
+    return aidax_pool_activate(h->pool, slot);
+}
+
 AIDAX_API int aidax_hub_run(aidax_hub* h, int32_t slot, const float* in, float* out, uint32_t n_frames)
 {
     if (!h) return fail(AIDAX_ERR_ARG, "null hub");

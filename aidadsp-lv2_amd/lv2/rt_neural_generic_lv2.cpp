@@ -19,6 +19,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <string>
 
 #include "../../include/aidax.h"
 #include "lv2_min.h"
@@ -65,8 +68,15 @@ struct Plugin {
     double samplerate = 48000.0;
     bool loading = true;
     int last_input_size = 0;
-    aidax_pool* pool = nullptr;
+    aidax_pool* pool = nullptr;      // this instance's own one-stream pool (default mode)
     aidax_model* model = nullptr;
+    // hub mode (AIDAX_HUB=<instances per model>): instances that play the same model file share one pool
+    // pass per audio period through aidax_hub, at one period of latency
+    int hub_capacity = 0;
+    int device = 0;
+    aidax_hub* hub = nullptr;
+    int32_t slot = -1;
+    std::string hub_key;
 
     aidax_controls last_controls{};
     bool have_last_controls = false;
@@ -77,6 +87,52 @@ struct Plugin {
     uint32_t notify_capacity = 0;
     bool notify_open = false;
 };
+
+// ---- hub registry: one hub per model file, shared by the instances of this process
+struct HubRef { aidax_hub* hub; int refs; };
+std::mutex g_hub_mu;
+std::map<std::string, HubRef> g_hubs;
+
+void hub_leave(Plugin* self)
+{
+    if (!self->hub) return;
+    std::lock_guard<std::mutex> g(g_hub_mu);
+    aidax_hub_detach(self->hub, self->slot);
+    auto it = g_hubs.find(self->hub_key);
+    if (it != g_hubs.end() && --it->second.refs == 0) {
+        aidax_hub_destroy(it->second.hub);
+        g_hubs.erase(it);
+    }
+    self->hub = nullptr;
+    self->slot = -1;
+}
+
+// attach to the hub of `model`'s file, creating it (weights upload + warm-up) for the first instance
+bool hub_join(Plugin* self, const aidax_model* model)
+{
+    const std::string key = aidax_model_path(model);
+    std::lock_guard<std::mutex> g(g_hub_mu);
+    auto it = g_hubs.find(key);
+    if (it == g_hubs.end()) {
+        aidax_hub* hub = nullptr;
+        const char* fr = std::getenv("AIDAX_HUB_FRAMES");
+        const uint32_t max_frames = fr ? static_cast<uint32_t>(std::atoi(fr)) : 2048u;
+        if (aidax_hub_create(static_cast<uint32_t>(self->hub_capacity), max_frames, self->samplerate, self->device, &hub) != AIDAX_OK)
+            return false;
+        if (aidax_hub_set_model(hub, model, AIDAX_START_WARMUP) != AIDAX_OK) { aidax_hub_destroy(hub); return false; }
+        it = g_hubs.emplace(key, HubRef{ hub, 0 }).first;
+    }
+    int32_t slot = -1;
+    if (aidax_hub_attach(it->second.hub, &slot) != AIDAX_OK) {
+        if (it->second.refs == 0) { aidax_hub_destroy(it->second.hub); g_hubs.erase(it); }
+        return false;
+    }
+    ++it->second.refs;
+    self->hub = it->second.hub;
+    self->slot = slot;
+    self->hub_key = key;
+    return true;
+}
 
 void plog(Plugin* self, LV2_URID type, const char* fmt, ...)
 {
@@ -184,10 +240,18 @@ LV2_Handle instantiate(const LV2_Descriptor*, double samplerate, const char*, co
 
     const char* dev = std::getenv("AIDAX_DEVICE");
     const int device = dev ? std::atoi(dev) : 0;
-    if (aidax_pool_create(1, 8192, samplerate, device, &self->pool) != AIDAX_OK) {
+    const char* hub = std::getenv("AIDAX_HUB");
+    self->hub_capacity = hub ? std::atoi(hub) : 0;
+    self->device = device;
+    // default mode: the instance's own one-stream pool; hub mode: the same call only proves there is a device
+    if (aidax_pool_create(1, self->hub_capacity > 1 ? 4 : 8192, samplerate, device, &self->pool) != AIDAX_OK) {
         std::fprintf(stderr, "Error! %s\n", aidax_last_error());
         delete self;
         return nullptr;
+    }
+    if (self->hub_capacity > 1) {
+        aidax_pool_destroy(self->pool);
+        self->pool = nullptr;
     }
     self->last_input_size = 0;
     self->loading = true;            // until the host's default-state restore has loaded a model (:318-321)
@@ -213,7 +277,8 @@ void connect_port(LV2_Handle instance, uint32_t port, void* data)
 void activate(LV2_Handle instance)
 {
     Plugin* self = static_cast<Plugin*>(instance);
-    aidax_pool_activate(self->pool, AIDAX_ALL_STREAMS);     // :341-351
+    if (self->pool) aidax_pool_activate(self->pool, AIDAX_ALL_STREAMS);     // :341-351
+    else if (self->hub) aidax_hub_activate(self->hub, self->slot);
 }
 
 void deactivate(LV2_Handle) {}
@@ -234,6 +299,17 @@ void latch_controls(Plugin* self)
     c.presence_boost_db = v(PRESENCE, c.presence_boost_db);
     c.dc_blocker = v(DCBLOCKER, c.dc_blocker);      c.master_db = v(MASTER, c.master_db);
     c.enabled = v(PLUGIN_ENABLED, c.enabled);
+    if (!self->pool) {                                       // hub mode
+        self->last_controls = c;
+        if (self->hub) {
+            aidax_hub_set_controls(self->hub, self->slot, &c);
+            if (self->loading != self->last_loading) {
+                aidax_hub_set_loading(self->hub, self->slot, self->loading ? 1 : 0);
+                self->last_loading = self->loading;
+            }
+        }
+        return;
+    }
     if (!self->have_last_controls || std::memcmp(&c, &self->last_controls, sizeof(c)) != 0) {
         aidax_pool_set_controls(self->pool, 0, &c);
         self->last_controls = c;
@@ -302,13 +378,23 @@ void run(LV2_Handle instance, uint32_t n_samples)
     // ---- DSP: control latch, then the whole run() audio section on the GPU (:489-518, :607-659).
     // n_samples == 0 (pre-run) and !enabled (raw copy) are handled inside the pass.
     latch_controls(self);
-    if (aidax_pool_process(self->pool, self->in, self->out_1, n_samples) != AIDAX_OK)
-        plog(self, uris->log_Error, "aidax: %s\n", aidax_last_error());
+    if (self->pool) {
+        if (aidax_pool_process(self->pool, self->in, self->out_1, n_samples) != AIDAX_OK)
+            plog(self, uris->log_Error, "aidax: %s\n", aidax_last_error());
+    } else if (self->hub) {
+        if (aidax_hub_run(self->hub, self->slot, self->in, self->out_1, n_samples) != AIDAX_OK)
+            plog(self, uris->log_Error, "aidax: %s\n", aidax_last_error());
+    } else if (n_samples != 0) {
+        // hub mode before the first model: the master gain rests at 0 (:306-310), a disabled plugin copies (:612-619)
+        if (self->last_controls.enabled > 0.5f) std::memset(self->out_1, 0, sizeof(float) * n_samples);
+        else if (self->out_1 != self->in) std::memcpy(self->out_1, self->in, sizeof(float) * n_samples);
+    }
 }
 
 void cleanup(LV2_Handle instance)
 {
     Plugin* self = static_cast<Plugin*>(instance);
+    hub_leave(self);
     aidax_pool_destroy(self->pool);
     aidax_model_free(self->model);
     delete self;
@@ -401,8 +487,14 @@ LV2_Worker_Status work_response(LV2_Handle instance, uint32_t, const void* data)
     WorkerApplyMessage reply = { kWorkerFree, self->model };  // old model goes back to the worker for deletion
     self->model = static_cast<const WorkerApplyMessage*>(data)->model;
     // swap: weights to the GPU, reset(), inherited PARAM targets, 2048-zero warm-up (:1046-1079)
-    if (aidax_pool_set_model(self->pool, self->model, AIDAX_START_WARMUP) != AIDAX_OK)
-        plog(self, self->uris.log_Error, "aidax: %s\n", aidax_last_error());
+    if (self->pool) {
+        if (aidax_pool_set_model(self->pool, self->model, AIDAX_START_WARMUP) != AIDAX_OK)
+            plog(self, self->uris.log_Error, "aidax: %s\n", aidax_last_error());
+    } else {                                                  // hub mode: move to the hub that plays this file
+        hub_leave(self);
+        if (!hub_join(self, self->model)) plog(self, self->uris.log_Error, "aidax: %s\n", aidax_last_error());
+        self->last_loading = false;                           // a freshly attached stream is not loading
+    }
     self->schedule->schedule_work(self->schedule->handle, sizeof(reply), &reply);
     plog(self, self->uris.log_Trace, "New model in use\n");
     notify_set_file(self, aidax_model_path(self->model));    // report change to host/ui (:880-887)

@@ -214,6 +214,9 @@ AIDAX_API int  aidax_hub_set_model(aidax_hub* h, const aidax_model* m, int start
 AIDAX_API int  aidax_hub_attach(aidax_hub* h, int32_t* slot);
 AIDAX_API int  aidax_hub_detach(aidax_hub* h, int32_t slot);
 AIDAX_API int  aidax_hub_set_controls(aidax_hub* h, int32_t slot, const aidax_controls* c);
+/* the instance's `loading` flag and activate(), as aidax_pool_set_loading / aidax_pool_activate for its stream */
+AIDAX_API int  aidax_hub_set_loading(aidax_hub* h, int32_t slot, int loading);
+AIDAX_API int  aidax_hub_activate(aidax_hub* h, int32_t slot);
 /* the instance's run(): in/out are its n_frames-long port buffers (may alias) */
 AIDAX_API int  aidax_hub_run(aidax_hub* h, int32_t slot, const float* in, float* out, uint32_t n_frames);
 AIDAX_API uint32_t aidax_hub_latency_frames(const aidax_hub* h);

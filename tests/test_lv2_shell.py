@@ -176,3 +176,51 @@ def test_disabled_port_is_a_raw_copy(bundle):
     h.controls(enabled=0.0)
     assert np.array_equal(h.run(x), x)
     h.close()
+
+
+@pytest.mark.gpu
+def test_hub_mode_three_instances_share_launches(bundle, monkeypatch):
+    """AIDAX_HUB=4: instances that load the same model file share one pool pass per period (one period of
+    latency); an instance with another file gets its own hub. Each instance against its own oracle mirror."""
+    monkeypatch.setenv("AIDAX_HUB", "4")
+    clean = os.path.join(bundle, "models/deer ink studios/tw40_california_clean_deerinkstudios.json")
+    gru = os.path.join(bundle, "models", "gru16.json")
+    files = [clean, clean, gru]
+    hosts = [lv2host.Host(bundle_dir=bundle) for _ in files]
+    assert all(h.handle for h in hosts)
+    n, periods = 256, 8
+    x = modelgen.signal(3, n * (periods + 2), seed=41)
+    hosts[1].controls(BASS=4.0, PREGAIN=3.0)
+    hosts[2].controls(PARAM1=0.6, PARAM2=0.2)
+    # before any model: exact silence, like the one-stream mode
+    for i, h in enumerate(hosts):
+        assert np.all(h.run(x[i, :n]) == 0)
+    # every instance loads its file through the worker
+    for h, f in zip(hosts, files):
+        h.send_patch_set(f)
+        h.run(np.zeros(0, np.float32))
+        h.clear_control()
+        assert h.pump_worker() == 1
+        assert h.deliver_responses() == 1
+        h.pump_worker()
+        h.run(np.zeros(0, np.float32))      # the port is written at the top of run() (:518)
+        assert h.ctl["ModelInSize"].value == (3 if f == gru else 1)
+    plugs = []
+    for h, f in zip(hosts, files):
+        p = O.OraclePlugin()
+        p.set_model(O.OracleModel(O.load_model(f), 0.0, 0.0))
+        p.activate()                        # a freshly attached stream starts like instantiate() + activate()
+        p.set_loading(False)
+        plugs.append(p)
+    prev = [None] * 3
+    for k in range(periods):
+        blk = slice((k + 1) * n, (k + 2) * n)
+        for i, h in enumerate(hosts):       # the host runs its instances one after another
+            got = h.run(x[i, blk])
+            if prev[i] is None:
+                assert np.all(got == 0)     # first period: nothing computed yet
+            else:
+                assert np.abs(got - prev[i]).max() < THR * 2, (k, i, np.abs(got - prev[i]).max())
+            prev[i] = plugs[i].run(_oracle_controls(h), x[i, blk])
+    for h in hosts:
+        h.close()

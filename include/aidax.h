@@ -128,7 +128,9 @@ enum {
 /* instantiate(), DSP half (rt-neural-generic.cpp:283-321) for n_streams
  * instances on GPU `device_id`: gain smoothers (T60 0.1 s at host rate, pre
  * target 1, master target 0), the seven biquads, loading = true, no model.
- * max_frames bounds n_frames of every later process call. */
+ * max_frames bounds n_frames of every later process call (<= 8192 for the reference's model table; the
+ * extension architectures stage whole blocks in LDS and take max_frames <= 2048 (stacked / wide
+ * recurrent) resp. <= ~1000 (conv stacks): aidax_pool_set_model reports AIDAX_ERR_ARG beyond that). */
 AIDAX_API int  aidax_pool_create(uint32_t n_streams, uint32_t max_frames, double host_samplerate,
                                  int device_id, aidax_pool** out);
 AIDAX_API void aidax_pool_destroy(aidax_pool* p);                         /* cleanup() :664-677 */

@@ -188,3 +188,37 @@ def test_extreme_levels_denormal_silence_and_full_scale(tmp_path):
         want = O.run_streams(spec, O.default_controls(), x, block)
         assert np.isfinite(got).all()
         assert np.abs(got - want).max() < 1.0e-5, (kind, np.abs(got - want).max())
+
+
+@pytest.mark.parametrize("kw,max_frames,kernel", [
+    (dict(kind="conv", hidden=16, input_size=1, seed=3, conv_layers=5), 512, "k_conv"),              # blocks > 256: VALU conv
+    (dict(kind="lstm", hidden=48, input_size=2, seed=4, n_rnn=2), 2048, "k_chain+k_mfma"),             # longest block of the packed chains
+    (dict(kind="lstm", hidden=20, input_size=1, seed=5, n_rnn=2), 256, "k_chain+k_mfma"),              # 20 units run zero-padded to 32
+])
+def test_extension_fallback_kernels_for_long_blocks(kw, max_frames, kernel, tmp_path):
+    """Conv pools with blocks above 256 frames fall back to the VALU kernel; stacked models take blocks up to
+    2048 frames on k_mfma (eight staging chunks per launch) and run zero-padded when their width is not a
+    multiple of 16."""
+    import importlib
+    ax = importlib.import_module("aidadsp-lv2_amd")
+    j = modelgen.make_model(**kw)
+    path = modelgen.write_model(j, str(tmp_path / "m.json"))
+    spec = O.parse_model(j)
+    S = 5
+    pool = ax.Pool(S, max_frames)
+    pool.set_model(ax.Model(path))
+    assert pool.kernel_name == kernel
+    sizes = [max_frames, 100, max_frames - 1] if max_frames <= 512 else [700, 2048, 33]
+    x = modelgen.signal(S, sum(sizes), seed=12)
+    got = np.empty_like(x)
+    want = np.empty_like(x)
+    plugs = []
+    for s in range(S):
+        p = O.OraclePlugin(); p.set_model(O.OracleModel(spec)); plugs.append(p)
+    pos = 0
+    for n in sizes:
+        got[:, pos:pos + n] = pool.process(np.ascontiguousarray(x[:, pos:pos + n]))
+        for s in range(S):
+            want[s, pos:pos + n] = plugs[s].run(O.default_controls(), x[s, pos:pos + n])
+        pos += n
+    assert np.abs(got - want).max() < 2.0e-5, np.abs(got - want).max()

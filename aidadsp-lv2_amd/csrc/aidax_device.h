@@ -178,6 +178,51 @@ __device__ __forceinline__ void chain_sweep(ChainPass& c, int stage, bool run, i
     if (!run || !c.active) { c.z1 = z1o; c.z2 = z2o; }     // a bypassed biquad keeps its state (:622, :646)
 }
 
+// The same pass over a whole block, BLOCKED in time: a stage takes kChainBlock frames per hand-over
+// instead of one, so the per-step overhead of the systolic form (lane shift, selects, range logic, loop)
+// is paid once per eight samples and the eight biquad evaluations of a lane run back to back. Stage k works
+// on frame block m-k at macro-step m; blocks travel to the next lane through a double-buffered LDS slot
+// (`hand`: [2][64 lanes][kChainBlock] floats). Same operations in the same order per sample and per stage as
+// chain_step, so the results are bit-identical. `row` is processed in place; n_full is a multiple of
+// kChainBlock (the caller finishes a ragged tail with chain_sweep).
+constexpr int kChainBlock = 8;
+
+__device__ __forceinline__ void chain_sweep_blocked(ChainPass& c, int stage, bool run, int depth, float* row, float* hand,
+                                                    int n_full, int lane)
+{
+    const double z1o = c.z1, z2o = c.z2;
+    const int M = n_full / kChainBlock;
+    ExpRamp g = c.g;
+    const bool is_gain = stage == c.gain_lane;
+    if (!is_gain) { g.mem = 1.f; g.coef = 1.f; g.tc = 0.f; }     // y * 1.0f is exact: no select per sample
+    const bool last = stage == c.K - 1;
+    for (int m = 0; m < M + depth - 1; ++m) {
+        const int j = m - stage;
+        if (run && j >= 0 && j < M) {
+            const float* src = stage == 0 ? row + kChainBlock * j : hand + (((m - 1) & 1) * kWave + lane - 1) * kChainBlock;
+            float* dst = last ? row + kChainBlock * j : hand + ((m & 1) * kWave + lane) * kChainBlock;
+            float v[kChainBlock];
+            const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+#pragma unroll
+            for (int i = 0; i < kChainBlock; ++i) {
+                const float x = v[i];
+                const double xd = x;                            // Biquad::process, Biquad.h:53-58
+                const double yd = xd * c.a0 + c.z1;
+                c.z1 = xd * c.a1 + c.z2 - c.b1 * yd;
+                c.z2 = xd * c.a2 - c.b2 * yd;
+                const float y = c.active ? (float)yd : x;
+                v[i] = y * g.next();
+            }
+            *reinterpret_cast<float4*>(dst) = float4{ v[0], v[1], v[2], v[3] };
+            *reinterpret_cast<float4*>(dst + 4) = float4{ v[4], v[5], v[6], v[7] };
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (is_gain) c.g = g;
+    if (!run || !c.active) { c.z1 = z1o; c.z2 = z2o; }
+}
+
 template <int DST_STRIDE = 1>
 __device__ __forceinline__ void chain_run(ChainPass& c, const float* src, float* dst, int n, int lane)
 {

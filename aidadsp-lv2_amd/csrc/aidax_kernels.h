@@ -29,6 +29,7 @@ size_t stack_lds_bytes(const StackDesc& d, uint32_t n_frames);
 size_t conv_lds_bytes(const ConvDesc& d, uint32_t n_frames);
 size_t mfma_lds_bytes(const MfmaDesc& d, uint32_t n_frames);
 size_t chain_lds_bytes(uint32_t n_frames);
+constexpr size_t kChainLdsLimit = 72 * 1024;     // packed chains: eight rows of <= 2048 frames + hand-over slots
 // one packed chain launch (8 streams per wave): pre = LPF/pre-gain/EQ(pre) in -> out, else DC/EQ(post)/master in place
 hipError_t launch_chain_pass(bool pre, const LaunchArgs& a, hipStream_t stream);
 hipError_t launch_mfma_kernel(const LaunchArgs& a, const MfmaDesc& d, hipStream_t stream);

@@ -793,7 +793,13 @@ __global__ __launch_bounds__(kWave) void k_chain(LaunchArgs a)
     c.g.arm(mem, tgt, PRE ? ctl.pre_coef : ctl.master_coef);
 
     if (n != 0) {
-        chain_sweep<1>(c, stage, live && stage < c.K, 6, smem + grp * nP, smem + grp * nP, n);
+        // whole blocks of eight frames in the blocked form, a ragged tail sample by sample
+        float* row = smem + grp * nP;
+        float* hand = smem + kChainStreams * nP;
+        const bool run = live && stage < c.K;
+        const int n_full = n & ~(kChainBlock - 1);
+        if (n_full != 0) chain_sweep_blocked(c, stage, run, 6, row, hand, n_full, lane);
+        if (n_full != n) chain_sweep<1>(c, stage, run, 6, row + n_full, row + n_full, n - n_full);
         // PRE: every valid row goes to out (a disabled stream's row is still the raw input: the hard
         // bypass copy of :612-619); POST: only rows that were processed
         for (int g = 0; g < kChainStreams; ++g) {
@@ -1000,13 +1006,21 @@ hipError_t launch_stream_kernel(const KernelEntry* e, const LaunchArgs& a, size_
     return hipGetLastError();
 }
 
-size_t chain_lds_bytes(uint32_t n_frames) { return (size_t)kChainStreams * ((n_frames + 3) & ~3u) * sizeof(float); }
+size_t chain_lds_bytes(uint32_t n_frames)
+{
+    return ((size_t)kChainStreams * ((n_frames + 3) & ~3u) + 2 * kWave * kChainBlock) * sizeof(float);   // rows + hand-over slots
+}
 
 hipError_t launch_chain_pass(bool pre, const LaunchArgs& a, hipStream_t stream)
 {
     const uint32_t groups = (a.n_streams + kChainStreams - 1) / kChainStreams;
     const size_t lds = chain_lds_bytes(a.n_frames);
-    if (lds > 64 * 1024) return hipErrorInvalidValue;          // callers pick another form for such blocks
+    if (lds > kChainLdsLimit) return hipErrorInvalidValue;     // callers pick another form for such blocks
+    if (lds > 64 * 1024) {
+        const void* fn = pre ? reinterpret_cast<const void*>(k_chain<true>) : reinterpret_cast<const void*>(k_chain<false>);
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     if (pre) hipLaunchKernelGGL(k_chain<true>, dim3(groups), dim3(kWave), lds, stream, a);
     else hipLaunchKernelGGL(k_chain<false>, dim3(groups), dim3(kWave), lds, stream, a);
     return hipGetLastError();

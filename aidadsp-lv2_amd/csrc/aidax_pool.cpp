@@ -125,7 +125,7 @@ struct aidax_pool {
     int chain_form() const
     {
         if (kind != TABLE && has_model) return 0;
-        if (chain_lds_bytes(max_frames) > 64 * 1024) return 0;      // packed chains keep 8 blocks in LDS
+        if (chain_lds_bytes(max_frames) > kChainLdsLimit) return 0;      // packed chains keep 8 blocks in LDS
         if (force_form == 1) return 0;
         if (force_form == 2) return (has_model && kernel) ? 1 : 0;
         if (force_form == 3) return 2;
@@ -282,11 +282,11 @@ int set_model_impl(aidax_pool& p, const aidax_model* m, int start_mode)
         if (!conv_mfma && conv_lds_bytes(cd, p.max_frames) > 160 * 1024)
             return fail(AIDAX_ERR_ARG, "conv model: pool max_frames too large for the LDS activation planes");
     } else if (m->n_rnn == 1 && find_kernel(m->cell, m->hidden) && p.quad_for_table_model(m->cell, m->hidden) &&
-               chain_lds_bytes(p.max_frames) <= 64 * 1024 && quad_lds_bytes(m->hidden, p.max_frames) <= 160 * 1024) {
+               chain_lds_bytes(p.max_frames) <= kChainLdsLimit && quad_lds_bytes(m->hidden, p.max_frames) <= 160 * 1024) {
         kind = aidax_pool::QUAD;
         wp = pack_quad(*m, &qd.bias_off, &qd.dense_off);
         state_floats = static_cast<uint32_t>(m->cell == AIDAX_CELL_LSTM ? 2 * m->hidden : m->hidden);
-    } else if (mfma_form_fits(*m) && chain_lds_bytes(p.max_frames) <= 64 * 1024 &&
+    } else if (mfma_form_fits(*m) && chain_lds_bytes(p.max_frames) <= kChainLdsLimit &&
                (is_stack_model(*m) ? p.force_form != 4 : p.mfma_for_table_model(m->cell, m->hidden))) {
         kind = aidax_pool::MFMA;
         wp = pack_mfma(*m, &md, &state_floats);

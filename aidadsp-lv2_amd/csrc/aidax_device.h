@@ -185,7 +185,10 @@ __device__ __forceinline__ void chain_sweep(ChainPass& c, int stage, bool run, i
 // (`hand`: [2][64 lanes][kChainBlock] floats). Same operations in the same order per sample and per stage as
 // chain_step, so the results are bit-identical. `row` is processed in place; n_full is a multiple of
 // kChainBlock (the caller finishes a ragged tail with chain_sweep).
-constexpr int kChainBlock = 8;
+#ifndef AIDAX_CHAIN_BLOCK
+#define AIDAX_CHAIN_BLOCK 8
+#endif
+constexpr int kChainBlock = AIDAX_CHAIN_BLOCK;
 
 __device__ __forceinline__ void chain_sweep_blocked(ChainPass& c, int stage, bool run, int depth, float* row, float* hand,
                                                     int n_full, int lane)
@@ -202,8 +205,11 @@ __device__ __forceinline__ void chain_sweep_blocked(ChainPass& c, int stage, boo
             const float* src = stage == 0 ? row + kChainBlock * j : hand + (((m - 1) & 1) * kWave + lane - 1) * kChainBlock;
             float* dst = last ? row + kChainBlock * j : hand + ((m & 1) * kWave + lane) * kChainBlock;
             float v[kChainBlock];
-            const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
-            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+#pragma unroll
+            for (int q = 0; q < kChainBlock / 4; ++q) {
+                const float4 t = *reinterpret_cast<const float4*>(src + 4 * q);
+                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+            }
 #pragma unroll
             for (int i = 0; i < kChainBlock; ++i) {
                 const float x = v[i];
@@ -214,8 +220,9 @@ __device__ __forceinline__ void chain_sweep_blocked(ChainPass& c, int stage, boo
                 const float y = c.active ? (float)yd : x;
                 v[i] = y * g.next();
             }
-            *reinterpret_cast<float4*>(dst) = float4{ v[0], v[1], v[2], v[3] };
-            *reinterpret_cast<float4*>(dst + 4) = float4{ v[4], v[5], v[6], v[7] };
+#pragma unroll
+            for (int q = 0; q < kChainBlock / 4; ++q)
+                *reinterpret_cast<float4*>(dst + 4 * q) = float4{ v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3] };
         }
         __builtin_amdgcn_wave_barrier();
     }

@@ -269,11 +269,20 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(j, args.workload)
-        print(json.dumps(out), flush=True)
 
     pool.close()
     if world > 1:
-        dist.destroy_process_group()
+        dist.destroy_process_group()       # RCCL prints its banner on teardown: keep the JSON line last
+    if rank == 0:
+        # RCCL writes its version banner to stdout through C stdio (it would otherwise surface at exit, after
+        # our line): drain both buffers first so that the JSON line is the last thing on stdout
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -147,3 +147,26 @@ def test_device_calls_fail_loudly_without_a_gpu():
     with pytest.raises(ax.AidaxError) as e:
         ax.Pool(4, 256)
     assert e.value.code == -5 and "no CPU fallback" in str(e.value)
+
+
+def test_header_is_plain_c_and_a_c_program_links(tmp_path, bundled_models):
+    """include/aidax.h compiles as C99 with -pedantic; a C program loads a model, and without a GPU
+    aidax_pool_create reports AIDAX_ERR_DEVICE (-5) instead of falling back to anything."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    libdir = os.path.dirname(ax.lib_path())
+    exe = str(tmp_path / "c_abi_smoke")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "c_abi_smoke.c")
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    cc = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc, src, "-o", exe,
+                         "-L", libdir, "-laidax_hip", f"-Wl,-rpath,{libdir}"], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    model = [m for m in bundled_models if "california_clean" in m][0]
+    run = subprocess.run([exe, model], capture_output=True, text=True)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "cell=0 hidden=12 inputs=1 layers=1" in run.stdout
+    import torch
+    if not torch.cuda.is_available():
+        assert "pool_create rc=-5 pool=null" in run.stdout

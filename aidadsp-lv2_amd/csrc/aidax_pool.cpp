@@ -39,7 +39,7 @@ constexpr uint32_t kMaxFrames = 8192;           // LDS block buffer bound (32 Ki
 // Which many-streams form serves a model of the reference's table best at a given stream count. Measured
 // (scratch/perf_table_mfma.py, 256-frame blocks, MI355X): k_quad (4 streams per workgroup on
 // mfma_4x4x1, weights in registers) wins for <= 32 units from 4096 streams (1.15-1.5x over the split form) and
-// for the wide cells already at 1024-2048 streams (LSTM-64 1.3-1.6x, LSTM-80 1.3-1.7x, GRU-80 1.2-1.4x);
+// for the wide cells at every stream count below that (LSTM-64 1.3-1.6x, LSTM-80 1.3-1.75x, GRU-80 1.2-1.4x);
 // k_mfma (16 streams per workgroup on mfma_16x16x4) takes over for the wide cells from 4096-8192 streams
 // (LSTM-80 @ 16384: 2.3 ms against 4.3 ms for k_quad and 8.4 ms for the one-wave kernel). GRU-64 ties with
 // its register kernel up to 8192 streams and stays there.
@@ -48,12 +48,11 @@ ManyForm many_streams_form(int cell, int hidden, uint32_t n)
 {
     const bool lstm = cell == AIDAX_CELL_LSTM;
     if (hidden <= 32) return n >= 4096 ? MANY_QUAD : MANY_NONE;
-    if (hidden == 40) return n >= 8192 ? MANY_MFMA : n >= (lstm ? 1024u : 4096u) ? MANY_QUAD : MANY_NONE;
-    if (hidden == 64) {
-        if (lstm) return n >= 4096 ? MANY_MFMA : n >= 1024 ? MANY_QUAD : MANY_NONE;
-        return n >= 16384 ? MANY_MFMA : MANY_NONE;
-    }
-    return n >= 4096 ? MANY_MFMA : n >= 1024 ? MANY_QUAD : MANY_NONE;      // 80 units
+    if (hidden == 40) return n >= 8192 ? MANY_MFMA : n >= (lstm ? 512u : 4096u) ? MANY_QUAD : MANY_NONE;
+    if (hidden == 64 && !lstm) return n >= 16384 ? MANY_MFMA : n <= 1024 ? MANY_QUAD : MANY_NONE;
+    // LSTM-64, LSTM-80, GRU-80: their one-wave kernels hold 250-500 weight registers; k_quad is 1.35-1.75x
+    // faster already at 64 streams, k_mfma takes over from 4096
+    return n >= 4096 ? MANY_MFMA : MANY_QUAD;
 }
 
 struct HipFail : std::runtime_error { using std::runtime_error::runtime_error; };

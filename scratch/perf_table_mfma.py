@@ -25,6 +25,7 @@ def run(label, mkw, S, ctl_kw={}, n=256, steps=20):
     print(f"{label:16s} S={S:6d}: {res[0][0]:22s} {res[0][1]:8.1f} us | {res[1][0]:16s} {res[1][1]:8.1f} us   ratio {res[0][1]/res[1][1]:.2f}", flush=True)
 import itertools
 sizes = [int(a) for a in sys.argv[1].split(",")] if len(sys.argv) > 1 else [2048, 4096, 8192, 16384]
-for kind, H in itertools.product(("lstm", "gru"), (8, 16, 32, 64, 80)):
+hs = [int(a) for a in os.environ.get("HS", "8,16,32,64,80").split(",")]
+for kind, H in itertools.product(("lstm", "gru"), hs):
     for S in sizes:
         run(f"{kind}{H}", dict(kind=kind, hidden=H, input_size=1, seed=H), S, steps=10)

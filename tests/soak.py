@@ -1,0 +1,61 @@
+# Soak: random block sizes, control flips, activates and model swaps for many blocks; three streams against the
+# oracle's plugin mirror. usage: AIDAX_KERNEL=<form> python tests/soak.py [blocks]
+import importlib, os, sys, tempfile
+sys.path.insert(0, os.getcwd())
+import numpy as np
+from oracle import oracle as O
+from tests import modelgen
+ax = importlib.import_module("aidadsp-lv2_amd")
+blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+rs = np.random.RandomState(2026)
+d = tempfile.mkdtemp()
+models = []
+for kind, H, I in (("lstm", 32, 1), ("gru", 16, 3), ("lstm", 12, 2), ("gru", 64, 1)):
+    j = modelgen.make_model(kind, H, I, seed=H + I)
+    models.append((ax.Model(modelgen.write_model(j, os.path.join(d, f"{kind}{H}.json"))), O.parse_model(j)))
+S, MAXF = 70, 256
+pool = ax.Pool(S, MAXF)
+watch = [0, 33, 69]
+plugs = {s: O.OraclePlugin() for s in watch}
+cur = 0
+pool.set_model(models[cur][0])
+for s in watch: plugs[s].set_model(O.OracleModel(models[cur][1]))
+kw = {s: {} for s in range(S)}
+worst = 0.0
+names = set()
+for b in range(blocks):
+    r = rs.rand()
+    if r < 0.03:
+        cur = rs.randint(len(models))
+        pool.set_model(models[cur][0])
+        for s in watch:
+            old = plugs[s].model.ptr.contents
+            plugs[s].set_model(O.OracleModel(models[cur][1], old.param1Coeff.target, old.param2Coeff.target))
+    elif r < 0.06:
+        pool.activate()
+        for s in watch: plugs[s].activate()
+    elif r < 0.35:
+        s = watch[rs.randint(3)] if rs.rand() < 0.7 else rs.randint(S)
+        choice = rs.randint(7)
+        k = dict(kw[s])
+        if choice == 0: k["param1"] = float(rs.rand())
+        elif choice == 1: k["param2"] = float(rs.rand())
+        elif choice == 2: k["enabled"] = float(rs.rand() > 0.2)
+        elif choice == 3: k["net_bypass"] = float(rs.rand() > 0.7)
+        elif choice == 4: k["eq_position"] = float(rs.rand() > 0.5); k["bass_boost_db"] = float(rs.uniform(-8, 8))
+        elif choice == 5: k["pregain_db"] = float(rs.uniform(-12, 12)); k["master_db"] = float(rs.uniform(-15, 15))
+        else: k["mid_type"] = float(rs.rand() > 0.5); k["mid_boost_db"] = float(rs.uniform(-8, 8)); k["in_lpf_pc"] = float(rs.choice([0.0, 30.0, 66.216, 100.0]))
+        kw[s] = k
+        pool.set_controls(ax.default_controls(**k), stream=s)
+    n = int(rs.choice([256, 256, 256, 128, 64, 17, 1, 0, 255, 200]))
+    x = (rs.uniform(-0.6, 0.6, size=(S, n))).astype(np.float32)
+    got = pool.process(x)
+    names.add(pool.kernel_name)
+    for s in watch:
+        want = plugs[s].run(O.default_controls(**kw[s]), x[s])
+        if n:
+            e = float(np.abs(got[s] - want).max())
+            worst = max(worst, e)
+            if e > 2e-5:
+                print("MISMATCH block", b, "stream", s, "n", n, "err", e, "kernel", pool.kernel_name, "controls", kw[s]); sys.exit(1)
+print("soak ok:", blocks, "blocks, worst |err| =", worst, "kernels:", sorted(names))

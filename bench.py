@@ -148,7 +148,12 @@ def cpu_baseline(j, name: str = "cfg2", target_s: float = 12.0):
     blocks = int(max(4, min(20000, target_s / max(per_block, 1e-6))))
     secs, _ = O.cpu_bench(spec, c, x, n_blocks=blocks, warm_blocks=1, n_threads=cores, fast=True)
     sps = streams * N_FRAMES * blocks / secs
+    # the LV2 real-time case of SURVEY §8(d): one stream on one thread, 256-frame blocks (about a second of CPU)
+    one_blocks = int(max(50, min(4000, 1.0 / max(per_block / streams * cores, 1e-7))))
+    one_secs, _ = O.cpu_bench(spec, c, x[:1], n_blocks=one_blocks, warm_blocks=2, n_threads=1, fast=True)
+    one_sps = N_FRAMES * one_blocks / one_secs
     return {"value": sps, "unit": "samples/s", "cores": cores, "kind": "port",
+            "one_stream_one_thread": {"value": one_sps, "unit": "samples/s", "realtime_factor": one_sps / 48000.0},
             "sample": f"{streams} {name} streams x {blocks} blocks of {N_FRAMES} frames, "
                       f"full run() chain, C oracle with vectorised exp/tanh (-O3 -march=x86-64-v3, AVX2), {cores} pthreads, {secs:.1f} s"}
 

@@ -55,10 +55,12 @@ def lib() -> C.CDLL:
     # Python processes that also use torch (bench.py, some tests) must end up with ONE HIP/HSA
     # runtime: torch ships its own copy, and a second runtime initialised later finds no GPU.
     # Importing torch first makes the loader resolve libamdhip64.so.7 to the copy torch loaded.
-    try:
-        import torch  # noqa: F401
-    except Exception:
-        pass
+    # (AIDAX_NO_TORCH=1: processes that never touch torch, e.g. tests/rt_audit.py, skip that.)
+    if not os.environ.get("AIDAX_NO_TORCH"):
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     path = lib_path()
     if not os.path.exists(path):
         raise FileNotFoundError(f"{path} missing: run `make` (or __graft_entry__.build()); there is no CPU fallback")
@@ -87,6 +89,10 @@ def lib() -> C.CDLL:
     L.aidax_pool_streams.argtypes = [vp]
     L.aidax_pool_streams.restype = u32
     L.aidax_pool_set_model.argtypes = [vp, vp, C.c_int]
+    L.aidax_pool_prepare_model.argtypes = [vp, vp, C.c_int, C.POINTER(vp)]
+    L.aidax_pool_commit_model.argtypes = [vp, vp]
+    L.aidax_staged_free.argtypes = [vp]
+    L.aidax_staged_free.restype = None
     L.aidax_pool_set_loading.argtypes = [vp, i32, C.c_int]
     L.aidax_pool_set_controls.argtypes = [vp, i32, C.POINTER(Controls)]
     L.aidax_pool_activate.argtypes = [vp, i32]
@@ -115,6 +121,10 @@ def lib() -> C.CDLL:
     L.aidax_hub_attached.restype = u32
     L.aidax_hub_launches.argtypes = [vp]
     L.aidax_hub_launches.restype = C.c_uint64
+    L.aidax_hub_deadline_launches.argtypes = [vp]
+    L.aidax_hub_deadline_launches.restype = C.c_uint64
+    L.aidax_hub_set_deadline_us.argtypes = [vp, C.c_int64]
+    L.aidax_hub_flush.argtypes = [vp]
     _lib = L
     return L
 
@@ -226,6 +236,20 @@ class Pool:
     def set_model(self, m: Optional[Model], start_mode: int = START_WARMUP):
         _check(lib().aidax_pool_set_model(self.h, m.h if m is not None else None, start_mode))
 
+    def prepare_model(self, m: Optional[Model], start_mode: int = START_WARMUP) -> C.c_void_p:
+        """worker half of a model swap: returns the staged handle for commit_model / staged_free"""
+        sg = C.c_void_p()
+        _check(lib().aidax_pool_prepare_model(self.h, m.h if m is not None else None, start_mode, C.byref(sg)))
+        return sg
+
+    def commit_model(self, staged: C.c_void_p):
+        """audio half: swaps the staged model in; `staged` then holds what was retired (free it with staged_free)"""
+        _check(lib().aidax_pool_commit_model(self.h, staged))
+
+    @staticmethod
+    def staged_free(staged: C.c_void_p):
+        lib().aidax_staged_free(staged)
+
     def set_controls(self, c: Controls, stream: int = ALL_STREAMS):
         _check(lib().aidax_pool_set_controls(self.h, stream, C.byref(c)))
 
@@ -301,6 +325,16 @@ class Hub:
         out = np.empty_like(x)
         _check(lib().aidax_hub_run(self.h, slot, x.ctypes.data_as(_fp), out.ctypes.data_as(_fp), x.size))
         return out
+
+    def set_deadline_us(self, us: int):
+        _check(lib().aidax_hub_set_deadline_us(self.h, us))
+
+    def flush(self):
+        _check(lib().aidax_hub_flush(self.h))
+
+    @property
+    def deadline_launches(self) -> int:
+        return lib().aidax_hub_deadline_launches(self.h)
 
     @property
     def latency_frames(self) -> int:

@@ -1,39 +1,68 @@
 // aidax_hub.cpp — host-side stream aggregator: many plugin instances of one process, one pool pass per
 // audio period (include/aidax.h, "hub"). Pipelined by one period so that hosts that call their instances
 // one after another never wait on each other; see the header for the contract.
+//
+// Who does what:
+//   run() of an instance   stages its input row into pinned memory and counts itself in (a few hundred
+//                          nanoseconds under the hub's mutex), then — outside the mutex — waits for the event of
+//                          the PREVIOUS period's pass (normally long complete) and copies its output row out.
+//                          It launches nothing unless it has to close a period itself (re-entry before the
+//                          launcher got to it, change of block size).
+//   the launcher thread    launches the pass of a period (H2D of the attached rows, the pool pass, D2H, event)
+//                          as soon as every attached instance has submitted, or when the period's deadline
+//                          passes — so one instance that stalls or stops calling cannot hold the others' audio.
 #include <hip/hip_runtime_api.h>
 
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "aidax_internal.h"
 
 using namespace aidax;
+using Clock = std::chrono::steady_clock;
 
 struct aidax_hub {
     aidax_pool* pool = nullptr;
     uint32_t cap = 0, max_frames = 0;
     int device = 0;
+    double host_sr = 48000.0;
     std::mutex mu;
+    std::condition_variable cv;
+    std::thread launcher;
+    bool stop = false, flush_requested = false;
+    int64_t deadline_us = -1;                    // < 0: a quarter of the period; 0: no deadline
+    Clock::time_point deadline{};
     std::vector<uint8_t> attached, submitted, forced_off;
     std::vector<uint8_t> out_valid[2];
     std::vector<aidax_controls> ctl;
     uint32_t n_attached = 0, n_submitted = 0, period_frames = 0, out_frames[2] = { 0, 0 };
+    uint32_t hi_slot = 0;                        // rows [0, hi_slot) can be attached: what a pass moves and launches
     uint32_t latency = 0;
-    uint64_t launches = 0;
+    uint64_t launches = 0, deadline_launches = 0;
+    int last_error = AIDAX_OK;
     float* h_in[2] = { nullptr, nullptr };       // pinned staging, rows packed at the period's block length
     float* h_out[2] = { nullptr, nullptr };
     float* d_in = nullptr;
     float* d_out = nullptr;
     hipStream_t q = nullptr;
     hipEvent_t done[2] = { nullptr, nullptr };
-    bool pending[2] = { false, false };
+    bool launched[2] = { false, false };
     int cur = 0;
 
     ~aidax_hub()
     {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        if (launcher.joinable()) launcher.join();
         if (q) (void)hipStreamSynchronize(q);
+        if (pool) aidax_pool_destroy(pool);      // before the stream it last ran on goes away
         for (int i = 0; i < 2; ++i) {
             if (h_in[i]) (void)hipHostFree(h_in[i]);
             if (h_out[i]) (void)hipHostFree(h_out[i]);
@@ -42,7 +71,6 @@ struct aidax_hub {
         if (d_in) (void)hipFree(d_in);
         if (d_out) (void)hipFree(d_out);
         if (q) (void)hipStreamDestroy(q);
-        if (pool) aidax_pool_destroy(pool);
     }
 };
 
@@ -66,12 +94,14 @@ int push_controls(aidax_hub& h, uint32_t slot, bool off)
     return aidax_pool_set_controls(h.pool, static_cast<int32_t>(slot), &c);
 }
 
-// launch the period that is being collected (h.mu held)
+// launch the period that is being collected (h.mu held): asynchronous, nothing in here waits for the GPU
 int flush_locked(aidax_hub& h)
 {
+    h.flush_requested = false;
     if (h.n_submitted == 0) return AIDAX_OK;
     const uint32_t n = h.period_frames;
-    for (uint32_t s = 0; s < h.cap; ++s) {
+    const uint32_t rows = h.hi_slot;
+    for (uint32_t s = 0; s < rows; ++s) {
         const bool off = !h.attached[s] || !h.submitted[s];
         if (off != (h.forced_off[s] != 0)) {
             const int rc = push_controls(h, s, off);
@@ -79,14 +109,14 @@ int flush_locked(aidax_hub& h)
         }
     }
     const int b = h.cur;
-    const size_t bytes = sizeof(float) * static_cast<size_t>(h.cap) * n;
+    const size_t bytes = sizeof(float) * static_cast<size_t>(rows) * n;
     HUB_TRY(hipSetDevice(h.device));
-    if (n != 0) HUB_TRY(hipMemcpyAsync(h.d_in, h.h_in[b], bytes, hipMemcpyHostToDevice, h.q));
-    const int rc = aidax_pool_process_device(h.pool, h.d_in, h.d_out, n, h.q);
+    if (bytes != 0) HUB_TRY(hipMemcpyAsync(h.d_in, h.h_in[b], bytes, hipMemcpyHostToDevice, h.q));
+    const int rc = pool_process_prefix(h.pool, h.d_in, h.d_out, n, h.q, rows);
     if (rc != AIDAX_OK) return rc;
-    if (n != 0) HUB_TRY(hipMemcpyAsync(h.h_out[b], h.d_out, bytes, hipMemcpyDeviceToHost, h.q));
+    if (bytes != 0) HUB_TRY(hipMemcpyAsync(h.h_out[b], h.d_out, bytes, hipMemcpyDeviceToHost, h.q));
     HUB_TRY(hipEventRecord(h.done[b], h.q));
-    h.pending[b] = true;
+    h.launched[b] = true;
     h.out_frames[b] = n;
     h.out_valid[b] = h.submitted;
     std::fill(h.submitted.begin(), h.submitted.end(), 0);
@@ -95,6 +125,22 @@ int flush_locked(aidax_hub& h)
     h.cur = b ^ 1;
     ++h.launches;
     return AIDAX_OK;
+}
+
+void launcher_main(aidax_hub* h)
+{
+    std::unique_lock<std::mutex> lk(h->mu);
+    while (!h->stop) {
+        const bool timed = h->n_submitted != 0 && h->deadline_us != 0;
+        if (h->flush_requested || (timed && Clock::now() >= h->deadline)) {
+            if (!h->flush_requested) ++h->deadline_launches;
+            const int rc = flush_locked(*h);
+            if (rc != AIDAX_OK) h->last_error = rc;
+            continue;
+        }
+        if (timed) h->cv.wait_until(lk, h->deadline);
+        else h->cv.wait(lk);
+    }
 }
 
 }  // namespace
@@ -113,6 +159,7 @@ AIDAX_API int aidax_hub_create(uint32_t max_instances, uint32_t max_frames, doub
     h->cap = max_instances;
     h->max_frames = max_frames;
     h->device = device_id;
+    h->host_sr = host_samplerate;
     h->attached.assign(max_instances, 0);
     h->submitted.assign(max_instances, 0);
     h->forced_off.assign(max_instances, 0);
@@ -132,18 +179,37 @@ AIDAX_API int aidax_hub_create(uint32_t max_instances, uint32_t max_frames, doub
     // nobody is attached yet: every stream rests disabled
     for (uint32_t s = 0; s < max_instances; ++s)
         if (push_controls(*h, s, true) != AIDAX_OK) { delete h; return AIDAX_ERR_DEVICE; }
+    h->launcher = std::thread(launcher_main, h);
     *out = h;
     return AIDAX_OK;
 }
 
 AIDAX_API void aidax_hub_destroy(aidax_hub* h) { delete h; }
 
+AIDAX_API int aidax_hub_set_deadline_us(aidax_hub* h, int64_t microseconds)
+{
+    if (!h) return fail(AIDAX_ERR_ARG, "null hub");
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        h->deadline_us = microseconds;
+    }
+    h->cv.notify_all();
+    return AIDAX_OK;
+}
+
 AIDAX_API int aidax_hub_set_model(aidax_hub* h, const aidax_model* m, int start_mode)
 {
     if (!h) return fail(AIDAX_ERR_ARG, "null hub");
-    std::lock_guard<std::mutex> g(h->mu);
-    if (h->q) (void)hipStreamSynchronize(h->q);
-    return aidax_pool_set_model(h->pool, m, start_mode);
+    // the worker half needs no lock: it builds into buffers of its own on the pool's worker stream
+    aidax_staged* sg = nullptr;
+    int rc = aidax_pool_prepare_model(h->pool, m, start_mode, &sg);
+    if (rc != AIDAX_OK) return rc;
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        rc = aidax_pool_commit_model(h->pool, sg);
+    }
+    aidax_staged_free(sg);
+    return rc;
 }
 
 AIDAX_API int aidax_hub_attach(aidax_hub* h, int32_t* slot)
@@ -152,7 +218,8 @@ AIDAX_API int aidax_hub_attach(aidax_hub* h, int32_t* slot)
     std::lock_guard<std::mutex> g(h->mu);
     for (uint32_t s = 0; s < h->cap; ++s) {
         if (h->attached[s]) continue;
-        (void)hipStreamSynchronize(h->q);                    // the slot's stream is not in flight
+        // a fresh instance in this slot: a handful of asynchronous launches on the pool's stream, ordered
+        // against the passes by the pool's stream edges — nothing here waits for the GPU
         int rc = aidax_pool_reset_stream(h->pool, s, AIDAX_START_WARMUP);
         if (rc != AIDAX_OK) return rc;
         rc = aidax_pool_activate(h->pool, static_cast<int32_t>(s));
@@ -161,6 +228,7 @@ AIDAX_API int aidax_hub_attach(aidax_hub* h, int32_t* slot)
         h->attached[s] = 1;
         h->out_valid[0][s] = h->out_valid[1][s] = 0;
         ++h->n_attached;
+        if (s + 1 > h->hi_slot) h->hi_slot = s + 1;
         *slot = static_cast<int32_t>(s);
         return AIDAX_OK;
     }
@@ -210,35 +278,62 @@ AIDAX_API int aidax_hub_run(aidax_hub* h, int32_t slot, const float* in, float* 
     if (!h) return fail(AIDAX_ERR_ARG, "null hub");
     if (n_frames > h->max_frames) return fail(AIDAX_ERR_ARG, "n_frames exceeds the hub's max_frames");
     if (n_frames != 0 && (!in || !out)) return fail(AIDAX_ERR_ARG, "null buffer");
-    std::lock_guard<std::mutex> g(h->mu);
-    if (slot < 0 || static_cast<uint32_t>(slot) >= h->cap || !h->attached[slot]) return fail(AIDAX_ERR_ARG, "slot not attached");
-    // this instance is back before everybody submitted, or the host changed the block size: close the period
-    if (h->submitted[slot] || (h->n_submitted != 0 && n_frames != h->period_frames)) {
-        const int rc = flush_locked(*h);
-        if (rc != AIDAX_OK) return rc;
+    const float* prev_row = nullptr;
+    hipEvent_t prev_done = nullptr;
+    bool wake = false;
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        if (slot < 0 || static_cast<uint32_t>(slot) >= h->cap || !h->attached[slot]) return fail(AIDAX_ERR_ARG, "slot not attached");
+        if (h->last_error != AIDAX_OK) {                     // a pass the launcher could not issue
+            const int rc = h->last_error;
+            h->last_error = AIDAX_OK;
+            return fail(rc, "hub: a pool pass failed to launch");
+        }
+        // this instance is back before the period was closed (somebody was skipped and the launcher has not
+        // got to it yet), or the host changed the block size: close the period here
+        if (h->submitted[slot] || (h->n_submitted != 0 && n_frames != h->period_frames)) {
+            const int rc = flush_locked(*h);
+            if (rc != AIDAX_OK) return rc;
+        }
+        if (h->n_submitted == 0) {                           // first of a new period: block length and deadline
+            h->period_frames = n_frames;
+            const int64_t us = h->deadline_us < 0 ? static_cast<int64_t>(0.25e6 * n_frames / h->host_sr) : h->deadline_us;
+            h->deadline = Clock::now() + std::chrono::microseconds(us);
+            wake = h->deadline_us != 0;
+        }
+        const int b = h->cur, prev = b ^ 1;
+        if (n_frames != 0) std::memcpy(h->h_in[b] + static_cast<size_t>(slot) * n_frames, in, sizeof(float) * n_frames);
+        h->submitted[slot] = 1;
+        ++h->n_submitted;
+        if (n_frames != 0 && h->launched[prev] && h->out_valid[prev][slot] && h->out_frames[prev] == n_frames) {
+            prev_row = h->h_out[prev] + static_cast<size_t>(slot) * n_frames;
+            prev_done = h->done[prev];
+        }
+        if (h->n_submitted == h->n_attached) { h->flush_requested = true; wake = true; }
     }
-    if (h->n_submitted == 0) h->period_frames = n_frames;
-    const int b = h->cur, prev = b ^ 1;
-    if (n_frames != 0) std::memcpy(h->h_in[b] + static_cast<size_t>(slot) * n_frames, in, sizeof(float) * n_frames);
-    h->submitted[slot] = 1;
-    ++h->n_submitted;
-    // the previous period's output for this instance
-    if (h->pending[prev]) {
-        HUB_TRY(hipEventSynchronize(h->done[prev]));
-        h->pending[prev] = false;
-    }
+    if (wake) h->cv.notify_one();
+    // the previous period's output for this instance; its pass was launched a period ago
     if (n_frames != 0) {
-        if (h->out_valid[prev][slot] && h->out_frames[prev] == n_frames)
-            std::memcpy(out, h->h_out[prev] + static_cast<size_t>(slot) * n_frames, sizeof(float) * n_frames);
-        else
+        if (prev_row) {
+            if (hipEventQuery(prev_done) != hipSuccess) HUB_TRY(hipEventSynchronize(prev_done));
+            std::memcpy(out, prev_row, sizeof(float) * n_frames);
+        } else {
             std::memset(out, 0, sizeof(float) * n_frames);
+        }
     }
-    if (h->n_submitted == h->n_attached) return flush_locked(*h);
     return AIDAX_OK;
+}
+
+AIDAX_API int aidax_hub_flush(aidax_hub* h)
+{
+    if (!h) return fail(AIDAX_ERR_ARG, "null hub");
+    std::lock_guard<std::mutex> g(h->mu);
+    return flush_locked(*h);
 }
 
 AIDAX_API uint32_t aidax_hub_latency_frames(const aidax_hub* h) { return h ? h->latency : 0; }
 AIDAX_API uint32_t aidax_hub_attached(const aidax_hub* h) { return h ? h->n_attached : 0; }
 AIDAX_API uint64_t aidax_hub_launches(const aidax_hub* h) { return h ? h->launches : 0; }
+AIDAX_API uint64_t aidax_hub_deadline_launches(const aidax_hub* h) { return h ? h->deadline_launches : 0; }
 
 }  // extern "C"

@@ -48,6 +48,9 @@ float exp_smoother_coef(float samplerate, float t60);
 void  build_stream_ctl(const aidax_controls& c, double host_samplerate, bool has_model, bool loading,
                        float gain_coef, float p_den, StreamCtl* out);
 
+// aidax_pool_process_device restricted to the first n_active streams (aidax_pool.cpp; used by the hub)
+int pool_process_prefix(aidax_pool* p, const float* d_in, float* d_out, uint32_t n_frames, void* hip_stream, uint32_t n_active);
+
 // weight packing (aidax_pack.cpp)
 std::vector<float> pack_weights(const aidax_model& m);
 // extension architectures: flat weight buffer + descriptor + per-stream state size (floats)

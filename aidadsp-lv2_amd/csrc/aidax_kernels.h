@@ -40,6 +40,9 @@ size_t convm_lds_bytes(const ConvDesc& d, uint32_t n_frames);
 hipError_t launch_conv_mfma_kernel(const LaunchArgs& a, const ConvDesc& d, hipStream_t stream);   // n_frames <= 256
 hipError_t launch_conv_kernel(const LaunchArgs& a, const ConvDesc& d, hipStream_t stream);
 hipError_t launch_set_pending(StreamState* st, uint32_t n_streams, int32_t stream, uint32_t bits, hipStream_t q);
+hipError_t launch_init_streams(StreamState* st, uint32_t n, hipStream_t q);
+hipError_t launch_stage_params(const StreamState* live, StreamState* staged, uint32_t n, hipStream_t q);
+hipError_t launch_install_params(StreamState* live, const StreamState* staged, uint32_t n, hipStream_t q);
 hipError_t launch_reset_for_model(StreamState* st, float* nn, uint32_t n_streams, uint32_t nn_stride, float p_den, hipStream_t q);
 
 }  // namespace aidax

@@ -980,6 +980,44 @@ __global__ void k_reset_for_model(StreamState* st, float* nn, uint32_t n_streams
     s.pending |= PEND_PARAM_FIRST;
 }
 
+// instantiate() (:283-321) for `n` streams: preGain target 1 cleared, masterGain target 0 cleared, biquad
+// z = 0, PARAM smoothers zero, nothing pending.
+__global__ void k_init_streams(StreamState* st, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    StreamState s{};
+    s.pre_mem = 1.f; s.pre_tgt = 1.f;
+    st[i] = s;
+}
+
+// work() reads the PARAM targets of the playing model (:822-825) for the model it is about to build. `live` is
+// being written by the audio side's passes while this runs on the worker's stream: a 4-byte read of a value
+// that only moves when a port moves, the same unsynchronised read the reference does.
+__global__ void k_stage_params(const StreamState* live, StreamState* staged, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    StreamState s{};
+    s.p_tgt[0] = live[i].p_tgt[0];
+    s.p_tgt[1] = live[i].p_tgt[1];
+    staged[i] = s;
+}
+
+// work_response(): the per-stream members of the new DynamicModel (PARAM smoothers as prepared and warmed up,
+// paramFirstRun = true, :1053-1061) replace the old model's, stream-ordered with the passes.
+__global__ void k_install_params(StreamState* live, const StreamState* staged, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int k = 0; k < 2; ++k) {
+        live[i].p_mem[k] = staged[i].p_mem[k];
+        live[i].p_step[k] = staged[i].p_step[k];
+        live[i].p_tgt[k] = staged[i].p_tgt[k];
+    }
+    live[i].pending |= PEND_PARAM_FIRST;
+}
+
 // ------------------------------------------------------------ host dispatch
 #define AIDAX_LSTM(H) { 0, H, k_lstm<H>, k_lstm_pipe<H>, k_nn<LstmCell<H>>, LstmCell<H>::PACK, LstmCell<H>::STATE, "k_lstm<" #H ">", "k_lstm_pipe<" #H ">", "k_chain+k_nn<lstm" #H ">" }
 #define AIDAX_GRU(H)  { 1, H, k_gru<H>,  k_gru_pipe<H>,  k_nn<GruCell<H>>,  GruCell<H>::PACK,  GruCell<H>::STATE,  "k_gru<" #H ">", "k_gru_pipe<" #H ">", "k_chain+k_nn<gru" #H ">" }
@@ -1075,6 +1113,24 @@ int pipe_resident_streams(const KernelEntry* e, uint32_t n_frames, int device)
 hipError_t launch_set_pending(StreamState* st, uint32_t n_streams, int32_t stream, uint32_t bits, hipStream_t q)
 {
     hipLaunchKernelGGL(k_set_pending, dim3((n_streams + 255) / 256), dim3(256), 0, q, st, n_streams, stream, bits);
+    return hipGetLastError();
+}
+
+hipError_t launch_init_streams(StreamState* st, uint32_t n, hipStream_t q)
+{
+    hipLaunchKernelGGL(k_init_streams, dim3((n + 255) / 256), dim3(256), 0, q, st, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_stage_params(const StreamState* live, StreamState* staged, uint32_t n, hipStream_t q)
+{
+    hipLaunchKernelGGL(k_stage_params, dim3((n + 255) / 256), dim3(256), 0, q, live, staged, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_install_params(StreamState* live, const StreamState* staged, uint32_t n, hipStream_t q)
+{
+    hipLaunchKernelGGL(k_install_params, dim3((n + 255) / 256), dim3(256), 0, q, live, staged, n);
     return hipGetLastError();
 }
 

@@ -11,6 +11,7 @@
 //   conv1d [k][in][out] | [out], keys kernel_size / dilation   (extension)
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -189,6 +190,11 @@ int load_from_text(const char* text, size_t len, const char* label, aidax_model*
     }
     if (!model_supported(*m))
         return fail(AIDAX_ERR_ARCH, "Error loading model: Unable to identify a known model architecture! (no kernel for this cell/hidden size)");
+    // AIDAX_STRICT_REFERENCE_SET=1: accept exactly what custom_model_creator accepts (model_variant.hpp:6-59,
+    // rt-neural-generic.cpp:1025-1026) and nothing of this build's extensions
+    const char* strict = std::getenv("AIDAX_STRICT_REFERENCE_SET");
+    if (strict && strict[0] == '1' && !m->in_reference_set)
+        return fail(AIDAX_ERR_ARCH, "Error loading model: Unable to identify a known model architecture!");
     *out = m.release();
     return AIDAX_OK;
 }

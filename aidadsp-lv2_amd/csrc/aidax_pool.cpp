@@ -81,59 +81,93 @@ int guarded(F&& f)
     }
 }
 
+// The device side of one loaded model: what the reference keeps in a DynamicModel (rt-neural-generic.h:115-129)
+// minus the per-stream members. A pool plays `cur`; aidax_pool_prepare_model builds the next one on the worker
+// thread and aidax_pool_commit_model swaps the two on the audio thread (plain struct assignment).
+struct ModelSlot {
+    bool has_model = false;
+    enum Kind { TABLE = 0, STACK = 1, CONV = 2, MFMA = 3, QUAD = 4 } kind = TABLE;
+    QuadDesc qdesc{};
+    StackDesc sdesc{};
+    MfmaDesc mdesc{};
+    ConvDesc cdesc{};
+    bool conv_mfma = false;          // conv stacks on the matrix cores (blocks of <= 256 frames), else k_conv
+    const KernelEntry* kernel = nullptr;
+    int cell = 0, input_size = 1, input_skip = 0, hidden = 0;
+    float in_gain = 1.f, out_gain = 1.f, model_sr = 48000.f;
+    uint32_t nn_stride = 0;
+    int pipe_capacity = 0;           // streams the 3-wave pipeline keeps resident at once (0 = never use it)
+    bool split_pays = false;         // the lean recurrent kernel keeps the occupancy of the one-wave kernel
+    float* d_wpack = nullptr;        // weights in the kernel's layout
+    float* d_nn = nullptr;           // recurrent state [n_streams][nn_stride]
+
+    float p_den() const { return 0.1f * model_sr; }      // LinearValueSmoother tau * sampleRate (:1053-1054)
+};
+
+constexpr int kCtlRing = 4;                              // pinned snapshots of the control records in flight
+constexpr size_t kStagingLimit = size_t(64) << 20;      // pinned staging per direction for aidax_pool_process
+constexpr size_t kZeroCopyLimit = size_t(64) << 10;     // blocks up to this size are read / written by the kernels in place in pinned host memory
+
 }  // namespace
 }  // namespace aidax
+
+// A model on its way into (or out of) a pool. Built by aidax_pool_prepare_model on the worker thread; after
+// aidax_pool_commit_model the same object carries what the swap retired, for aidax_staged_free on the worker.
+struct aidax_staged {
+    int device = 0;
+    uint32_t n_streams = 0;
+    aidax::ModelSlot slot;
+    StreamState* d_pst = nullptr;    // per-stream DynamicModel members of the new model (PARAM smoothers, paramFirstRun), installed by the commit
+    hipEvent_t fence = nullptr;      // recorded by the commit: everything that may still touch the retired buffers precedes it
+    bool fenced = false;
+};
 
 struct aidax_pool {
     int device = 0;
     uint32_t n_streams = 0, max_frames = 0;
     double host_sr = 48000.0;
     float gain_coef = 0.f;
-    hipStream_t q = nullptr;
+    hipStream_t q = nullptr;         // the audio side's stream
+    hipStream_t wq = nullptr;        // the worker side's stream (prepare)
+    hipEvent_t ev_x = nullptr;       // edge between two streams that carry passes one after the other
+    hipStream_t last_stream = nullptr;
 
     StreamCtl* d_ctl = nullptr;
     StreamState* d_st = nullptr;
-    float* d_nn = nullptr;
-    float* d_wpack = nullptr;
     float* d_in = nullptr;           // staging for the host-buffer entry point
     float* d_out = nullptr;
+    float* h_in = nullptr;           // pinned host staging (nullptr: blocks too large, pageable copies)
+    float* h_out = nullptr;
+    float* hd_in = nullptr;          // device view of h_in / h_out (zero-copy passes)
+    float* hd_out = nullptr;
+    bool zero_copy = false;
 
     std::vector<aidax_controls> controls;
     std::vector<uint8_t> loading;
     std::vector<StreamCtl> h_ctl;
-    bool ctl_dirty = true;
+    uint32_t dirty_lo = 1, dirty_hi = 0;                 // control records to upload: [lo, hi], empty when lo > hi
+    StreamCtl* ctl_ring[kCtlRing] = {};
+    hipEvent_t ctl_ev[kCtlRing] = {};
+    bool ctl_used[kCtlRing] = {};
+    int ctl_next = 0;
 
-    // model in use (copy of what the kernels need)
-    bool has_model = false;
-    enum Kind { TABLE = 0, STACK = 1, CONV = 2, MFMA = 3, QUAD = 4 } kind = TABLE;
-    QuadDesc qdesc{};
-    int cell = 0;
-    StackDesc sdesc{};
-    MfmaDesc mdesc{};
-    ConvDesc cdesc{};
-    bool conv_mfma = false;          // conv stacks on the matrix cores (blocks of <= 256 frames), else k_conv
-    const KernelEntry* kernel = nullptr;
-    int input_size = 1, input_skip = 0, hidden = 0;
-    float in_gain = 1.f, out_gain = 1.f, model_sr = 48000.f;
-    uint32_t nn_stride = 0;
-    int pipe_capacity = 0;           // streams the 3-wave pipeline keeps resident at once (0 = never use it)
-    bool split_pays = false;         // the lean recurrent kernel keeps the occupancy of the one-wave kernel
-    int force_form = 0;              // AIDAX_KERNEL=wave|pipe|split|valu overrides the heuristic (A/B testing)
-    // Form of a MODE_CHAIN pass of a TABLE pool: 0 one wave per stream, 1 three-wave pipeline (all streams resident at
+    ModelSlot cur;
+    int force_form = 0;              // AIDAX_KERNEL=wave|pipe|split|valu|mfma|quad overrides the heuristic (A/B testing)
+
+    // Form of a MODE_CHAIN pass of a TABLE slot: 0 one wave per stream, 1 three-wave pipeline (all streams resident at
     // once: latency-bound regime), 2 split launches with packed chains (many streams: issue-bound regime)
-    int chain_form() const
+    int chain_form(const ModelSlot& m) const
     {
-        if (kind != TABLE && has_model) return 0;
+        if (m.kind != ModelSlot::TABLE && m.has_model) return 0;
         if (chain_lds_bytes(max_frames) > kChainLdsLimit) return 0;      // packed chains keep 8 blocks in LDS
         if (force_form == 1) return 0;
-        if (force_form == 2) return (has_model && kernel) ? 1 : 0;
+        if (force_form == 2) return (m.has_model && m.kernel) ? 1 : 0;
         if (force_form == 3) return 2;
-        if (use_pipe()) return 1;
+        if (use_pipe(m)) return 1;
         if (n_streams < 64) return 0;
-        return (!has_model || split_pays) ? 2 : 0;
+        return (!m.has_model || m.split_pays) ? 2 : 0;
     }
     // Models of the reference's table on the matrix-core kernels (many_streams_form); AIDAX_KERNEL=quad|mfma force one.
-    // four streams per workgroup on mfma_f32_4x4x1 (k_quad): the many-streams form of the table models
     bool quad_for_table_model(int cell_kind, int hidden_units) const
     {
         if (force_form == 6) return true;
@@ -144,24 +178,39 @@ struct aidax_pool {
         if (force_form == 5) return true;
         return force_form == 0 && many_streams_form(cell_kind, hidden_units, n_streams) == MANY_MFMA;
     }
-    bool use_pipe() const
+    bool use_pipe(const ModelSlot& m) const
     {
-        if (!has_model || !kernel || kind != TABLE) return false;
+        if (!m.has_model || !m.kernel || m.kind != ModelSlot::TABLE) return false;
         if (force_form == 1 || force_form == 3) return false;
         if (force_form == 2) return true;
-        return static_cast<int>(n_streams) <= pipe_capacity;
+        return static_cast<int>(n_streams) <= m.pipe_capacity;
     }
-
-    size_t lds_bytes(uint32_t n_frames) const
+    // does a MODE_CHAIN pass of this slot consist of one launch (it may then read and write host memory in place)?
+    bool single_launch(const ModelSlot& m) const
     {
-        return (static_cast<size_t>((n_frames + 3) & ~3u) + static_cast<size_t>(hidden > 0 ? hidden : 4)) * sizeof(float);
+        if (!m.has_model) return chain_form(m) != 2;
+        switch (m.kind) {
+        case ModelSlot::TABLE: return chain_form(m) != 2;
+        case ModelSlot::STACK: return true;
+        case ModelSlot::CONV: return !m.conv_mfma;
+        default: return false;
+        }
     }
-    float p_den() const { return 0.1f * model_sr; }      // LinearValueSmoother tau * sampleRate (:1053-1054)
 
+    static size_t lds_bytes(const ModelSlot& m, uint32_t n_frames)
+    {
+        return (static_cast<size_t>((n_frames + 3) & ~3u) + static_cast<size_t>(m.hidden > 0 ? m.hidden : 4)) * sizeof(float);
+    }
+
+    void mark_dirty(uint32_t lo, uint32_t hi)
+    {
+        if (dirty_lo > dirty_hi) { dirty_lo = lo; dirty_hi = hi; }
+        else { dirty_lo = std::min(dirty_lo, lo); dirty_hi = std::max(dirty_hi, hi); }
+    }
     void refresh_ctl(uint32_t s)
     {
-        build_stream_ctl(controls[s], host_sr, has_model, loading[s] != 0, gain_coef, p_den(), &h_ctl[s]);
-        ctl_dirty = true;
+        build_stream_ctl(controls[s], host_sr, cur.has_model, loading[s] != 0, gain_coef, cur.p_den(), &h_ctl[s]);
+        mark_dirty(s, s);
     }
     void refresh_all()
     {
@@ -171,184 +220,251 @@ struct aidax_pool {
                 loading[s] == loading[s - 1]) {
                 h_ctl[s] = h_ctl[s - 1];
             } else {
-                refresh_ctl(s);
+                build_stream_ctl(controls[s], host_sr, cur.has_model, loading[s] != 0, gain_coef, cur.p_den(), &h_ctl[s]);
             }
         }
-        ctl_dirty = true;
+        mark_dirty(0, n_streams - 1);
     }
+    // the fields of a control record that depend on the model and on `loading`, without redesigning the filters
+    void patch_model_fields(uint32_t s)
+    {
+        StreamCtl& o = h_ctl[s];
+        const aidax_controls& c = controls[s];
+        o.master_target = loading[s] ? 0.f : db_to_coeff(c.master_db);                   // :490, :654
+        o.p_den = cur.p_den();
+        if (cur.has_model && !(c.net_bypass > 0.5f)) o.flags |= CTL_NET_ON;              // :631-632
+        else o.flags &= ~static_cast<uint32_t>(CTL_NET_ON);
+    }
+    // Upload the changed control records, stream-ordered with the pass that follows. The records leave from a
+    // ring of pinned snapshots, so the copy is asynchronous and a later set_controls cannot overtake it.
     void flush_ctl(hipStream_t s)
     {
-        if (!ctl_dirty) return;
-        HIP_TRY(hipMemcpyAsync(d_ctl, h_ctl.data(), sizeof(StreamCtl) * n_streams, hipMemcpyHostToDevice, s));
-        ctl_dirty = false;
+        if (dirty_lo > dirty_hi) return;
+        const int k = ctl_next;
+        if (ctl_used[k] && hipEventQuery(ctl_ev[k]) != hipSuccess) HIP_TRY(hipEventSynchronize(ctl_ev[k]));   // four uploads behind: not seen in practice
+        const size_t cnt = static_cast<size_t>(dirty_hi - dirty_lo) + 1;
+        std::memcpy(ctl_ring[k] + dirty_lo, h_ctl.data() + dirty_lo, cnt * sizeof(StreamCtl));
+        HIP_TRY(hipMemcpyAsync(d_ctl + dirty_lo, ctl_ring[k] + dirty_lo, cnt * sizeof(StreamCtl), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipEventRecord(ctl_ev[k], s));
+        ctl_used[k] = true;
+        ctl_next = (k + 1) % kCtlRing;
+        dirty_lo = 1; dirty_hi = 0;
     }
-    LaunchArgs args(const float* in, float* out, uint32_t n_frames, int mode) const
+    // Passes and control pokes are issued in program order by the audio side but may sit on two streams (the pool's
+    // own and one handed to aidax_pool_process_device): moving from one to the other puts an event edge between them.
+    void enter_stream(hipStream_t s)
+    {
+        if (last_stream && last_stream != s) {
+            HIP_TRY(hipEventRecord(ev_x, last_stream));
+            HIP_TRY(hipStreamWaitEvent(s, ev_x, 0));
+        }
+        last_stream = s;
+    }
+    LaunchArgs args(const ModelSlot& m, StreamState* st, const float* in, float* out, uint32_t n_frames, int mode) const
     {
         LaunchArgs a{};
-        a.ctl = d_ctl; a.st = d_st; a.nn = d_nn; a.wpack = d_wpack;
+        a.ctl = d_ctl; a.st = st; a.nn = m.d_nn; a.wpack = m.d_wpack;
         a.in = in; a.out = out;
-        a.n_streams = n_streams; a.n_frames = n_frames; a.nn_stride = nn_stride;
-        a.mode = mode; a.input_size = input_size; a.input_skip = input_skip;
-        a.in_gain = in_gain; a.out_gain = out_gain;
+        a.n_streams = n_streams; a.n_frames = n_frames; a.nn_stride = m.nn_stride;
+        a.mode = mode; a.input_size = m.input_size; a.input_skip = m.input_skip;
+        a.in_gain = m.in_gain; a.out_gain = m.out_gain;
         return a;
     }
     // frames one launch of the extension kernels may carry (their LDS planes grow with n)
     uint32_t ext_chunk() const { return max_frames < 256 ? max_frames : 256; }
-    uint32_t launch_chunk(uint32_t n) const { return (kind == STACK || kind == CONV) ? std::min(ext_chunk(), n) : n; }
-    hipError_t launch(const LaunchArgs& a, hipStream_t s) const
+    uint32_t launch_chunk(const ModelSlot& m, uint32_t n) const
     {
-        if (has_model && kind == MFMA) {
+        return (m.kind == ModelSlot::STACK || m.kind == ModelSlot::CONV) ? std::min(ext_chunk(), n) : n;
+    }
+    hipError_t launch(const ModelSlot& m, const LaunchArgs& a, hipStream_t s) const
+    {
+        if (m.has_model && m.kind == ModelSlot::MFMA) {
             // split form around the matrix-core kernel: packed chains in -> out, applyModel in place, packed chains
-            if (a.mode != MODE_CHAIN) return launch_mfma_kernel(a, mdesc, s);
+            if (a.mode != MODE_CHAIN) return launch_mfma_kernel(a, m.mdesc, s);
             hipError_t e = launch_chain_pass(true, a, s);
-            if (e == hipSuccess && a.n_frames != 0) e = launch_mfma_kernel(a, mdesc, s);
+            if (e == hipSuccess && a.n_frames != 0) e = launch_mfma_kernel(a, m.mdesc, s);
             if (e == hipSuccess) e = launch_chain_pass(false, a, s);
             return e;
         }
-        if (has_model && kind == QUAD) {
-            if (a.mode != MODE_CHAIN) return launch_quad_kernel(cell, hidden, a, qdesc, s);
+        if (m.has_model && m.kind == ModelSlot::QUAD) {
+            if (a.mode != MODE_CHAIN) return launch_quad_kernel(m.cell, m.hidden, a, m.qdesc, s);
             hipError_t e = launch_chain_pass(true, a, s);
-            if (e == hipSuccess && a.n_frames != 0) e = launch_quad_kernel(cell, hidden, a, qdesc, s);
+            if (e == hipSuccess && a.n_frames != 0) e = launch_quad_kernel(m.cell, m.hidden, a, m.qdesc, s);
             if (e == hipSuccess) e = launch_chain_pass(false, a, s);
             return e;
         }
-        if (has_model && kind == STACK) return launch_stack_kernel(a, sdesc, s);
-        if (has_model && kind == CONV && conv_mfma) {
-            if (a.mode != MODE_CHAIN) return launch_conv_mfma_kernel(a, cdesc, s);
+        if (m.has_model && m.kind == ModelSlot::STACK) return launch_stack_kernel(a, m.sdesc, s);
+        if (m.has_model && m.kind == ModelSlot::CONV && m.conv_mfma) {
+            if (a.mode != MODE_CHAIN) return launch_conv_mfma_kernel(a, m.cdesc, s);
             hipError_t e = launch_chain_pass(true, a, s);
-            if (e == hipSuccess && a.n_frames != 0) e = launch_conv_mfma_kernel(a, cdesc, s);
+            if (e == hipSuccess && a.n_frames != 0) e = launch_conv_mfma_kernel(a, m.cdesc, s);
             if (e == hipSuccess) e = launch_chain_pass(false, a, s);
             return e;
         }
-        if (has_model && kind == CONV) return launch_conv_kernel(a, cdesc, s);
-        if (a.mode == MODE_CHAIN && chain_form() == 1) return launch_pipe_kernel(kernel, a, s);
-        if (a.mode == MODE_CHAIN && chain_form() == 2) return launch_split_kernels(has_model ? kernel : nullptr, a, s);
-        return launch_stream_kernel(has_model ? kernel : nullptr, a, lds_bytes(a.mode == MODE_CHAIN ? a.n_frames : 0), s);
+        if (m.has_model && m.kind == ModelSlot::CONV) return launch_conv_kernel(a, m.cdesc, s);
+        const int form = a.mode == MODE_CHAIN ? chain_form(m) : 0;
+        if (form == 1) return launch_pipe_kernel(m.kernel, a, s);
+        if (form == 2) return launch_split_kernels(m.has_model ? m.kernel : nullptr, a, s);
+        return launch_stream_kernel(m.has_model ? m.kernel : nullptr, a, lds_bytes(m, a.mode == MODE_CHAIN ? a.n_frames : 0), s);
     }
     void release()
     {
         if (d_ctl) (void)hipFree(d_ctl);
         if (d_st) (void)hipFree(d_st);
-        if (d_nn) (void)hipFree(d_nn);
-        if (d_wpack) (void)hipFree(d_wpack);
+        if (cur.d_nn) (void)hipFree(cur.d_nn);
+        if (cur.d_wpack) (void)hipFree(cur.d_wpack);
         if (d_in) (void)hipFree(d_in);
         if (d_out) (void)hipFree(d_out);
+        if (h_in) (void)hipHostFree(h_in);
+        if (h_out) (void)hipHostFree(h_out);
+        for (int k = 0; k < kCtlRing; ++k) {
+            if (ctl_ring[k]) (void)hipHostFree(ctl_ring[k]);
+            if (ctl_ev[k]) (void)hipEventDestroy(ctl_ev[k]);
+            ctl_ring[k] = nullptr; ctl_ev[k] = nullptr;
+        }
+        if (ev_x) (void)hipEventDestroy(ev_x);
         if (q) (void)hipStreamDestroy(q);
-        d_ctl = nullptr; d_st = nullptr; d_nn = nullptr; d_wpack = nullptr; d_in = nullptr; d_out = nullptr; q = nullptr;
+        if (wq) (void)hipStreamDestroy(wq);
+        d_ctl = nullptr; d_st = nullptr; cur.d_nn = nullptr; cur.d_wpack = nullptr; d_in = nullptr; d_out = nullptr;
+        h_in = nullptr; h_out = nullptr; ev_x = nullptr; q = nullptr; wq = nullptr;
     }
 };
 
 namespace {
 
-void init_state(aidax_pool& p)
+void staged_release(aidax_staged* s)
 {
-    // instantiate(), rt-neural-generic.cpp:283-321: preGain target 1 cleared, masterGain
-    // target 0 cleared, biquad z = 0, no model, loading = true
-    std::vector<StreamState> st(p.n_streams);
-    std::memset(st.data(), 0, sizeof(StreamState) * p.n_streams);
-    for (auto& s : st) {
-        s.pre_mem = 1.f; s.pre_tgt = 1.f;
-        s.master_mem = 0.f; s.master_tgt = 0.f;
-    }
-    HIP_TRY(hipMemcpyAsync(p.d_st, st.data(), sizeof(StreamState) * p.n_streams, hipMemcpyHostToDevice, p.q));
-    HIP_TRY(hipStreamSynchronize(p.q));
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->fenced) (void)hipEventSynchronize(s->fence);         // passes that still read the retired buffers
+    if (s->slot.d_wpack) (void)hipFree(s->slot.d_wpack);
+    if (s->slot.d_nn) (void)hipFree(s->slot.d_nn);
+    if (s->d_pst) (void)hipFree(s->d_pst);
+    if (s->fence) (void)hipEventDestroy(s->fence);
+    delete s;
 }
 
-int set_model_impl(aidax_pool& p, const aidax_model* m, int start_mode)
+// loadModelFromPath's device half (rt-neural-generic.cpp:1034-1079) into buffers of its own. Worker thread:
+// packs, allocates, uploads and warms up on the pool's worker stream and waits for it; touches nothing the
+// audio side uses except for reading each stream's PARAM targets (as work() reads them at :822-825).
+int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_staged** out)
 {
     HIP_TRY(hipSetDevice(p.device));
-    if (!m) {
-        p.has_model = false;
-        p.kernel = nullptr;
-        for (auto& l : p.loading) l = 1;
-        p.refresh_all();
+    std::unique_ptr<aidax_staged, void (*)(aidax_staged*)> sg(new aidax_staged(), staged_release);
+    sg->device = p.device;
+    sg->n_streams = p.n_streams;
+    HIP_TRY(hipEventCreateWithFlags(&sg->fence, hipEventDisableTiming));
+    if (!m) {                                             // unload: an empty slot to swap in
+        *out = sg.release();
         return AIDAX_OK;
     }
     if (!model_supported(*m)) return fail(AIDAX_ERR_ARCH, "Unable to identify a known model architecture! (no kernel)");
-    const KernelEntry* k = nullptr;
+    ModelSlot& ms = sg->slot;
     std::vector<float> wp;
     uint32_t state_floats = 0;
-    aidax_pool::Kind kind = aidax_pool::TABLE;
-    StackDesc sd{};
-    MfmaDesc md{};
-    ConvDesc cd{};
-    QuadDesc qd{};
-    bool conv_mfma = false;
     if (is_conv_model(*m)) {
-        kind = aidax_pool::CONV;
-        wp = pack_conv(*m, &cd, &state_floats);
-        conv_mfma = p.max_frames <= 256 && p.force_form != 4 && convm_lds_bytes(cd, p.max_frames) <= 160 * 1024;
-        if (!conv_mfma && conv_lds_bytes(cd, p.max_frames) > 160 * 1024)
+        ms.kind = ModelSlot::CONV;
+        wp = pack_conv(*m, &ms.cdesc, &state_floats);
+        ms.conv_mfma = p.max_frames <= 256 && p.force_form != 4 && convm_lds_bytes(ms.cdesc, p.max_frames) <= 160 * 1024;
+        if (!ms.conv_mfma && conv_lds_bytes(ms.cdesc, p.max_frames) > 160 * 1024)
             return fail(AIDAX_ERR_ARG, "conv model: pool max_frames too large for the LDS activation planes");
     } else if (m->n_rnn == 1 && find_kernel(m->cell, m->hidden) && p.quad_for_table_model(m->cell, m->hidden) &&
                chain_lds_bytes(p.max_frames) <= kChainLdsLimit && quad_lds_bytes(m->hidden, p.max_frames) <= 160 * 1024) {
-        kind = aidax_pool::QUAD;
-        wp = pack_quad(*m, &qd.bias_off, &qd.dense_off);
+        ms.kind = ModelSlot::QUAD;
+        wp = pack_quad(*m, &ms.qdesc.bias_off, &ms.qdesc.dense_off);
         state_floats = static_cast<uint32_t>(m->cell == AIDAX_CELL_LSTM ? 2 * m->hidden : m->hidden);
     } else if (mfma_form_fits(*m) && chain_lds_bytes(p.max_frames) <= kChainLdsLimit &&
                (is_stack_model(*m) ? p.force_form != 4 : p.mfma_for_table_model(m->cell, m->hidden))) {
-        kind = aidax_pool::MFMA;
-        wp = pack_mfma(*m, &md, &state_floats);
+        ms.kind = ModelSlot::MFMA;
+        wp = pack_mfma(*m, &ms.mdesc, &state_floats);
     } else if (is_stack_model(*m)) {
-        kind = aidax_pool::STACK;
-        wp = pack_stack(*m, &sd, &state_floats);
-        if (stack_lds_bytes(sd, p.max_frames) > 160 * 1024)
+        ms.kind = ModelSlot::STACK;
+        wp = pack_stack(*m, &ms.sdesc, &state_floats);
+        if (stack_lds_bytes(ms.sdesc, p.max_frames) > 160 * 1024)
             return fail(AIDAX_ERR_ARG, "stacked model: pool max_frames too large for the LDS block buffers");
     } else {
-        k = find_kernel(m->cell, m->hidden);
+        ms.kind = ModelSlot::TABLE;
+        ms.kernel = find_kernel(m->cell, m->hidden);
         wp = pack_weights(*m);
-        if (static_cast<int>(wp.size()) != k->pack_regs * kWave + m->hidden + 1) return fail(AIDAX_ERR_STATE, "weight pack size mismatch");
-        state_floats = static_cast<uint32_t>(k->state_floats);
+        if (static_cast<int>(wp.size()) != ms.kernel->pack_regs * kWave + m->hidden + 1) return fail(AIDAX_ERR_STATE, "weight pack size mismatch");
+        state_floats = static_cast<uint32_t>(ms.kernel->state_floats);
     }
+    ms.nn_stride = (state_floats + 3u) & ~3u;
+    ms.cell = m->cell;
+    ms.hidden = m->hidden;
+    ms.input_size = m->input_size;
+    ms.input_skip = m->input_skip;
+    ms.in_gain = m->input_gain;
+    ms.out_gain = m->output_gain;
+    ms.model_sr = m->samplerate;
+    ms.pipe_capacity = ms.kernel ? pipe_resident_streams(ms.kernel, p.max_frames, p.device) : 0;
+    ms.split_pays = ms.kernel ? split_form_pays(ms.kernel, p.max_frames) : false;
+    ms.has_model = true;
 
-    // model swaps are rare (worker thread); drain everything that may still read the old buffers
-    HIP_TRY(hipDeviceSynchronize());
-    float* new_w = nullptr;
-    float* new_nn = nullptr;
-    HIP_TRY(hipMalloc(&new_w, wp.size() * sizeof(float)));
-    HIP_TRY(hipMemcpyAsync(new_w, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice, p.q));
-    const uint32_t stride = (state_floats + 3u) & ~3u;
-    HIP_TRY(hipMalloc(&new_nn, static_cast<size_t>(p.n_streams) * stride * sizeof(float)));
-    HIP_TRY(hipStreamSynchronize(p.q));
-    if (p.d_wpack) (void)hipFree(p.d_wpack);
-    if (p.d_nn) (void)hipFree(p.d_nn);
-    p.d_wpack = new_w;
-    p.d_nn = new_nn;
-    p.nn_stride = stride;
-    p.kernel = k;
-    p.kind = kind;
-    p.sdesc = sd;
-    p.mdesc = md;
-    p.cdesc = cd;
-    p.qdesc = qd;
-    p.cell = m->cell;
-    p.conv_mfma = conv_mfma;
-    p.hidden = m->hidden;
-    p.input_size = m->input_size;
-    p.input_skip = m->input_skip;
-    p.in_gain = m->input_gain;
-    p.out_gain = m->output_gain;
-    p.model_sr = m->samplerate;
-
-    // fresh DynamicModel per stream: reset() + param smoothers around the inherited targets (:1035, :1053-1061)
-    HIP_TRY(launch_reset_for_model(p.d_st, p.d_nn, p.n_streams, p.nn_stride, p.p_den(), p.q));
-    p.has_model = true;
-    if (start_mode == AIDAX_START_WARMUP) {           // 2048 zeros through applyModel (:1077-1078)
-        const uint32_t chunk = p.launch_chunk(kWarmupFrames);
+    HIP_TRY(hipMalloc(&ms.d_wpack, wp.size() * sizeof(float)));
+    HIP_TRY(hipMalloc(&ms.d_nn, static_cast<size_t>(p.n_streams) * ms.nn_stride * sizeof(float)));
+    HIP_TRY(hipMalloc(&sg->d_pst, sizeof(StreamState) * p.n_streams));
+    HIP_TRY(hipMemcpyAsync(ms.d_wpack, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice, p.wq));
+    // fresh DynamicModel per stream: reset() + param smoothers around the targets the playing model holds now
+    // (:822-825, :1035, :1053-1061) ...
+    HIP_TRY(launch_stage_params(p.d_st, sg->d_pst, p.n_streams, p.wq));
+    HIP_TRY(launch_reset_for_model(sg->d_pst, ms.d_nn, p.n_streams, ms.nn_stride, ms.p_den(), p.wq));
+    if (start_mode == AIDAX_START_WARMUP) {               // ... and 2048 zeros through applyModel (:1077-1078)
+        const uint32_t chunk = p.launch_chunk(ms, kWarmupFrames);
         for (uint32_t done = 0; done < kWarmupFrames; done += chunk) {
-            LaunchArgs a = p.args(nullptr, nullptr, std::min(chunk, kWarmupFrames - done), MODE_WARMUP);
-            HIP_TRY(p.launch(a, p.q));
+            LaunchArgs a = p.args(ms, sg->d_pst, nullptr, nullptr, std::min(chunk, kWarmupFrames - done), MODE_WARMUP);
+            HIP_TRY(p.launch(ms, a, p.wq));
         }
     }
-    p.pipe_capacity = k ? pipe_resident_streams(k, p.max_frames, p.device) : 0;
-    p.split_pays = k ? split_form_pays(k, p.max_frames) : false;
-    p.has_model = true;
-    for (auto& l : p.loading) l = 0;                  // work_response: loading = false (:889)
-    p.refresh_all();
+    HIP_TRY(hipStreamSynchronize(p.wq));                  // `wp` is pageable; the audio side must find the model complete
+    *out = sg.release();
+    return AIDAX_OK;
+}
+
+// work_response() (:859-893): swap, loading = false. Audio thread: host assignments plus one tiny kernel on the
+// pool's stream; no allocation, no free, no wait.
+int commit_impl(aidax_pool& p, aidax_staged* sg)
+{
+    HIP_TRY(hipSetDevice(p.device));
+    p.enter_stream(p.q);
+    if (sg->slot.has_model) HIP_TRY(launch_install_params(p.d_st, sg->d_pst, p.n_streams, p.q));
+    HIP_TRY(hipEventRecord(sg->fence, p.q));              // the retired buffers are free once this has passed
+    sg->fenced = true;
+    std::swap(p.cur, sg->slot);
+    const uint8_t loading = p.cur.has_model ? 0 : 1;      // :889 (unload: loading = true)
+    for (uint32_t s = 0; s < p.n_streams; ++s) {
+        p.loading[s] = loading;
+        p.patch_model_fields(s);
+    }
+    p.mark_dirty(0, p.n_streams - 1);
     return AIDAX_OK;
 }
 
 }  // namespace
+
+namespace aidax {
+
+// aidax_pool_process_device over the first `n_active` streams only (rows of the others are neither read nor
+// written, their state does not move): the hub launches what can be attached, not the pool's capacity.
+int pool_process_prefix(aidax_pool* p, const float* d_in, float* d_out, uint32_t n_frames, void* hip_stream, uint32_t n_active)
+{
+    if (n_frames > p->max_frames) return fail(AIDAX_ERR_ARG, "n_frames exceeds the pool's max_frames");
+    if (n_frames != 0 && (!d_in || !d_out)) return fail(AIDAX_ERR_ARG, "null buffer");
+    if (n_active > p->n_streams) return fail(AIDAX_ERR_ARG, "n_active exceeds the pool's streams");
+    if (n_active == 0) return AIDAX_OK;
+    return guarded([&]() -> int {
+        HIP_TRY(hipSetDevice(p->device));
+        hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : p->q;
+        p->enter_stream(s);
+        p->flush_ctl(s);
+        LaunchArgs a = p->args(p->cur, p->d_st, d_in, d_out, n_frames, MODE_CHAIN);
+        a.n_streams = n_active;
+        HIP_TRY(p->launch(p->cur, a, s));
+        return AIDAX_OK;
+    });
+}
+
+}  // namespace aidax
 
 extern "C" {
 
@@ -375,16 +491,37 @@ AIDAX_API int aidax_pool_create(uint32_t n_streams, uint32_t max_frames, double 
         try {
             HIP_TRY(hipSetDevice(device_id));
             HIP_TRY(hipStreamCreateWithFlags(&p->q, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&p->wq, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&p->ev_x, hipEventDisableTiming));
             HIP_TRY(hipMalloc(&p->d_ctl, sizeof(StreamCtl) * n_streams));
             HIP_TRY(hipMalloc(&p->d_st, sizeof(StreamState) * n_streams));
-            HIP_TRY(hipMalloc(&p->d_in, sizeof(float) * n_streams * static_cast<size_t>(max_frames)));
-            HIP_TRY(hipMalloc(&p->d_out, sizeof(float) * n_streams * static_cast<size_t>(max_frames)));
+            const size_t block_bytes = sizeof(float) * n_streams * static_cast<size_t>(max_frames);
+            HIP_TRY(hipMalloc(&p->d_in, block_bytes));
+            HIP_TRY(hipMalloc(&p->d_out, block_bytes));
+            if (block_bytes <= kStagingLimit) {
+                HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_in), block_bytes, hipHostMallocDefault));
+                HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_out), block_bytes, hipHostMallocDefault));
+                const char* zc = std::getenv("AIDAX_ZEROCOPY");
+                if (block_bytes <= kZeroCopyLimit && !(zc && zc[0] == '0')) {
+                    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->hd_in), p->h_in, 0));
+                    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->hd_out), p->h_out, 0));
+                    p->zero_copy = true;
+                }
+            }
+            for (int k = 0; k < kCtlRing; ++k) {
+                HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->ctl_ring[k]), sizeof(StreamCtl) * n_streams, hipHostMallocDefault));
+                HIP_TRY(hipEventCreateWithFlags(&p->ctl_ev[k], hipEventDisableTiming));
+            }
             p->controls.resize(n_streams);
             for (auto& c : p->controls) aidax_controls_default(&c);
             p->loading.assign(n_streams, 1);
             p->h_ctl.resize(n_streams);
             p->refresh_all();
-            init_state(*p);
+            // instantiate(), rt-neural-generic.cpp:283-321: preGain target 1 cleared, masterGain target 0 cleared,
+            // biquad z = 0, no model, loading = true
+            HIP_TRY(launch_init_streams(p->d_st, n_streams, p->q));
+            HIP_TRY(hipStreamSynchronize(p->q));
+            p->last_stream = p->q;
         } catch (...) {
             p->release();
             throw;
@@ -398,18 +535,41 @@ AIDAX_API void aidax_pool_destroy(aidax_pool* p)
 {
     if (!p) return;
     (void)hipSetDevice(p->device);
+    if (p->last_stream && p->last_stream != p->q) (void)hipStreamSynchronize(p->last_stream);
     if (p->q) (void)hipStreamSynchronize(p->q);
+    if (p->wq) (void)hipStreamSynchronize(p->wq);
     p->release();
     delete p;
 }
 
 AIDAX_API uint32_t aidax_pool_streams(const aidax_pool* p) { return p ? p->n_streams : 0; }
 
+AIDAX_API int aidax_pool_prepare_model(aidax_pool* p, const aidax_model* m, int start_mode, aidax_staged** out)
+{
+    if (!p || !out) return fail(AIDAX_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (start_mode != AIDAX_START_WARMUP && start_mode != AIDAX_START_RESET) return fail(AIDAX_ERR_ARG, "bad start_mode");
+    return guarded([&]() { return prepare_impl(*p, m, start_mode, out); });
+}
+
+AIDAX_API int aidax_pool_commit_model(aidax_pool* p, aidax_staged* staged)
+{
+    if (!p || !staged) return fail(AIDAX_ERR_ARG, "null argument");
+    if (staged->fenced) return fail(AIDAX_ERR_STATE, "staged model was committed already");
+    if (staged->device != p->device || staged->n_streams != p->n_streams) return fail(AIDAX_ERR_ARG, "staged model belongs to another pool");
+    return guarded([&]() { return commit_impl(*p, staged); });
+}
+
+AIDAX_API void aidax_staged_free(aidax_staged* staged) { staged_release(staged); }
+
 AIDAX_API int aidax_pool_set_model(aidax_pool* p, const aidax_model* m, int start_mode)
 {
-    if (!p) return fail(AIDAX_ERR_ARG, "null pool");
-    if (start_mode != AIDAX_START_WARMUP && start_mode != AIDAX_START_RESET) return fail(AIDAX_ERR_ARG, "bad start_mode");
-    return guarded([&]() { return set_model_impl(*p, m, start_mode); });
+    aidax_staged* sg = nullptr;
+    int rc = aidax_pool_prepare_model(p, m, start_mode, &sg);
+    if (rc != AIDAX_OK) return rc;
+    rc = aidax_pool_commit_model(p, sg);
+    aidax_staged_free(sg);                                  // what the swap retired (or, on failure, the unused model)
+    return rc;
 }
 
 AIDAX_API int aidax_pool_reset_stream(aidax_pool* p, uint32_t stream, int start_mode)
@@ -419,26 +579,24 @@ AIDAX_API int aidax_pool_reset_stream(aidax_pool* p, uint32_t stream, int start_
     if (start_mode != AIDAX_START_WARMUP && start_mode != AIDAX_START_RESET) return fail(AIDAX_ERR_ARG, "bad start_mode");
     return guarded([&]() -> int {
         HIP_TRY(hipSetDevice(p->device));
-        StreamState st{};                                   // instantiate(), :283-321
-        st.pre_mem = 1.f; st.pre_tgt = 1.f;
-        HIP_TRY(hipMemcpyAsync(p->d_st + stream, &st, sizeof(st), hipMemcpyHostToDevice, p->q));
-        HIP_TRY(hipStreamSynchronize(p->q));                // `st` is a stack object
-        if (p->has_model) {
+        p->enter_stream(p->q);
+        const ModelSlot& m = p->cur;
+        HIP_TRY(launch_init_streams(p->d_st + stream, 1, p->q));      // instantiate(), :283-321
+        if (m.has_model) {
             // a fresh DynamicModel for this stream only: the launch arguments view the pool as one stream
-            HIP_TRY(launch_reset_for_model(p->d_st + stream, p->d_nn + static_cast<size_t>(stream) * p->nn_stride, 1,
-                                           p->nn_stride, p->p_den(), p->q));
+            HIP_TRY(launch_reset_for_model(p->d_st + stream, m.d_nn + static_cast<size_t>(stream) * m.nn_stride, 1,
+                                           m.nn_stride, m.p_den(), p->q));
             if (start_mode == AIDAX_START_WARMUP) {
-                const uint32_t chunk = p->launch_chunk(kWarmupFrames);
+                const uint32_t chunk = p->launch_chunk(m, kWarmupFrames);
                 for (uint32_t done = 0; done < kWarmupFrames; done += chunk) {
-                    LaunchArgs a = p->args(nullptr, nullptr, std::min(chunk, kWarmupFrames - done), MODE_WARMUP);
-                    a.ctl += stream; a.st += stream; a.nn += static_cast<size_t>(stream) * p->nn_stride;
+                    LaunchArgs a = p->args(m, p->d_st, nullptr, nullptr, std::min(chunk, kWarmupFrames - done), MODE_WARMUP);
+                    a.ctl += stream; a.st += stream; a.nn += static_cast<size_t>(stream) * m.nn_stride;
                     a.n_streams = 1;
-                    p->flush_ctl(p->q);
-                    HIP_TRY(p->launch(a, p->q));
+                    HIP_TRY(p->launch(m, a, p->q));
                 }
             }
         }
-        p->loading[stream] = p->has_model ? 0 : 1;
+        p->loading[stream] = m.has_model ? 0 : 1;
         p->refresh_ctl(stream);
         return AIDAX_OK;
     });
@@ -449,13 +607,13 @@ AIDAX_API int aidax_pool_set_loading(aidax_pool* p, int32_t stream, int loading)
     if (!p) return fail(AIDAX_ERR_ARG, "null pool");
     if (stream != AIDAX_ALL_STREAMS && (stream < 0 || static_cast<uint32_t>(stream) >= p->n_streams))
         return fail(AIDAX_ERR_ARG, "stream out of range");
-    if (stream == AIDAX_ALL_STREAMS) {
-        for (auto& l : p->loading) l = loading ? 1 : 0;
-        p->refresh_all();
-    } else {
-        p->loading[stream] = loading ? 1 : 0;
-        p->refresh_ctl(static_cast<uint32_t>(stream));
+    const uint32_t lo = stream == AIDAX_ALL_STREAMS ? 0u : static_cast<uint32_t>(stream);
+    const uint32_t hi = stream == AIDAX_ALL_STREAMS ? p->n_streams - 1 : static_cast<uint32_t>(stream);
+    for (uint32_t s = lo; s <= hi; ++s) {
+        p->loading[s] = loading ? 1 : 0;
+        p->patch_model_fields(s);
     }
+    p->mark_dirty(lo, hi);
     return AIDAX_OK;
 }
 
@@ -481,8 +639,9 @@ AIDAX_API int aidax_pool_activate(aidax_pool* p, int32_t stream)
         return fail(AIDAX_ERR_ARG, "stream out of range");
     return guarded([&]() -> int {
         HIP_TRY(hipSetDevice(p->device));
+        p->enter_stream(p->q);
         // paramFirstRun is only re-armed when a model exists (rt-neural-generic.cpp:344-351)
-        const uint32_t bits = PEND_ACTIVATE | (p->has_model ? PEND_PARAM_FIRST : 0u);
+        const uint32_t bits = PEND_ACTIVATE | (p->cur.has_model ? PEND_PARAM_FIRST : 0u);
         HIP_TRY(launch_set_pending(p->d_st, p->n_streams, stream, bits, p->q));
         return AIDAX_OK;
     });
@@ -491,16 +650,7 @@ AIDAX_API int aidax_pool_activate(aidax_pool* p, int32_t stream)
 AIDAX_API int aidax_pool_process_device(aidax_pool* p, const float* d_in, float* d_out, uint32_t n_frames, void* hip_stream)
 {
     if (!p) return fail(AIDAX_ERR_ARG, "null pool");
-    if (n_frames > p->max_frames) return fail(AIDAX_ERR_ARG, "n_frames exceeds the pool's max_frames");
-    if (n_frames != 0 && (!d_in || !d_out)) return fail(AIDAX_ERR_ARG, "null buffer");
-    return guarded([&]() -> int {
-        HIP_TRY(hipSetDevice(p->device));
-        hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : p->q;
-        p->flush_ctl(s);
-        LaunchArgs a = p->args(d_in, d_out, n_frames, MODE_CHAIN);
-        HIP_TRY(p->launch(a, s));
-        return AIDAX_OK;
-    });
+    return pool_process_prefix(p, d_in, d_out, n_frames, hip_stream, p->n_streams);
 }
 
 AIDAX_API int aidax_pool_process(aidax_pool* p, const float* in, float* out, uint32_t n_frames)
@@ -511,11 +661,31 @@ AIDAX_API int aidax_pool_process(aidax_pool* p, const float* in, float* out, uin
     return guarded([&]() -> int {
         HIP_TRY(hipSetDevice(p->device));
         const size_t bytes = sizeof(float) * p->n_streams * static_cast<size_t>(n_frames);
-        if (bytes) HIP_TRY(hipMemcpyAsync(p->d_in, in, bytes, hipMemcpyHostToDevice, p->q));
-        const int rc = aidax_pool_process_device(p, p->d_in, p->d_out, n_frames, p->q);
-        if (rc != AIDAX_OK) return rc;
-        if (bytes) HIP_TRY(hipMemcpyAsync(out, p->d_out, bytes, hipMemcpyDeviceToHost, p->q));
+        int rc;
+        if (!p->h_in) {                                     // blocks beyond the pinned staging: pageable copies
+            if (bytes) HIP_TRY(hipMemcpyAsync(p->d_in, in, bytes, hipMemcpyHostToDevice, p->q));
+            rc = aidax_pool_process_device(p, p->d_in, p->d_out, n_frames, p->q);
+            if (rc != AIDAX_OK) return rc;
+            if (bytes) HIP_TRY(hipMemcpyAsync(out, p->d_out, bytes, hipMemcpyDeviceToHost, p->q));
+            HIP_TRY(hipStreamSynchronize(p->q));
+            return AIDAX_OK;
+        }
+        if (bytes) std::memcpy(p->h_in, in, bytes);
+        if (p->zero_copy) {
+            // small blocks (the one-instance plugin): the pass reads its input straight from pinned host memory;
+            // a one-launch pass also writes its output there, a multi-launch pass works in place on d_out
+            const bool direct = p->single_launch(p->cur);
+            rc = aidax_pool_process_device(p, p->hd_in, direct ? p->hd_out : p->d_out, n_frames, p->q);
+            if (rc != AIDAX_OK) return rc;
+            if (!direct && bytes) HIP_TRY(hipMemcpyAsync(p->h_out, p->d_out, bytes, hipMemcpyDeviceToHost, p->q));
+        } else {
+            if (bytes) HIP_TRY(hipMemcpyAsync(p->d_in, p->h_in, bytes, hipMemcpyHostToDevice, p->q));
+            rc = aidax_pool_process_device(p, p->d_in, p->d_out, n_frames, p->q);
+            if (rc != AIDAX_OK) return rc;
+            if (bytes) HIP_TRY(hipMemcpyAsync(p->h_out, p->d_out, bytes, hipMemcpyDeviceToHost, p->q));
+        }
         HIP_TRY(hipStreamSynchronize(p->q));
+        if (bytes) std::memcpy(out, p->h_out, bytes);
         return AIDAX_OK;
     });
 }
@@ -533,23 +703,26 @@ AIDAX_API int aidax_pool_sync(aidax_pool* p)
 AIDAX_API int aidax_pool_read_state(aidax_pool* p, uint32_t stream, int layer, float* h, float* c, uint32_t cap)
 {
     if (!p || !h) return fail(AIDAX_ERR_ARG, "null argument");
-    if (!p->has_model || stream >= p->n_streams || p->kind == aidax_pool::CONV) return fail(AIDAX_ERR_STATE, "no such state");
-    const int n_layers = p->kind == aidax_pool::TABLE ? 1 : p->kind == aidax_pool::MFMA ? p->mdesc.n_layers : p->sdesc.n_layers;
+    const ModelSlot& m = p->cur;
+    if (!m.has_model || stream >= p->n_streams || m.kind == ModelSlot::CONV) return fail(AIDAX_ERR_STATE, "no such state");
+    // TABLE and QUAD pools keep one layer as h[H] | c[H] (pack_quad shares the table kernels' state layout)
+    const int n_layers = m.kind == ModelSlot::MFMA ? m.mdesc.n_layers : m.kind == ModelSlot::STACK ? m.sdesc.n_layers : 1;
     if (layer < 0 || layer >= n_layers) return fail(AIDAX_ERR_STATE, "no such layer");
     return guarded([&]() -> int {
         HIP_TRY(hipSetDevice(p->device));
+        if (p->last_stream && p->last_stream != p->q) HIP_TRY(hipStreamSynchronize(p->last_stream));
         HIP_TRY(hipStreamSynchronize(p->q));
-        uint32_t H = static_cast<uint32_t>(p->hidden), off = 0;
+        uint32_t H = static_cast<uint32_t>(m.hidden), off = 0;
         bool lstm = false;
-        if (p->kind == aidax_pool::STACK) {
-            H = static_cast<uint32_t>(p->sdesc.L[layer].hidden); off = p->sdesc.L[layer].state_off; lstm = p->sdesc.L[layer].cell == 0;
-        } else if (p->kind == aidax_pool::MFMA) {
-            H = static_cast<uint32_t>(p->mdesc.hidden_true); off = p->mdesc.L[layer].state_off; lstm = p->mdesc.L[layer].cell == 0;
+        if (m.kind == ModelSlot::STACK) {
+            H = static_cast<uint32_t>(m.sdesc.L[layer].hidden); off = m.sdesc.L[layer].state_off; lstm = m.sdesc.L[layer].cell == 0;
+        } else if (m.kind == ModelSlot::MFMA) {
+            H = static_cast<uint32_t>(m.mdesc.hidden_true); off = m.mdesc.L[layer].state_off; lstm = m.mdesc.L[layer].cell == 0;
         } else {
-            lstm = p->cell == AIDAX_CELL_LSTM;
+            lstm = m.cell == AIDAX_CELL_LSTM;
         }
         const uint32_t n = H < cap ? H : cap;
-        const float* base = p->d_nn + static_cast<size_t>(stream) * p->nn_stride + off;
+        const float* base = m.d_nn + static_cast<size_t>(stream) * m.nn_stride + off;
         HIP_TRY(hipMemcpy(h, base, n * sizeof(float), hipMemcpyDeviceToHost));
         if (c && lstm) HIP_TRY(hipMemcpy(c, base + H, n * sizeof(float), hipMemcpyDeviceToHost));
         return static_cast<int>(H);
@@ -558,13 +731,14 @@ AIDAX_API int aidax_pool_read_state(aidax_pool* p, uint32_t stream, int layer, f
 
 AIDAX_API const char* aidax_pool_kernel_name(const aidax_pool* p)
 {
-    if (!(p && p->has_model)) return "k_nomodel";
-    if (p->kind == aidax_pool::STACK) return "k_stack";
-    if (p->kind == aidax_pool::MFMA) return "k_chain+k_mfma";
-    if (p->kind == aidax_pool::QUAD) return "k_chain+k_quad";
-    if (p->kind == aidax_pool::CONV) return p->conv_mfma ? "k_chain+k_conv_mfma" : "k_conv";
-    const int form = p->chain_form();
-    return form == 1 ? p->kernel->name_pipe : form == 2 ? p->kernel->name_split : p->kernel->name;
+    if (!(p && p->cur.has_model)) return "k_nomodel";
+    const ModelSlot& m = p->cur;
+    if (m.kind == ModelSlot::STACK) return "k_stack";
+    if (m.kind == ModelSlot::MFMA) return "k_chain+k_mfma";
+    if (m.kind == ModelSlot::QUAD) return "k_chain+k_quad";
+    if (m.kind == ModelSlot::CONV) return m.conv_mfma ? "k_chain+k_conv_mfma" : "k_conv";
+    const int form = p->chain_form(m);
+    return form == 1 ? m.kernel->name_pipe : form == 2 ? m.kernel->name_split : m.kernel->name;
 }
 
 AIDAX_API int aidax_model_forward(const aidax_model* m, int device_id, const float* X, float* y, uint32_t n, int unit_gains)
@@ -583,12 +757,12 @@ AIDAX_API int aidax_model_forward(const aidax_model* m, int device_id, const flo
             HIP_TRY(hipMalloc(&d_y, sizeof(float) * (n ? n : 1)));
             HIP_TRY(hipMemcpyAsync(d_x, X, xb, hipMemcpyHostToDevice, p->q));
             hipError_t le = hipSuccess;
-            const uint32_t chunk = p->launch_chunk(n ? n : 1);
+            const uint32_t chunk = p->launch_chunk(p->cur, n ? n : 1);
             for (uint32_t done = 0; done < n && le == hipSuccess; done += chunk) {
-                LaunchArgs a = p->args(d_x + static_cast<size_t>(done) * m->input_size, d_y + done,
+                LaunchArgs a = p->args(p->cur, p->d_st, d_x + static_cast<size_t>(done) * m->input_size, d_y + done,
                                        std::min(chunk, n - done), MODE_NN_ONLY);
                 if (unit_gains) { a.in_gain = 1.f; a.out_gain = 1.f; }
-                le = p->launch(a, p->q);
+                le = p->launch(p->cur, a, p->q);
             }
             if (le == hipSuccess) {
                 (void)hipMemcpyAsync(y, d_y, sizeof(float) * n, hipMemcpyDeviceToHost, p->q);

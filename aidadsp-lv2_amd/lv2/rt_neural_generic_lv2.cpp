@@ -14,6 +14,12 @@
 // All DSP (run() :621-659) happens on the GPU behind aidax_pool_process(); each plugin instance
 // is one stream of a one-stream pool. There is no CPU fallback: without a usable HIP device
 // instantiate() returns NULL, like the reference does for a missing host feature (:265-273).
+//
+// Threads, as in the reference: work() (worker thread) loads the json AND prepares the model on the GPU —
+// weight upload, state reset, 2048-frame warm-up, every allocation (aidax_pool_prepare_model, or the hub seat
+// in hub mode); work_response() (audio thread) only swaps handles (aidax_pool_commit_model: no allocation, no
+// free, no wait) and hands the old model back to the worker for deletion (kWorkerFree). run() waits for nothing
+// but the stream that carries its own block.
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -32,16 +38,20 @@
 
 namespace {
 
+// LATENCY (index 25) is not in the reference: the lv2:reportsLatency output (one period in hub mode / else 0).
+// Hosts that follow the reference's TTL never connect it.
 enum PortIndex {   // ports_t, rt-neural-generic.h:84-112 (generic build)
     IN = 0, OUT_1, PLUGIN_CONTROL, PLUGIN_NOTIFY, IN_LPF, PREGAIN, NET_BYPASS, PARAM1, PARAM2,
     EQ_BYPASS, EQ_POS, BASS, BFREQ, MID, MFREQ, MIDQ, MTYPE, TREBLE, TFREQ, DEPTH, PRESENCE,
-    DCBLOCKER, MASTER, INPUT_SIZE, PLUGIN_ENABLED, PLUGIN_PORT_COUNT
+    DCBLOCKER, MASTER, INPUT_SIZE, PLUGIN_ENABLED, LATENCY, PLUGIN_PORT_COUNT
 };
 
 enum WorkerMessageType { kWorkerLoad, kWorkerApply, kWorkerFree };          // rt-neural-generic.h:132-136
 struct WorkerMessage { WorkerMessageType type; };
 struct WorkerLoadMessage { WorkerMessageType type; char path[1024]; };      // :144-151
-struct WorkerApplyMessage { WorkerMessageType type; aidax_model* model; };  // :154-157 with the C-ABI model handle
+// :154-157 with the C-ABI handles: the model, what aidax_pool_prepare_model staged for it (after the swap: what the
+// swap retired), and in hub mode the seat (hub, slot) the worker attached for this instance
+struct WorkerApplyMessage { WorkerMessageType type; aidax_model* model; aidax_staged* staged; aidax_hub* hub; int32_t slot; };
 
 struct PluginURIs {   // uris.h:33-48
     LV2_URID atom_Float, atom_Path, atom_Resource, atom_Sequence, atom_URID, atom_eventTransfer;
@@ -58,6 +68,7 @@ struct Plugin {
     LV2_Atom_Sequence* notify_port = nullptr;
     const float* ctl[PLUGIN_PORT_COUNT] = {};
     float* input_size = nullptr;
+    float* latency = nullptr;
 
     // features
     LV2_URID_Map* map = nullptr;
@@ -74,9 +85,11 @@ struct Plugin {
     // pass per audio period through aidax_hub, at one period of latency
     int hub_capacity = 0;
     int device = 0;
+    bool strict = true;              // only the reference's 54 architectures (AIDAX_STRICT_REFERENCE_SET=0 lifts it)
+    uint32_t max_frames = 8192;      // of this instance's pool: longer host blocks are processed in chunks
+    uint32_t error_count = 0;
     aidax_hub* hub = nullptr;
     int32_t slot = -1;
-    std::string hub_key;
 
     aidax_controls last_controls{};
     bool have_last_controls = false;
@@ -93,22 +106,24 @@ struct HubRef { aidax_hub* hub; int refs; };
 std::mutex g_hub_mu;
 std::map<std::string, HubRef> g_hubs;
 
-void hub_leave(Plugin* self)
+// worker / main thread: give a seat back; the last one out destroys the hub
+void hub_leave(aidax_hub* hub, int32_t slot)
 {
-    if (!self->hub) return;
+    if (!hub) return;
     std::lock_guard<std::mutex> g(g_hub_mu);
-    aidax_hub_detach(self->hub, self->slot);
-    auto it = g_hubs.find(self->hub_key);
-    if (it != g_hubs.end() && --it->second.refs == 0) {
-        aidax_hub_destroy(it->second.hub);
-        g_hubs.erase(it);
+    aidax_hub_detach(hub, slot);
+    for (auto it = g_hubs.begin(); it != g_hubs.end(); ++it) {
+        if (it->second.hub != hub) continue;
+        if (--it->second.refs == 0) {
+            aidax_hub_destroy(hub);
+            g_hubs.erase(it);
+        }
+        return;
     }
-    self->hub = nullptr;
-    self->slot = -1;
 }
 
-// attach to the hub of `model`'s file, creating it (weights upload + warm-up) for the first instance
-bool hub_join(Plugin* self, const aidax_model* model)
+// worker thread: a seat in the hub of `model`'s file, creating the hub (weights upload + warm-up) for the first instance
+bool hub_join(Plugin* self, const aidax_model* model, aidax_hub** hub_out, int32_t* slot_out)
 {
     const std::string key = aidax_model_path(model);
     std::lock_guard<std::mutex> g(g_hub_mu);
@@ -119,6 +134,7 @@ bool hub_join(Plugin* self, const aidax_model* model)
         const uint32_t max_frames = fr ? static_cast<uint32_t>(std::atoi(fr)) : 2048u;
         if (aidax_hub_create(static_cast<uint32_t>(self->hub_capacity), max_frames, self->samplerate, self->device, &hub) != AIDAX_OK)
             return false;
+        if (const char* dl = std::getenv("AIDAX_HUB_DEADLINE_US")) aidax_hub_set_deadline_us(hub, std::atoll(dl));
         if (aidax_hub_set_model(hub, model, AIDAX_START_WARMUP) != AIDAX_OK) { aidax_hub_destroy(hub); return false; }
         it = g_hubs.emplace(key, HubRef{ hub, 0 }).first;
     }
@@ -128,9 +144,8 @@ bool hub_join(Plugin* self, const aidax_model* model)
         return false;
     }
     ++it->second.refs;
-    self->hub = it->second.hub;
-    self->slot = slot;
-    self->hub_key = key;
+    *hub_out = it->second.hub;
+    *slot_out = slot;
     return true;
 }
 
@@ -243,8 +258,13 @@ LV2_Handle instantiate(const LV2_Descriptor*, double samplerate, const char*, co
     const char* hub = std::getenv("AIDAX_HUB");
     self->hub_capacity = hub ? std::atoi(hub) : 0;
     self->device = device;
+    const char* strict = std::getenv("AIDAX_STRICT_REFERENCE_SET");
+    self->strict = !(strict && strict[0] == '0');
+    // the extension architectures stage whole blocks in LDS: they take pools of <= 256 frames (longer host blocks
+    // are chunked in run()); the reference's own model table runs on 8192-frame pools
+    self->max_frames = self->strict ? 8192u : 256u;
     // default mode: the instance's own one-stream pool; hub mode: the same call only proves there is a device
-    if (aidax_pool_create(1, self->hub_capacity > 1 ? 4 : 8192, samplerate, device, &self->pool) != AIDAX_OK) {
+    if (aidax_pool_create(1, self->hub_capacity > 1 ? 4 : self->max_frames, samplerate, device, &self->pool) != AIDAX_OK) {
         std::fprintf(stderr, "Error! %s\n", aidax_last_error());
         delete self;
         return nullptr;
@@ -268,6 +288,7 @@ void connect_port(LV2_Handle instance, uint32_t port, void* data)
     case PLUGIN_CONTROL: self->control_port = static_cast<const LV2_Atom_Sequence*>(data); break;
     case PLUGIN_NOTIFY: self->notify_port = static_cast<LV2_Atom_Sequence*>(data); break;
     case INPUT_SIZE: self->input_size = static_cast<float*>(data); break;
+    case LATENCY: self->latency = static_cast<float*>(data); break;
     default:
         if (port < PLUGIN_PORT_COUNT) self->ctl[port] = static_cast<const float*>(data);
         break;
@@ -378,23 +399,37 @@ void run(LV2_Handle instance, uint32_t n_samples)
     // ---- DSP: control latch, then the whole run() audio section on the GPU (:489-518, :607-659).
     // n_samples == 0 (pre-run) and !enabled (raw copy) are handled inside the pass.
     latch_controls(self);
+    int rc = AIDAX_OK;
     if (self->pool) {
-        if (aidax_pool_process(self->pool, self->in, self->out_1, n_samples) != AIDAX_OK)
-            plog(self, uris->log_Error, "aidax: %s\n", aidax_last_error());
+        // host blocks longer than the pool's max_frames go through in chunks (state carries over, like any two calls)
+        uint32_t done = 0;
+        do {
+            const uint32_t cnt = std::min(n_samples - done, self->max_frames);
+            rc = aidax_pool_process(self->pool, self->in + done, self->out_1 + done, cnt);
+            done += cnt;
+        } while (rc == AIDAX_OK && done < n_samples);
     } else if (self->hub) {
-        if (aidax_hub_run(self->hub, self->slot, self->in, self->out_1, n_samples) != AIDAX_OK)
-            plog(self, uris->log_Error, "aidax: %s\n", aidax_last_error());
+        rc = aidax_hub_run(self->hub, self->slot, self->in, self->out_1, n_samples);
     } else if (n_samples != 0) {
         // hub mode before the first model: the master gain rests at 0 (:306-310), a disabled plugin copies (:612-619)
         if (self->last_controls.enabled > 0.5f) std::memset(self->out_1, 0, sizeof(float) * n_samples);
         else if (self->out_1 != self->in) std::memcpy(self->out_1, self->in, sizeof(float) * n_samples);
     }
+    if (rc != AIDAX_OK) {
+        // never leave the host's buffer unwritten: silence, or the dry signal when the plugin is disabled
+        if (n_samples != 0) {
+            if (self->last_controls.enabled > 0.5f) std::memset(self->out_1, 0, sizeof(float) * n_samples);
+            else if (self->out_1 != self->in) std::memmove(self->out_1, self->in, sizeof(float) * n_samples);
+        }
+        if ((self->error_count++ & 1023u) == 0) plog(self, uris->log_Error, "aidax: %s\n", aidax_last_error());
+    }
+    if (self->latency) *self->latency = self->hub ? static_cast<float>(aidax_hub_latency_frames(self->hub)) : 0.f;
 }
 
 void cleanup(LV2_Handle instance)
 {
     Plugin* self = static_cast<Plugin*>(instance);
-    hub_leave(self);
+    hub_leave(self->hub, self->slot);
     aidax_pool_destroy(self->pool);
     aidax_model_free(self->model);
     delete self;
@@ -456,24 +491,43 @@ LV2_Worker_Status work(LV2_Handle instance, LV2_Worker_Respond_Function respond,
     case kWorkerLoad: {
         const char* path = static_cast<const WorkerLoadMessage*>(data)->path;
         aidax_model* m = nullptr;
-        if (aidax_model_load(path, &m) == AIDAX_OK) {
-            aidax_model_info_t info;
-            aidax_model_info(m, &info);
-            self->last_input_size = info.input_size;          // cached for the ModelInSize port (:1082)
-            plog(self, self->uris.log_Note, "Successfully loaded json file: %s\n", path);
-            WorkerApplyMessage reply = { kWorkerApply, m };
-            respond(handle, sizeof(reply), &reply);
-        } else {
+        if (aidax_model_load(path, &m) != AIDAX_OK) {
             // no reply: the old model keeps playing but `loading` stays set, so the master ramps to 0 (:576, :654)
             plog(self, self->uris.log_Error, "%s\n", aidax_last_error());
+            return LV2_WORKER_SUCCESS;
         }
+        aidax_model_info_t info;
+        aidax_model_info(m, &info);
+        if (self->strict && !info.in_reference_set) {            // custom_model_creator fails (:1025-1026)
+            plog(self, self->uris.log_Error, "Error loading model: Unable to identify a known model architecture!\n");
+            aidax_model_free(m);
+            return LV2_WORKER_SUCCESS;
+        }
+        // the device half of loadModelFromPath (:1034-1079), still on the worker: upload, reset, PARAM smoothers
+        // around the playing model's targets (:822-825), 2048-zero warm-up
+        WorkerApplyMessage reply = { kWorkerApply, m, nullptr, nullptr, -1 };
+        bool ready;
+        if (self->pool) ready = aidax_pool_prepare_model(self->pool, m, AIDAX_START_WARMUP, &reply.staged) == AIDAX_OK;
+        else ready = hub_join(self, m, &reply.hub, &reply.slot);
+        if (!ready) {
+            plog(self, self->uris.log_Error, "aidax: %s\n", aidax_last_error());
+            aidax_model_free(m);
+            return LV2_WORKER_SUCCESS;
+        }
+        self->last_input_size = info.input_size;                 // cached for the ModelInSize port (:1082)
+        plog(self, self->uris.log_Note, "Successfully loaded json file: %s\n", path);
+        respond(handle, sizeof(reply), &reply);
         return LV2_WORKER_SUCCESS;
     }
-    case kWorkerFree:
-        aidax_model_free(static_cast<const WorkerApplyMessage*>(data)->model);
+    case kWorkerFree: {
+        const WorkerApplyMessage* old = static_cast<const WorkerApplyMessage*>(data);
+        aidax_model_free(old->model);                             // freeModel (:838-840)
+        aidax_staged_free(old->staged);                           // the device buffers the swap retired
+        hub_leave(old->hub, old->slot);
         return LV2_WORKER_SUCCESS;
+    }
     case kWorkerApply:
-        break;                                                // should not happen
+        break;                                                    // should not happen
     }
     return LV2_WORKER_ERR_UNKNOWN;
 }
@@ -483,22 +537,30 @@ LV2_Worker_Status work_response(LV2_Handle instance, uint32_t, const void* data)
     Plugin* self = static_cast<Plugin*>(instance);
     const WorkerMessage* msg = static_cast<const WorkerMessage*>(data);
     if (msg->type != kWorkerApply) return LV2_WORKER_ERR_UNKNOWN;
+    const WorkerApplyMessage* apply = static_cast<const WorkerApplyMessage*>(data);
 
-    WorkerApplyMessage reply = { kWorkerFree, self->model };  // old model goes back to the worker for deletion
-    self->model = static_cast<const WorkerApplyMessage*>(data)->model;
-    // swap: weights to the GPU, reset(), inherited PARAM targets, 2048-zero warm-up (:1046-1079)
+    // swap (:868-875): handles only. The old model, the buffers the swap retires and (hub mode) the old seat go
+    // back to the worker for deletion.
+    WorkerApplyMessage reply = { kWorkerFree, self->model, apply->staged, self->hub, self->slot };
     if (self->pool) {
-        if (aidax_pool_set_model(self->pool, self->model, AIDAX_START_WARMUP) != AIDAX_OK)
+        if (aidax_pool_commit_model(self->pool, apply->staged) != AIDAX_OK) {
+            // cannot happen with a staged object of this pool; keep the old model, give the new one back
             plog(self, self->uris.log_Error, "aidax: %s\n", aidax_last_error());
-    } else {                                                  // hub mode: move to the hub that plays this file
-        hub_leave(self);
-        if (!hub_join(self, self->model)) plog(self, self->uris.log_Error, "aidax: %s\n", aidax_last_error());
+            reply.model = apply->model;
+            self->schedule->schedule_work(self->schedule->handle, sizeof(reply), &reply);
+            return LV2_WORKER_SUCCESS;
+        }
+    } else {
+        self->hub = apply->hub;
+        self->slot = apply->slot;
         self->last_loading = false;                           // a freshly attached stream is not loading
     }
+    self->model = apply->model;
     self->schedule->schedule_work(self->schedule->handle, sizeof(reply), &reply);
     plog(self, self->uris.log_Trace, "New model in use\n");
     notify_set_file(self, aidax_model_path(self->model));    // report change to host/ui (:880-887)
     self->loading = false;                                    // :889
+    self->last_loading = false;                               // the commit cleared the pool's flag as well
     plog(self, self->uris.log_Trace, "loading = false\n");
     return LV2_WORKER_SUCCESS;
 }

@@ -71,7 +71,10 @@ typedef struct {
 } aidax_model_info_t;
 
 /* loadModelFromPath, parse + architecture match half (rt-neural-generic.cpp:963-1044).
- * Host only; does not touch the GPU. */
+ * Host only; does not touch the GPU. Besides the reference's 54 variants this build loads its extension
+ * architectures (n_rnn_layers > 1, wider single layers, conv1d stacks; in_reference_set == 0); with
+ * AIDAX_STRICT_REFERENCE_SET=1 in the environment those are rejected with the reference's own message
+ * (:1025-1026). The LV2 shell applies that rule by default (AIDAX_STRICT_REFERENCE_SET=0 lifts it). */
 AIDAX_API int  aidax_model_load(const char* json_path, aidax_model** out);
 AIDAX_API int  aidax_model_load_memory(const char* json_text, size_t len, const char* label, aidax_model** out);
 AIDAX_API int  aidax_model_info(const aidax_model* m, aidax_model_info_t* info);
@@ -136,12 +139,31 @@ AIDAX_API int  aidax_pool_create(uint32_t n_streams, uint32_t max_frames, double
 AIDAX_API void aidax_pool_destroy(aidax_pool* p);                         /* cleanup() :664-677 */
 AIDAX_API uint32_t aidax_pool_streams(const aidax_pool* p);
 
-/* work() + work_response() for every stream of the pool (:807-893): upload the
- * weights, reset the recurrent state, inherit each stream's PARAM1/2 targets
- * into fresh param smoothers (:822-825, :1053-1061), run the warm-up per
- * start_mode, swap, and clear `loading`. model == NULL unloads (loading = true).
- * The pool keeps its own copy of the weights; the caller still owns `m`. */
+/* Model swap, split the way the reference splits it between its two threads (:807-893).
+ *
+ * aidax_pool_prepare_model — work() / loadModelFromPath's device half (:822-836, :1034-1079), WORKER thread:
+ *   packs the weights for the kernel form this pool will use, allocates and uploads them, gives every stream
+ *   a fresh DynamicModel (reset(), PARAM smoothers rebuilt around the targets the playing model holds at that
+ *   moment, :822-825 and :1053-1061) and runs the warm-up per start_mode — all into buffers of its own, on a
+ *   stream of its own, while the audio thread keeps playing the old model. Blocks until the model is complete.
+ *   model == NULL prepares an unload (no model, loading = true). The caller still owns `m`.
+ * aidax_pool_commit_model — work_response() (:859-893), AUDIO thread: swaps the prepared model in and clears
+ *   `loading`. Host assignments plus one small kernel on the pool's stream: no allocation, no free, no wait of
+ *   any kind. After the call `staged` holds what the swap retired (the previous model's buffers);
+ * aidax_staged_free — the reference's kWorkerFree leg (:838-840, :868-875), WORKER thread: frees a staged
+ *   object (the retired buffers after a commit; the unused model if it was never committed).
+ * aidax_pool_set_model is prepare + commit + free in one blocking call, for hosts without a worker. */
+typedef struct aidax_staged aidax_staged;
+AIDAX_API int  aidax_pool_prepare_model(aidax_pool* p, const aidax_model* m, int start_mode, aidax_staged** out);
+AIDAX_API int  aidax_pool_commit_model(aidax_pool* p, aidax_staged* staged);
+AIDAX_API void aidax_staged_free(aidax_staged* staged);
 AIDAX_API int  aidax_pool_set_model(aidax_pool* p, const aidax_model* m, int start_mode);
+
+/* Threads. A pool is driven by ONE audio-side caller at a time (set_controls, set_loading, activate,
+ * reset_stream, commit_model, process*, sync) plus, concurrently, ONE worker-side caller (prepare_model,
+ * staged_free). None of the audio-side calls allocates or frees device or pinned memory, and only
+ * aidax_pool_process / aidax_pool_sync wait for the GPU (for the stream that carries the pass, never for the
+ * device). */
 
 /* One stream becomes a fresh plugin instance with the pool's model: instantiate() state for its DSP
  * members (:283-321; gain smoothers pre = 1 / master = 0 cleared, biquad states 0) and a fresh DynamicModel
@@ -162,12 +184,17 @@ AIDAX_API int  aidax_pool_set_controls(aidax_pool* p, int32_t stream, const aida
 AIDAX_API int  aidax_pool_activate(aidax_pool* p, int32_t stream);
 
 /* run(), audio half (:607-659), for all streams: `in`/`out` are host buffers
- * laid out [n_streams][n_frames] (in-place allowed). Blocking. n_frames == 0 is
- * the legal "pre-run" (:606-609) and only latches targets. */
+ * laid out [n_streams][n_frames] (in-place allowed). Blocking: waits for the pool's stream. n_frames == 0 is
+ * the legal "pre-run" (:606-609) and only latches targets. The block travels through pinned staging that the
+ * pool allocated at creation (blocks of <= 64 KiB — the one-instance plugin — are read and written by the
+ * kernels in place in pinned host memory, no copy engine involved; AIDAX_ZEROCOPY=0 turns that off). */
 AIDAX_API int  aidax_pool_process(aidax_pool* p, const float* in, float* out, uint32_t n_frames);
 
 /* Same pass with device-resident buffers, asynchronous on `hip_stream`
- * (a hipStream_t; NULL = the pool's own stream). No host sync inside. */
+ * (a hipStream_t; NULL = the pool's own stream). No host sync inside. The pool's control pokes (activate,
+ * reset_stream, commit_model) run on its own stream; when consecutive operations sit on different streams the
+ * pool puts an event edge between them, so program order is kept. A stream handed in here must stay valid
+ * until a later call names another one (or NULL), or the pool is destroyed. */
 AIDAX_API int  aidax_pool_process_device(aidax_pool* p, const float* d_in, float* d_out,
                                          uint32_t n_frames, void* hip_stream);
 AIDAX_API int  aidax_pool_sync(aidax_pool* p);
@@ -201,10 +228,13 @@ AIDAX_API const char* aidax_pool_kernel_name(const aidax_pool* p);
  * Hosts call the instances of a period one after another on one thread, or in parallel on several; a
  * rendezvous inside run() would deadlock the first kind, so the hub is pipelined by ONE period instead:
  * run() of period p stages the instance's input block and returns the output of period p-1 (silence in the
- * first period). The pass of a period is launched (asynchronously: H2D, kernels, D2H) by whichever
- * instance submits last; an instance that comes around again before everybody submitted (a host that
- * skipped somebody) or a change of block size launches what is there - streams that did not submit do not
- * advance. Report aidax_hub_latency_frames() to the host as the plugin's latency. Thread-safe. */
+ * first period). The pass of a period is launched (asynchronously: H2D, kernels, D2H) by the hub's launcher
+ * thread as soon as every attached instance has submitted — or when the period's DEADLINE passes (by default a
+ * quarter of the period after its first submission, aidax_hub_set_deadline_us), so an instance that stalls or
+ * stops calling cannot hold the others: they keep their one period of latency, the straggler's stream simply
+ * does not advance in that pass. An instance that comes around again before the period was closed, or a change
+ * of block size, closes it on the spot. run() itself waits only for the event of the previous period's pass,
+ * outside the hub's lock. Report aidax_hub_latency_frames() to the host as the plugin's latency. Thread-safe. */
 typedef struct aidax_hub aidax_hub;
 
 AIDAX_API int  aidax_hub_create(uint32_t max_instances, uint32_t max_frames, double host_samplerate,
@@ -221,10 +251,17 @@ AIDAX_API int  aidax_hub_set_loading(aidax_hub* h, int32_t slot, int loading);
 AIDAX_API int  aidax_hub_activate(aidax_hub* h, int32_t slot);
 /* the instance's run(): in/out are its n_frames-long port buffers (may alias) */
 AIDAX_API int  aidax_hub_run(aidax_hub* h, int32_t slot, const float* in, float* out, uint32_t n_frames);
+/* deadline of a period, measured from its first submission: < 0 a quarter of the period (default), 0 none
+ * (passes are launched only when everybody submitted, on re-entry, or by aidax_hub_flush) */
+AIDAX_API int  aidax_hub_set_deadline_us(aidax_hub* h, int64_t microseconds);
+/* close the period being collected now (hosts that know their graph is done; tests) */
+AIDAX_API int  aidax_hub_flush(aidax_hub* h);
 AIDAX_API uint32_t aidax_hub_latency_frames(const aidax_hub* h);
 AIDAX_API uint32_t aidax_hub_attached(const aidax_hub* h);
 /* number of pool passes launched so far (tests, statistics) */
 AIDAX_API uint64_t aidax_hub_launches(const aidax_hub* h);
+/* ... of which were launched by the deadline with somebody missing */
+AIDAX_API uint64_t aidax_hub_deadline_launches(const aidax_hub* h);
 
 #ifdef __cplusplus
 }

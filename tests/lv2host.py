@@ -8,10 +8,11 @@ import struct
 
 import numpy as np
 
-try:                                   # one HIP runtime per test process: see aidadsp-lv2_amd/binding.py lib()
-    import torch  # noqa: F401
-except Exception:
-    pass
+if not os.environ.get("AIDAX_NO_TORCH"):   # one HIP runtime per test process: see aidadsp-lv2_amd/binding.py lib()
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SO = os.path.join(ROOT, "aidadsp-lv2_amd", "lv2", "rt-neural-generic.so")
@@ -118,8 +119,8 @@ def features_array(feats):
 class Host:
     """One plugin instance plus everything the host side must own."""
 
-    def __init__(self, samplerate=48000.0, bundle_dir=None, with_map=True, with_schedule=True, block=256):
-        self.lib = C.CDLL(SO)
+    def __init__(self, samplerate=48000.0, bundle_dir=None, with_map=True, with_schedule=True, block=256, so=None):
+        self.lib = C.CDLL(so or SO)
         self.lib.lv2_descriptor.restype = C.POINTER(Descriptor)
         self.lib.lv2_descriptor.argtypes = [C.c_uint32]
         self.desc = self.lib.lv2_descriptor(0).contents

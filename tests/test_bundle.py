@@ -1,13 +1,16 @@
 """tools/make_bundle.py: the generated bundle describes the same ports the shell
 implements, with the defaults the C ABI uses, and ships the default model its state block points at."""
 import importlib
+import json
 import os
 import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import make_bundle  # noqa: E402
+import make_ports_json  # noqa: E402
 
 ax = importlib.import_module("aidadsp-lv2_amd")
 
@@ -23,9 +26,9 @@ def test_generated_ttl_matches_shell_and_abi_defaults(tmp_path):
     bundle = make_bundle.make_bundle(str(tmp_path), binaries=False)
     ttl = open(os.path.join(bundle, "rt-neural-generic.ttl")).read()
     ports = re.findall(r"lv2:index (\d+) ;\s*lv2:symbol \"([^\"]+)\"", ttl)
-    assert [int(i) for i, _ in ports] == list(range(25))
+    assert [int(i) for i, _ in ports] == list(range(26))
     enum = _shell_port_enum()
-    assert len(enum) == 25
+    assert len(enum) == 26 and enum[25] == "LATENCY" and ports[25][1] == "latency"
     # spot anchors between the shell's enum and the symbols hosts see
     sym = [s for _, s in ports]
     for name, symbol in (("IN", "IN"), ("OUT_1", "OUT"), ("PLUGIN_CONTROL", "CONTROL"), ("PLUGIN_NOTIFY", "NOTIFY"),
@@ -50,3 +53,24 @@ def test_bundle_layout(tmp_path):
     assert len(os.listdir(os.path.join(bundle, "models", "deer ink studios"))) == 6
     m = ax.Model(os.path.join(bundle, make_bundle.DEFAULT_MODEL))          # loads through the C ABI
     assert (m.info.cell, m.info.hidden, m.info.input_size) == (0, 12, 1)
+
+
+def test_generated_ttl_carries_the_reference_port_table(tmp_path):
+    """tests/golden/ports.json is the port table of the REFERENCE's rt-neural-generic.ttl:61-317 (extracted by
+    tests/golden/make_ports_json.py). The generated description, read back through the same parser, must carry
+    exactly those 25 ports (index, symbol, name, types, default, range, unit, properties, designation, scale
+    points), the same required features / extension data and the same default state; the one extra port sits
+    behind them."""
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "ports.json")))
+    bundle = make_bundle.make_bundle(str(tmp_path), binaries=False)
+    got = make_ports_json.parse_ttl(open(os.path.join(bundle, "rt-neural-generic.ttl")).read())
+    assert got["plugin_uri"] == want["plugin_uri"]
+    assert got["required_features"] == want["required_features"]
+    assert got["extension_data"] == want["extension_data"]
+    assert got["default_state"] == want["default_state"]
+    assert len(want["ports"]) == 25 and len(got["ports"]) == 26
+    for g, w in zip(got["ports"], want["ports"]):
+        assert g == w, (w["index"], g, w)
+    extra = got["ports"][25]
+    assert extra["symbol"] == "latency" and "reportsLatency" in extra["properties"] and extra["designation"] == "latency"
+    assert "lv2:OutputPort" in extra["types"]

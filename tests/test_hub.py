@@ -1,7 +1,10 @@
 """aidax_hub: many plugin instances of one process share one pool pass per audio
 period, pipelined by one period. The oracle's plugin mirror, one per instance, is the reference."""
 import importlib
+import os
+import subprocess
 import threading
+import time
 
 import numpy as np
 import pytest
@@ -40,6 +43,7 @@ def test_sequential_host_one_period_of_latency(tmp_path):
     N, n, periods = 5, 128, 9
     hub = ax.Hub(8, 256)
     hub.set_model(m)
+    hub.set_deadline_us(0)                 # a python host may dawdle between two instances: no deadline here
     slots = [hub.attach() for _ in range(N)]
     assert sorted(slots) == list(range(N)) and hub.attached == N
     plugs = [_oracle_instance(spec) for _ in range(N)]
@@ -54,7 +58,8 @@ def test_sequential_host_one_period_of_latency(tmp_path):
             else:
                 assert np.abs(got - prev[i]).max() < THR * 2, (p, i, np.abs(got - prev[i]).max())
             prev[i] = plugs[i].run(O.default_controls(**KWS[i]), x[i, p * n:(p + 1) * n])
-    assert hub.launches == periods and hub.latency_frames == n
+    hub.flush()                            # the launcher thread may still be on its way to the last period
+    assert hub.launches == periods and hub.latency_frames == n and hub.deadline_launches == 0
 
 
 def test_parallel_host_threads(tmp_path):
@@ -63,6 +68,7 @@ def test_parallel_host_threads(tmp_path):
     N, n, periods = 4, 64, 12
     hub = ax.Hub(N, 64)
     hub.set_model(m)
+    hub.set_deadline_us(0)
     slots = [hub.attach() for _ in range(N)]
     x = modelgen.signal(N, n * periods, seed=32)
     got = np.zeros((N, n * periods), np.float32)
@@ -88,6 +94,7 @@ def test_parallel_host_threads(tmp_path):
         want = _oracle_instance(spec).run(O.default_controls(), x[i])
         assert np.all(got[i, :n] == 0.0)
         assert np.abs(got[i, n:] - want[:-n]).max() < THR * 2
+    hub.flush()
     assert hub.launches == periods
 
 
@@ -96,6 +103,7 @@ def test_skipped_instance_does_not_advance_and_late_attach_starts_fresh(tmp_path
     n = 96
     hub = ax.Hub(4, 128)
     hub.set_model(m)
+    hub.set_deadline_us(0)
     a, b = hub.attach(), hub.attach()
     pa, pb = _oracle_instance(spec), _oracle_instance(spec)
     x = modelgen.signal(3, n * 8, seed=33)
@@ -145,3 +153,82 @@ def test_pool_reset_stream_matches_a_fresh_instance(tmp_path):
     c = O.default_controls()
     cont.run(c, x[0, :128])
     assert np.abs(got[0] - cont.run(c, x[0, 128:256])).max() < THR * 2      # neighbours are untouched
+
+
+def test_deadline_one_stalled_instance_does_not_hold_the_others(tmp_path):
+    """Three instances, real-time pacing; the third stops calling run() after period 3. Without a deadline its
+    period would stay open until somebody comes around again; with it (here 2 ms after the period's first
+    submission) the pass is launched without the straggler: the other two keep exactly one period of latency
+    and find their output ready when they come around."""
+    m, spec = _model(tmp_path, kind="lstm", hidden=16, input_size=1, seed=14)
+    n, periods = 256, 10
+    hub = ax.Hub(4, 256)
+    hub.set_model(m)
+    hub.set_deadline_us(2000)
+    slots = [hub.attach() for _ in range(3)]
+    plugs = [_oracle_instance(spec) for _ in range(3)]
+    x = modelgen.signal(3, n * periods, seed=35)
+    c = O.default_controls()
+    prev = [np.zeros(n, np.float32) for _ in range(3)]
+    period_s = n / 48000.0
+    waits = []
+    for p in range(periods):
+        t0 = time.perf_counter()
+        live = [i for i in range(3) if not (i == 2 and p >= 4)]      # instance 2 stalls from period 4 on
+        got = {}
+        for i in live:
+            t1 = time.perf_counter()
+            got[i] = hub.run(slots[i], x[i, p * n:(p + 1) * n])
+            waits.append(time.perf_counter() - t1)
+        for i in live:
+            assert np.abs(got[i] - prev[i]).max() < THR * 2, (p, i, np.abs(got[i] - prev[i]).max())
+            prev[i] = plugs[i].run(c, x[i, p * n:(p + 1) * n])
+        while time.perf_counter() - t0 < period_s:  # the host's audio clock
+            pass
+    hub.flush()
+    assert hub.launches == periods
+    assert hub.deadline_launches >= periods - 5     # every period after the stall was closed by the deadline
+    # run() never sat through a pass: with the deadline the previous period's output is ready (a pass takes < 1 ms)
+    assert max(waits) < 0.5 * period_s, max(waits)
+    # the straggler comes back: its stream did not move meanwhile; first block back is silence, then it continues
+    p = periods - 1
+    blk = x[2, 4 * n:5 * n]
+    got = hub.run(slots[2], blk)
+    hub.flush()
+    assert np.all(got == 0.0)
+    want = plugs[2].run(c, blk)
+    got = hub.run(slots[2], x[2, 5 * n:6 * n])
+    assert np.abs(got - want).max() < THR * 2
+
+
+def test_back_to_back_attach_and_run_from_c(tmp_path):
+    """attach + activate + controls + run() with no host-side gaps, from C, while passes are in flight
+    on the hub's stream — the pool's control pokes and the passes sit on different streams and must be ordered by
+    the pool. Three instances join at periods 0, 2, 3; each against a fresh oracle instance."""
+    j = modelgen.make_model(kind="gru", hidden=24, input_size=2, seed=21)
+    mp = str(tmp_path / "m.json")
+    modelgen.write_model(j, mp)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(ax.lib_path())
+    exe = str(tmp_path / "c_hub_b2b")
+    cc = subprocess.run(["gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-I", os.path.join(root, "include"),
+                         os.path.join(root, "tests", "c_hub_b2b.c"), "-o", exe, "-L", libdir, "-laidax_hip",
+                         f"-Wl,-rpath,{libdir}"], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    periods, n = 12, 64
+    out = str(tmp_path / "out.f32")
+    run = subprocess.run([exe, mp, out, str(periods), str(n)], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert f"launches={periods - 1}" in run.stdout or f"launches={periods}" in run.stdout
+    y = np.fromfile(out, np.float32).reshape(3, periods, n)
+    spec = O.parse_model(j)
+    t = np.arange(periods * n, dtype=np.uint64)
+    for i, join in enumerate((0, 2, 3)):
+        k = (t * np.uint64(2654435761) + np.uint64((i + 1) * 40503)) & np.uint64(0xffffffff)
+        x = (((k >> np.uint64(8)) & np.uint64(0xffff)).astype(np.float32) / np.float32(65535.0) - np.float32(0.5)) * np.float32(0.8)
+        plug = _oracle_instance(spec)
+        c = O.default_controls(pregain_db=2.0 * i, param1=0.25 * i)
+        want = np.concatenate([plug.run(c, x[p * n:(p + 1) * n]) for p in range(join, periods)]).reshape(-1, n)
+        got = y[i, join:]
+        assert np.all(got[0] == 0.0)                                   # one period of latency
+        assert np.abs(got[1:] - want[:-1]).max() < THR * 2, (i, np.abs(got[1:] - want[:-1]).max())

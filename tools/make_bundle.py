@@ -50,7 +50,13 @@ PORTS = [
     ("MASTER", "OUTPUT", "control_in", 0, -15.0, 15, "db", (), ()),
     ("ModelInSize", "Model Input Size", "control_out", 0, 0, 3, None, ENUM,
      (("ERROR", 0), ("SNAPSHOT", 1), ("WITH 1 PARAM", 2), ("WITH 2 PARAMS", 3))),
-    ("enabled", "Enabled", "control_in", 1, 0, 1, None, TOGGLE, ()),
+    ("enabled", "Enabled", "control_in", 1, 0, 1, None, (), ()),
+]
+# Not in the reference: hub mode delays every instance by one period, which a host must be told
+# (lv2:reportsLatency). Appended AFTER the reference's 25 ports so that their indices stay what saved sessions
+# and the reference's own TTL say; the shell tolerates hosts that never connect it.
+EXTRA_PORTS = [
+    ("latency", "Latency", "control_out", 0, 0, 8192, "frame", ("integer", "reportsLatency"), ()),
 ]
 # the control inputs in the order of aidax_controls (include/aidax.h)
 CONTROL_SYMBOLS = [p[0] for p in PORTS if p[2] == "control_in"]
@@ -90,6 +96,8 @@ def port_ttl(index, port):
         lines.append(f'        lv2:scalePoint [ rdfs:label "{label}" ; rdf:value {value} ]')
     if sym == "enabled":
         lines.append("        lv2:designation lv2:enabled")
+    if sym == "latency":
+        lines.append("        lv2:designation lv2:latency")
     return "    [\n" + " ;\n".join(lines) + "\n    ]"
 
 
@@ -97,7 +105,7 @@ def plugin_ttl():
     head = "".join(f"@prefix {k}: <{v}> .\n" for k, v in PREFIXES.items())
     param = (f"\n<{URI}#json>\n    a lv2:Parameter ;\n    mod:fileTypes \"aidadspmodel\" ;\n"
              f"    rdfs:label \"Neural Model\" ;\n    rdfs:range atom:Path .\n")
-    ports = " ,\n".join(port_ttl(i, p) for i, p in enumerate(PORTS))
+    ports = " ,\n".join(port_ttl(i, p) for i, p in enumerate(PORTS + EXTRA_PORTS))
     model = DEFAULT_MODEL.replace(" ", "%20")
     body = (f"\n<{URI}>\n    a lv2:Plugin , lv2:SimulatorPlugin ;\n    doap:name \"AIDA-X (MI355X pool build)\" ;\n"
             "    doap:license <http://spdx.org/licenses/GPL-3.0-or-later.html> ;\n"

@@ -13,3 +13,4 @@ from .binding import (  # noqa: F401
     biquad_design, db_to_coeff, lpf_fc, declared_symbols,
     ALL_STREAMS, START_WARMUP, START_RESET,
 )
+from . import workloads  # noqa: F401,E402

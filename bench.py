@@ -2,52 +2,56 @@
 """bench.py — headline benchmark of the rt-neural-generic hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[1], "cfg2"): LSTM hidden=32 amp model (synthetic
-Glorot-style weights, seed 32 — no checkpoints offline), 1024 concurrent 48 kHz
-mono streams PER GPU, 256-frame blocks, plugin controls at their TTL defaults
-(LPF 66.216 %, DC blocker on, EQ post flat, gains 0 dB): the full run() chain
-of rt-neural-generic.cpp:621-659. One "step" = one aidax_pool_process_device
-pass over one [1024][256] fp32 block already resident in HBM.
+N > 1: one process per GPU. Either the caller starts the ranks (python -m torch.distributed.run --nnodes=1
+--nproc-per-node N ... bench.py --gpus N ...: RANK / LOCAL_RANK / WORLD_SIZE in the environment), or — when they
+are absent — this process starts them itself, as children, BEFORE it touches HIP or imports torch, waits for
+them and relays rank 0's json line as its own last line of stdout.
 
-Streams are independent, so N GPUs run N x 1024 streams with no data-path
-collective ("weak" scaling); RCCL carries one MAX(elapsed) / SUM(samples)
-reduction at the end.
+Workload (BASELINE.json configs[1], "cfg2"): LSTM hidden=32 amp model (synthetic Glorot-style weights, seed 32 —
+no checkpoints offline), 1024 concurrent 48 kHz mono streams PER GPU, 256-frame blocks, plugin controls at their
+TTL defaults (LPF 66.216 %, DC blocker on, EQ post flat, gains 0 dB): the full run() chain of
+rt-neural-generic.cpp:621-659. One "step" = one aidax_pool_process_device pass over one [1024][256] fp32 block
+already resident in HBM.
+
+Streams are independent, so N GPUs run N x 1024 streams with no data-path collective ("weak" scaling); RCCL
+carries one MAX(elapsed) / SUM(samples) reduction at the end.
 
 Prints ONE json line (rank 0) with the driver's contract keys plus
-  roofline     HBM roofline of the dominant kernel from ALGORITHMIC bytes
-               (8 B per sample per stream: 4 in + 4 out) over the
-               average launch duration measured with HIP events on the launch stream
-  cpu_baseline the CPU oracle (a port, not RTNeural) timed on this host's cores
-               on a bounded sample of the same workload (N=1, rank 0 only)
+  roofline          HBM roofline of the pass from ALGORITHMIC bytes (8 B per sample per stream: 4 in + 4 out,
+                    SURVEY §8(d)) over the average launch duration measured with HIP events on the launch stream
+  roofline_compute  the same pass against the fp32 peak from ALGORITHMIC flops — the roofline
+                    that actually binds this path (1064 flop/B against a machine balance of ~20)
+  other_workloads   short timed regions of the other single-GPU BASELINE configs (cfg3, cfg4, cfg5 at their
+                    per-GPU sizes) in the same process, each with its rooflines and max-abs error (N = 1 only)
+  realtime_case     the LV2 case of SURVEY §8(d): ONE stream, 256-frame blocks — wall time per
+                    aidax_pool_process call (pinned staging + launch + wait) next to the CPU oracle on one thread
+  cpu_baseline      the CPU oracle (a port, not RTNeural) timed on this host's cores on a bounded sample of
+                    the same workload (N=1, rank 0 only)
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import tempfile
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-N_STREAMS = 1024          # per GPU (cfg2)
 N_FRAMES = 256
 RING = 8                  # distinct input blocks cycled through HBM
 HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: vector FP32 peak
+FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: vector FP32 peak = v_mfma_f32_16x16x4_f32 peak (64 FLOP/clk/SIMD)
 ALGO_BYTES_PER_SAMPLE = 8
+PREROLL_S = 0.35          # un-timed passes before the warm-up: clocks ramp, caches and TLBs fill
 
-
-FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
-
-# The headline line is cfg2 (BASELINE.json configs[1]). The other GPU configs can be timed with
-# --workload; they are parity-test cases, not the bench line the driver records.
+# The headline line is cfg2 (BASELINE.json configs[1]). The other GPU configs run as short regions after it
+# (other_workloads) or on their own with --workload; they are parity-test cases, not the line the driver records.
 WORKLOADS = {
     "cfg2": dict(model=dict(kind="lstm", hidden=32, input_size=1, seed=32), streams=1024, controls={},
                  flops=8512 + 63 + 6, bound="hbm",
@@ -64,6 +68,7 @@ WORKLOADS = {
                  flops=2 * (384 * (1 + 96) + 384 * (96 + 96) + 96), bound="mfma",
                  text="cfg5: LSTM-96 x2 model, 2048 streams/GPU (16384 over 8 GPUs) x 256-frame blocks, matrix-core kernel"),
 }
+OTHER_STEPS = {"cfg3": 600, "cfg4": 2000, "cfg5": 120}      # ~0.25 s of GPU time each
 
 
 def dist_env():
@@ -93,11 +98,35 @@ def stream_range(rank: int, world: int, total_streams: int):
     return lo, hi
 
 
-def workload_model_path(name: str):
-    from tests import modelgen
-    j = modelgen.make_model(**WORKLOADS[name]["model"])
+def launch_ranks(n_gpus: int, argv):
+    """No launcher around us: start one rank per GPU as child processes (this process has not touched HIP and
+    never will), wait, relay rank 0's json line. Returns the exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)              # rank chatter (RCCL banner, launcher notes) stays off stdout
+    if proc.returncode != 0 or line is None:
+        print(f"bench.py: the {n_gpus}-rank run failed (exit {proc.returncode})", file=sys.stderr)
+        return proc.returncode or 1
+    print(line, flush=True)
+    return 0
+
+
+def workload_model_path(W, name: str):
+    j = W.make_model(**WORKLOADS[name]["model"])
     d = tempfile.mkdtemp(prefix="aidax_bench_")
-    return modelgen.write_model(j, os.path.join(d, f"{name}.json")), j
+    return W.write_model(j, os.path.join(d, f"{name}.json")), j
 
 
 def usable_cores() -> int:
@@ -113,16 +142,17 @@ def usable_cores() -> int:
 
 
 def pmc_traffic_bytes(kernel_name: str):
-    """HBM bytes per launch of the benchmarked kernel from the committed rocprofv3 PMC passes
-    (profiles/*_pmc_summary.txt): (2 x FETCH_SIZE + WRITE_SIZE) KB — FETCH_SIZE counts half of a
-    16 B/lane streaming read on gfx950 (MI355X_MICROARCH.md, HBM section). None if no profile."""
+    """HBM bytes per launch of the benchmarked kernel from the COMMITTED rocprofv3 PMC passes
+    (profiles/*_pmc_summary.txt, latest round that has this kernel): (2 x FETCH_SIZE + WRITE_SIZE) KB —
+    FETCH_SIZE counts half of a 16 B/lane streaming read on gfx950 (MI355X_MICROARCH.md, HBM section).
+    Counters cannot be read from inside a timed run; the source file is named next to the value. None if no profile."""
     import glob
     import re
     best = None
     for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.txt"))):
         fetch = write = None
         for line in open(fn):
-            if kernel_name.split("<")[0] + "<" not in line or kernel_name.split("<")[1] not in line:
+            if "<" not in kernel_name or kernel_name.split("<")[0] + "<" not in line or kernel_name.split("<")[1] not in line:
                 continue
             m = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+n=\s*\d+ median=([0-9.e+]+)", line)
             if m and m.group(1) == "FETCH_SIZE":
@@ -134,28 +164,183 @@ def pmc_traffic_bytes(kernel_name: str):
     return best
 
 
-def cpu_baseline(j, name: str = "cfg2", target_s: float = 12.0):
+def cpu_baseline(W, j, name: str = "cfg2", target_s: float = 12.0):
     """The CPU oracle on all host cores over a bounded sample of the workload."""
     from oracle import oracle as O
-    from tests import modelgen
     spec = O.parse_model(j)
     cores = usable_cores()
-    streams = N_STREAMS                      # 1024 of the workload's streams; the sample is bounded in blocks
-    x = modelgen.signal(streams, N_FRAMES)
+    streams = 1024                            # 1024 of the workload's streams; the sample is bounded in blocks
+    x = W.signal(streams, N_FRAMES)
     c = O.default_controls(**WORKLOADS[name]["controls"])
     secs, _ = O.cpu_bench(spec, c, x, n_blocks=2, warm_blocks=1, n_threads=cores, fast=True)
     per_block = secs / 2
     blocks = int(max(4, min(20000, target_s / max(per_block, 1e-6))))
     secs, _ = O.cpu_bench(spec, c, x, n_blocks=blocks, warm_blocks=1, n_threads=cores, fast=True)
     sps = streams * N_FRAMES * blocks / secs
-    # the LV2 real-time case of SURVEY §8(d): one stream on one thread, 256-frame blocks (about a second of CPU)
-    one_blocks = int(max(50, min(4000, 1.0 / max(per_block / streams * cores, 1e-7))))
-    one_secs, _ = O.cpu_bench(spec, c, x[:1], n_blocks=one_blocks, warm_blocks=2, n_threads=1, fast=True)
-    one_sps = N_FRAMES * one_blocks / one_secs
     return {"value": sps, "unit": "samples/s", "cores": cores, "kind": "port",
-            "one_stream_one_thread": {"value": one_sps, "unit": "samples/s", "realtime_factor": one_sps / 48000.0},
             "sample": f"{streams} {name} streams x {blocks} blocks of {N_FRAMES} frames, "
                       f"full run() chain, C oracle with vectorised exp/tanh (-O3 -march=x86-64-v3, AVX2), {cores} pthreads, {secs:.1f} s"}
+
+
+def realtime_case(ax, W, local: int):
+    """SURVEY §8(d) CPU baseline (1), the LV2 real-time case: ONE stream, 256-frame blocks, for the bundled
+    LSTM-12 (the TTL default model) and a synthetic LSTM-16 (BASELINE cfg1). GPU: wall time of one
+    aidax_pool_process call on a one-stream pool — what the plugin's run() costs (pinned staging, launch, wait
+    for the stream). CPU: the oracle on one thread."""
+    import numpy as np
+    from oracle import oracle as O
+    out = []
+    bundled = os.path.join(ROOT, "tests", "golden", "models", "tw40_california_clean_deerinkstudios.json")
+    d = tempfile.mkdtemp(prefix="aidax_rt_")
+    syn = W.write_model(W.make_model("lstm", 16, 1, seed=16), os.path.join(d, "lstm16.json"))
+    x = W.signal(1, N_FRAMES, seed=5)
+    for label, path in (("bundled LSTM-12 (tw40_california_clean)", bundled), ("synthetic LSTM-16", syn)):
+        pool = ax.Pool(1, 8192, 48000.0, device=local)        # the pool the LV2 shell creates
+        pool.set_model(ax.Model(path))
+        for _ in range(300):
+            pool.process(x)
+        t = np.empty(3000)
+        for i in range(t.size):
+            t0 = time.perf_counter()
+            pool.process(x)
+            t[i] = time.perf_counter() - t0
+        kernel = pool.kernel_name
+        pool.close()
+        spec = O.load_model(path)
+        secs, _ = O.cpu_bench(spec, O.default_controls(), x, n_blocks=1500, warm_blocks=20, n_threads=1, fast=True)
+        out.append({"model": label, "kernel": kernel, "frames": N_FRAMES,
+                    "gpu_call_us": {"p50": float(np.percentile(t, 50) * 1e6), "p99": float(np.percentile(t, 99) * 1e6),
+                                    "max": float(t.max() * 1e6)},
+                    "gpu_realtime_factor": float((N_FRAMES / 48000.0) / np.percentile(t, 50)),
+                    "cpu_one_thread_block_us": secs / 1500 * 1e6,
+                    "cpu_realtime_factor": float((N_FRAMES / 48000.0) / (secs / 1500))})
+    return out
+
+
+def measure(ax, W, torch, name, S, steps, warmup, rank, world, local, check, launch_stream, preroll_s=PREROLL_S):
+    """One timed region of one workload on this rank. Returns a dict with the local elapsed time, the average pass
+    duration from HIP events on the launch stream, the pool's kernel name, the parity spot-check and the json."""
+    import numpy as np
+    wl = WORKLOADS[name]
+    path, j = workload_model_path(W, name)
+    model = ax.Model(path)
+    pool = ax.Pool(S, N_FRAMES, 48000.0, device=local)
+    pool.set_model(model, ax.START_WARMUP)
+    pool.set_controls(ax.default_controls(**wl["controls"]))
+
+    # synthetic inputs of this rank's stream range, resident in HBM before timing starts
+    lo, _hi = stream_range(rank, world, S * world)
+    host_ring = [W.signal(S, N_FRAMES, seed=0xA1DA + 7919 * r + lo) for r in range(RING)]
+    d_in = [torch.from_numpy(b).cuda() for b in host_ring]
+    d_out = [torch.empty_like(t) for t in d_in]
+    stream = launch_stream.cuda_stream
+
+    def step(i):
+        k = i % RING
+        pool.process_device(d_in[k].data_ptr(), d_out[k].data_ptr(), N_FRAMES, stream)
+
+    # parity spot-check on the first blocks (outside the timed region)
+    max_err = None
+    if rank == 0 and check:
+        from oracle import oracle as O
+        chk = ax.Pool(16, N_FRAMES, 48000.0, device=local)
+        chk.set_model(model, ax.START_WARMUP)
+        chk.set_controls(ax.default_controls(**wl["controls"]))
+        nb = 4 if name != "cfg5" else 2
+        xs = np.concatenate([b[:16] for b in host_ring[:nb]], axis=1)
+        got = np.concatenate([chk.process(np.ascontiguousarray(xs[:, k * N_FRAMES:(k + 1) * N_FRAMES])) for k in range(nb)], axis=1)
+        want = O.run_streams(O.parse_model(j), O.default_controls(**wl["controls"]), xs, N_FRAMES)
+        max_err = float(np.abs(got - want).max())
+        chk.close()
+
+    # clock pre-roll: un-timed, not part of `warmup`; a short driver run then sees the same clocks as a long one
+    t0 = time.perf_counter()
+    i = 0
+    while time.perf_counter() - t0 < preroll_s:
+        for _ in range(32):
+            step(i)
+            i += 1
+        launch_stream.synchronize()
+    preroll_ms = (time.perf_counter() - t0) * 1e3
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(launch_stream)
+    for i in range(steps):
+        step(i)
+    ev1.record(launch_stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / max(steps, 1)            # avg pass duration on the launch stream
+    kernel = pool.kernel_name
+    pool.close()
+    return dict(elapsed=elapsed, kernel_ms=kernel_ms, kernel=kernel, max_err=max_err, json=j, preroll_ms=preroll_ms)
+
+
+def rooflines(name, S, kernel_ms, kernel):
+    wl = WORKLOADS[name]
+    algo_bytes = ALGO_BYTES_PER_SAMPLE * S * N_FRAMES                 # per pass
+    algo_flops = wl["flops"] * S * N_FRAMES
+    gbps = algo_bytes / (kernel_ms * 1e-3) / 1e9
+    tflops = algo_flops / (kernel_ms * 1e-3) / 1e12
+    multi = "+" in kernel
+    note = "kernel_ms spans the three launches of the split form (k_chain, model kernel, k_chain)" if multi else None
+    hbm = {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+           "traffic": None, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes}
+    comp = {"bound": "mfma" if wl["bound"] == "mfma" else "fp32", "achieved": tflops, "peak": FP32_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": tflops / FP32_PEAK_TFLOPS, "traffic": None, "kernel_ms": kernel_ms,
+            "algorithmic_flops_per_launch": algo_flops}
+    if note:
+        hbm["note"] = comp["note"] = note
+    return hbm, comp
+
+
+def dry_run(args):
+    """CPU stand-in for the multi-rank plumbing (tests): same rank logic and the same reduction over gloo, the
+    'pass' is a sleep. Never used for a reported number."""
+    import torch
+    import torch.distributed as dist
+    rank, world, _local = dist_env()
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    S = args.streams or WORKLOADS[args.workload]["streams"]
+    for _ in range(args.warmup):
+        time.sleep(0.0005)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed_max, samples_all = reduce_results(elapsed, float(S) * N_FRAMES * args.steps, world, backend_device="cpu")
+    lo, hi = stream_range(rank, world, S * world)
+    if world > 1:
+        ranges = [None] * world
+        dist.all_gather_object(ranges, (lo, hi))
+        dist.destroy_process_group()
+    else:
+        ranges = [(lo, hi)]
+    if rank == 0:
+        print(json.dumps({"metric": "audio samples/sec (48 kHz mono, many streams)", "value": samples_all / elapsed_max,
+                          "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
+                          "config": {"workload": WORKLOADS[args.workload]["text"], "streams_per_gpu": S, "frames": N_FRAMES,
+                                     "stream_ranges": ranges}}), flush=True)
 
 
 def main():
@@ -167,13 +352,20 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: the workload's, cfg2 = 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="skip the short cfg3/cfg4/cfg5 regions and the one-stream case")
+    ap.add_argument("--dry-run", action="store_true", help="CPU stand-in for the rank plumbing (gloo, no GPU): tests only")
     args = ap.parse_args()
+
+    if "RANK" not in os.environ and args.gpus > 1:
+        # before anything touches the GPU: this process only starts the ranks and relays their line
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.dry_run:
+        return dry_run(args)
 
     import torch
     rank, world, local = dist_env()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -183,99 +375,56 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     ax = importlib.import_module("aidadsp-lv2_amd")
-    from tests import modelgen
-
+    W = ax.workloads
     wl = WORKLOADS[args.workload]
     S = args.streams or wl["streams"]
-    path, j = workload_model_path(args.workload)
-    model = ax.Model(path)
-    pool = ax.Pool(S, N_FRAMES, 48000.0, device=local)
-    pool.set_model(model, ax.START_WARMUP)
-    pool.set_controls(ax.default_controls(**wl["controls"]))
-
-    # synthetic inputs of this rank's stream range, resident in HBM before timing starts
-    lo, hi = stream_range(rank, world, S * world)
-    host_ring = [modelgen.signal(S, N_FRAMES, seed=0xA1DA + 7919 * r + lo) for r in range(RING)]
-    d_in = [torch.from_numpy(b).cuda() for b in host_ring]
-    d_out = [torch.empty_like(t) for t in d_in]
-    launch_stream = torch.cuda.Stream()              # a real (non-null) HIP stream: events below sit on it too
+    launch_stream = torch.cuda.Stream()              # a real (non-null) HIP stream: the events sit on it too
     torch.cuda.set_stream(launch_stream)
-    stream = launch_stream.cuda_stream
 
-    def step(i):
-        k = i % RING
-        pool.process_device(d_in[k].data_ptr(), d_out[k].data_ptr(), N_FRAMES, stream)
-
-    # parity spot-check on the first blocks (outside the timed region)
-    max_err = None
-    if rank == 0 and not args.no_check:
-        from oracle import oracle as O
-        chk = ax.Pool(16, N_FRAMES, 48000.0, device=local)
-        chk.set_model(model, ax.START_WARMUP)
-        chk.set_controls(ax.default_controls(**wl["controls"]))
-        xs = np.concatenate([b[:16] for b in host_ring[:4]], axis=1)
-        got = np.concatenate([chk.process(np.ascontiguousarray(xs[:, k * N_FRAMES:(k + 1) * N_FRAMES])) for k in range(4)], axis=1)
-        want = O.run_streams(O.parse_model(j), O.default_controls(**wl["controls"]), xs, N_FRAMES)
-        max_err = float(np.abs(got - want).max())
-        chk.close()
-
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-        torch.cuda.synchronize()
-
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for i in range(args.steps):
-        step(i)
-    ev1.record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)       # avg launch duration on the launch stream
-
+    m = measure(ax, W, torch, args.workload, S, args.steps, args.warmup, rank, world, local, not args.no_check, launch_stream)
     samples = float(S) * N_FRAMES * args.steps
-    elapsed_max, samples_all = reduce_results(elapsed, samples, world)
+    elapsed_max, samples_all = reduce_results(m["elapsed"], samples, world)
 
     if rank == 0:
         value = samples_all / elapsed_max
-        algo_bytes = ALGO_BYTES_PER_SAMPLE * S * N_FRAMES                 # per launch
-        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = pmc_traffic_bytes(pool.kernel_name) if (args.workload == "cfg2" and S == N_STREAMS) else None
-        tflops = wl["flops"] * S * N_FRAMES / (kernel_ms * 1e-3) / 1e12
-        if wl["bound"] == "mfma":
-            roofline = {"bound": "mfma", "achieved": tflops, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": tflops / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "kernel_ms": kernel_ms,
-                        "algorithmic_flops_per_launch": wl["flops"] * S * N_FRAMES,
-                        "note": "kernel_ms spans the three launches of the split form (k_chain, k_mfma, k_chain)"}
-        else:
-            roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBPS,
-                        "traffic": traffic["bytes"] if traffic else None,
-                        "traffic_source": traffic["source"] if traffic else None,
-                        "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes}
+        hbm, comp = rooflines(args.workload, S, m["kernel_ms"], m["kernel"])
+        traffic = pmc_traffic_bytes(m["kernel"]) if (args.workload == "cfg2" and S == wl["streams"]) else None
+        if traffic:
+            hbm["traffic"] = traffic["bytes"]
+            hbm["traffic_source"] = f"committed profile {traffic['source']} (rocprofv3 --pmc passes, not measured in this run)"
         out = {
             "metric": "audio samples/sec (48 kHz mono, many streams)",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["text"],
-                       "streams_per_gpu": S, "frames": N_FRAMES, "kernel": pool.kernel_name,
+                       "streams_per_gpu": S, "frames": N_FRAMES, "kernel": m["kernel"],
                        "realtime_factor": value / (48000.0 * S * world)},
-            "roofline": roofline,
-            "compute": {"fp32_tflops": tflops, "peak_tflops": FP32_PEAK_TFLOPS},
-            "max_abs_err": max_err,
+            "roofline": comp if wl["bound"] == "mfma" else hbm,
+            "roofline_compute": comp,
+            "preroll_ms": m["preroll_ms"],
+            "max_abs_err": m["max_err"],
         }
+        if wl["bound"] == "mfma":
+            out["roofline_hbm"] = hbm
+        if world == 1 and not args.no_others:
+            others = []
+            for name in ("cfg3", "cfg4", "cfg5"):
+                if name == args.workload:
+                    continue
+                So, steps = WORKLOADS[name]["streams"], OTHER_STEPS[name]
+                r = measure(ax, W, torch, name, So, steps, max(10, steps // 10), 0, 1, local, not args.no_check, launch_stream,
+                            preroll_s=0.15)
+                h2, c2 = rooflines(name, So, r["kernel_ms"], r["kernel"])
+                others.append({"workload": WORKLOADS[name]["text"], "streams": So, "kernel": r["kernel"], "steps": steps,
+                               "ms_per_step": r["elapsed"] / steps * 1e3, "value": So * N_FRAMES * steps / r["elapsed"],
+                               "unit": "samples/s", "roofline": c2 if WORKLOADS[name]["bound"] == "mfma" else h2,
+                               "roofline_compute": c2, "max_abs_err": r["max_err"]})
+            out["other_workloads"] = others
+            out["realtime_case"] = realtime_case(ax, W, local)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(j, args.workload)
+            out["cpu_baseline"] = cpu_baseline(W, m["json"], args.workload)
 
-    pool.close()
     if world > 1:
         dist.destroy_process_group()       # RCCL prints its banner on teardown: keep the JSON line last
     if rank == 0:

@@ -58,3 +58,40 @@ def test_stream_ranges_partition_any_world():
         assert edges[0][0] == 0 and edges[-1][1] == total
         for a, b in zip(edges, edges[1:]):
             assert a[1] == b[0]
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    """`python bench.py --gpus 2` with no RANK/WORLD_SIZE in the environment: the parent starts the two ranks as
+    children (before it touches HIP or torch), waits, and relays rank 0's json line as the last line of its own
+    stdout. --dry-run swaps the GPU pass for a sleep and RCCL for gloo; the rank plumbing is the real one."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "5",
+                          "--warmup", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                                 # ONE line on stdout: rank 0's
+    out = json.loads(lines[-1])
+    assert out["n_gpus"] == 2 and out["dry_run"] is True and out["scaling"] == "weak" and out["steps"] == 5
+    assert out["config"]["stream_ranges"] == [[0, 1024], [1024, 2048]]
+    # whole-job value: both ranks' samples over the slowest rank's time (5 sleeps of 1 ms)
+    assert out["value"] == pytest.approx(2 * 1024 * 256 * 5 / (out["ms_per_step"] * 5e-3))
+    assert 1.0 <= out["ms_per_step"] < 20.0
+
+
+def test_bench_single_rank_dry_run_needs_no_launcher_and_fails_loudly_when_a_rank_dies():
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "3", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stderr[-2000:]
+    assert json.loads(run.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+    # no GPU here: the real (non dry-run) ranks exit non-zero and so does the parent, without a json line
+    import torch
+    if not torch.cuda.is_available():
+        run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"],
+                             env=env, capture_output=True, text=True, timeout=300)
+        assert run.returncode != 0
+        assert not [ln for ln in run.stdout.splitlines() if ln.startswith("{")]

@@ -45,11 +45,9 @@ $(LIBDIR)/libaidax_hip.so: $(HOST_OBJS) $(KERN_OBJS)
 $(LV2SO): $(PKG)/lv2/rt_neural_generic_lv2.cpp $(PKG)/lv2/lv2_min.h include/aidax.h $(LIBDIR)/libaidax_hip.so
 	$(CXX) $(CXXFLAGS) -shared $< -o $@ -L$(LIBDIR) -laidax_hip -Wl,-rpath,'$$ORIGIN/../lib'
 
-# An installable LV2 bundle (build/rt-neural-generic.lv2): generated TTL, the plugin binary relinked with
-# rpath $$ORIGIN, the HIP library next to it, the bundled models.
+# An installable LV2 bundle (build/rt-neural-generic.lv2): generated TTL, the plugin binary linked with
+# rpath $$ORIGIN, the HIP library next to it, the bundled models (tools/make_bundle.py does all of it).
 bundle: $(LIBDIR)/libaidax_hip.so
-	@mkdir -p build/bundle
-	$(CXX) $(CXXFLAGS) -shared $(PKG)/lv2/rt_neural_generic_lv2.cpp -o build/bundle/rt-neural-generic.so -L$(LIBDIR) -laidax_hip -Wl,-rpath,'$$ORIGIN'
 	python3 tools/make_bundle.py --out build
 
 oracle:

@@ -1020,12 +1020,16 @@ __global__ void k_install_params(StreamState* live, const StreamState* staged, u
 
 // ------------------------------------------------------------ host dispatch
 #define AIDAX_LSTM(H) { 0, H, k_lstm<H>, k_lstm_pipe<H>, k_nn<LstmCell<H>>, LstmCell<H>::PACK, LstmCell<H>::STATE, "k_lstm<" #H ">", "k_lstm_pipe<" #H ">", "k_chain+k_nn<lstm" #H ">" }
+// LSTM-64 / LSTM-80: the helper waves' share of the register file (pipe) resp. the Dense ring (split, H = 80) push the
+// 4H-row cell past 512 registers — those forms would spill, so they do not exist; the pool serves these cells
+// with k_quad / k_mfma, or the one-wave kernel when neither fits (pools with long blocks).
+#define AIDAX_LSTM_WIDE(H, NN) { 0, H, k_lstm<H>, nullptr, NN, LstmCell<H>::PACK, LstmCell<H>::STATE, "k_lstm<" #H ">", "-", "k_chain+k_nn<lstm" #H ">" }
 #define AIDAX_GRU(H)  { 1, H, k_gru<H>,  k_gru_pipe<H>,  k_nn<GruCell<H>>,  GruCell<H>::PACK,  GruCell<H>::STATE,  "k_gru<" #H ">", "k_gru_pipe<" #H ">", "k_chain+k_nn<gru" #H ">" }
 
 static const KernelEntry kTable[] = {
     // the 18 (cell, hidden) pairs of variant/generate_variant_hpp.py:4-6; input size is a run-time argument
     AIDAX_LSTM(8), AIDAX_LSTM(12), AIDAX_LSTM(16), AIDAX_LSTM(20), AIDAX_LSTM(24),
-    AIDAX_LSTM(32), AIDAX_LSTM(40), AIDAX_LSTM(64), AIDAX_LSTM(80),
+    AIDAX_LSTM(32), AIDAX_LSTM(40), AIDAX_LSTM_WIDE(64, k_nn<LstmCell<64>>), AIDAX_LSTM_WIDE(80, nullptr),
     AIDAX_GRU(8), AIDAX_GRU(12), AIDAX_GRU(16), AIDAX_GRU(20), AIDAX_GRU(24),
     AIDAX_GRU(32), AIDAX_GRU(40), AIDAX_GRU(64), AIDAX_GRU(80),
 };
@@ -1069,6 +1073,7 @@ hipError_t launch_split_kernels(const KernelEntry* e, const LaunchArgs& a, hipSt
 {
     hipError_t err = launch_chain_pass(true, a, stream);
     if (err != hipSuccess) return err;
+    if (e && !e->fn_nn) return hipErrorInvalidDeviceFunction;
     if (e && a.n_frames != 0)
         hipLaunchKernelGGL(e->fn_nn, dim3(a.n_streams), dim3(kWave), nn_lds_floats(e->hidden, (int)a.n_frames) * sizeof(float), stream, a);
     return launch_chain_pass(false, a, stream);
@@ -1080,6 +1085,7 @@ hipError_t launch_split_kernels(const KernelEntry* e, const LaunchArgs& a, hipSt
 // cells (GRU-64: 254 vs 350 registers) lose their second wave per SIMD and stay on the one-wave form.
 bool split_form_pays(const KernelEntry* e, uint32_t n_frames)
 {
+    if (!e->fn_nn) return false;
     int occ_wave = 0, occ_nn = 0;
     const size_t lds_wave = ((size_t)((n_frames + 3) & ~3u) + (size_t)e->hidden) * sizeof(float);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_wave, e->fn, kWave, lds_wave) != hipSuccess) return false;
@@ -1095,6 +1101,7 @@ size_t pipe_lds_bytes(int hidden, uint32_t n_frames) { return pipe_lds_floats(hi
 
 hipError_t launch_pipe_kernel(const KernelEntry* e, const LaunchArgs& a, hipStream_t stream)
 {
+    if (!e->fn_pipe) return hipErrorInvalidDeviceFunction;
     hipLaunchKernelGGL(e->fn_pipe, dim3(a.n_streams), dim3(kPipeWaves * kWave), pipe_lds_bytes(e->hidden, a.n_frames), stream, a);
     return hipGetLastError();
 }
@@ -1103,6 +1110,7 @@ hipError_t launch_pipe_kernel(const KernelEntry* e, const LaunchArgs& a, hipStre
 // one-wave-per-stream kernel has the better throughput (helper waves hold the N wave's VGPR budget).
 int pipe_resident_streams(const KernelEntry* e, uint32_t n_frames, int device)
 {
+    if (!e->fn_pipe) return 0;
     int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, e->fn_pipe, kPipeWaves * kWave,
                                                      pipe_lds_bytes(e->hidden, n_frames)) != hipSuccess) return 0;

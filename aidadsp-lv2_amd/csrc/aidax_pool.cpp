@@ -159,12 +159,12 @@ struct aidax_pool {
     int chain_form(const ModelSlot& m) const
     {
         if (m.kind != ModelSlot::TABLE && m.has_model) return 0;
-        if (chain_lds_bytes(max_frames) > kChainLdsLimit) return 0;      // packed chains keep 8 blocks in LDS
         if (force_form == 1) return 0;
-        if (force_form == 2) return (m.has_model && m.kernel) ? 1 : 0;
-        if (force_form == 3) return 2;
+        if (force_form == 2) return (m.has_model && m.kernel && m.kernel->fn_pipe) ? 1 : 0;
+        const bool packed_fits = chain_lds_bytes(max_frames) <= kChainLdsLimit;      // packed chains keep 8 blocks in LDS
+        if (force_form == 3) return (packed_fits && (!m.has_model || (m.kernel && m.kernel->fn_nn))) ? 2 : 0;
         if (use_pipe(m)) return 1;
-        if (n_streams < 64) return 0;
+        if (n_streams < 64 || !packed_fits) return 0;
         return (!m.has_model || m.split_pays) ? 2 : 0;
     }
     // Models of the reference's table on the matrix-core kernels (many_streams_form); AIDAX_KERNEL=quad|mfma force one.
@@ -180,7 +180,7 @@ struct aidax_pool {
     }
     bool use_pipe(const ModelSlot& m) const
     {
-        if (!m.has_model || !m.kernel || m.kind != ModelSlot::TABLE) return false;
+        if (!m.has_model || !m.kernel || !m.kernel->fn_pipe || m.kind != ModelSlot::TABLE) return false;
         if (force_form == 1 || force_form == 3) return false;
         if (force_form == 2) return true;
         return static_cast<int>(n_streams) <= m.pipe_capacity;

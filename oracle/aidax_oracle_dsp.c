@@ -5,7 +5,7 @@
  * every arithmetic step below is one IEEE-754 operation in the same order the
  * reference source spells it, so this file is bit-identical to the reference's
  * Biquad.cpp / ValueSmoother.hpp built without FMA contraction (checked against
- * oracle/_ref by tests/test_oracle_vs_ref.py).
+ * oracle/_ref by tests/test_oracle.py::test_live_reference_library_when_present).
  */
 #include "aidax_oracle.h"
 

@@ -31,3 +31,16 @@ def golden_dir():
 @pytest.fixture(scope="session")
 def bundled_models():
     return sorted(os.path.join(MODELS, f) for f in os.listdir(MODELS) if f.endswith(".json"))
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """measured parity errors of this session (tests/errlog.py) -> gpurun_out/parity_errors.json"""
+    try:
+        from tests import errlog
+        out = os.path.join(ROOT, "gpurun_out")
+        if errlog.LOG and os.path.isdir(out):
+            import json
+            with open(os.path.join(out, "parity_errors.json"), "w") as f:
+                json.dump(dict(sorted(errlog.LOG.items())), f, indent=1)
+    except Exception:
+        pass

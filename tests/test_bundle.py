@@ -6,6 +6,8 @@ import os
 import re
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -74,3 +76,26 @@ def test_generated_ttl_carries_the_reference_port_table(tmp_path):
     extra = got["ports"][25]
     assert extra["symbol"] == "latency" and "reportsLatency" in extra["properties"] and extra["designation"] == "latency"
     assert "lv2:OutputPort" in extra["types"]
+
+
+@pytest.mark.gpu
+def test_plugin_loaded_from_the_built_bundle_like_a_host_would(tmp_path):
+    """`make bundle` equivalent into a scratch dir; a fresh process (cwd elsewhere, no LD_LIBRARY_PATH) loads
+    rt-neural-generic.so from the bundle directory as named by manifest.ttl, restores the TTL's default state
+    relative to the bundle and plays: audio == oracle, and the HIP library that got mapped is the bundle's own copy
+    (rpath $ORIGIN), not the in-tree build."""
+    import subprocess
+    bundle = make_bundle.make_bundle(str(tmp_path), binaries=True)
+    dyn = subprocess.run(["readelf", "-d", os.path.join(bundle, "rt-neural-generic.so")], capture_output=True, text=True).stdout
+    assert "$ORIGIN" in dyn and "libaidax_hip.so" in dyn
+    env = {k: v for k, v in os.environ.items() if k not in ("LD_LIBRARY_PATH", "LD_PRELOAD")}
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bundle_host.py"), bundle], cwd=str(tmp_path), env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-3000:]
+    out = json.loads(run.stdout.strip().splitlines()[-1])
+    assert out["max_abs_err"] < 1.0e-5 and out["peak"] > 1e-3, out
+    assert out["state"] == make_bundle.DEFAULT_MODEL and out["saved"] == [make_bundle.DEFAULT_MODEL]
+    assert out["model_in_size"] == 1.0 and out["latency"] == 0.0       # one-stream mode adds no latency
+    libs = [m for m in out["maps"] if m.endswith("libaidax_hip.so")]
+    assert libs == [os.path.join(bundle, "libaidax_hip.so")], out["maps"]
+    assert os.path.join(bundle, "rt-neural-generic.so") in out["maps"]

@@ -18,12 +18,13 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
-from tests import modelgen
+from tests import errlog, modelgen
 
 pytestmark = pytest.mark.gpu
 
 ax = importlib.import_module("aidadsp-lv2_amd")
-THR = 1.0e-5
+THR = 1.0e-5          # the reference's own bar (TEST_MODEL_THR). The bounds below sit at ~10x the errors measured on
+                      # MI355X (gpurun_out/parity_errors.json via tests/errlog.py: 7e-8 .. 3.6e-7), so a 100x regression fails.
 
 
 def _model_file(tmp_path, name, **kw):
@@ -54,7 +55,7 @@ def test_bundled_models_self_test_on_gpu(bundled_models):
         assert n_err == 0 and max_err < THR, (path, n_err, max_err)
         spec = O.load_model(path)
         ref = O.OracleModel(spec, warmup=False).test_model(spec.input_batch, spec.output_batch)[2]
-        assert np.abs(out - ref).max() < 4e-6
+        errlog.bound(np.abs(out - ref).max(), 4e-6, "gpu_parity:57")
 
 
 @pytest.mark.parametrize("name", sorted(modelgen.GOLDEN_CASES))
@@ -64,8 +65,8 @@ def test_torch_goldens_on_gpu(name, golden_dir, tmp_path):
     path, spec = _model_file(tmp_path, name, **kw)
     y = ax.Model(path).forward(g["X"], unit_gains=True)
     skip = g["X"][:, 0] if kw.get("in_skip") else 0.0      # fixtures hold the bare network; applyModel adds x
-    assert np.abs(y - (g["y"] + skip)).max() < THR, (name, np.abs(y - (g["y"] + skip)).max())
-    assert np.abs(y - (O.net_run(spec, g["X"]) + skip)).max() < THR
+    errlog.bound(np.abs(y - (g["y"] + skip)).max(), 2e-6, "gpu_parity:67")
+    errlog.bound(np.abs(y - (O.net_run(spec, g["X"]) + skip)).max(), 2e-6, "gpu_parity:68")
 
 
 @pytest.mark.parametrize("form", ["registers", "mfma", "quad"])
@@ -83,7 +84,7 @@ def test_every_reference_variant_runs_and_matches_oracle(cell, hidden, form, tmp
         X = modelgen.golden_inputs(f"{cell}{hidden}_{isz}", isz)[:768]
         y = ax.Model(path).forward(X, unit_gains=True)
         ref = O.net_run(spec, X)
-        assert np.abs(y - ref).max() < THR, (cell, hidden, isz, np.abs(y - ref).max())
+        errlog.bound(np.abs(y - ref).max(), 2e-6, "gpu_parity:86")
 
 
 # ------------------------------------------------------------------ pure DSP chain
@@ -172,12 +173,12 @@ def test_per_stream_controls_and_disable_bypass(bundled_models):
         if kw.get("enabled") == 0.0 or kw.get("net_bypass") == 1.0:
             assert np.array_equal(got[s], want), kw          # no NN in circuit
         else:
-            assert np.abs(got[s] - want).max() < THR * 2.0, (kw, np.abs(got[s] - want).max())
+            errlog.bound(np.abs(got[s] - want).max(), 4e-6, "gpu_parity:175")
 
 
 # ------------------------------------------------------------------ full chain
 
-def _chain_case(tmp_path, name, model_kw, ctl_kw, S=4, n=2048, block=256, warm=True, tol=THR):
+def _chain_case(tmp_path, name, model_kw, ctl_kw, S=4, n=2048, block=256, warm=True, tol=2e-6):
     path, spec = _model_file(tmp_path, name, **model_kw)
     m = ax.Model(path)
     x = modelgen.signal(S, n, seed=77)
@@ -188,7 +189,7 @@ def _chain_case(tmp_path, name, model_kw, ctl_kw, S=4, n=2048, block=256, warm=T
     got = _run_gpu(pool, x, block)
     want = O.run_streams(spec, co, x, block, warmup=warm)
     err = np.abs(got - want).max()
-    assert err < tol, (name, err)
+    errlog.bound(err, tol, "gpu_parity:191")
     return pool, spec, got, want
 
 
@@ -198,7 +199,7 @@ def test_cfg2_lstm32_default_controls(tmp_path):
 
 def test_lstm32_skip_and_gains(tmp_path):
     _chain_case(tmp_path, "skip", dict(kind="lstm", hidden=32, input_size=1, seed=33, in_skip=1, in_gain=-3.0, out_gain=4.5),
-                dict(master_db=3.0), tol=THR * 3.0)
+                dict(master_db=3.0), tol=2e-6)
 
 
 def test_cfg3_gru64_conditioned_eq_post(tmp_path):
@@ -226,7 +227,7 @@ def test_cfg3_gru64_conditioned_eq_post(tmp_path):
         for s in range(S):
             want[s, b:b + block] = plugs[s].run(O.default_controls(**kw), x[s, b:b + block])
     err = np.abs(got - want).max()
-    assert err < THR * 2.5, err                                             # EQ boosts add up to ~ +8 dB
+    errlog.bound(err, 1.5e-6, "gpu_parity:229")
 
 
 def test_cfg1_bundled_lstm12_one_stream_full_chain(bundled_models):
@@ -237,7 +238,7 @@ def test_cfg1_bundled_lstm12_one_stream_full_chain(bundled_models):
     pool.set_model(ax.Model(path))
     got = _run_gpu(pool, x, 256)
     want = O.run_streams(spec, O.default_controls(), x, 256)
-    assert np.abs(got - want).max() < THR
+    errlog.bound(np.abs(got - want).max(), 4e-6, "gpu_parity:240")
 
 
 def test_warmup_state_matches_oracle_and_reset_mode_is_zero(bundled_models):
@@ -286,7 +287,7 @@ def test_activate_and_model_swap_semantics(tmp_path, bundled_models):
         got = pool.process(np.ascontiguousarray(x[:, b:b + 128]))
         for s in range(2):
             want = plugs[s].run(O.default_controls(**kw), x[s, b:b + 128])
-            assert np.abs(got[s] - want).max() < THR * 2.5, (bi, s, np.abs(got[s] - want).max())
+            errlog.bound(np.abs(got[s] - want).max(), 1.5e-6, "gpu_parity:289")
 
 
 def test_long_run_drift_48000_samples(tmp_path):
@@ -339,7 +340,7 @@ def test_full_size_properties(name, kw, S, ckw, kernel, tmp_path):
     want = O.run_streams(spec, co, base, block)
     first = np.array([np.argmax(idx == k) for k in range(16)])
     err = np.abs(got[first] - want).max()
-    assert err < THR * 2, (name, err)
+    errlog.bound(err, 1.5e-6, "gpu_parity:342")
     assert np.isfinite(got).all()
 
 
@@ -397,13 +398,13 @@ def test_extension_models_full_chain(kind, kw, form, tmp_path, monkeypatch):
     got = _run_gpu(pool, x, block)
     want = O.run_streams(spec, co, x, block)
     err = np.abs(got - want).max()
-    assert err < THR * 2, (kind, err)
+    errlog.bound(err, 1.5e-6, "gpu_parity:400")
     # block-size invariance on the device (history / state carried across launches)
     pool2 = ax.Pool(S, 256)
     pool2.set_model(m)
     pool2.set_controls(cg)
     got2 = _run_gpu(pool2, x, 256)
-    assert np.abs(got2 - got).max() < 2e-6
+    errlog.bound(np.abs(got2 - got).max(), 1e-7, "gpu_parity:406")
 
 
 @pytest.mark.parametrize("name,kw", [
@@ -455,7 +456,7 @@ def test_matrix_core_form_ragged_blocks_and_per_stream_controls(name, kw, tmp_pa
         elif c0.get("net_bypass", 0.0) == 1.0:
             assert np.array_equal(got[s], want), s                           # no NN in circuit: bit-exact
         else:
-            assert np.abs(got[s] - want).max() < THR * 4, (name, s, np.abs(got[s] - want).max())
+            errlog.bound(np.abs(got[s] - want).max(), 2e-6, "gpu_parity:458")
 
 
 def test_matrix_core_form_model_swap_and_activate(tmp_path, bundled_models):
@@ -486,7 +487,7 @@ def test_matrix_core_form_model_swap_and_activate(tmp_path, bundled_models):
             want[i].append(plug[i].run(co, x[s, bi * n:(bi + 1) * n]))
     got = np.concatenate(got, axis=1)
     for i, s in enumerate((0, S - 1)):
-        assert np.abs(got[s] - np.concatenate(want[i])).max() < THR * 2
+        errlog.bound(np.abs(got[s] - np.concatenate(want[i])).max(), 1e-6, "gpu_parity:489")
 
 
 def test_stacked_model_state_readback(tmp_path):
@@ -539,7 +540,7 @@ def test_every_kernel_form_passes_the_same_chain_cases(form, tmp_path, monkeypat
         if kw.get("enabled") == 0.0 or kw.get("net_bypass") == 1.0:
             assert np.array_equal(got[s], want), (form, s)
         else:
-            assert np.abs(got[s] - want).max() < THR * 3, (form, s, np.abs(got[s] - want).max())
+            errlog.bound(np.abs(got[s] - want).max(), 1e-6, "gpu_parity:542")
     # (2) conditioned GRU, params ramping block by block, activate in the middle, then a model swap
     pa, spec_a = _model_file(tmp_path, "f2", kind="gru", hidden=24, input_size=3, seed=11)
     pb, spec_b = _model_file(tmp_path, "f3", kind="lstm", hidden=12, input_size=2, seed=12)
@@ -565,7 +566,7 @@ def test_every_kernel_form_passes_the_same_chain_cases(form, tmp_path, monkeypat
         g = pool.process(np.ascontiguousarray(x2[:, b:b + 128]))
         for s in range(S2):
             w = plugs[s].run(O.default_controls(**kw), x2[s, b:b + 128])
-            assert np.abs(g[s] - w).max() < THR * 2.5, (form, bi, s, np.abs(g[s] - w).max())
+            errlog.bound(np.abs(g[s] - w).max(), 1e-6, "gpu_parity:568")
     # (3) no model at all (chain only, loading cleared): bit-exact in every form
     x3 = modelgen.signal(66, 300, seed=3)
     pool = ax.Pool(66, 300)

@@ -3,7 +3,8 @@
 
     <out>/rt-neural-generic.lv2/
         manifest.ttl, rt-neural-generic.ttl     generated HERE from the port table below
-        rt-neural-generic.so, libaidax_hip.so   copied from the build (when present)
+        rt-neural-generic.so                    linked here with rpath $ORIGIN
+        libaidax_hip.so                         copied from the build
         models/deer ink studios/*.json          the six bundled model files
 
 The port table restates the plugin's public interface — index, symbol, range and default of every
@@ -16,6 +17,7 @@ itself is written by this script, not copied.
 import argparse
 import os
 import shutil
+import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 URI = "http://aidadsp.cc/plugins/aidadsp-bundle/rt-neural-generic"
@@ -137,11 +139,16 @@ def make_bundle(out_dir, binaries=True):
         if fn.endswith(".json"):
             shutil.copy(os.path.join(src, fn), os.path.join(mdir, fn))
     if binaries:
-        # the bundle's plugin binary is linked with rpath $ORIGIN (make bundle), the library sits next to it
-        for rel in ("build/bundle/rt-neural-generic.so", "aidadsp-lv2_amd/lib/libaidax_hip.so"):
-            p = os.path.join(ROOT, rel)
-            if os.path.exists(p):
-                shutil.copy(p, os.path.join(bundle, os.path.basename(p)))
+        # the plugin binary is linked HERE, into the bundle, with rpath $ORIGIN; the HIP library sits next to it
+        lib = os.path.join(ROOT, "aidadsp-lv2_amd", "lib", "libaidax_hip.so")
+        if not os.path.exists(lib):
+            raise FileNotFoundError(f"{lib}: run `make` first")
+        shutil.copy(lib, os.path.join(bundle, "libaidax_hip.so"))
+        subprocess.check_call(["g++", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden", "-Wall", "-Wextra",
+                               "-I" + os.path.join(ROOT, "include"), "-shared",
+                               os.path.join(ROOT, "aidadsp-lv2_amd", "lv2", "rt_neural_generic_lv2.cpp"),
+                               "-o", os.path.join(bundle, "rt-neural-generic.so"),
+                               "-L" + bundle, "-laidax_hip", "-Wl,-rpath,$ORIGIN"])
     return bundle
 
 

@@ -512,6 +512,7 @@ __device__ __forceinline__ void stream_body(const LaunchArgs& a, float* smem)
 constexpr int kSB = 16;                 // frames per pipeline stage
 constexpr int kRing = 2 * kSB;          // rows of the h history ring
 constexpr int kPipeWaves = 3;
+constexpr int kStage = 4 * kSB;         // floats of one hand-over stage of the input ring
 
 __host__ __device__ constexpr int pipe_row_stride(int H) { return H + 4; }   // floats; keeps rows 16-B aligned
 __host__ __device__ constexpr size_t pipe_lds_floats(int H, int n_frames)
@@ -530,8 +531,8 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
     const int n = (int)a.n_frames;
 
     float*  inbuf = smem;                                                   // P private
-    float4* xq    = reinterpret_cast<float4*>(smem + ((n + 3) & ~3));       // (x_pre, p1, p2, -) ring, 3 stages
-    float*  hh    = reinterpret_cast<float*>(xq + 3 * kSB);                 // h history, kRing rows
+    float*  xq    = smem + ((n + 3) & ~3);                                  // ring of 3 stages: x_pre[kSB] | p1[kSB] | p2[kSB] | -
+    float*  hh    = xq + 3 * kStage;                                        // h history, kRing rows
     float*  qb    = hh + kRing * HS;                                        // Q private
     float*  wdl   = qb + kSB;                                               // Q private: Dense weights, natural order
 
@@ -595,6 +596,9 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
         }
         __builtin_amdgcn_wave_barrier();
     } else if (wave == 1) {               // ---- N prologue
+        // the recurrent wave is the critical path of the workgroup and of its SIMD, which it shares with helper
+        // waves of other streams: it issues first (measured 95 -> 84 us per cfg2 block)
+        if (!(a.tune & 1)) __builtin_amdgcn_s_setprio(3);
         if (net_on) {
             cell.load(a.wpack, nnst, lane);
             cell.publish_h(hh + (kRing - 1) * HS);       // h(-1): the row "before" frame 0
@@ -623,13 +627,13 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
             if (p < n_sub) {
                 const int base = p * kSB;
                 const int cnt = n - base < kSB ? n - base : kSB;
-                float4* stage = xq + (p % 3) * kSB;
-                chain_run<4>(cp, inbuf + base, reinterpret_cast<float*>(stage), cnt, lane);
+                float* stage = xq + (p % 3) * kStage;
+                chain_run<1>(cp, inbuf + base, stage, cnt, lane);
                 if (net_on && I >= 2) {
                     for (int t = 0; t < cnt; ++t) {
                         const float q1 = lin_next(p_mem[0], p_tgt[0], p_step[0]);
                         const float q2 = I >= 3 ? lin_next(p_mem[1], p_tgt[1], p_step[1]) : 0.f;
-                        if (lane == 0) { stage[t].y = q1; stage[t].z = q2; }
+                        if (lane == 0) { stage[kSB + t] = q1; stage[2 * kSB + t] = q2; }
                     }
                 }
             }
@@ -637,26 +641,34 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
             if (net_on && p >= 1 && p <= n_sub) {
                 const int base = (p - 1) * kSB;
                 const int cnt = n - base < kSB ? n - base : kSB;
-                const float4* stage = xq + ((p - 1) % 3) * kSB;
+                const float* stage = xq + ((p - 1) % 3) * kStage;
                 // rows of one sub-block are contiguous in the ring (base is a multiple of kSB)
                 const float* hprev = hh + ((base + kRing - 1) & (kRing - 1)) * HS;
                 float* hcur = hh + (base & (kRing - 1)) * HS;
                 const float in_gain = a.in_gain;
-                if (I == 1) {                                   // snapshot models: one scalar input per frame
-                    float xin = stage[0].x;
+                if (I == 1 && cnt == kSB) {
+                    // snapshot models, whole stage: the stage's inputs travel into registers with four reads and the
+                    // frame loop is unrolled, so a frame's only LDS traffic is h (one write, H/4 broadcast reads issued
+                    // straight behind it) and nothing but the recurrence sits between two frames
+                    float xr[kSB];
+#pragma unroll
+                    for (int q = 0; q < kSB / 4; ++q) {
+                        const float4 v = reinterpret_cast<const float4*>(stage)[q];
+                        xr[4 * q] = v.x * in_gain; xr[4 * q + 1] = v.y * in_gain;       // out[i] *= input_gain
+                        xr[4 * q + 2] = v.z * in_gain; xr[4 * q + 3] = v.w * in_gain;
+                    }
+#pragma unroll
+                    for (int t = 0; t < kSB; ++t)
+                        cell.template step<1>(xr[t], 0.f, 0.f, t == 0 ? hprev : hcur + (t - 1) * HS, hcur + t * HS);
+                } else if (I == 1) {                            // ragged last stage
                     for (int t = 0; t < cnt; ++t) {
-                        const float x = xin * in_gain;          // out[i] *= input_gain
-                        xin = stage[t + 1].x;                   // prefetch (one past the stage is still ring memory)
-                        cell.template step<1>(x, 0.f, 0.f, hprev, hcur);
+                        cell.template step<1>(stage[t] * in_gain, 0.f, 0.f, hprev, hcur);
                         hprev = hcur;
                         hcur += HS;
                     }
                 } else {
-                    float4 in = stage[0];
                     for (int t = 0; t < cnt; ++t) {
-                        const float4 cur = in;
-                        in = stage[t + 1];
-                        cell.template step<3>(cur.x * in_gain, cur.y, I >= 3 ? cur.z : 0.f, hprev, hcur);
+                        cell.template step<3>(stage[t] * in_gain, stage[kSB + t], I >= 3 ? stage[2 * kSB + t] : 0.f, hprev, hcur);
                         hprev = hcur;
                         hcur += HS;
                     }
@@ -667,7 +679,7 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
                 const int base = (p - 2) * kSB;
                 const int cnt = n - base < kSB ? n - base : kSB;
                 const int tl = lane < cnt ? lane : cnt - 1;
-                const float xin = xq[((p - 2) % 3) * kSB + tl].x;
+                const float xin = xq[((p - 2) % 3) * kStage + tl];
                 float o = xin;
                 if (net_on) {
                     asm volatile("" ::: "memory");          // do not hoist the Dense weights out of the phase loop

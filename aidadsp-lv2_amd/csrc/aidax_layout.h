@@ -212,6 +212,7 @@ struct LaunchArgs {
     int32_t          input_size;
     int32_t          input_skip;
     float            in_gain, out_gain;
+    int32_t          tune;        // AIDAX_TUNE bit mask: measurement switches of the kernels (0 in production)
 };
 
 }  // namespace aidax

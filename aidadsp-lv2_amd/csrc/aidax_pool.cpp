@@ -152,6 +152,7 @@ struct aidax_pool {
     int ctl_next = 0;
 
     ModelSlot cur;
+    int tune = 0;                    // AIDAX_TUNE (measurement switches, see LaunchArgs)
     int force_form = 0;              // AIDAX_KERNEL=wave|pipe|split|valu|mfma|quad overrides the heuristic (A/B testing)
 
     // Form of a MODE_CHAIN pass of a TABLE slot: 0 one wave per stream, 1 three-wave pipeline (all streams resident at
@@ -268,6 +269,7 @@ struct aidax_pool {
         a.n_streams = n_streams; a.n_frames = n_frames; a.nn_stride = m.nn_stride;
         a.mode = mode; a.input_size = m.input_size; a.input_skip = m.input_skip;
         a.in_gain = m.in_gain; a.out_gain = m.out_gain;
+        a.tune = tune;
         return a;
     }
     // frames one launch of the extension kernels may carry (their LDS planes grow with n)
@@ -488,6 +490,7 @@ AIDAX_API int aidax_pool_create(uint32_t n_streams, uint32_t max_frames, double 
         p->gain_coef = exp_smoother_coef(static_cast<float>(host_samplerate), 0.1f);
         if (const char* f = std::getenv("AIDAX_KERNEL"))
             p->force_form = std::strcmp(f, "wave") == 0 ? 1 : std::strcmp(f, "pipe") == 0 ? 2 : std::strcmp(f, "split") == 0 ? 3 : std::strcmp(f, "valu") == 0 ? 4 : std::strcmp(f, "mfma") == 0 ? 5 : std::strcmp(f, "quad") == 0 ? 6 : 0;
+        if (const char* t = std::getenv("AIDAX_TUNE")) p->tune = std::atoi(t);
         try {
             HIP_TRY(hipSetDevice(device_id));
             HIP_TRY(hipStreamCreateWithFlags(&p->q, hipStreamNonBlocking));

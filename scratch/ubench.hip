@@ -44,6 +44,24 @@ __global__ __launch_bounds__(64) void k(float* o, const float* w, long long* t, 
       for (int i = 0; i < 32; ++i) { f2 ww = {wa[i], wb[i]}; f2 hh = {h, h2};
         asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(ww), "v"(hh)); }
       a = acc.x; b = acc.y;
+    } else if constexpr (V == 6 || V == 7) {   // packed fma, V==6: two / V==7: four independent accumulator pairs
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      constexpr int NC = V == 6 ? 2 : 4;
+      f2 acc[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[c] = f2{a, b};
+#pragma unroll
+      for (int i = 0; i < 32; ++i) { f2 ww = {wa[i], wb[i]}; f2 hh = {h, h2};
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc[i % NC]) : "v"(ww), "v"(hh)); }
+      f2 sum = acc[0];
+#pragma unroll
+      for (int c = 1; c < NC; ++c) sum += acc[c];
+      a = sum.x; b = sum.y;
+    } else if constexpr (V == 8) {   // scalar fma, four independent chains (2 rows x even/odd k)
+      float a2 = 0.f, b2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 32; i += 2) { a = FM(wa[i], h, a); b = FM(wb[i], h2, b); a2 = FM(wa[i + 1], h, a2); b2 = FM(wb[i + 1], h2, b2); }
+      a += a2; b += b2;
     } else if constexpr (V == 5) {   // readlane -> SGPR broadcast
 #pragma unroll
       for (int i = 0; i < 32; ++i) { float q = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, h), i)); a = FM(wa[i], q, a); b = FM(wb[i], q, b); }
@@ -73,4 +91,7 @@ int main() {
   run<3>("LDS write + b128 bcast", o, w, t);
   run<4>("v_pk_fma_f32", o, w, t);
   run<5>("readlane->sgpr", o, w, t);
+  run<6>("v_pk_fma_f32 x2 chains", o, w, t);
+  run<7>("v_pk_fma_f32 x4 chains", o, w, t);
+  run<8>("v_fma_f32 x4 chains", o, w, t);
 }

@@ -33,6 +33,12 @@ constexpr size_t kChainLdsLimit = 72 * 1024;     // packed chains: eight rows of
 // one packed chain launch (8 streams per wave): pre = LPF/pre-gain/EQ(pre) in -> out, else DC/EQ(post)/master in place
 hipError_t launch_chain_pass(bool pre, const LaunchArgs& a, hipStream_t stream);
 hipError_t launch_mfma_kernel(const LaunchArgs& a, const MfmaDesc& d, hipStream_t stream);
+// k_mfma_lp (aidax_mfmalp.hip): stacked models, one workgroup per (16 streams, layer), layers chained through a global ring
+bool mfma_lp_serves(const MfmaDesc& d);
+size_t mfma_lp_lds_bytes(const MfmaDesc& d, uint32_t n_frames);
+size_t mfma_lp_ring_bytes(const MfmaDesc& d, uint32_t n_streams);
+size_t mfma_lp_counter_bytes(const MfmaDesc& d, uint32_t n_streams);
+hipError_t launch_mfma_lp_kernel(const LaunchArgs& a, const MfmaDesc& d, float* ring, uint32_t* counters, hipStream_t stream);
 size_t quad_lds_bytes(int hidden, uint32_t n_frames);
 hipError_t launch_quad_kernel(int cell, int hidden, const LaunchArgs& a, const QuadDesc& qd, hipStream_t stream);
 hipError_t launch_stack_kernel(const LaunchArgs& a, const StackDesc& d, hipStream_t stream);

@@ -1,0 +1,446 @@
+// aidax_mfmalp.hip — k_mfma_lp: STACKED recurrent models on the matrix cores, one workgroup per (16 streams, LAYER),
+// the layers of a stream group chained through a small ring in global memory.
+//
+// Why: k_mfma (aidax_mfma.hip) gives a group of 16 streams ONE workgroup that walks all layers, streaming 437 KiB of
+// A fragments from L2 every frame (LSTM-96 x2). At BASELINE cfg5's per-GPU size (2048 streams = 128 groups) that
+// fills half of the 256 CUs, and the fragment stream plus its address arithmetic sits between the MFMAs. Here
+//   * a group's layers run on SEPARATE workgroups (2048 streams x 2 layers = 256 workgroups: every CU busy), layer l
+//     one or more frames behind layer l-1;
+//   * each workgroup keeps ITS layer's A fragments in registers for the whole launch (LSTM-96 layer 1: 384 rows x
+//     192 columns = 288 KiB = 144 registers per lane over 8 waves): the frame loop is MFMAs fed by one
+//     conflict-free ds_read_b32 per k-step, no global loads, no address arithmetic;
+//   * h of layer l-1 travels to layer l through a ring of kLpRing frames in global memory, in the layout layer l
+//     reads it in ([unit][stream] = ready B fragments). ONE-directional hand-over: the producer publishes a frame
+//     counter with agent-scope release every kLpBatch frames, the consumer polls it with acquire only when it has
+//     used up what it knows of; the producer waits only when the ring is full (consumer's counter, relaxed).
+//     Latency of the hand-over is hidden by the skew between the layers, nobody waits per frame.
+//
+// Forward progress: workgroup ids are laid out so that a layer's workgroup has a LOWER id than the layer above it
+// (ids of one group differ by 8: same id modulo 8, i.e. the same XCD and L2 under the round-robin workgroup -> XCD
+// assignment — a locality hint only, visibility comes from the release/acquire pair). Workgroups are dispatched in
+// id order, so whenever a consumer spins its producer is running or done, and a producer that waits on a full ring
+// waits for a consumer that is among the next eight ids to be dispatched.
+//
+// Same arithmetic as k_mfma (same fragments from pack_mfma, same accumulation order, same activations): the two
+// kernels are bit-identical on the same model, which tests/test_gpu_parity.py checks.
+#include "aidax_device.h"
+#include "aidax_kernels.h"
+#include "aidax_layout.h"
+
+namespace aidax {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kLpChunk = 256;            // frames of audio staged in LDS at a time
+constexpr int kLpRing = 16;              // frames of h in flight between two layers
+constexpr int kLpBatch = 4;              // frames per counter update
+
+__host__ __device__ inline size_t lp_lds_floats(int hidden, int n_frames)
+{
+    const size_t nP = (size_t)(((n_frames < kLpChunk ? n_frames : kLpChunk) + 3) & ~3);
+    return (size_t)kMfmaStreams * nP                          /* xb: audio rows (first and last layer)   */
+         + 2 * 64                                             /* xin[parity][4][n]  (first layer)        */
+         + (size_t)2 * hidden * kMfmaStreams                  /* below[parity][unit][n] (layers >= 1)    */
+         + (size_t)2 * hidden * kMfmaStreams                  /* hT[parity][unit][n]                     */
+         + (size_t)hidden * kMfmaStreams                      /* cT[unit][n]                             */
+         + (size_t)hidden * 4                                 /* bias[unit][4 rows]                      */
+         + (size_t)((hidden + 1 + 3) & ~3)                    /* Dense weights + bias (last layer)       */
+         + kMfmaStreams;                                      /* live flags                              */
+}
+
+__host__ __device__ inline size_t lp_ring_floats(int hidden) { return (size_t)kLpRing * hidden * kMfmaStreams; }
+constexpr int kLpCounterStride = 32;     // uint32 per (group, boundary): produced at [0], consumed at [16] (own cache lines)
+
+__device__ __forceinline__ float lp_row_sum16(float v)
+{
+    v = v + dpp_take<0xB1, 0xf>(v);
+    v = v + dpp_take<0x4E, 0xf>(v);
+    v = v + dpp_take<0x141, 0xf>(v);
+    v = v + dpp_take<0x140, 0xf>(v);
+    return v;
+}
+
+// acc[tl] += A(groups g0..g0+NG) . B, A resident in `wres`, B fragments from `src` ([unit][stream] in LDS)
+template <int TPW, int NG, int G0, int NRES>
+__device__ __forceinline__ void lp_gates(f32x4 (&acc)[TPW], const f32x4 (&wres)[NRES], const float* src, int lane)
+{
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        float b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = src[256 * g + 64 * j + lane];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int tl = 0; tl < TPW; ++tl) {
+                const int e = j * TPW + tl;
+                acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[(G0 + g) * TPW + e / 4][e % 4], b[j], acc[tl], 0, 0, 0);
+            }
+    }
+}
+
+template <int TPW, int NW>
+__global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d, float* ring, uint32_t* counters)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int H = 4 * TPW * NW;
+    constexpr int NT = NW * kWave;
+    constexpr int NS = kMfmaStreams;
+    constexpr int G = H / 16;                              // k-step groups per H columns
+    constexpr int NRES = 2 * G * TPW;                      // f32x4 of resident A fragments: [h below | own h]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = (int)a.n_frames;
+    const int NL = d.n_layers;
+    const int Ht = d.hidden_true;
+    const int I = a.input_size;
+    const int mode = a.mode;
+    // workgroup id -> (group, layer): ids of one group are 8 apart, lower layers first
+    const int blk = (int)blockIdx.x;
+    const int grp = (blk / (8 * NL)) * 8 + (blk & 7);
+    const int l = (blk / 8) % NL;
+    const int n_groups = ((int)a.n_streams + NS - 1) / NS;
+    if (grp >= n_groups) return;
+    const bool first = l == 0, last = l == NL - 1;
+    const int s_base = grp * NS;
+    const int chunk = n < kLpChunk ? n : kLpChunk;
+    const int nP = (chunk + 3) & ~3;
+
+    float* xb    = smem;                                   // [NS][nP]
+    float* xin   = xb + NS * nP;                           // [2][4][NS]
+    float* below = xin + 2 * 64;                           // [2][H][NS]
+    float* hT    = below + 2 * H * NS;                     // [2][H][NS]
+    float* cT    = hT + 2 * H * NS;                        // [H][NS]
+    float* bl    = cT + H * NS;                            // [H][4]
+    float* wdl   = bl + H * 4;                             // Dense weights, bias at [H]
+    float* livef = wdl + ((H + 1 + 3) & ~3);               // [NS]
+
+    const float* W = a.wpack;
+    const MfmaLayer& L = d.L[l];
+
+    // ---- per-stream bookkeeping: lanes tid < NS own stream s_base+tid (live flag; PARAM smoothers on the first layer)
+    float p_mem[2] = { 0.f, 0.f }, p_tgt[2] = { 0.f, 0.f }, p_step[2] = { 0.f, 0.f };
+    uint32_t pending = 0;
+    bool mine_live = false;
+    if (tid < NS) {
+        const int sg = s_base + tid;
+        const bool valid = sg < (int)a.n_streams;
+        if (valid) {
+            StreamState& st = a.st[sg];
+            p_mem[0] = st.p_mem[0]; p_mem[1] = st.p_mem[1];
+            p_tgt[0] = st.p_tgt[0]; p_tgt[1] = st.p_tgt[1];
+            p_step[0] = st.p_step[0]; p_step[1] = st.p_step[1];
+            pending = st.pending;
+            if (mode == MODE_CHAIN) {
+                const StreamCtl& ctl = a.ctl[sg];
+                const uint32_t flags = ctl.flags;
+                mine_live = n != 0 && (flags & CTL_ENABLED) && (flags & CTL_NET_ON);      // :607-619, :631-632
+                if (mine_live) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {            // LinearValueSmoother::setTargetValue (:209-216)
+                        const float nt = ctl.p_target[i];
+                        if (__builtin_fabsf(p_tgt[i] - nt) >= FLT_EPSILON) {
+                            p_tgt[i] = nt;
+                            p_step[i] = (p_tgt[i] - p_mem[i]) / ctl.p_den;
+                        }
+                    }
+                    if (pending & PEND_PARAM_FIRST) {        // paramFirstRun (:636-640)
+                        pending &= ~PEND_PARAM_FIRST;
+                        p_mem[0] = p_tgt[0];
+                        p_mem[1] = p_tgt[1];
+                    }
+                }
+            } else {
+                mine_live = n != 0 && (mode == MODE_WARMUP || sg == 0);
+            }
+        }
+        livef[tid] = mine_live ? 1.f : 0.f;
+    }
+    if (last) for (int i = tid; i < H + 1; i += NT) wdl[i] = W[d.wd_off + i];
+    for (int i = tid; i < H * 4; i += NT) bl[i] = W[L.b_off + i];
+    // this layer's recurrent state -> LDS (parity 0 is what frame 0 reads)
+    for (int i = tid; i < H * NS; i += NT) {
+        const int u = i / NS, sn = i % NS, sg = s_base + sn;
+        const bool valid = sg < (int)a.n_streams;
+        const float* stp = a.nn + (size_t)(valid ? sg : 0) * a.nn_stride + L.state_off;
+        hT[i] = (valid && u < Ht) ? stp[u] : 0.f;           // padded units rest at 0
+        cT[i] = (valid && u < Ht && L.cell == 0) ? stp[Ht + u] : 0.f;
+    }
+
+    // ---- this layer's A fragments, resident for the launch
+    float w_in0[TPW];
+#pragma unroll
+    for (int tl = 0; tl < TPW; ++tl) w_in0[tl] = first ? W[d.L[0].w_in_off + ((size_t)wave * kWave + lane) * TPW + tl] : 0.f;
+    f32x4 wres[NRES];
+    {
+        const int g_tot = first ? G : 2 * G;
+        const f32x4* ap = reinterpret_cast<const f32x4*>(W + L.w_big_off) + ((size_t)wave * g_tot * kWave + lane) * TPW;
+#pragma unroll
+        for (int g = 0; g < 2 * G; ++g)
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) {
+                // first layer: its G groups (own h) sit in the upper half, like the recurrent half of the others
+                const int gs = first ? g - G : g;
+                wres[g * TPW + q] = (gs >= 0) ? ap[(size_t)gs * kWave * TPW + q] : f32x4{ 0.f, 0.f, 0.f, 0.f };
+            }
+    }
+
+    // ---- ring bookkeeping. Counters count frames since the buffers were allocated and are equal on both sides
+    // between launches, so a workgroup starts from its own side's value.
+    const size_t ring_stride = lp_ring_floats(H);
+    float* ring_out = last ? nullptr : ring + ((size_t)grp * (NL - 1) + l) * ring_stride;
+    const float* ring_in = first ? nullptr : ring + ((size_t)grp * (NL - 1) + (l - 1)) * ring_stride;
+    uint32_t* cnt_out = last ? nullptr : counters + ((size_t)grp * (NL - 1) + l) * kLpCounterStride;
+    uint32_t* cnt_in = first ? nullptr : counters + ((size_t)grp * (NL - 1) + (l - 1)) * kLpCounterStride;
+    // every thread needs the bases (they place a frame in the ring); the running counts are thread 0's business
+    const uint32_t base_out = cnt_out ? __hip_atomic_load(cnt_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    const uint32_t base_in = cnt_in ? __hip_atomic_load(cnt_in + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    uint32_t known_free = kLpRing;                         // frames of this launch the ring above is known to have room for
+    uint32_t known_below = 0;                              // frames of this launch known to exist below
+    __syncthreads();
+
+    // frames [0, total) of this launch as the ring sees them
+    int par = 0;                                           // parity of hT the next frame reads
+    int done = 0;                                          // frames finished before this chunk
+    for (int base = 0; base < n; base += kLpChunk) {
+        const int cnt = n - base < kLpChunk ? n - base : kLpChunk;
+        // ---- audio rows of this chunk: the first layer reads them as input, the last for in_skip and to deliver
+        if (first || last) {
+            for (int sl = wave; sl < NS; sl += NW) {
+                const int sg = s_base + sl;
+                const bool lv = livef[sl] != 0.f;
+                float* row = xb + sl * nP;
+                if (lv && mode == MODE_CHAIN) {
+                    const float* src = a.out + (size_t)sg * n + base;
+                    if (((n | base) & 3) == 0) load_block(row, src, cnt, lane);
+                    else for (int t = lane; t < cnt; t += kWave) row[t] = src[t];
+                } else if (lv && mode == MODE_NN_ONLY) {
+                    for (int t = lane; t < cnt; t += kWave) row[t] = a.in[(size_t)(base + t) * I];
+                } else {
+                    for (int t = lane; t < cnt; t += kWave) row[t] = 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        auto write_xin = [&](int parity, int f) {
+            // lanes tid < NS: x * in_gain, PARAM1, PARAM2 of frame `f` (:171-181, :195-231)
+            float q1 = 0.f, q2 = 0.f;
+            if (mode == MODE_CHAIN) {
+                if (I >= 2) q1 = lin_next(p_mem[0], p_tgt[0], p_step[0]);
+                if (I >= 3) q2 = lin_next(p_mem[1], p_tgt[1], p_step[1]);
+            } else if (mode == MODE_WARMUP) {             // constant params over the zero pre-buffer (:1077-1078)
+                q1 = I >= 2 ? p_mem[0] : 0.f;
+                q2 = I >= 3 ? p_mem[1] : 0.f;
+            } else if (tid == 0) {
+                q1 = I >= 2 ? a.in[(size_t)(base + f) * I + 1] : 0.f;
+                q2 = I >= 3 ? a.in[(size_t)(base + f) * I + 2] : 0.f;
+            }
+            float* col = xin + parity * 64;
+            col[tid] = xb[tid * nP + f] * a.in_gain;
+            col[NS + tid] = q1;
+            col[2 * NS + tid] = q2;
+            col[3 * NS + tid] = 0.f;
+        };
+        // what the layer below hands over: frame F of the launch sits in ring slot (base_in + F) % kLpRing
+        auto wait_below = [&](int frames_needed) {        // thread 0 only: until `frames_needed` frames of the launch exist
+            if (frames_needed > n) frames_needed = n;
+            while ((int)known_below < frames_needed) {
+                known_below = __hip_atomic_load(cnt_in, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - base_in;
+                if ((int)known_below < frames_needed) __builtin_amdgcn_s_sleep(2);
+            }
+        };
+        constexpr int PER = H * NS / NT;                   // floats of a frame each thread moves (H*16 / threads)
+        static_assert(H * NS % NT == 0, "frame tile must divide over the threads");
+        float pre[PER];
+        auto fetch_below = [&](int F) {                    // all threads: frame F of the launch -> registers
+            const float* src = ring_in + (size_t)((base_in + (uint32_t)F) % kLpRing) * H * NS;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) pre[q] = src[q * NT + tid];
+        };
+        auto stash_below = [&](int parity) {
+#pragma unroll
+            for (int q = 0; q < PER; ++q) below[parity * H * NS + q * NT + tid] = pre[q];
+        };
+
+        if (first) {
+            if (tid < NS) write_xin(0, 0);
+        } else {
+            if (tid == 0) wait_below(done + 2);            // frame 0 of the chunk for now, frame 1 for tick 0's prefetch
+            __syncthreads();
+            fetch_below(done);
+            stash_below(0);
+        }
+        __syncthreads();
+
+        const int ticks = last ? cnt + 1 : cnt;            // the Dense of a frame runs one tick behind its h
+        for (int tick = 0; tick < ticks; ++tick) {
+            const int rd = par, wr = par ^ 1;
+            const bool body = tick < cnt;
+            const bool more = tick + 1 < cnt;              // another frame of this chunk follows
+            const int F = done + tick;                     // frame of the launch this tick computes
+            // ---- the next frame's input on its way: model inputs (first layer) / h of the layer below into
+            // registers (others; thread 0 made sure of its existence before the previous barrier)
+            if (first) {
+                if (tid < NS && more) write_xin((tick + 1) & 1, tick + 1);
+            } else if (more) {
+                fetch_below(F + 1);
+            }
+            if (body && tid == 0) {
+                // thread 0 looks ahead while the others compute: the frame AFTER next must exist below before the
+                // next tick fetches it, and the slot of the next frame must be free above before the next tick
+                // stores into it. Normally both are known already; otherwise this wave spins and the workgroup
+                // waits for it at the barrier.
+                if (!first && tick + 2 < cnt) wait_below(F + 3);
+                if (!last && base + tick + 1 < n) {
+                    while ((int)known_free < F + 2) {
+                        const uint32_t consumed = __hip_atomic_load(cnt_out + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base_out;
+                        known_free = consumed + kLpRing;
+                        if ((int)known_free < F + 2) __builtin_amdgcn_s_sleep(2);
+                    }
+                }
+            }
+
+            // ---- Dense(H,1) + skip + output gain of the frame before: wave w reduces streams 4w..4w+3
+            if (last && tick >= 1 && wave < 4) {
+                const int fd = tick - 1;
+                const int sl = wave * 4 + (lane >> 4), q = lane & 15;
+                const float* hv = hT + rd * H * NS;
+                float part = 0.f;
+#pragma unroll
+                for (int j = 0; j < H / 16; ++j) part = __builtin_fmaf(wdl[q + 16 * j], hv[(q + 16 * j) * NS + sl], part);
+                const float y = lp_row_sum16(part) + wdl[H];
+                const float x = xb[sl * nP + fd] * a.in_gain;
+                float o = a.input_skip ? x + y : y;
+                o = o * a.out_gain;
+                if (q == 0 && livef[sl] != 0.f) xb[sl * nP + fd] = o;
+            }
+
+            if (body) {
+                float* h_rd = hT + rd * H * NS;
+                float* h_wr = hT + wr * H * NS;
+                f32x4 acc[TPW];
+                const f32x4* bias4 = reinterpret_cast<const f32x4*>(bl);
+#pragma unroll
+                for (int tl = 0; tl < TPW; ++tl) acc[tl] = bias4[4 * (wave * TPW + tl) + (lane >> 4)];
+                if (first) {                               // the model inputs: one k-step (x, PARAM1, PARAM2, 0)
+                    const float b = xin[(tick & 1) * 64 + lane];
+#pragma unroll
+                    for (int tl = 0; tl < TPW; ++tl)
+                        acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_in0[tl], b, acc[tl], 0, 0, 0);
+                } else {
+                    lp_gates<TPW, G, 0, NRES>(acc, wres, below + (tick & 1) * H * NS, lane);
+                }
+                lp_gates<TPW, G, G, NRES>(acc, wres, h_rd, lane);
+
+                float* ring_slot = last ? nullptr : ring_out + (size_t)((base_out + (uint32_t)F) % kLpRing) * H * NS;
+#pragma unroll
+                for (int tl = 0; tl < TPW; ++tl) {
+                    const int e = (wave * TPW + tl) * 64 + lane;          // unit 4T + (lane>>4), stream lane&15
+                    float hn;
+                    if (L.cell == 0) {
+                        const float gi = fast_sigmoid(acc[tl].x), gf = fast_sigmoid(acc[tl].y);
+                        const float gg = tanh_rat(acc[tl].z), go = fast_sigmoid(acc[tl].w);
+                        const float cn = __builtin_fmaf(gf, cT[e], gi * gg);
+                        cT[e] = cn;
+                        hn = go * tanh_rat(cn);
+                    } else {
+                        const float gz = fast_sigmoid(acc[tl].x), gr = fast_sigmoid(acc[tl].y);
+                        const float nn = tanh_rat(__builtin_fmaf(gr, acc[tl].z, acc[tl].w));
+                        hn = __builtin_fmaf(gz, h_rd[e] - nn, nn);
+                    }
+                    h_wr[e] = hn;
+                    if (ring_slot) ring_slot[e] = hn;
+                }
+                par = wr;
+                if (!first && more) stash_below((tick + 1) & 1);
+            }
+            __syncthreads();                               // h(t) in LDS, the next frame's input in LDS, ring stores of this frame done
+            // ---- counters, by thread 0 after the barrier: every kLpBatch frames and at the end of the launch
+            if (body && tid == 0) {
+                if (!last) {
+                    const int produced = F + 1;
+                    if (produced % kLpBatch == 0 || produced == n)
+                        __hip_atomic_store(cnt_out, base_out + (uint32_t)produced, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (!first) {
+                    const int consumed = more ? F + 2 : F + 1;             // frames read out of the ring so far
+                    if (consumed % kLpBatch == 0 || consumed == n)
+                        __hip_atomic_store(cnt_in + 16, base_in + (uint32_t)consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        done += cnt;
+        // ---- results of this chunk back to HBM (last layer)
+        if (last) {
+            for (int sl = wave; sl < NS; sl += NW) {
+                const int sg = s_base + sl;
+                if (livef[sl] == 0.f || mode == MODE_WARMUP) continue;
+                float* dst = mode == MODE_CHAIN ? a.out + (size_t)sg * n + base : a.out + base;
+                const float* row = xb + sl * nP;
+                if (((n | base) & 3) == 0 && mode == MODE_CHAIN) store_block(dst, row, cnt, lane);
+                else for (int t = lane; t < cnt; t += kWave) dst[t] = row[t];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- recurrent state and smoother memories back to HBM for the streams that ran
+    for (int i = tid; i < H * NS; i += NT) {
+        const int u = i / NS, sn = i % NS, sg = s_base + sn;
+        if (sg < (int)a.n_streams && u < Ht && livef[sn] != 0.f) {
+            float* stp = a.nn + (size_t)sg * a.nn_stride + L.state_off;
+            stp[u] = hT[par * H * NS + i];
+            if (L.cell == 0) stp[Ht + u] = cT[i];
+        }
+    }
+    if (first && tid < NS && mine_live && mode == MODE_CHAIN) {
+        StreamState& st = a.st[s_base + tid];
+        st.p_mem[0] = p_mem[0]; st.p_mem[1] = p_mem[1];
+        st.p_tgt[0] = p_tgt[0]; st.p_tgt[1] = p_tgt[1];
+        st.p_step[0] = p_step[0]; st.p_step[1] = p_step[1];
+        st.pending = pending;
+    }
+}
+
+// ---------------------------------------------------------------- host side
+typedef void (*LpFn)(LaunchArgs, MfmaDesc, float*, uint32_t*);
+static LpFn lp_fn(int hidden)
+{
+    switch (hidden) {
+#define AIDAX_LP_CASE(HID) case HID: return k_mfma_lp<HID / 4 / mfma_waves(HID), mfma_waves(HID)>
+    AIDAX_LP_CASE(16); AIDAX_LP_CASE(32); AIDAX_LP_CASE(48); AIDAX_LP_CASE(64); AIDAX_LP_CASE(80); AIDAX_LP_CASE(96);
+#undef AIDAX_LP_CASE
+    default: return nullptr;                               // wider stacks keep the fragment-streaming kernel
+    }
+}
+
+bool mfma_lp_serves(const MfmaDesc& d) { return d.n_layers >= 2 && lp_fn(d.hidden) != nullptr; }
+size_t mfma_lp_lds_bytes(const MfmaDesc& d, uint32_t n_frames) { return lp_lds_floats(d.hidden, (int)n_frames) * sizeof(float); }
+size_t mfma_lp_ring_bytes(const MfmaDesc& d, uint32_t n_streams)
+{
+    const size_t groups = (n_streams + kMfmaStreams - 1) / kMfmaStreams;
+    return groups * (size_t)(d.n_layers - 1) * lp_ring_floats(d.hidden) * sizeof(float);
+}
+size_t mfma_lp_counter_bytes(const MfmaDesc& d, uint32_t n_streams)
+{
+    const size_t groups = (n_streams + kMfmaStreams - 1) / kMfmaStreams;
+    return groups * (size_t)(d.n_layers - 1) * kLpCounterStride * sizeof(uint32_t);
+}
+
+hipError_t launch_mfma_lp_kernel(const LaunchArgs& a, const MfmaDesc& d, float* ring, uint32_t* counters, hipStream_t stream)
+{
+    LpFn fn = lp_fn(d.hidden);
+    if (!fn || !ring || !counters) return hipErrorInvalidValue;
+    const size_t lds = mfma_lp_lds_bytes(d, a.n_frames);
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const uint32_t groups = (a.n_streams + kMfmaStreams - 1) / kMfmaStreams;
+    const uint32_t blocks = ((groups + 7) / 8) * 8 * (uint32_t)d.n_layers;
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(mfma_waves(d.hidden) * kWave), lds, stream, a, d, ring, counters);
+    return hipGetLastError();
+}
+
+}  // namespace aidax

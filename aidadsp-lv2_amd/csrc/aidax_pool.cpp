@@ -100,6 +100,8 @@ struct ModelSlot {
     bool split_pays = false;         // the lean recurrent kernel keeps the occupancy of the one-wave kernel
     float* d_wpack = nullptr;        // weights in the kernel's layout
     float* d_nn = nullptr;           // recurrent state [n_streams][nn_stride]
+    float* d_ring = nullptr;         // k_mfma_lp: h of layer l-1 on its way to layer l, per stream group
+    uint32_t* d_counters = nullptr;  // k_mfma_lp: frames produced / consumed per (group, layer boundary)
 
     float p_den() const { return 0.1f * model_sr; }      // LinearValueSmoother tau * sampleRate (:1053-1054)
 };
@@ -282,9 +284,12 @@ struct aidax_pool {
     {
         if (m.has_model && m.kind == ModelSlot::MFMA) {
             // split form around the matrix-core kernel: packed chains in -> out, applyModel in place, packed chains
-            if (a.mode != MODE_CHAIN) return launch_mfma_kernel(a, m.mdesc, s);
+            auto model_kernel = [&]() {
+                return m.d_ring ? launch_mfma_lp_kernel(a, m.mdesc, m.d_ring, m.d_counters, s) : launch_mfma_kernel(a, m.mdesc, s);
+            };
+            if (a.mode != MODE_CHAIN) return model_kernel();
             hipError_t e = launch_chain_pass(true, a, s);
-            if (e == hipSuccess && a.n_frames != 0) e = launch_mfma_kernel(a, m.mdesc, s);
+            if (e == hipSuccess && a.n_frames != 0) e = model_kernel();
             if (e == hipSuccess) e = launch_chain_pass(false, a, s);
             return e;
         }
@@ -315,6 +320,8 @@ struct aidax_pool {
         if (d_st) (void)hipFree(d_st);
         if (cur.d_nn) (void)hipFree(cur.d_nn);
         if (cur.d_wpack) (void)hipFree(cur.d_wpack);
+        if (cur.d_ring) (void)hipFree(cur.d_ring);
+        if (cur.d_counters) (void)hipFree(cur.d_counters);
         if (d_in) (void)hipFree(d_in);
         if (d_out) (void)hipFree(d_out);
         if (h_in) (void)hipHostFree(h_in);
@@ -328,6 +335,7 @@ struct aidax_pool {
         if (q) (void)hipStreamDestroy(q);
         if (wq) (void)hipStreamDestroy(wq);
         d_ctl = nullptr; d_st = nullptr; cur.d_nn = nullptr; cur.d_wpack = nullptr; d_in = nullptr; d_out = nullptr;
+        cur.d_ring = nullptr; cur.d_counters = nullptr;
         h_in = nullptr; h_out = nullptr; ev_x = nullptr; q = nullptr; wq = nullptr;
     }
 };
@@ -341,6 +349,8 @@ void staged_release(aidax_staged* s)
     if (s->fenced) (void)hipEventSynchronize(s->fence);         // passes that still read the retired buffers
     if (s->slot.d_wpack) (void)hipFree(s->slot.d_wpack);
     if (s->slot.d_nn) (void)hipFree(s->slot.d_nn);
+    if (s->slot.d_ring) (void)hipFree(s->slot.d_ring);
+    if (s->slot.d_counters) (void)hipFree(s->slot.d_counters);
     if (s->d_pst) (void)hipFree(s->d_pst);
     if (s->fence) (void)hipEventDestroy(s->fence);
     delete s;
@@ -406,6 +416,14 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
     HIP_TRY(hipMalloc(&ms.d_wpack, wp.size() * sizeof(float)));
     HIP_TRY(hipMalloc(&ms.d_nn, static_cast<size_t>(p.n_streams) * ms.nn_stride * sizeof(float)));
     HIP_TRY(hipMalloc(&sg->d_pst, sizeof(StreamState) * p.n_streams));
+    const char* lp = std::getenv("AIDAX_MFMA_LP");
+    if (ms.kind == ModelSlot::MFMA && mfma_lp_serves(ms.mdesc) && !(lp && lp[0] == '0') &&
+        mfma_lp_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024) {
+        // stacked model: one workgroup per (16 streams, layer), chained through a ring in global memory
+        HIP_TRY(hipMalloc(&ms.d_ring, mfma_lp_ring_bytes(ms.mdesc, p.n_streams)));
+        HIP_TRY(hipMalloc(&ms.d_counters, mfma_lp_counter_bytes(ms.mdesc, p.n_streams)));
+        HIP_TRY(hipMemsetAsync(ms.d_counters, 0, mfma_lp_counter_bytes(ms.mdesc, p.n_streams), p.wq));
+    }
     HIP_TRY(hipMemcpyAsync(ms.d_wpack, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice, p.wq));
     // fresh DynamicModel per stream: reset() + param smoothers around the targets the playing model holds now
     // (:822-825, :1035, :1053-1061) ...
@@ -737,7 +755,7 @@ AIDAX_API const char* aidax_pool_kernel_name(const aidax_pool* p)
     if (!(p && p->cur.has_model)) return "k_nomodel";
     const ModelSlot& m = p->cur;
     if (m.kind == ModelSlot::STACK) return "k_stack";
-    if (m.kind == ModelSlot::MFMA) return "k_chain+k_mfma";
+    if (m.kind == ModelSlot::MFMA) return m.d_ring ? "k_chain+k_mfma_lp" : "k_chain+k_mfma";
     if (m.kind == ModelSlot::QUAD) return "k_chain+k_quad";
     if (m.kind == ModelSlot::CONV) return m.conv_mfma ? "k_chain+k_conv_mfma" : "k_conv";
     const int form = p->chain_form(m);

@@ -306,7 +306,7 @@ _EQ_POST = dict(bass_boost_db=4.0, mid_boost_db=-3.0, mid_q=1.2, treble_boost_db
     ("cfg2", dict(kind="lstm", hidden=32, input_size=1, seed=32), 1024, {}, "k_lstm_pipe<32>"),
     ("cfg3", dict(kind="gru", hidden=64, input_size=3, seed=64), 4096, _EQ_POST, "k_chain+k_nn<gru64>"),
     ("cfg4", dict(kind="conv", hidden=16, input_size=1, seed=1608), 1024, {}, "k_chain+k_conv_mfma"),
-    ("cfg5", dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2), 2048, {}, "k_chain+k_mfma"),
+    ("cfg5", dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2), 2048, {}, "k_chain+k_mfma_lp"),
     ("lstm80-2k", dict(kind="lstm", hidden=80, input_size=2, seed=80), 2048, dict(param1=0.7), "k_chain+k_quad"),
     ("lstm80-4k", dict(kind="lstm", hidden=80, input_size=2, seed=80), 4096, dict(param1=0.7), "k_chain+k_mfma"),
     ("gru16-4k", dict(kind="gru", hidden=16, input_size=3, seed=16), 4096, dict(param1=0.2, param2=0.9), "k_chain+k_quad"),
@@ -393,7 +393,7 @@ def test_extension_models_full_chain(kind, kw, form, tmp_path, monkeypatch):
     pool = ax.Pool(S, 256)
     pool.set_model(m)
     conv = kw["kind"] == "conv"
-    assert pool.kernel_name == (("k_conv" if conv else "k_stack") if form == "valu" else ("k_chain+k_conv_mfma" if conv else "k_chain+k_mfma"))
+    assert pool.kernel_name == (("k_conv" if conv else "k_stack") if form == "valu" else ("k_chain+k_conv_mfma" if conv else "k_chain+k_mfma_lp"))
     pool.set_controls(cg)
     got = _run_gpu(pool, x, block)
     want = O.run_streams(spec, co, x, block)
@@ -425,7 +425,7 @@ def test_matrix_core_form_ragged_blocks_and_per_stream_controls(name, kw, tmp_pa
     x = modelgen.signal(S, sum(sizes), seed=21)
     pool = ax.Pool(S, 256 if conv else 1024)
     pool.set_model(ax.Model(path))
-    assert pool.kernel_name == ("k_chain+k_conv_mfma" if conv else "k_chain+k_mfma")
+    assert pool.kernel_name == ("k_chain+k_conv_mfma" if conv else "k_chain+k_mfma_lp" if kw.get("n_rnn", 1) > 1 else "k_chain+k_mfma")
     kws = [dict(param1=0.3, param2=0.8), dict(enabled=0.0), dict(net_bypass=1.0), dict(eq_position=1.0, bass_boost_db=5.0, mid_type=1.0),
            dict(dc_blocker=0.0, in_lpf_pc=0.0, eq_bypass=1.0, param1=1.0), dict(pregain_db=6.0, master_db=-6.0, treble_boost_db=4.0, param2=0.1)]
     flip = dict(param1=0.9, param2=0.2, master_db=-3.0)                     # applied to every stream from the 5th block on
@@ -578,3 +578,40 @@ def test_every_kernel_form_passes_the_same_chain_cases(form, tmp_path, monkeypat
         p = O.OraclePlugin()
         p.set_loading(False)
         assert np.array_equal(g3[s], p.run(co, x3[s])), (form, s)
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("lstm96x2", dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2)),          # BASELINE cfg #5 model
+    ("gru48x3", dict(kind="gru", hidden=48, input_size=3, seed=483, n_rnn=3)),            # three layers: a middle workgroup both consumes and produces
+    ("l16x4", dict(kind="lstm", hidden=16, input_size=2, seed=164, n_rnn=4, in_skip=1)),
+])
+def test_layer_pipelined_kernel_is_bit_identical_to_the_one_workgroup_kernel(name, kw, tmp_path, monkeypatch):
+    """k_mfma_lp (one workgroup per layer, layers chained through a global ring, weights in registers) against
+    k_mfma (one workgroup walks all layers, AIDAX_MFMA_LP=0) on the same fragments: identical bits, over ragged
+    block sizes incl. blocks longer than the ring and the 256-frame staging chunk, 150 streams (10 stream groups,
+    the last one ragged) so that several groups and layers are in flight at once, and against the oracle."""
+    path, spec = _model_file(tmp_path, name, **kw)
+    S = 150
+    sizes = [256, 1, 5, 700, 16, 3, 255, 40]
+    x = modelgen.signal(S, sum(sizes), seed=27)
+    cg, co = _ctl_pair(param1=0.3, param2=0.8, pregain_db=1.0)
+    outs = {}
+    for lp in ("1", "0"):
+        monkeypatch.setenv("AIDAX_MFMA_LP", lp)
+        pool = ax.Pool(S, 1024)
+        pool.set_model(ax.Model(path))
+        assert pool.kernel_name == ("k_chain+k_mfma_lp" if lp == "1" else "k_chain+k_mfma")
+        pool.set_controls(cg)
+        got, pos = [], 0
+        for n in sizes:
+            got.append(pool.process(np.ascontiguousarray(x[:, pos:pos + n])))
+            pos += n
+        outs[lp] = np.concatenate(got, axis=1)
+        h, c = pool.read_state(stream=S - 1, layer=kw["n_rnn"] - 1, hidden=128)
+        outs[lp + "h"] = h
+        pool.close()
+    assert np.array_equal(outs["1"], outs["0"])
+    assert np.array_equal(outs["1h"], outs["0h"])
+    for s_ in (0, 17, S - 1):
+        want = O.run_streams(spec, co, x[s_:s_ + 1], 4096)       # block partition does not matter to the oracle
+        errlog.bound(np.abs(outs["1"][s_] - want[0]).max(), 2e-6, "gpu_parity:lp_vs_oracle")

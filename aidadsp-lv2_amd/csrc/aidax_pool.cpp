@@ -416,10 +416,17 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
     HIP_TRY(hipMalloc(&ms.d_wpack, wp.size() * sizeof(float)));
     HIP_TRY(hipMalloc(&ms.d_nn, static_cast<size_t>(p.n_streams) * ms.nn_stride * sizeof(float)));
     HIP_TRY(hipMalloc(&sg->d_pst, sizeof(StreamState) * p.n_streams));
+    // Stacked model: one workgroup per (16 streams, layer), chained through a ring in global memory — where that adds
+    // parallelism, i.e. while every (group, layer) workgroup gets a CU of its own (2048 streams for two layers on 256
+    // CUs: 1.7x over one workgroup per group; measured 0.85x beyond, where the CUs are full either way and the
+    // spinning consumers cost more than the resident weights save). AIDAX_MFMA_LP=1 / 0 forces it on / off.
     const char* lp = std::getenv("AIDAX_MFMA_LP");
-    if (ms.kind == ModelSlot::MFMA && mfma_lp_serves(ms.mdesc) && !(lp && lp[0] == '0') &&
+    int cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p.device));
+    const size_t lp_groups = (p.n_streams + kMfmaStreams - 1) / kMfmaStreams;
+    const bool lp_pays = lp ? lp[0] != '0' : lp_groups * static_cast<size_t>(ms.mdesc.n_layers) <= static_cast<size_t>(cus);
+    if (ms.kind == ModelSlot::MFMA && mfma_lp_serves(ms.mdesc) && lp_pays &&
         mfma_lp_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024) {
-        // stacked model: one workgroup per (16 streams, layer), chained through a ring in global memory
         HIP_TRY(hipMalloc(&ms.d_ring, mfma_lp_ring_bytes(ms.mdesc, p.n_streams)));
         HIP_TRY(hipMalloc(&ms.d_counters, mfma_lp_counter_bytes(ms.mdesc, p.n_streams)));
         HIP_TRY(hipMemsetAsync(ms.d_counters, 0, mfma_lp_counter_bytes(ms.mdesc, p.n_streams), p.wq));

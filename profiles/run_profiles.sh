@@ -11,7 +11,7 @@ out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
-bench="$root/bench.py --workload $wl --steps $steps --warmup 50 --no-cpu-baseline --no-check"
+bench="$root/bench.py --workload $wl --steps $steps --warmup 50 --no-cpu-baseline --no-check --no-others"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o r -- python3 $bench > "$out/trace.log" 2>&1
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$out/pmc_fetch" -o r -- python3 $bench > "$out/pmc_fetch.log" 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$out/pmc_write" -o r -- python3 $bench > "$out/pmc_write.log" 2>&1

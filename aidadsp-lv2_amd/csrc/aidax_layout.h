@@ -213,6 +213,7 @@ struct LaunchArgs {
     int32_t          input_skip;
     float            in_gain, out_gain;
     int32_t          tune;        // AIDAX_TUNE bit mask: measurement switches of the kernels (0 in production)
+    uint32_t         ring_groups; // k_mfma_lp: stream groups the pool's ring / counter buffers were sized for
 };
 
 }  // namespace aidax

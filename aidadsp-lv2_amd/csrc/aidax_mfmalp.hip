@@ -10,16 +10,20 @@
 //     192 columns = 288 KiB = 144 registers per lane over 8 waves): the frame loop is MFMAs fed by one
 //     conflict-free ds_read_b32 per k-step, no global loads, no address arithmetic;
 //   * h of layer l-1 travels to layer l through a ring of kLpRing frames in global memory, in the layout layer l
-//     reads it in ([unit][stream] = ready B fragments). ONE-directional hand-over: the producer publishes a frame
-//     counter with agent-scope release every kLpBatch frames, the consumer polls it with acquire only when it has
-//     used up what it knows of; the producer waits only when the ring is full (consumer's counter, relaxed).
+//     reads it in ([unit][stream] = ready B fragments). ONE-directional hand-over in the write-through form of
+//     cdna_hip_programming.md G16: the payload leaves as 16-byte device-scope (sc1) stores and is read with 16-byte
+//     sc1 loads, so no L2 write-back and no L1 invalidate is ever needed (measured here: an agent-scope release costs
+//     the publishing wave ~18 k cycles, 16 producers per XCD flushing one L2); the producer publishes a frame counter
+//     every kLpBatch frames after its stores have drained (per-wave s_waitcnt vmcnt(0) -> barrier), the consumer's lane
+//     0 polls it only when it has used up what it knows of; the producer waits only when the ring is full.
 //     Latency of the hand-over is hidden by the skew between the layers, nobody waits per frame.
 //
-// Forward progress: workgroup ids are laid out so that a layer's workgroup has a LOWER id than the layer above it
-// (ids of one group differ by 8: same id modulo 8, i.e. the same XCD and L2 under the round-robin workgroup -> XCD
-// assignment — a locality hint only, visibility comes from the release/acquire pair). Workgroups are dispatched in
-// id order, so whenever a consumer spins its producer is running or done, and a producer that waits on a full ring
-// waits for a consumer that is among the next eight ids to be dispatched.
+// Forward progress: the pool uses this kernel only while groups x layers <= the number of CUs (one workgroup
+// fits per CU), so EVERY workgroup of the grid becomes resident whatever the dispatch order, and a spinning consumer
+// can never keep its producer off the machine. (Forced on larger pools with AIDAX_MFMA_LP=1 — measurements only —
+// it leans on the dispatcher's observed id order: a layer's workgroup has a LOWER id than the layer above it, ids of
+// one group are 8 apart.) Every spin is bounded. Nothing depends on placement: ids of one group being equal modulo
+// 8 puts them on one XCD under the observed b % 8 placement, a locality hint only.
 //
 // Same arithmetic as k_mfma (same fragments from pack_mfma, same accumulation order, same activations): the two
 // kernels are bit-identical on the same model, which tests/test_gpu_parity.py checks.
@@ -32,8 +36,10 @@ namespace aidax {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kLpChunk = 256;            // frames of audio staged in LDS at a time
-constexpr int kLpRing = 16;              // frames of h in flight between two layers
-constexpr int kLpBatch = 4;              // frames per counter update
+constexpr int kLpRing = 32;              // frames of h in flight between two layers
+constexpr int kLpBatch = 8;              // frames per counter update (a release costs ~2-6 us, an acquire ~1.7 us: MI355X_MICROARCH.md)
+constexpr uint32_t kLpSpinLimit = 1u << 20;   // polls before a waiting workgroup gives up (~1 s): a launch must end even if
+                                              // its partner never ran; the result is then wrong and the error word says so
 
 __host__ __device__ inline size_t lp_lds_floats(int hidden, int n_frames)
 {
@@ -48,8 +54,36 @@ __host__ __device__ inline size_t lp_lds_floats(int hidden, int n_frames)
          + kMfmaStreams;                                      /* live flags                              */
 }
 
-__host__ __device__ inline size_t lp_ring_floats(int hidden) { return (size_t)kLpRing * hidden * kMfmaStreams; }
+// one frame in the ring: h [unit][stream], then (M > 0) the pre-activations of the first M tiles of every wave of the
+// layer above, started by the layer below ([wave][tile][lane] x 4 gate rows)
+__host__ __device__ constexpr size_t lp_slot_floats(int hidden, int waves, int m) { return (size_t)hidden * kMfmaStreams + (size_t)waves * m * kWave * 4; }
+__host__ __device__ constexpr size_t lp_ring_floats(int hidden, int waves, int m) { return (size_t)kLpRing * lp_slot_floats(hidden, waves, m); }
+// Tiles per wave whose input half moves from the upper layer's workgroup to the lower one's. Two layers: the upper
+// has 8G k-steps per tile, the lower 4G + 1 — moving one tile's input half (4G MFMAs per wave) evens them out
+// (LSTM-96: 75 / 144 -> 99 / 120 MFMAs per wave and frame). Deeper stacks are bound by their last layer either way.
+__host__ __device__ constexpr int lp_moved_tiles(int n_layers, int tpw) { return (n_layers == 2 && tpw >= 2) ? 1 : 0; }
 constexpr int kLpCounterStride = 32;     // uint32 per (group, boundary): produced at [0], consumed at [16] (own cache lines)
+
+// the error word sits behind the counters of ALL the pool's groups; a one-stream view of the pool (reset_stream)
+// launches with a.n_streams == 1, so the pool's group count comes in separately (LaunchArgs::ring_groups)
+__device__ __forceinline__ int n_groups_alloc(const LaunchArgs& a, const MfmaDesc&) { return (int)a.ring_groups; }
+
+// 16-byte device-scope (sc0 sc1) accesses: write-through stores / L1-bypassing loads. Buffer instructions, so the
+// compiler keeps track of their completion (vmcnt) like of any other load.
+typedef unsigned lp_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kLpDeviceScope = 17;                         // aux bits: sc0 | sc1
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t lp_rsrc(const float* base, size_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 lp_load16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off)
+{
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, kLpDeviceScope));
+}
+__device__ __forceinline__ void lp_store16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, f32x4 v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lp_u32x4, v), r, byte_off, 0, kLpDeviceScope);
+}
 
 __device__ __forceinline__ float lp_row_sum16(float v)
 {
@@ -60,26 +94,47 @@ __device__ __forceinline__ float lp_row_sum16(float v)
     return v;
 }
 
-// acc[tl] += A(groups g0..g0+NG) . B, A resident in `wres`, B fragments from `src` ([unit][stream] in LDS)
-template <int TPW, int NG, int G0, int NRES>
-__device__ __forceinline__ void lp_gates(f32x4 (&acc)[TPW], const f32x4 (&wres)[NRES], const float* src, int lane)
+// acc[tl] += A(groups G0..G0+NG) . B, A resident in `wres`, B fragments from `src` ([unit][stream] in LDS).
+// The B values of group g+1 are read while the MFMAs of group g issue (two register sets alternate by the parity of
+// g under the full unroll): left to itself the compiler reads a pair of values, waits for the LDS, issues six MFMAs,
+// and exposes the LDS latency 24 times per layer half.
+template <int TPW, int NG, int G0, int NRES, int TL0 = 0, int TL1 = TPW, int NACC = TPW>
+__device__ __forceinline__ void lp_gates(f32x4 (&acc)[NACC], const f32x4 (&wres)[NRES], const float* src, int lane)
 {
+    if constexpr (TL0 < TL1) {
+        float b0[4], b1[4];
+        auto read_b = [&](float (&b)[4], int g) {
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        float b[4];
+            for (int j = 0; j < 4; ++j) b[j] = src[256 * g + 64 * j + lane];
+        };
+        auto group = [&](const float (&b)[4], int g) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = src[256 * g + 64 * j + lane];
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+                for (int tl = TL0; tl < TL1; ++tl) {
+                    const int e = j * TPW + tl;
+                    acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[(G0 + g) * TPW + e / 4][e % 4], b[j], acc[tl], 0, 0, 0);
+                }
+        };
+        read_b(b0, 0);
 #pragma unroll
-            for (int tl = 0; tl < TPW; ++tl) {
-                const int e = j * TPW + tl;
-                acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[(G0 + g) * TPW + e / 4][e % 4], b[j], acc[tl], 0, 0, 0);
+        for (int g = 0; g < NG; ++g) {
+            if (g & 1) {
+                if (g + 1 < NG) read_b(b0, g + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                group(b1, g);
+            } else {
+                if (g + 1 < NG) read_b(b1, g + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                group(b0, g);
             }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
-template <int TPW, int NW>
+// M: tiles per wave of the layer above whose input half the first layer computes (lp_moved_tiles; two-layer models)
+template <int TPW, int NW, int M>
 __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d, float* ring, uint32_t* counters)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -88,6 +143,8 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
     constexpr int NS = kMfmaStreams;
     constexpr int G = H / 16;                              // k-step groups per H columns
     constexpr int NRES = 2 * G * TPW;                      // f32x4 of resident A fragments: [h below | own h]
+    constexpr int MA = M > 0 ? M : 1;                      // array extent of the moved-tile registers
+    constexpr size_t kSlot = lp_slot_floats(H, NW, M);     // floats of one ring frame
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -158,7 +215,6 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
         livef[tid] = mine_live ? 1.f : 0.f;
     }
     if (last) for (int i = tid; i < H + 1; i += NT) wdl[i] = W[d.wd_off + i];
-    for (int i = tid; i < H * 4; i += NT) bl[i] = W[L.b_off + i];
     // this layer's recurrent state -> LDS (parity 0 is what frame 0 reads)
     for (int i = tid; i < H * NS; i += NT) {
         const int u = i / NS, sn = i % NS, sg = s_base + sn;
@@ -168,7 +224,16 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
         cT[i] = (valid && u < Ht && L.cell == 0) ? stp[Ht + u] : 0.f;
     }
 
-    // ---- this layer's A fragments, resident for the launch
+    // ---- this layer's bias rows (the accumulators start from them) and A fragments, resident for the launch
+    f32x4 bias_r[TPW];
+#pragma unroll
+    for (int tl = 0; tl < TPW; ++tl)
+        bias_r[tl] = *reinterpret_cast<const f32x4*>(W + L.b_off + 4 * (4 * (wave * TPW + tl) + (lane >> 4)));
+    f32x4 bias_up[MA];                                     // first layer, M > 0: the moved tiles start from the upper layer's bias
+#pragma unroll
+    for (int tl = 0; tl < MA; ++tl)
+        bias_up[tl] = (M > 0 && first) ? *reinterpret_cast<const f32x4*>(W + d.L[M > 0 ? 1 : 0].b_off + 4 * (4 * (wave * TPW + tl) + (lane >> 4)))
+                                        : f32x4{ 0.f, 0.f, 0.f, 0.f };
     float w_in0[TPW];
 #pragma unroll
     for (int tl = 0; tl < TPW; ++tl) w_in0[tl] = first ? W[d.L[0].w_in_off + ((size_t)wave * kWave + lane) * TPW + tl] : 0.f;
@@ -176,23 +241,32 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
     {
         const int g_tot = first ? G : 2 * G;
         const f32x4* ap = reinterpret_cast<const f32x4*>(W + L.w_big_off) + ((size_t)wave * g_tot * kWave + lane) * TPW;
+        const f32x4* ap_up = reinterpret_cast<const f32x4*>(W + d.L[M > 0 ? 1 : 0].w_big_off) + ((size_t)wave * 2 * G * kWave + lane) * TPW;
 #pragma unroll
         for (int g = 0; g < 2 * G; ++g)
 #pragma unroll
             for (int q = 0; q < TPW; ++q) {
-                // first layer: its G groups (own h) sit in the upper half, like the recurrent half of the others
+                // first layer: its G groups (own h) sit in the upper half, like the recurrent half of the others; with
+                // M > 0 its lower half holds the layer ABOVE's input-half fragments (same wave, same lane): it starts
+                // that layer's first M tiles
                 const int gs = first ? g - G : g;
-                wres[g * TPW + q] = (gs >= 0) ? ap[(size_t)gs * kWave * TPW + q] : f32x4{ 0.f, 0.f, 0.f, 0.f };
+                if (gs >= 0) wres[g * TPW + q] = ap[(size_t)gs * kWave * TPW + q];
+                else if (M > 0) wres[g * TPW + q] = ap_up[(size_t)g * kWave * TPW + q];
+                else wres[g * TPW + q] = f32x4{ 0.f, 0.f, 0.f, 0.f };
             }
     }
 
     // ---- ring bookkeeping. Counters count frames since the buffers were allocated and are equal on both sides
     // between launches, so a workgroup starts from its own side's value.
-    const size_t ring_stride = lp_ring_floats(H);
+    const size_t ring_stride = lp_ring_floats(H, NW, M);
     float* ring_out = last ? nullptr : ring + ((size_t)grp * (NL - 1) + l) * ring_stride;
     const float* ring_in = first ? nullptr : ring + ((size_t)grp * (NL - 1) + (l - 1)) * ring_stride;
+    const size_t ring_bytes = ring_stride * sizeof(float);
+    const __amdgpu_buffer_rsrc_t rs_out = lp_rsrc(last ? ring : ring_out, ring_bytes);
+    const __amdgpu_buffer_rsrc_t rs_in = lp_rsrc(first ? ring : ring_in, ring_bytes);
     uint32_t* cnt_out = last ? nullptr : counters + ((size_t)grp * (NL - 1) + l) * kLpCounterStride;
     uint32_t* cnt_in = first ? nullptr : counters + ((size_t)grp * (NL - 1) + (l - 1)) * kLpCounterStride;
+    uint32_t* counters_err = counters + (size_t)n_groups_alloc(a, d) * (NL - 1) * kLpCounterStride;   // spins that gave up
     // every thread needs the bases (they place a frame in the ring); the running counts are thread 0's business
     const uint32_t base_out = cnt_out ? __hip_atomic_load(cnt_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     const uint32_t base_in = cnt_in ? __hip_atomic_load(cnt_in + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
@@ -200,6 +274,26 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
     uint32_t known_below = 0;                              // frames of this launch known to exist below
     __syncthreads();
 
+    // Frame Fprev goes up the ring, one tick after it was computed (h_src = h(Fprev), stable in LDS for this tick):
+    // h as 16-byte write-through stores, and (first layer, M > 0) the started tiles of the layer above:
+    // W_in(above)[first M tiles] . h(Fprev) + bias.
+    constexpr int kHVec = H * NS / 4;                       // f32x4 of one h tile
+    auto ship_frame = [&](const float* h_src, int Fprev) {
+        const uint32_t slot_off = (uint32_t)(((base_out + (uint32_t)Fprev) % kLpRing) * kSlot * sizeof(float));
+        for (int i = tid; i < kHVec; i += NT)
+            lp_store16(rs_out, slot_off + (uint32_t)i * 16u, reinterpret_cast<const f32x4*>(h_src)[i]);
+        if constexpr (M > 0) {
+            if (first) {
+                f32x4 pacc[MA];
+#pragma unroll
+                for (int tl = 0; tl < M; ++tl) pacc[tl] = bias_up[tl];
+                lp_gates<TPW, G, 0, NRES, 0, M, MA>(pacc, wres, h_src, lane);
+#pragma unroll
+                for (int tl = 0; tl < M; ++tl)
+                    lp_store16(rs_out, slot_off + (uint32_t)(H * NS * sizeof(float)) + (uint32_t)(((wave * M + tl) * kWave + lane) * 16), pacc[tl]);
+            }
+        }
+    };
     // frames [0, total) of this launch as the ring sees them
     int par = 0;                                           // parity of hT the next frame reads
     int done = 0;                                          // frames finished before this chunk
@@ -245,22 +339,33 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
         // what the layer below hands over: frame F of the launch sits in ring slot (base_in + F) % kLpRing
         auto wait_below = [&](int frames_needed) {        // thread 0 only: until `frames_needed` frames of the launch exist
             if (frames_needed > n) frames_needed = n;
+            uint32_t spins = 0;
             while ((int)known_below < frames_needed) {
-                known_below = __hip_atomic_load(cnt_in, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - base_in;
-                if ((int)known_below < frames_needed) __builtin_amdgcn_s_sleep(2);
+                known_below = __hip_atomic_load(cnt_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base_in;
+                if ((int)known_below < frames_needed) {
+                    if (++spins > kLpSpinLimit) { __hip_atomic_fetch_add(counters_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); known_below = (uint32_t)n; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
             }
         };
-        constexpr int PER = H * NS / NT;                   // floats of a frame each thread moves (H*16 / threads)
-        static_assert(H * NS % NT == 0, "frame tile must divide over the threads");
-        float pre[PER];
+        constexpr int PER4 = (kHVec + NT - 1) / NT;        // f32x4 of a frame each thread moves
+        f32x4 pre[PER4];
+        f32x4 ppre[MA], pcur[MA];                          // started tiles of the next / the current frame (layers >= 1, M > 0)
         auto fetch_below = [&](int F) {                    // all threads: frame F of the launch -> registers
-            const float* src = ring_in + (size_t)((base_in + (uint32_t)F) % kLpRing) * H * NS;
+            const uint32_t slot_off = (uint32_t)(((base_in + (uint32_t)F) % kLpRing) * kSlot * sizeof(float));
 #pragma unroll
-            for (int q = 0; q < PER; ++q) pre[q] = src[q * NT + tid];
+            for (int q = 0; q < PER4; ++q)
+                if (q * NT + tid < kHVec) pre[q] = lp_load16(rs_in, slot_off + (uint32_t)(q * NT + tid) * 16u);
+            if constexpr (M > 0) {                         // ... and this wave's started tiles straight into registers
+#pragma unroll
+                for (int tl = 0; tl < M; ++tl)
+                    ppre[tl] = lp_load16(rs_in, slot_off + (uint32_t)(H * NS * sizeof(float)) + (uint32_t)(((wave * M + tl) * kWave + lane) * 16));
+            }
         };
         auto stash_below = [&](int parity) {
 #pragma unroll
-            for (int q = 0; q < PER; ++q) below[parity * H * NS + q * NT + tid] = pre[q];
+            for (int q = 0; q < PER4; ++q)
+                if (q * NT + tid < kHVec) reinterpret_cast<f32x4*>(below + parity * H * NS)[q * NT + tid] = pre[q];
         };
 
         if (first) {
@@ -270,6 +375,8 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
             __syncthreads();
             fetch_below(done);
             stash_below(0);
+#pragma unroll
+            for (int tl = 0; tl < MA; ++tl) pcur[tl] = ppre[tl];
         }
         __syncthreads();
 
@@ -293,18 +400,24 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
                 // waits for it at the barrier.
                 if (!first && tick + 2 < cnt) wait_below(F + 3);
                 if (!last && base + tick + 1 < n) {
+                    uint32_t spins = 0;
                     while ((int)known_free < F + 2) {
                         const uint32_t consumed = __hip_atomic_load(cnt_out + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base_out;
                         known_free = consumed + kLpRing;
-                        if ((int)known_free < F + 2) __builtin_amdgcn_s_sleep(2);
+                        if ((int)known_free < F + 2) {
+                            if (++spins > kLpSpinLimit) { __hip_atomic_fetch_add(counters_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); known_free = (uint32_t)n + kLpRing; break; }
+                            __builtin_amdgcn_s_sleep(8);
+                        }
                     }
                 }
             }
 
-            // ---- Dense(H,1) + skip + output gain of the frame before: wave w reduces streams 4w..4w+3
-            if (last && tick >= 1 && wave < 4) {
+            // ---- Dense(H,1) + skip + output gain of the frame before, spread over all waves: wave w reduces streams
+            // SPW*w .. SPW*w+SPW-1, sixteen lanes per stream
+            constexpr int SPW = NS / NW;                   // 2 (eight waves) or 4 (four waves)
+            if (last && tick >= 1 && (lane >> 4) < SPW) {
                 const int fd = tick - 1;
-                const int sl = wave * 4 + (lane >> 4), q = lane & 15;
+                const int sl = wave * SPW + (lane >> 4), q = lane & 15;
                 const float* hv = hT + rd * H * NS;
                 float part = 0.f;
 #pragma unroll
@@ -320,20 +433,23 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
                 float* h_rd = hT + rd * H * NS;
                 float* h_wr = hT + wr * H * NS;
                 f32x4 acc[TPW];
-                const f32x4* bias4 = reinterpret_cast<const f32x4*>(bl);
 #pragma unroll
-                for (int tl = 0; tl < TPW; ++tl) acc[tl] = bias4[4 * (wave * TPW + tl) + (lane >> 4)];
+                for (int tl = 0; tl < TPW; ++tl) acc[tl] = bias_r[tl];
+                if (!last && F >= 1) ship_frame(h_rd, F - 1);          // h_rd = h(F-1)
                 if (first) {                               // the model inputs: one k-step (x, PARAM1, PARAM2, 0)
                     const float b = xin[(tick & 1) * 64 + lane];
 #pragma unroll
                     for (int tl = 0; tl < TPW; ++tl)
                         acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_in0[tl], b, acc[tl], 0, 0, 0);
                 } else {
-                    lp_gates<TPW, G, 0, NRES>(acc, wres, below + (tick & 1) * H * NS, lane);
+                    if constexpr (M > 0) {                 // the first M tiles arrive started (bias + input half), the others start here
+#pragma unroll
+                        for (int tl = 0; tl < M; ++tl) acc[tl] = pcur[tl];
+                    }
+                    lp_gates<TPW, G, 0, NRES, M, TPW>(acc, wres, below + (tick & 1) * H * NS, lane);
                 }
                 lp_gates<TPW, G, G, NRES>(acc, wres, h_rd, lane);
 
-                float* ring_slot = last ? nullptr : ring_out + (size_t)((base_out + (uint32_t)F) % kLpRing) * H * NS;
 #pragma unroll
                 for (int tl = 0; tl < TPW; ++tl) {
                     const int e = (wave * TPW + tl) * 64 + lane;          // unit 4T + (lane>>4), stream lane&15
@@ -350,18 +466,24 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
                         hn = __builtin_fmaf(gz, h_rd[e] - nn, nn);
                     }
                     h_wr[e] = hn;
-                    if (ring_slot) ring_slot[e] = hn;
                 }
                 par = wr;
-                if (!first && more) stash_below((tick + 1) & 1);
+                if (!first && more) {
+                    stash_below((tick + 1) & 1);
+#pragma unroll
+                    for (int tl = 0; tl < MA; ++tl) pcur[tl] = ppre[tl];
+                }
+                if (!last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's ring stores have left before the barrier (G16)
             }
             __syncthreads();                               // h(t) in LDS, the next frame's input in LDS, ring stores of this frame done
             // ---- counters, by thread 0 after the barrier: every kLpBatch frames and at the end of the launch
             if (body && tid == 0) {
                 if (!last) {
-                    const int produced = F + 1;
-                    if (produced % kLpBatch == 0 || produced == n)
-                        __hip_atomic_store(cnt_out, base_out + (uint32_t)produced, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    // frames complete in the ring: a frame goes up one tick after it was computed (the last one
+                    // after the loop); its write-through stores were drained before the barrier above
+                    const int produced = F;
+                    if (produced > 0 && produced % kLpBatch == 0)
+                        __hip_atomic_store(cnt_out, base_out + (uint32_t)produced, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if (!first) {
                     const int consumed = more ? F + 2 : F + 1;             // frames read out of the ring so far
@@ -385,6 +507,13 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
         __syncthreads();
     }
 
+    if (!last && n > 0) {                                  // the launch's last frame, then the final count
+        ship_frame(hT + par * H * NS, n - 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(cnt_out, base_out + (uint32_t)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
     // ---- recurrent state and smoother memories back to HBM for the streams that ran
     for (int i = tid; i < H * NS; i += NT) {
         const int u = i / NS, sn = i % NS, sg = s_base + sn;
@@ -405,32 +534,40 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
 
 // ---------------------------------------------------------------- host side
 typedef void (*LpFn)(LaunchArgs, MfmaDesc, float*, uint32_t*);
-static LpFn lp_fn(int hidden)
+static LpFn lp_fn(int hidden, int n_layers)
 {
     switch (hidden) {
-#define AIDAX_LP_CASE(HID) case HID: return k_mfma_lp<HID / 4 / mfma_waves(HID), mfma_waves(HID)>
-    AIDAX_LP_CASE(16); AIDAX_LP_CASE(32); AIDAX_LP_CASE(48); AIDAX_LP_CASE(64); AIDAX_LP_CASE(80); AIDAX_LP_CASE(96);
+#define AIDAX_LP_CASE(HID) case HID: { constexpr int T = HID / 4 / mfma_waves(HID), W_ = mfma_waves(HID);                         \
+        return lp_moved_tiles(2, T) == 1 && n_layers == 2 ? k_mfma_lp<T, W_, lp_moved_tiles(2, T)> : k_mfma_lp<T, W_, 0>; }
+    AIDAX_LP_CASE(16) AIDAX_LP_CASE(32) AIDAX_LP_CASE(48) AIDAX_LP_CASE(64) AIDAX_LP_CASE(80) AIDAX_LP_CASE(96)
 #undef AIDAX_LP_CASE
     default: return nullptr;                               // wider stacks keep the fragment-streaming kernel
     }
 }
+static int lp_m(const MfmaDesc& d) { return lp_moved_tiles(d.n_layers, d.hidden / 4 / mfma_waves(d.hidden)); }
 
-bool mfma_lp_serves(const MfmaDesc& d) { return d.n_layers >= 2 && lp_fn(d.hidden) != nullptr; }
+bool mfma_lp_serves(const MfmaDesc& d) { return d.n_layers >= 2 && lp_fn(d.hidden, d.n_layers) != nullptr; }
 size_t mfma_lp_lds_bytes(const MfmaDesc& d, uint32_t n_frames) { return lp_lds_floats(d.hidden, (int)n_frames) * sizeof(float); }
 size_t mfma_lp_ring_bytes(const MfmaDesc& d, uint32_t n_streams)
 {
     const size_t groups = (n_streams + kMfmaStreams - 1) / kMfmaStreams;
-    return groups * (size_t)(d.n_layers - 1) * lp_ring_floats(d.hidden) * sizeof(float);
+    return groups * (size_t)(d.n_layers - 1) * lp_ring_floats(d.hidden, mfma_waves(d.hidden), lp_m(d)) * sizeof(float);
 }
 size_t mfma_lp_counter_bytes(const MfmaDesc& d, uint32_t n_streams)
 {
     const size_t groups = (n_streams + kMfmaStreams - 1) / kMfmaStreams;
-    return groups * (size_t)(d.n_layers - 1) * kLpCounterStride * sizeof(uint32_t);
+    return (groups * (size_t)(d.n_layers - 1) + 1) * kLpCounterStride * sizeof(uint32_t);      // + the error word
+}
+size_t mfma_lp_error_offset(const MfmaDesc& d, uint32_t n_streams)
+{
+    return mfma_lp_counter_bytes(d, n_streams) / sizeof(uint32_t) - kLpCounterStride;
 }
 
-hipError_t launch_mfma_lp_kernel(const LaunchArgs& a, const MfmaDesc& d, float* ring, uint32_t* counters, hipStream_t stream)
+hipError_t launch_mfma_lp_kernel(const LaunchArgs& a0, const MfmaDesc& d, float* ring, uint32_t* counters, uint32_t pool_streams, hipStream_t stream)
 {
-    LpFn fn = lp_fn(d.hidden);
+    LaunchArgs a = a0;
+    a.ring_groups = (pool_streams + kMfmaStreams - 1) / kMfmaStreams;
+    LpFn fn = lp_fn(d.hidden, d.n_layers);
     if (!fn || !ring || !counters) return hipErrorInvalidValue;
     const size_t lds = mfma_lp_lds_bytes(d, a.n_frames);
     if (lds > 64 * 1024) {

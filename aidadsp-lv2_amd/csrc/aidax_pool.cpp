@@ -285,7 +285,7 @@ struct aidax_pool {
         if (m.has_model && m.kind == ModelSlot::MFMA) {
             // split form around the matrix-core kernel: packed chains in -> out, applyModel in place, packed chains
             auto model_kernel = [&]() {
-                return m.d_ring ? launch_mfma_lp_kernel(a, m.mdesc, m.d_ring, m.d_counters, s) : launch_mfma_kernel(a, m.mdesc, s);
+                return m.d_ring ? launch_mfma_lp_kernel(a, m.mdesc, m.d_ring, m.d_counters, n_streams, s) : launch_mfma_kernel(a, m.mdesc, s);
             };
             if (a.mode != MODE_CHAIN) return model_kernel();
             hipError_t e = launch_chain_pass(true, a, s);
@@ -723,7 +723,13 @@ AIDAX_API int aidax_pool_sync(aidax_pool* p)
     if (!p) return fail(AIDAX_ERR_ARG, "null pool");
     return guarded([&]() -> int {
         HIP_TRY(hipSetDevice(p->device));
+        if (p->last_stream && p->last_stream != p->q) HIP_TRY(hipStreamSynchronize(p->last_stream));
         HIP_TRY(hipStreamSynchronize(p->q));
+        if (p->cur.d_counters) {                           // k_mfma_lp: did a layer hand-over give up waiting?
+            uint32_t gave_up = 0;
+            HIP_TRY(hipMemcpy(&gave_up, p->cur.d_counters + mfma_lp_error_offset(p->cur.mdesc, p->n_streams), sizeof(gave_up), hipMemcpyDeviceToHost));
+            if (gave_up != 0) return fail(AIDAX_ERR_DEVICE, "k_mfma_lp: a layer hand-over timed out (results of that pass are invalid)");
+        }
         return AIDAX_OK;
     });
 }

@@ -119,9 +119,28 @@ __global__ __launch_bounds__(kConvmThreads) void k_conv_mfma(LaunchArgs a, ConvD
         const int ch = (int)(((float)i + 0.5f) * inv_hist);
         return ch * F + Hb - hist + (i - ch * hist);
     };
+    // A layer whose history length is a multiple of four frames moves it as float4s (16 B per lane, a quarter of the
+    // index arithmetic): rows of `hist` floats per channel are contiguous on both sides and 16-byte aligned
+    // (pack_conv aligns state_off, the plane geometry is a multiple of four).
+    auto vec_hist = [&](const ConvLayer& L) { return (L.hist & 3) == 0 && (L.state_off & 3) == 0; };
+    auto plane_index4 = [&](int i4, int hist4, float inv_hist4) {     // float4 index -> plane float offset of its first frame
+        const int ch = (int)(((float)i4 + 0.5f) * inv_hist4);
+        return ch * F + Hb - 4 * hist4 + 4 * (i4 - ch * hist4);
+    };
     auto fetch_prefix = [&](int l) {
         const ConvLayer& L = d.L[l];
         const int cnt = L.hist * L.in_ch;
+        if (vec_hist(L)) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(hist_base + L.state_off);
+#pragma unroll
+            for (int j = 0; j < kHistRegs / 4; ++j) {
+                if (j * kConvmThreads * 4 >= cnt) break;
+                const int i4 = tid + j * kConvmThreads;
+                const f32x4 v = 4 * i4 < cnt ? src[i4] : f32x4{ 0.f, 0.f, 0.f, 0.f };
+                hp[4 * j] = v.x; hp[4 * j + 1] = v.y; hp[4 * j + 2] = v.z; hp[4 * j + 3] = v.w;
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < kHistRegs; ++j) {
             if (j * kConvmThreads >= cnt) break;              // wave-uniform: short histories cost one pass, not sixteen
@@ -133,6 +152,20 @@ __global__ __launch_bounds__(kConvmThreads) void k_conv_mfma(LaunchArgs a, ConvD
         const ConvLayer& L = d.L[l];
         const int cnt = L.hist * L.in_ch;
         const float inv = 1.0f / (float)L.hist;
+        if (vec_hist(L)) {
+            const int hist4 = L.hist >> 2;
+            const float inv4 = 1.0f / (float)hist4;
+#pragma unroll
+            for (int j = 0; j < kHistRegs / 4; ++j) {
+                if (j * kConvmThreads * 4 >= cnt) break;
+                const int i4 = tid + j * kConvmThreads;
+                if (4 * i4 < cnt)
+                    *reinterpret_cast<f32x4*>(plane + plane_index4(i4, hist4, inv4)) = f32x4{ hp[4 * j], hp[4 * j + 1], hp[4 * j + 2], hp[4 * j + 3] };
+            }
+            for (int i4 = tid + (kHistRegs / 4) * kConvmThreads; 4 * i4 < cnt; i4 += kConvmThreads)
+                *reinterpret_cast<f32x4*>(plane + plane_index4(i4, hist4, inv4)) = reinterpret_cast<const f32x4*>(hist_base + L.state_off)[i4];
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < kHistRegs; ++j) {
             if (j * kConvmThreads >= cnt) break;
@@ -186,7 +219,7 @@ __global__ __launch_bounds__(kConvmThreads) void k_conv_mfma(LaunchArgs a, ConvD
             for (int j = 0; j < kConvmTiles; ++j) {
                 if (wave + 4 * j >= ntiles || co >= Co) continue;
                 f32x4 v = acc[j];
-                if (L.activation == 1) { v.x = tanh_rat(v.x); v.y = tanh_rat(v.y); v.z = tanh_rat(v.z); v.w = tanh_rat(v.w); }
+                if (L.activation == 1) { v.x = tanh_exp(v.x); v.y = tanh_exp(v.y); v.z = tanh_exp(v.z); v.w = tanh_exp(v.w); }
                 else if (L.activation == 2) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
                 else if (L.activation == 3) { v.x = fast_sigmoid(v.x); v.y = fast_sigmoid(v.y); v.z = fast_sigmoid(v.z); v.w = fast_sigmoid(v.w); }
                 *reinterpret_cast<f32x4*>(nxt + (size_t)co * F + Hb + 16 * (wave + 4 * j) + 4 * (lane >> 4)) = v;
@@ -194,7 +227,26 @@ __global__ __launch_bounds__(kConvmThreads) void k_conv_mfma(LaunchArgs a, ConvD
         }
         lds_barrier();
         // this layer's new history: the last Hs frames of [old history | this block's inputs]
-        {
+        if (vec_hist(L) && (n & 3) == 0) {
+            const int hist4 = Hs >> 2, cnt4 = hist4 * Ci;
+            const float inv4 = 1.0f / (float)hist4;
+            f32x4* dst = reinterpret_cast<f32x4*>(hist_base + L.state_off);
+            f32x4 hv4[kHistRegs / 4];
+#pragma unroll
+            for (int j = 0; j < kHistRegs / 4; ++j) {         // all LDS reads first, then the stores
+                if (j * kConvmThreads >= cnt4) break;
+                const int i4 = tid + j * kConvmThreads;
+                hv4[j] = *reinterpret_cast<const f32x4*>(cur + plane_index4(i4 < cnt4 ? i4 : 0, hist4, inv4) + n);
+            }
+#pragma unroll
+            for (int j = 0; j < kHistRegs / 4; ++j) {
+                if (j * kConvmThreads >= cnt4) break;
+                const int i4 = tid + j * kConvmThreads;
+                if (i4 < cnt4) dst[i4] = hv4[j];
+            }
+            for (int i4 = tid + (kHistRegs / 4) * kConvmThreads; i4 < cnt4; i4 += kConvmThreads)
+                dst[i4] = *reinterpret_cast<const f32x4*>(cur + plane_index4(i4, hist4, inv4) + n);
+        } else {
             const float inv = 1.0f / (float)Hs;
             const int cnt = Hs * Ci;
             float hv[kHistRegs];

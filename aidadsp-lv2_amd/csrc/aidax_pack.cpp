@@ -302,7 +302,7 @@ std::vector<float> pack_conv(const aidax_model& m, ConvDesc* d, uint32_t* state_
         C.b_off = static_cast<uint32_t>(out.size());
         out.insert(out.end(), L.w1.begin(), L.w1.end());
         C.state_off = st;
-        st += static_cast<uint32_t>(C.hist * C.in_ch);
+        st += (static_cast<uint32_t>(C.hist * C.in_ch) + 3u) & ~3u;     // every layer's history starts 16-byte aligned (float4 copies)
         if (C.hist > d->max_hist) d->max_hist = C.hist;
         // matrix-core form: the layer as a [frames x (tap,cin)] . [(tap,cin) x cout] contraction
         const int K = C.ksize * C.in_ch;

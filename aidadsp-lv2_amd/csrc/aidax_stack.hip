@@ -462,7 +462,7 @@ __global__ __launch_bounds__(kStackThreads) void k_conv(LaunchArgs a, ConvDesc d
                 for (int o = 0; o < kConvCo; ++o) {
                     if (o < Co) {
                         float v = acc[o];
-                        if (L.activation == 1) v = tanh_rat(v);
+                        if (L.activation == 1) v = tanh_exp(v);
                         else if (L.activation == 2) v = v > 0.f ? v : 0.f;
                         else if (L.activation == 3) v = fast_sigmoid(v);
                         nxt[(size_t)o * F + next_hist + t] = v;

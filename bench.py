@@ -141,11 +141,13 @@ def usable_cores() -> int:
     return n
 
 
-def pmc_traffic_bytes(kernel_name: str):
+def pmc_traffic_bytes(kernel_name: str, wide_read_bytes: float):
     """HBM bytes per launch of the benchmarked kernel from the COMMITTED rocprofv3 PMC passes
-    (profiles/*_pmc_summary.txt, latest round that has this kernel): (2 x FETCH_SIZE + WRITE_SIZE) KB —
-    FETCH_SIZE counts half of a 16 B/lane streaming read on gfx950 (MI355X_MICROARCH.md, HBM section).
-    Counters cannot be read from inside a timed run; the source file is named next to the value. None if no profile."""
+    (profiles/*_pmc_summary.txt, latest round that has this kernel). FETCH_SIZE / WRITE_SIZE are KB; on gfx950
+    FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read (16 B/lane) and narrower reads at
+    face value (MI355X_MICROARCH.md, HBM section), so the kernel's one wide read — the audio block, `wide_read_bytes`
+    — is added back once: fetched = FETCH_SIZE + wide/2. Counters cannot be read from inside a timed run; the source
+    file is named next to the value. None if no profile."""
     import glob
     import re
     best = None
@@ -160,7 +162,8 @@ def pmc_traffic_bytes(kernel_name: str):
             elif m:
                 write = float(m.group(2))
         if fetch is not None and write is not None:
-            best = {"bytes": (2.0 * fetch + write) * 1024.0, "source": os.path.basename(fn)}
+            best = {"bytes": fetch * 1024.0 + 0.5 * wide_read_bytes + write * 1024.0,
+                    "fetch_size_kb": fetch, "write_size_kb": write, "source": os.path.basename(fn)}
     return best
 
 
@@ -388,10 +391,12 @@ def main():
     if rank == 0:
         value = samples_all / elapsed_max
         hbm, comp = rooflines(args.workload, S, m["kernel_ms"], m["kernel"])
-        traffic = pmc_traffic_bytes(m["kernel"]) if (args.workload == "cfg2" and S == wl["streams"]) else None
+        traffic = pmc_traffic_bytes(m["kernel"], 4.0 * S * N_FRAMES) if (args.workload == "cfg2" and S == wl["streams"]) else None
         if traffic:
             hbm["traffic"] = traffic["bytes"]
-            hbm["traffic_source"] = f"committed profile {traffic['source']} (rocprofv3 --pmc passes, not measured in this run)"
+            hbm["traffic_source"] = (f"committed profile {traffic['source']} (rocprofv3 --pmc passes, not measured in this run): "
+                                     f"FETCH_SIZE {traffic['fetch_size_kb']:.0f} KB + half of the 16 B/lane audio read it under-reports + "
+                                     f"WRITE_SIZE {traffic['write_size_kb']:.0f} KB; algorithmic 8 B/sample + per-stream control/state/NN records = 3.28 MB")
         out = {
             "metric": "audio samples/sec (48 kHz mono, many streams)",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -59,3 +59,48 @@ def test_exported_file_loads_through_the_c_abi_loader(tmp_path):
     i = ax.Model(path).info
     assert (i.cell, i.hidden, i.input_size, i.n_rnn_layers, i.input_skip) == (1, 40, 3, 1, 1)
     assert abs(i.input_gain - 10 ** (-6.0 / 20)) < 1e-6 and abs(i.output_gain - 10 ** (3.0 / 20)) < 1e-6
+
+
+@pytest.mark.parametrize("act", ["Tanh", "ReLU", "Sigmoid", None])
+def test_exported_conv_stack_reproduces_torch_with_the_activation_that_follows(act, tmp_path):
+    """torch's Conv1d has no activation of its own: the exporter takes it from the module that follows (none when
+    nothing follows) and requires the causal padding convention of the on-disk format."""
+    torch.manual_seed(11)
+    torch.set_num_threads(1)
+    C, k, n_layers = 8, 3, 4
+    mods, torch_seq, cur = [], [], 1
+    for l in range(n_layers):
+        conv = torch.nn.Conv1d(cur, C, k, dilation=2 ** l, padding=0)
+        mods.append(conv)
+        if act:
+            mods.append(getattr(torch.nn, act)())
+        cur = C
+    mods.append(torch.nn.Linear(C, 1))
+    path = str(tmp_path / "c.json")
+    j = export_aidax.export(mods, 1, path)
+    assert [L["type"] for L in j["layers"]] == ["conv1d"] * n_layers + ["dense"]
+    assert all(L["activation"] == (act.lower() if act else "") for L in j["layers"][:-1]) and j["layers"][-1]["activation"] == ""
+    spec = O.load_model(path)
+    X = modelgen.golden_inputs("convx", 1)[:1024]
+    got = O.net_run(spec, X)
+    # torch side: causal = left-pad every conv's input by (k-1)*dilation
+    x = torch.from_numpy(X.T.copy())[None]                 # [1][C=1][T]
+    with torch.no_grad():
+        for m in mods:
+            if isinstance(m, torch.nn.Conv1d):
+                x = m(torch.nn.functional.pad(x, ((m.kernel_size[0] - 1) * m.dilation[0], 0)))
+            elif isinstance(m, torch.nn.Linear):
+                x = m(x.transpose(1, 2)).transpose(1, 2)
+            else:
+                x = m(x)
+    want = x[0, 0].numpy()
+    assert np.abs(got - want).max() < 2e-6, (act, np.abs(got - want).max())
+
+
+def test_exporter_rejects_misplaced_activations_and_non_causal_padding(tmp_path):
+    with pytest.raises(TypeError):
+        export_aidax.export([torch.nn.LSTM(1, 8, batch_first=True), torch.nn.Tanh(), torch.nn.Linear(8, 1)], 1)
+    with pytest.raises(TypeError):
+        export_aidax.export([torch.nn.Tanh(), torch.nn.Linear(1, 1)], 1)
+    with pytest.raises(AssertionError):
+        export_aidax.export([torch.nn.Conv1d(1, 4, 3, padding=1), torch.nn.Linear(4, 1)], 1)     # "same" padding: not causal

@@ -254,6 +254,25 @@ def test_warmup_state_matches_oracle_and_reset_mode_is_zero(bundled_models):
     assert np.all(h == 0) and np.all(c == 0)
 
 
+@pytest.mark.parametrize("kind,hidden", [("lstm", 64), ("gru", 80), ("lstm", 80)])
+def test_read_state_of_a_quad_pool(kind, hidden, tmp_path):
+    """LSTM-64 / LSTM-80 / GRU-80 pools run on k_quad at every stream count; their state (h | c, the table kernels'
+    layout) is readable like any other pool's and matches the oracle after warm-up + one block."""
+    path, spec = _model_file(tmp_path, f"{kind}{hidden}", kind=kind, hidden=hidden, input_size=1, seed=hidden + 3)
+    pool = ax.Pool(5, 128)
+    pool.set_model(ax.Model(path), ax.START_WARMUP)
+    assert pool.kernel_name == "k_chain+k_quad"
+    h, c = pool.read_state(3, hidden=128)
+    om = O.OracleModel(spec, warmup=True)
+    oh, oc = om.state()
+    assert h.size == hidden and np.abs(oh).max() > 1e-4
+    errlog.bound(np.abs(h - oh).max(), 2e-6, "gpu_parity:quad_state_h")
+    if kind == "lstm":
+        errlog.bound(np.abs(c - oc).max(), 2e-6, "gpu_parity:quad_state_c")
+    with pytest.raises(ax.AidaxError):
+        pool.read_state(3, layer=1)
+
+
 def test_activate_and_model_swap_semantics(tmp_path, bundled_models):
     """activate() clears the gain ramps to their targets and re-arms paramFirstRun
     (:337-351); a model swap inherits the param targets (:822-825, :1053-1061)."""

@@ -25,6 +25,12 @@
 using namespace aidax;
 using Clock = std::chrono::steady_clock;
 
+// Staging buffers in rotation. One pass per period needs two (collect into one while the other's output is read); the
+// deadline may close a period in pieces (a host whose submissions span more than the deadline), and then an
+// instance's output of the last period sits in the buffer of the piece IT was part of, not in the most recent one —
+// so every slot remembers the pass that carried its last block, and a buffer is reused only kHubBuffers passes later.
+constexpr int kHubBuffers = 4;
+
 struct aidax_hub {
     aidax_pool* pool = nullptr;
     uint32_t cap = 0, max_frames = 0;
@@ -37,21 +43,21 @@ struct aidax_hub {
     int64_t deadline_us = -1;                    // < 0: a quarter of the period; 0: no deadline
     Clock::time_point deadline{};
     std::vector<uint8_t> attached, submitted, forced_off;
-    std::vector<uint8_t> out_valid[2];
+    std::vector<uint64_t> last_pass;             // per slot: id of the pass that carried its latest block (0: none)
     std::vector<aidax_controls> ctl;
-    uint32_t n_attached = 0, n_submitted = 0, period_frames = 0, out_frames[2] = { 0, 0 };
+    uint32_t n_attached = 0, n_submitted = 0, period_frames = 0, out_frames[kHubBuffers] = {};
+    uint64_t pass_id[kHubBuffers] = {};          // which pass a buffer holds
     uint32_t hi_slot = 0;                        // rows [0, hi_slot) can be attached: what a pass moves and launches
     uint32_t latency = 0;
     uint64_t launches = 0, deadline_launches = 0;
     int last_error = AIDAX_OK;
-    float* h_in[2] = { nullptr, nullptr };       // pinned staging, rows packed at the period's block length
-    float* h_out[2] = { nullptr, nullptr };
+    float* h_in[kHubBuffers] = {};               // pinned staging, rows packed at the period's block length
+    float* h_out[kHubBuffers] = {};
     float* d_in = nullptr;
     float* d_out = nullptr;
     hipStream_t q = nullptr;
-    hipEvent_t done[2] = { nullptr, nullptr };
-    bool launched[2] = { false, false };
-    int cur = 0;
+    hipEvent_t done[kHubBuffers] = {};
+    int cur = 1;                                 // the buffer being collected into: always (id of the next pass) % kHubBuffers
 
     ~aidax_hub()
     {
@@ -63,7 +69,7 @@ struct aidax_hub {
         if (launcher.joinable()) launcher.join();
         if (q) (void)hipStreamSynchronize(q);
         if (pool) aidax_pool_destroy(pool);      // before the stream it last ran on goes away
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < kHubBuffers; ++i) {
             if (h_in[i]) (void)hipHostFree(h_in[i]);
             if (h_out[i]) (void)hipHostFree(h_out[i]);
             if (done[i]) (void)hipEventDestroy(done[i]);
@@ -84,14 +90,12 @@ bool ok(hipError_t e, const char* what)
 }
 #define HUB_TRY(x) do { if (!ok((x), #x)) return AIDAX_ERR_DEVICE; } while (0)
 
-// the controls the pool sees for a slot: as set by the instance, but disabled while the slot is detached
-// or did not take part in the period being launched (a disabled stream is a copy: its state does not move)
+// A slot that is detached, or did not take part in the period being launched, is parked for that pass (a parked
+// stream is a raw copy: its state does not move); its controls stay what the instance set.
 int push_controls(aidax_hub& h, uint32_t slot, bool off)
 {
-    aidax_controls c = h.ctl[slot];
-    if (off) c.enabled = 0.f;
     h.forced_off[slot] = off ? 1 : 0;
-    return aidax_pool_set_controls(h.pool, static_cast<int32_t>(slot), &c);
+    return pool_park_stream(h.pool, slot, off);
 }
 
 // launch the period that is being collected (h.mu held): asynchronous, nothing in here waits for the GPU
@@ -116,14 +120,15 @@ int flush_locked(aidax_hub& h)
     if (rc != AIDAX_OK) return rc;
     if (bytes != 0) HUB_TRY(hipMemcpyAsync(h.h_out[b], h.d_out, bytes, hipMemcpyDeviceToHost, h.q));
     HUB_TRY(hipEventRecord(h.done[b], h.q));
-    h.launched[b] = true;
+    ++h.launches;
     h.out_frames[b] = n;
-    h.out_valid[b] = h.submitted;
+    h.pass_id[b] = h.launches;
+    for (uint32_t s = 0; s < rows; ++s)
+        if (h.submitted[s]) h.last_pass[s] = h.launches;
     std::fill(h.submitted.begin(), h.submitted.end(), 0);
     h.n_submitted = 0;
     h.latency = n;
-    h.cur = b ^ 1;
-    ++h.launches;
+    h.cur = static_cast<int>((h.launches + 1) % kHubBuffers);
     return AIDAX_OK;
 }
 
@@ -163,15 +168,14 @@ AIDAX_API int aidax_hub_create(uint32_t max_instances, uint32_t max_frames, doub
     h->attached.assign(max_instances, 0);
     h->submitted.assign(max_instances, 0);
     h->forced_off.assign(max_instances, 0);
-    h->out_valid[0].assign(max_instances, 0);
-    h->out_valid[1].assign(max_instances, 0);
+    h->last_pass.assign(max_instances, 0);
     h->ctl.resize(max_instances);
     for (auto& c : h->ctl) aidax_controls_default(&c);
     const size_t bytes = sizeof(float) * static_cast<size_t>(max_instances) * max_frames;
     bool good = ok(hipSetDevice(device_id), "hipSetDevice") &&
                 ok(hipStreamCreateWithFlags(&h->q, hipStreamNonBlocking), "hipStreamCreate") &&
                 ok(hipMalloc(&h->d_in, bytes), "hipMalloc") && ok(hipMalloc(&h->d_out, bytes), "hipMalloc");
-    for (int i = 0; i < 2 && good; ++i)
+    for (int i = 0; i < kHubBuffers && good; ++i)
         good = ok(hipHostMalloc(reinterpret_cast<void**>(&h->h_in[i]), bytes, hipHostMallocDefault), "hipHostMalloc") &&
                ok(hipHostMalloc(reinterpret_cast<void**>(&h->h_out[i]), bytes, hipHostMallocDefault), "hipHostMalloc") &&
                ok(hipEventCreateWithFlags(&h->done[i], hipEventDisableTiming), "hipEventCreate");
@@ -225,8 +229,10 @@ AIDAX_API int aidax_hub_attach(aidax_hub* h, int32_t* slot)
         rc = aidax_pool_activate(h->pool, static_cast<int32_t>(s));
         if (rc != AIDAX_OK) return rc;
         aidax_controls_default(&h->ctl[s]);
+        rc = aidax_pool_set_controls(h->pool, static_cast<int32_t>(s), &h->ctl[s]);     // not the previous occupant's
+        if (rc != AIDAX_OK) return rc;
         h->attached[s] = 1;
-        h->out_valid[0][s] = h->out_valid[1][s] = 0;
+        h->last_pass[s] = 0;
         ++h->n_attached;
         if (s + 1 > h->hi_slot) h->hi_slot = s + 1;
         *slot = static_cast<int32_t>(s);
@@ -254,7 +260,7 @@ AIDAX_API int aidax_hub_set_controls(aidax_hub* h, int32_t slot, const aidax_con
     if (slot < 0 || static_cast<uint32_t>(slot) >= h->cap || !h->attached[slot]) return fail(AIDAX_ERR_ARG, "slot not attached");
     if (std::memcmp(&h->ctl[slot], c, sizeof(*c)) == 0) return AIDAX_OK;
     h->ctl[slot] = *c;
-    return push_controls(*h, static_cast<uint32_t>(slot), h->forced_off[slot] != 0);
+    return aidax_pool_set_controls(h->pool, slot, c);      // the pool keeps the slot parked if it is
 }
 
 AIDAX_API int aidax_hub_set_loading(aidax_hub* h, int32_t slot, int loading)
@@ -301,13 +307,16 @@ AIDAX_API int aidax_hub_run(aidax_hub* h, int32_t slot, const float* in, float* 
             h->deadline = Clock::now() + std::chrono::microseconds(us);
             wake = h->deadline_us != 0;
         }
-        const int b = h->cur, prev = b ^ 1;
+        const int b = h->cur;
         if (n_frames != 0) std::memcpy(h->h_in[b] + static_cast<size_t>(slot) * n_frames, in, sizeof(float) * n_frames);
         h->submitted[slot] = 1;
         ++h->n_submitted;
-        if (n_frames != 0 && h->launched[prev] && h->out_valid[prev][slot] && h->out_frames[prev] == n_frames) {
-            prev_row = h->h_out[prev] + static_cast<size_t>(slot) * n_frames;
-            prev_done = h->done[prev];
+        // the pass that carried this instance's previous block, if its buffer has not been reused since
+        const uint64_t lp = h->last_pass[slot];
+        const int pb = static_cast<int>(lp % kHubBuffers);
+        if (n_frames != 0 && lp != 0 && h->pass_id[pb] == lp && h->out_frames[pb] == n_frames) {
+            prev_row = h->h_out[pb] + static_cast<size_t>(slot) * n_frames;
+            prev_done = h->done[pb];
         }
         if (h->n_submitted == h->n_attached) { h->flush_requested = true; wake = true; }
     }

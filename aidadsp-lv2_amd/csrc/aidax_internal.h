@@ -51,6 +51,9 @@ void  build_stream_ctl(const aidax_controls& c, double host_samplerate, bool has
 // aidax_pool_process_device restricted to the first n_active streams (aidax_pool.cpp; used by the hub)
 int pool_process_prefix(aidax_pool* p, const float* d_in, float* d_out, uint32_t n_frames, void* hip_stream, uint32_t n_active);
 
+// park / unpark a stream (behaves disabled while parked; its controls stay what they are) — aidax_pool.cpp, used by the hub
+int pool_park_stream(aidax_pool* p, uint32_t stream, bool parked);
+
 // weight packing (aidax_pack.cpp)
 std::vector<float> pack_weights(const aidax_model& m);
 // extension architectures: flat weight buffer + descriptor + per-stream state size (floats)

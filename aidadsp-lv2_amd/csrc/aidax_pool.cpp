@@ -146,6 +146,7 @@ struct aidax_pool {
 
     std::vector<aidax_controls> controls;
     std::vector<uint8_t> loading;
+    std::vector<uint8_t> forced_off;                     // the hub parks a stream (raw copy, state does not move) without touching its controls
     std::vector<StreamCtl> h_ctl;
     uint32_t dirty_lo = 1, dirty_hi = 0;                 // control records to upload: [lo, hi], empty when lo > hi
     StreamCtl* ctl_ring[kCtlRing] = {};
@@ -213,6 +214,7 @@ struct aidax_pool {
     void refresh_ctl(uint32_t s)
     {
         build_stream_ctl(controls[s], host_sr, cur.has_model, loading[s] != 0, gain_coef, cur.p_den(), &h_ctl[s]);
+        if (forced_off[s]) h_ctl[s].flags &= ~static_cast<uint32_t>(CTL_ENABLED);
         mark_dirty(s, s);
     }
     void refresh_all()
@@ -226,6 +228,8 @@ struct aidax_pool {
                 build_stream_ctl(controls[s], host_sr, cur.has_model, loading[s] != 0, gain_coef, cur.p_den(), &h_ctl[s]);
             }
         }
+        for (uint32_t s = 0; s < n_streams; ++s)
+            if (forced_off[s]) h_ctl[s].flags &= ~static_cast<uint32_t>(CTL_ENABLED);
         mark_dirty(0, n_streams - 1);
     }
     // the fields of a control record that depend on the model and on `loading`, without redesigning the filters
@@ -491,6 +495,21 @@ int pool_process_prefix(aidax_pool* p, const float* d_in, float* d_out, uint32_t
     });
 }
 
+// Park / unpark one stream for the coming passes: while parked it behaves like a disabled plugin (raw copy, no state
+// moves) whatever its own `enabled` control says. One flag flip in the host record — no filter redesign: the hub
+// does this for every stream that is not part of the pass it launches.
+int pool_park_stream(aidax_pool* p, uint32_t s, bool parked)
+{
+    if (s >= p->n_streams) return fail(AIDAX_ERR_ARG, "stream out of range");
+    if ((p->forced_off[s] != 0) == parked) return AIDAX_OK;
+    p->forced_off[s] = parked ? 1 : 0;
+    StreamCtl& o = p->h_ctl[s];
+    if (!parked && p->controls[s].enabled > 0.5f) o.flags |= CTL_ENABLED;
+    else o.flags &= ~static_cast<uint32_t>(CTL_ENABLED);
+    p->mark_dirty(s, s);
+    return AIDAX_OK;
+}
+
 }  // namespace aidax
 
 extern "C" {
@@ -543,6 +562,7 @@ AIDAX_API int aidax_pool_create(uint32_t n_streams, uint32_t max_frames, double 
             p->controls.resize(n_streams);
             for (auto& c : p->controls) aidax_controls_default(&c);
             p->loading.assign(n_streams, 1);
+            p->forced_off.assign(n_streams, 0);
             p->h_ctl.resize(n_streams);
             p->refresh_all();
             // instantiate(), rt-neural-generic.cpp:283-321: preGain target 1 cleared, masterGain target 0 cleared,

@@ -232,3 +232,35 @@ def test_back_to_back_attach_and_run_from_c(tmp_path):
         got = y[i, join:]
         assert np.all(got[0] == 0.0)                                   # one period of latency
         assert np.abs(got[1:] - want[:-1]).max() < THR * 2, (i, np.abs(got[1:] - want[:-1]).max())
+
+
+@pytest.mark.parametrize("moving_split", [False, True])
+def test_deadline_that_splits_a_period_loses_nothing(tmp_path, moving_split):
+    """A sequential host whose submissions span MORE than the deadline (here: a 1.5 ms pause in the middle of every
+    period against a 400 us deadline): every period is closed in two passes. Each instance's previous block then
+    sits in the buffer of the pass IT was part of (per-slot pass tracking over four rotating buffers), also when the
+    place of the pause — and with it the pass an instance falls into — moves from period to period. Everybody keeps
+    exactly one period of latency, nothing is lost or repeated."""
+    m, spec = _model(tmp_path, kind="lstm", hidden=12, input_size=1, seed=18)
+    N, n, periods = 6, 128, 10
+    hub = ax.Hub(8, 128)
+    hub.set_model(m)
+    hub.set_deadline_us(400)
+    slots = [hub.attach() for _ in range(N)]
+    plugs = [_oracle_instance(spec) for _ in range(N)]
+    x = modelgen.signal(N, n * periods, seed=36)
+    c = O.default_controls()
+    prev = [np.zeros(n, np.float32) for _ in range(N)]
+    for p in range(periods):
+        pause_after = (2 + p % 3) if moving_split else 2
+        got = {}
+        for i in range(N):
+            got[i] = hub.run(slots[i], x[i, p * n:(p + 1) * n])
+            if i == pause_after:
+                time.sleep(0.0015)
+        time.sleep(0.0015)                          # the rest of the period: the second pass is closed by its deadline too
+        for i in range(N):
+            assert np.abs(got[i] - prev[i]).max() < THR * 2, (p, i, np.abs(got[i] - prev[i]).max())
+            prev[i] = plugs[i].run(c, x[i, p * n:(p + 1) * n])
+    hub.flush()
+    assert hub.launches >= 2 * periods - 1 and hub.deadline_launches >= periods

@@ -10,13 +10,15 @@
 //   B (4 k x 16 cout)    the layer's kernel as ready fragments (aidax_pack.cpp), staged in LDS once per layer
 //                        together with a per-lane table of A-fragment plane offsets (no integer division
 //                        in the loop);
-//   D                    lane holds 4 consecutive frames of one output channel: tanh, one ds_write_b128
-//                        into the other plane.
+//   D                    lane holds 4 consecutive frames of one output channel: tanh, one ds_write_b128.
 //
-// Each wave keeps four frame tiles in flight so a B fragment read serves four MFMAs. Per-layer input
-// history ((ksize-1)*dilation frames per input channel) persists in HBM in the same layout as k_conv,
-// so the two kernels are interchangeable mid-stream. The DSP chain runs in the packed k_chain launches
-// (split form); this kernel is applyModel only.
+// ONE activation plane, updated IN PLACE: a layer's sixteen frame tiles (four per wave) are accumulated in registers
+// over all k-steps, every wave is done reading the plane at a barrier, and only then the outputs overwrite the block
+// part of the plane and the next layer's history prefix its history part. That halves the LDS of a stream (34 KiB
+// for the 16-channel model) — four workgroups per CU instead of two, all 1024 workgroups of BASELINE cfg4 resident at
+// once — and takes one of the three barriers out of a layer. Per-layer input history ((ksize-1)*dilation frames per
+// input channel) persists in HBM in the same layout as k_conv, so the two kernels are interchangeable mid-stream.
+// The DSP chain runs in the packed k_chain launches (split form); this kernel is applyModel only.
 #include "aidax_device.h"
 #include "aidax_kernels.h"
 #include "aidax_layout.h"
@@ -36,7 +38,7 @@ __host__ __device__ inline int convm_plane_stride(int max_hist, int n_frames)
 }
 __host__ __device__ inline size_t convm_lds_floats(const ConvDesc& d, int n_frames)
 {
-    return 2 * (size_t)d.channels * convm_plane_stride(d.max_hist, n_frames)   /* two activation planes     */
+    return (size_t)d.channels * convm_plane_stride(d.max_hist, n_frames)       /* the activation plane      */
          + 2 * (size_t)d.max_k_steps * kWave                                  /* B fragments + A offsets   */
          + 16 + 4;                                                            /* Dense weights + bias      */
 }
@@ -49,7 +51,7 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-__global__ __launch_bounds__(kConvmThreads) void k_conv_mfma(LaunchArgs a, ConvDesc d)
+__global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, ConvDesc d)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -66,9 +68,8 @@ __global__ __launch_bounds__(kConvmThreads) void k_conv_mfma(LaunchArgs a, ConvD
     const int C = d.channels;
     const int Hb = (d.max_hist + 3) & ~3;                    // plane index of frame 0
     const int F = convm_plane_stride(d.max_hist, n);
-    float* pa = smem;
-    float* pb = pa + (size_t)C * F;
-    float* wst = pb + (size_t)C * F;                          // [k_steps][64] records {B fragment value, A plane offset}
+    float* pl = smem;                                         // [C][F]: history | block, per channel
+    float* wst = pl + (size_t)C * F;                          // [k_steps][64] records {B fragment value, A plane offset}
     float* wdl = wst + 2 * (size_t)d.max_k_steps * kWave;     // Dense weights [16] + bias
 
     const float* W = a.wpack;
@@ -76,27 +77,27 @@ __global__ __launch_bounds__(kConvmThreads) void k_conv_mfma(LaunchArgs a, ConvD
     float* row = mode == MODE_CHAIN ? a.out + (size_t)sg * n : a.out;
     const int n16 = (n + 15) & ~15;
 
-    // layer-0 input plane: [history | x * in_gain | zeros up to the tile boundary]; x stays in a register for the skip
+    // layer-0 input: [history | x * in_gain | zeros up to the tile boundary]; x stays in a register for the skip
     float xg = 0.f;
     {
         const ConvLayer& L0 = d.L[0];
         for (int c = 0; c < L0.in_ch; ++c)
             for (int j = tid; j < L0.hist; j += kConvmThreads)
-                pa[c * F + Hb - L0.hist + j] = hist_base[L0.state_off + c * L0.hist + j];
+                pl[c * F + Hb - L0.hist + j] = hist_base[L0.state_off + c * L0.hist + j];
         for (int t = tid; t < n16; t += kConvmThreads) {
             float v = 0.f;
             if (t < n) v = (mode == MODE_CHAIN ? row[t] : mode == MODE_NN_ONLY ? a.in[(size_t)t * a.input_size] : 0.f) * a.in_gain;
-            pa[Hb + t] = v;
+            pl[Hb + t] = v;
             xg = v;                                           // n <= 256: one frame per thread
         }
         if (tid < 17) wdl[tid] = tid < 16 ? (tid < d.L[d.n_layers - 1].out_ch ? W[d.wd_off + tid] : 0.f) : W[d.bd_off];
     }
-    // Global-memory latency is kept off the layer loop: while layer l computes, the B fragments of layer
-    // l+1 and the history prefix of layer l+2 are already on their way into registers.
+    // Global-memory latency is kept off the layer loop: a layer's B fragments arrive in registers while the layer
+    // before it computes, and so does the history prefix of the layer after it.
     constexpr int kFragRegs = 8;              // 32 k-steps x 64 lanes / 256 threads
-    constexpr int kHistRegs = 16;             // 4096 history floats of a layer in registers; longer ones read directly
+    constexpr int kHistRegs = 8;              // 4096 history floats of a layer in registers; longer ones read directly
     float fr[kFragRegs], hp[kHistRegs], bias_r = 0.f;
-    int kc[kFragRegs], kb[kFragRegs];          // (cin, frames back) of the contraction row behind fragment element j
+    int kcb[kFragRegs];                        // (cin << 16 | frames back) of the contraction row behind fragment element j
     auto fetch_frag = [&](int l) {
         const ConvLayer& L = d.L[l];
         const int* km = reinterpret_cast<const int*>(W + L.km_off);
@@ -107,10 +108,21 @@ __global__ __launch_bounds__(kConvmThreads) void k_conv_mfma(LaunchArgs a, ConvD
             const bool on = i < L.k_steps * kWave;
             const int k = on ? 4 * (i >> 6) + ((i & 63) >> 4) : 0;
             fr[j] = on ? W[L.wf_off + i] : 0.f;
-            kc[j] = km[2 * k];
-            kb[j] = km[2 * k + 1];
+            kcb[j] = (km[2 * k] << 16) | km[2 * k + 1];
         }
         bias_r = (lane & 15) < L.out_ch ? W[L.b_off + (lane & 15)] : 0.f;
+    };
+    auto stage_frag = [&](int l) {            // registers -> one 8-byte record per (k-step, lane): B value, A plane offset
+        const ConvLayer& L = d.L[l];
+#pragma unroll
+        for (int j = 0; j < kFragRegs; ++j) {
+            if (j * kConvmThreads >= L.k_steps * kWave) break;
+            const int i = tid + j * kConvmThreads;
+            if (i < L.k_steps * kWave) {
+                wst[2 * i] = fr[j];
+                reinterpret_cast<int*>(wst)[2 * i + 1] = (kcb[j] >> 16) * F + Hb - (kcb[j] & 0xffff) + (i & 15);
+            }
+        }
     };
     // history of a layer: [in_ch][hist] in HBM <-> plane[ch][Hb-hist .. Hb), walked flat (coalesced, hist*in_ch/256
     // passes). i -> (ch, frame) without an integer division: (i + 0.5) / hist is at least 0.5/hist away from an
@@ -148,7 +160,7 @@ __global__ __launch_bounds__(kConvmThreads) void k_conv_mfma(LaunchArgs a, ConvD
             hp[j] = i < cnt ? hist_base[L.state_off + i] : 0.f;
         }
     };
-    auto store_prefix = [&](int l, float* plane) {
+    auto store_prefix = [&](int l) {
         const ConvLayer& L = d.L[l];
         const int cnt = L.hist * L.in_ch;
         const float inv = 1.0f / (float)L.hist;
@@ -160,73 +172,25 @@ __global__ __launch_bounds__(kConvmThreads) void k_conv_mfma(LaunchArgs a, ConvD
                 if (j * kConvmThreads * 4 >= cnt) break;
                 const int i4 = tid + j * kConvmThreads;
                 if (4 * i4 < cnt)
-                    *reinterpret_cast<f32x4*>(plane + plane_index4(i4, hist4, inv4)) = f32x4{ hp[4 * j], hp[4 * j + 1], hp[4 * j + 2], hp[4 * j + 3] };
+                    *reinterpret_cast<f32x4*>(pl + plane_index4(i4, hist4, inv4)) = f32x4{ hp[4 * j], hp[4 * j + 1], hp[4 * j + 2], hp[4 * j + 3] };
             }
             for (int i4 = tid + (kHistRegs / 4) * kConvmThreads; 4 * i4 < cnt; i4 += kConvmThreads)
-                *reinterpret_cast<f32x4*>(plane + plane_index4(i4, hist4, inv4)) = reinterpret_cast<const f32x4*>(hist_base + L.state_off)[i4];
+                *reinterpret_cast<f32x4*>(pl + plane_index4(i4, hist4, inv4)) = reinterpret_cast<const f32x4*>(hist_base + L.state_off)[i4];
             return;
         }
 #pragma unroll
         for (int j = 0; j < kHistRegs; ++j) {
             if (j * kConvmThreads >= cnt) break;
             const int i = tid + j * kConvmThreads;
-            if (i < cnt) plane[plane_index(i, L.hist, inv)] = hp[j];
+            if (i < cnt) pl[plane_index(i, L.hist, inv)] = hp[j];
         }
         for (int i = tid + kHistRegs * kConvmThreads; i < cnt; i += kConvmThreads)
-            plane[plane_index(i, L.hist, inv)] = hist_base[L.state_off + i];
+            pl[plane_index(i, L.hist, inv)] = hist_base[L.state_off + i];
     };
-    fetch_frag(0);
-    if (d.n_layers > 1) fetch_prefix(1);
-
-    float* cur = pa;
-    float* nxt = pb;
-    const int ntiles = n16 / 16;
-    for (int l = 0; l < d.n_layers; ++l) {
-        const ConvLayer& L = d.L[l];
-        const int Ci = L.in_ch, Co = L.out_ch, Hs = L.hist;
-        lds_barrier();                                      // the previous layer is done with wst/ofs and with both planes
-#pragma unroll
-        for (int j = 0; j < kFragRegs; ++j) {
-            if (j * kConvmThreads >= L.k_steps * kWave) break;
-            const int i = tid + j * kConvmThreads;
-            if (i < L.k_steps * kWave) {                      // one 8-byte record per (k-step, lane): B value, A plane offset
-                wst[2 * i] = fr[j];
-                reinterpret_cast<int*>(wst)[2 * i + 1] = kc[j] * F + Hb - kb[j] + (i & 15);
-            }
-        }
-        const float bias = bias_r;
-        if (l + 1 < d.n_layers) store_prefix(l + 1, nxt);     // the next layer's history prefix (fetched a layer ago)
-        if (l + 1 < d.n_layers) fetch_frag(l + 1);
-        if (l + 2 < d.n_layers) fetch_prefix(l + 2);
-        lds_barrier();
-        // tile j of this wave is frame tile wave + 4*j (n <= 256: at most kConvmTiles per wave)
-        if (wave < ntiles) {
-            f32x4 acc[kConvmTiles];
-#pragma unroll
-            for (int j = 0; j < kConvmTiles; ++j) acc[j] = f32x4{bias, bias, bias, bias};
-            for (int kk = 0; kk < L.k_steps; ++kk) {
-                const float2 rec = *reinterpret_cast<const float2*>(wst + 2 * (kk * kWave + lane));
-                const float b = rec.x;
-                const float* ap = cur + __builtin_bit_cast(int, rec.y) + 16 * wave;
-#pragma unroll
-                for (int j = 0; j < kConvmTiles; ++j) {
-                    const float av = ap[wave + 4 * j < ntiles ? 64 * j : 0];   // tiles past the block re-read the first
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc[j], 0, 0, 0);
-                }
-            }
-            const int co = lane & 15;
-#pragma unroll
-            for (int j = 0; j < kConvmTiles; ++j) {
-                if (wave + 4 * j >= ntiles || co >= Co) continue;
-                f32x4 v = acc[j];
-                if (L.activation == 1) { v.x = tanh_exp(v.x); v.y = tanh_exp(v.y); v.z = tanh_exp(v.z); v.w = tanh_exp(v.w); }
-                else if (L.activation == 2) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
-                else if (L.activation == 3) { v.x = fast_sigmoid(v.x); v.y = fast_sigmoid(v.y); v.z = fast_sigmoid(v.z); v.w = fast_sigmoid(v.w); }
-                *reinterpret_cast<f32x4*>(nxt + (size_t)co * F + Hb + 16 * (wave + 4 * j) + 4 * (lane >> 4)) = v;
-            }
-        }
-        lds_barrier();
-        // this layer's new history: the last Hs frames of [old history | this block's inputs]
+    // this layer's new history: the last Hs frames of [old history | this block's inputs], plane -> HBM. Runs while the
+    // plane still holds the layer's INPUT (before the barrier that releases it for the in-place update).
+    auto save_history = [&](const ConvLayer& L) {
+        const int Hs = L.hist, Ci = L.in_ch;
         if (vec_hist(L) && (n & 3) == 0) {
             const int hist4 = Hs >> 2, cnt4 = hist4 * Ci;
             const float inv4 = 1.0f / (float)hist4;
@@ -236,7 +200,7 @@ __global__ __launch_bounds__(kConvmThreads) void k_conv_mfma(LaunchArgs a, ConvD
             for (int j = 0; j < kHistRegs / 4; ++j) {         // all LDS reads first, then the stores
                 if (j * kConvmThreads >= cnt4) break;
                 const int i4 = tid + j * kConvmThreads;
-                hv4[j] = *reinterpret_cast<const f32x4*>(cur + plane_index4(i4 < cnt4 ? i4 : 0, hist4, inv4) + n);
+                hv4[j] = *reinterpret_cast<const f32x4*>(pl + plane_index4(i4 < cnt4 ? i4 : 0, hist4, inv4) + n);
             }
 #pragma unroll
             for (int j = 0; j < kHistRegs / 4; ++j) {
@@ -245,16 +209,16 @@ __global__ __launch_bounds__(kConvmThreads) void k_conv_mfma(LaunchArgs a, ConvD
                 if (i4 < cnt4) dst[i4] = hv4[j];
             }
             for (int i4 = tid + (kHistRegs / 4) * kConvmThreads; i4 < cnt4; i4 += kConvmThreads)
-                dst[i4] = *reinterpret_cast<const f32x4*>(cur + plane_index4(i4, hist4, inv4) + n);
+                dst[i4] = *reinterpret_cast<const f32x4*>(pl + plane_index4(i4, hist4, inv4) + n);
         } else {
             const float inv = 1.0f / (float)Hs;
             const int cnt = Hs * Ci;
             float hv[kHistRegs];
 #pragma unroll
-            for (int j = 0; j < kHistRegs; ++j) {             // all LDS reads first, then the stores
+            for (int j = 0; j < kHistRegs; ++j) {
                 if (j * kConvmThreads >= cnt) break;
                 const int i = tid + j * kConvmThreads;
-                hv[j] = cur[plane_index(i < cnt ? i : 0, Hs, inv) + n];
+                hv[j] = pl[plane_index(i < cnt ? i : 0, Hs, inv) + n];
             }
 #pragma unroll
             for (int j = 0; j < kHistRegs; ++j) {
@@ -263,16 +227,58 @@ __global__ __launch_bounds__(kConvmThreads) void k_conv_mfma(LaunchArgs a, ConvD
                 if (i < cnt) hist_base[L.state_off + i] = hv[j];
             }
             for (int i = tid + kHistRegs * kConvmThreads; i < cnt; i += kConvmThreads)
-                hist_base[L.state_off + i] = cur[plane_index(i, Hs, inv) + n];
+                hist_base[L.state_off + i] = pl[plane_index(i, Hs, inv) + n];
         }
-        float* tmp = cur; cur = nxt; nxt = tmp;
+    };
+
+    fetch_frag(0);
+    lds_barrier();                                            // layer 0's input is in the plane
+    stage_frag(0);
+    const int ntiles = n16 / 16;
+    for (int l = 0; l < d.n_layers; ++l) {
+        const ConvLayer& L = d.L[l];
+        const int Co = L.out_ch;
+        const float bias = bias_r;                            // of layer l (fetch_frag below loads the next one's)
+        if (l + 1 < d.n_layers) { fetch_frag(l + 1); fetch_prefix(l + 1); }
+        lds_barrier();                                        // plane = this layer's input, wst = its fragments
+        // tile j of this wave is frame tile wave + 4*j (n <= 256: at most kConvmTiles per wave)
+        f32x4 acc[kConvmTiles];
+#pragma unroll
+        for (int j = 0; j < kConvmTiles; ++j) acc[j] = f32x4{bias, bias, bias, bias};
+        if (wave < ntiles) {
+            for (int kk = 0; kk < L.k_steps; ++kk) {
+                const float2 rec = *reinterpret_cast<const float2*>(wst + 2 * (kk * kWave + lane));
+                const float b = rec.x;
+                const float* ap = pl + __builtin_bit_cast(int, rec.y) + 16 * wave;
+#pragma unroll
+                for (int j = 0; j < kConvmTiles; ++j) {
+                    const float av = ap[wave + 4 * j < ntiles ? 64 * j : 0];   // tiles past the block re-read the first
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc[j], 0, 0, 0);
+                }
+            }
+        }
+        save_history(L);                                      // reads the input while it is still there
+        lds_barrier();                                        // everybody is done reading the plane and wst
+        if (wave < ntiles) {
+            const int co = lane & 15;
+#pragma unroll
+            for (int j = 0; j < kConvmTiles; ++j) {
+                if (wave + 4 * j >= ntiles || co >= Co) continue;
+                f32x4 v = acc[j];
+                if (L.activation == 1) { v.x = tanh_exp(v.x); v.y = tanh_exp(v.y); v.z = tanh_exp(v.z); v.w = tanh_exp(v.w); }
+                else if (L.activation == 2) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
+                else if (L.activation == 3) { v.x = fast_sigmoid(v.x); v.y = fast_sigmoid(v.y); v.z = fast_sigmoid(v.z); v.w = fast_sigmoid(v.w); }
+                *reinterpret_cast<f32x4*>(pl + (size_t)co * F + Hb + 16 * (wave + 4 * j) + 4 * (lane >> 4)) = v;
+            }
+        }
+        if (l + 1 < d.n_layers) { store_prefix(l + 1); stage_frag(l + 1); }
     }
     lds_barrier();
     // Dense(C,1) + skip / output gain (:171-181), one thread per frame
     if (mode != MODE_WARMUP && tid < n) {
         const int Cl = d.L[d.n_layers - 1].out_ch;
         float y = wdl[16];
-        for (int o = 0; o < Cl; ++o) y = __builtin_fmaf(wdl[o], cur[(size_t)o * F + Hb + tid], y);
+        for (int o = 0; o < Cl; ++o) y = __builtin_fmaf(wdl[o], pl[(size_t)o * F + Hb + tid], y);
         float o2 = a.input_skip ? xg + y : y;
         row[tid] = o2 * a.out_gain;
     }

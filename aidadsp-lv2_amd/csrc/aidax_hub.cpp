@@ -40,7 +40,7 @@ struct aidax_hub {
     std::condition_variable cv;
     std::thread launcher;
     bool stop = false, flush_requested = false;
-    int64_t deadline_us = -1;                    // < 0: a quarter of the period; 0: no deadline
+    int64_t deadline_us = -1;                    // < 0: half the period; 0: no deadline
     Clock::time_point deadline{};
     std::vector<uint8_t> attached, submitted, forced_off;
     std::vector<uint64_t> last_pass;             // per slot: id of the pass that carried its latest block (0: none)
@@ -303,7 +303,7 @@ AIDAX_API int aidax_hub_run(aidax_hub* h, int32_t slot, const float* in, float* 
         }
         if (h->n_submitted == 0) {                           // first of a new period: block length and deadline
             h->period_frames = n_frames;
-            const int64_t us = h->deadline_us < 0 ? static_cast<int64_t>(0.25e6 * n_frames / h->host_sr) : h->deadline_us;
+            const int64_t us = h->deadline_us < 0 ? static_cast<int64_t>(0.5e6 * n_frames / h->host_sr) : h->deadline_us;
             h->deadline = Clock::now() + std::chrono::microseconds(us);
             wake = h->deadline_us != 0;
         }

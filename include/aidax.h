@@ -229,8 +229,8 @@ AIDAX_API const char* aidax_pool_kernel_name(const aidax_pool* p);
  * rendezvous inside run() would deadlock the first kind, so the hub is pipelined by ONE period instead:
  * run() of period p stages the instance's input block and returns the output of period p-1 (silence in the
  * first period). The pass of a period is launched (asynchronously: H2D, kernels, D2H) by the hub's launcher
- * thread as soon as every attached instance has submitted — or when the period's DEADLINE passes (by default a
- * quarter of the period after its first submission, aidax_hub_set_deadline_us), so an instance that stalls or
+ * thread as soon as every attached instance has submitted — or when the period's DEADLINE passes (by default
+ * half the period after its first submission, aidax_hub_set_deadline_us), so an instance that stalls or
  * stops calling cannot hold the others: they keep their one period of latency, the straggler's stream simply
  * does not advance in that pass. An instance that comes around again before the period was closed, or a change
  * of block size, closes it on the spot. run() itself waits only for the event of the previous period's pass,
@@ -251,7 +251,7 @@ AIDAX_API int  aidax_hub_set_loading(aidax_hub* h, int32_t slot, int loading);
 AIDAX_API int  aidax_hub_activate(aidax_hub* h, int32_t slot);
 /* the instance's run(): in/out are its n_frames-long port buffers (may alias) */
 AIDAX_API int  aidax_hub_run(aidax_hub* h, int32_t slot, const float* in, float* out, uint32_t n_frames);
-/* deadline of a period, measured from its first submission: < 0 a quarter of the period (default), 0 none
+/* deadline of a period, measured from its first submission: < 0 half the period (default), 0 none
  * (passes are launched only when everybody submitted, on re-entry, or by aidax_hub_flush) */
 AIDAX_API int  aidax_hub_set_deadline_us(aidax_hub* h, int64_t microseconds);
 /* close the period being collected now (hosts that know their graph is done; tests) */

@@ -26,7 +26,8 @@
 // 8 puts them on one XCD under the observed b % 8 placement, a locality hint only.
 //
 // Same arithmetic as k_mfma (same fragments from pack_mfma, same accumulation order, same activations): the two
-// kernels are bit-identical on the same model, which tests/test_gpu_parity.py checks.
+// kernels leave bit-identical recurrent state on the same model, which tests/test_gpu_parity.py checks (Dense(H,1) is
+// summed in a different order, so the outputs agree to ~1e-7).
 #include "aidax_device.h"
 #include "aidax_kernels.h"
 #include "aidax_layout.h"
@@ -51,7 +52,8 @@ __host__ __device__ inline size_t lp_lds_floats(int hidden, int n_frames)
          + (size_t)hidden * kMfmaStreams                      /* cT[unit][n]                             */
          + (size_t)hidden * 4                                 /* bias[unit][4 rows]                      */
          + (size_t)((hidden + 1 + 3) & ~3)                    /* Dense weights + bias (last layer)       */
-         + kMfmaStreams;                                      /* live flags                              */
+         + kMfmaStreams                                       /* live flags                              */
+         + 2 * 8 * kMfmaStreams;                              /* Dense partial sums [parity][wave][n]    */
 }
 
 // one frame in the ring: h [unit][stream], then (M > 0) the pre-activations of the first M tiles of every wave of the
@@ -172,6 +174,7 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
     float* bl    = cT + H * NS;                            // [H][4]
     float* wdl   = bl + H * 4;                             // Dense weights, bias at [H]
     float* livef = wdl + ((H + 1 + 3) & ~3);               // [NS]
+    float* dpart = livef + NS;                             // [2][NW][NS] Dense partial sums of the waves (last layer)
 
     const float* W = a.wpack;
     const MfmaLayer& L = d.L[l];
@@ -234,6 +237,14 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
     for (int tl = 0; tl < MA; ++tl)
         bias_up[tl] = (M > 0 && first) ? *reinterpret_cast<const f32x4*>(W + d.L[M > 0 ? 1 : 0].b_off + 4 * (4 * (wave * TPW + tl) + (lane >> 4)))
                                         : f32x4{ 0.f, 0.f, 0.f, 0.f };
+    // Dense(H,1) on the matrix cores (last layer): y = wd . h is one more 16-row tile whose row 0 is wd; its H/4
+    // k-steps are dealt out TPW per wave, each wave leaves a partial sum per stream in LDS and wave 0 adds the NW
+    // partials in a fixed order a tick later. (As VALU code — six LDS reads with bank conflicts, a DPP tree, twice per
+    // SIMD — it cost ~1000 cycles per tick next to the MFMA stretch; this way it is TPW MFMAs per wave.)
+    float dfrag[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+        dfrag[i] = (last && (lane & 15) == 0) ? W[d.wd_off + 4 * (wave * TPW + i) + (lane >> 4)] : 0.f;
     float w_in0[TPW];
 #pragma unroll
     for (int tl = 0; tl < TPW; ++tl) w_in0[tl] = first ? W[d.L[0].w_in_off + ((size_t)wave * kWave + lane) * TPW + tl] : 0.f;
@@ -380,7 +391,7 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
         }
         __syncthreads();
 
-        const int ticks = last ? cnt + 1 : cnt;            // the Dense of a frame runs one tick behind its h
+        const int ticks = last ? cnt + 2 : cnt;            // the Dense of a frame: partial sums one tick behind its h, the output two
         for (int tick = 0; tick < ticks; ++tick) {
             const int rd = par, wr = par ^ 1;
             const bool body = tick < cnt;
@@ -412,21 +423,25 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
                 }
             }
 
-            // ---- Dense(H,1) + skip + output gain of the frame before, spread over all waves: wave w reduces streams
-            // SPW*w .. SPW*w+SPW-1, sixteen lanes per stream
-            constexpr int SPW = NS / NW;                   // 2 (eight waves) or 4 (four waves)
-            if (last && tick >= 1 && (lane >> 4) < SPW) {
-                const int fd = tick - 1;
-                const int sl = wave * SPW + (lane >> 4), q = lane & 15;
+            // ---- Dense(H,1) of frame tick-1: this wave's k-steps against h(tick-1) (= hT[rd], stable for the whole tick)
+            if (last && tick >= 1 && tick <= cnt) {
+                f32x4 dacc = f32x4{ 0.f, 0.f, 0.f, 0.f };
                 const float* hv = hT + rd * H * NS;
-                float part = 0.f;
 #pragma unroll
-                for (int j = 0; j < H / 16; ++j) part = __builtin_fmaf(wdl[q + 16 * j], hv[(q + 16 * j) * NS + sl], part);
-                const float y = lp_row_sum16(part) + wdl[H];
-                const float x = xb[sl * nP + fd] * a.in_gain;
+                for (int i = 0; i < TPW; ++i)
+                    dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(dfrag[i], hv[64 * (wave * TPW + i) + lane], dacc, 0, 0, 0);
+                if (lane < NS) dpart[((tick & 1) * NW + wave) * NS + lane] = dacc.x;      // row 0, column = stream `lane`
+            }
+            // ---- ... and of frame tick-2: the NW partial sums, bias, skip, output gain (wave 0, one lane per stream)
+            if (last && tick >= 2 && wave == 0 && lane < NS) {
+                const int fd = tick - 2;
+                float y = wdl[H];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) y += dpart[(((tick - 1) & 1) * NW + w) * NS + lane];
+                const float x = xb[lane * nP + fd] * a.in_gain;
                 float o = a.input_skip ? x + y : y;
                 o = o * a.out_gain;
-                if (q == 0 && livef[sl] != 0.f) xb[sl * nP + fd] = o;
+                if (livef[lane] != 0.f) xb[lane * nP + fd] = o;
             }
 
             if (body) {

@@ -604,9 +604,9 @@ def test_every_kernel_form_passes_the_same_chain_cases(form, tmp_path, monkeypat
     ("gru48x3", dict(kind="gru", hidden=48, input_size=3, seed=483, n_rnn=3)),            # three layers: a middle workgroup both consumes and produces
     ("l16x4", dict(kind="lstm", hidden=16, input_size=2, seed=164, n_rnn=4, in_skip=1)),
 ])
-def test_layer_pipelined_kernel_is_bit_identical_to_the_one_workgroup_kernel(name, kw, tmp_path, monkeypatch):
+def test_layer_pipelined_kernel_keeps_the_state_of_the_one_workgroup_kernel_bit_for_bit(name, kw, tmp_path, monkeypatch):
     """k_mfma_lp (one workgroup per layer, layers chained through a global ring, weights in registers) against
-    k_mfma (one workgroup walks all layers, AIDAX_MFMA_LP=0) on the same fragments: identical bits, over ragged
+    k_mfma (one workgroup walks all layers, AIDAX_MFMA_LP=0) on the same fragments: identical state bits, over ragged
     block sizes incl. blocks longer than the ring and the 256-frame staging chunk, 150 streams (10 stream groups,
     the last one ragged) so that several groups and layers are in flight at once, and against the oracle."""
     path, spec = _model_file(tmp_path, name, **kw)
@@ -629,8 +629,11 @@ def test_layer_pipelined_kernel_is_bit_identical_to_the_one_workgroup_kernel(nam
         h, c = pool.read_state(stream=S - 1, layer=kw["n_rnn"] - 1, hidden=128)
         outs[lp + "h"] = h
         pool.close()
-    assert np.array_equal(outs["1"], outs["0"])
+    # same fragments, same accumulation order, same activations: the recurrent state is bit-identical; the outputs
+    # differ only by the order in which Dense(H,1) is summed (per-wave partial sums on the matrix cores there, an
+    # fma chain + lane tree here)
     assert np.array_equal(outs["1h"], outs["0h"])
+    errlog.bound(np.abs(outs["1"] - outs["0"]).max(), 5e-7, "gpu_parity:lp_vs_mfma_outputs")
     for s_ in (0, 17, S - 1):
         want = O.run_streams(spec, co, x[s_:s_ + 1], 4096)       # block partition does not matter to the oracle
         errlog.bound(np.abs(outs["1"][s_] - want[0]).max(), 2e-6, "gpu_parity:lp_vs_oracle")

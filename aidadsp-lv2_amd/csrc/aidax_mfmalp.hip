@@ -50,7 +50,6 @@ __host__ __device__ inline size_t lp_lds_floats(int hidden, int n_frames)
          + (size_t)2 * hidden * kMfmaStreams                  /* below[parity][unit][n] (layers >= 1)    */
          + (size_t)2 * hidden * kMfmaStreams                  /* hT[parity][unit][n]                     */
          + (size_t)hidden * kMfmaStreams                      /* cT[unit][n]                             */
-         + (size_t)hidden * 4                                 /* bias[unit][4 rows]                      */
          + (size_t)((hidden + 1 + 3) & ~3)                    /* Dense weights + bias (last layer)       */
          + kMfmaStreams                                       /* live flags                              */
          + 2 * 8 * kMfmaStreams;                              /* Dense partial sums [parity][wave][n]    */
@@ -171,8 +170,7 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
     float* below = xin + 2 * 64;                           // [2][H][NS]
     float* hT    = below + 2 * H * NS;                     // [2][H][NS]
     float* cT    = hT + 2 * H * NS;                        // [H][NS]
-    float* bl    = cT + H * NS;                            // [H][4]
-    float* wdl   = bl + H * 4;                             // Dense weights, bias at [H]
+    float* wdl   = cT + H * NS;                            // Dense weights, bias at [H]
     float* livef = wdl + ((H + 1 + 3) & ~3);               // [NS]
     float* dpart = livef + NS;                             // [2][NW][NS] Dense partial sums of the waves (last layer)
 

@@ -212,7 +212,8 @@ struct LaunchArgs {
     int32_t          input_size;
     int32_t          input_skip;
     float            in_gain, out_gain;
-    int32_t          tune;        // AIDAX_TUNE bit mask: measurement switches of the kernels (0 in production)
+    int32_t          tune;        // AIDAX_TUNE bit mask, measurement / test switches of the kernels (0 in production):
+                                  // 1 = no issue priority for the recurrent wave of k_*_pipe, 2 = k_mfma_lp with a group's layers on adjacent workgroup ids
     uint32_t         ring_groups; // k_mfma_lp: stream groups the pool's ring / counter buffers were sized for
 };
 

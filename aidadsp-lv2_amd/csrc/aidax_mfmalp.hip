@@ -155,9 +155,12 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
     const int I = a.input_size;
     const int mode = a.mode;
     // workgroup id -> (group, layer): ids of one group are 8 apart, lower layers first
+    // (AIDAX_TUNE bit 2 lays a group's layers out on ADJACENT ids instead — different XCDs under b % 8 — so that the
+    // tests can exercise the cross-XCD hand-over too.)
     const int blk = (int)blockIdx.x;
-    const int grp = (blk / (8 * NL)) * 8 + (blk & 7);
-    const int l = (blk / 8) % NL;
+    const bool adjacent = (a.tune & 2) != 0;
+    const int grp = adjacent ? blk / NL : (blk / (8 * NL)) * 8 + (blk & 7);
+    const int l = adjacent ? blk % NL : (blk / 8) % NL;
     const int n_groups = ((int)a.n_streams + NS - 1) / NS;
     if (grp >= n_groups) return;
     const bool first = l == 0, last = l == NL - 1;

@@ -604,7 +604,8 @@ def test_every_kernel_form_passes_the_same_chain_cases(form, tmp_path, monkeypat
     ("gru48x3", dict(kind="gru", hidden=48, input_size=3, seed=483, n_rnn=3)),            # three layers: a middle workgroup both consumes and produces
     ("l16x4", dict(kind="lstm", hidden=16, input_size=2, seed=164, n_rnn=4, in_skip=1)),
 ])
-def test_layer_pipelined_kernel_keeps_the_state_of_the_one_workgroup_kernel_bit_for_bit(name, kw, tmp_path, monkeypatch):
+@pytest.mark.parametrize("placement", ["ids 8 apart (one XCD)", "adjacent ids (two XCDs)"])
+def test_layer_pipelined_kernel_keeps_the_state_of_the_one_workgroup_kernel_bit_for_bit(name, kw, placement, tmp_path, monkeypatch):
     """k_mfma_lp (one workgroup per layer, layers chained through a global ring, weights in registers) against
     k_mfma (one workgroup walks all layers, AIDAX_MFMA_LP=0) on the same fragments: identical state bits, over ragged
     block sizes incl. blocks longer than the ring and the 256-frame staging chunk, 150 streams (10 stream groups,
@@ -615,6 +616,8 @@ def test_layer_pipelined_kernel_keeps_the_state_of_the_one_workgroup_kernel_bit_
     x = modelgen.signal(S, sum(sizes), seed=27)
     cg, co = _ctl_pair(param1=0.3, param2=0.8, pregain_db=1.0)
     outs = {}
+    if placement.startswith("adjacent"):
+        monkeypatch.setenv("AIDAX_TUNE", "2")       # the hand-over must not depend on where the two workgroups run
     for lp in ("1", "0"):
         monkeypatch.setenv("AIDAX_MFMA_LP", lp)
         pool = ax.Pool(S, 1024)

@@ -200,15 +200,14 @@ __device__ __forceinline__ void chain_sweep(ChainPass& c, int stage, bool run, i
 #endif
 constexpr int kChainBlock = AIDAX_CHAIN_BLOCK;
 
-__device__ __forceinline__ void chain_sweep_blocked(ChainPass& c, int stage, bool run, int depth, float* row, float* hand,
-                                                    int n_full, int lane)
+// PLAIN: every lane that runs has its biquad in circuit and every gain ramp of the wave sits on its fixed point
+// (mem * coef + tc == mem, so next() returns the same value for the rest of the block): the per-sample select
+// and the two ramp instructions drop out — 12 instructions per sample and stage instead of 15, same values.
+template <bool PLAIN>
+__device__ __forceinline__ void chain_blocks(ChainPass& c, ExpRamp& g, int stage, bool run, int depth, bool last,
+                                             float* row, float* hand, int M, int lane)
 {
-    const double z1o = c.z1, z2o = c.z2;
-    const int M = n_full / kChainBlock;
-    ExpRamp g = c.g;
-    const bool is_gain = stage == c.gain_lane;
-    if (!is_gain) { g.mem = 1.f; g.coef = 1.f; g.tc = 0.f; }     // y * 1.0f is exact: no select per sample
-    const bool last = stage == c.K - 1;
+    const float g_fixed = g.mem;
     for (int m = 0; m < M + depth - 1; ++m) {
         const int j = m - stage;
         if (run && j >= 0 && j < M) {
@@ -227,8 +226,12 @@ __device__ __forceinline__ void chain_sweep_blocked(ChainPass& c, int stage, boo
                 const double yd = xd * c.a0 + c.z1;
                 c.z1 = xd * c.a1 + c.z2 - c.b1 * yd;
                 c.z2 = xd * c.a2 - c.b2 * yd;
-                const float y = c.active ? (float)yd : x;
-                v[i] = y * g.next();
+                if constexpr (PLAIN) {
+                    v[i] = (float)yd * g_fixed;
+                } else {
+                    const float y = c.active ? (float)yd : x;
+                    v[i] = y * g.next();
+                }
             }
 #pragma unroll
             for (int q = 0; q < kChainBlock / 4; ++q)
@@ -236,6 +239,21 @@ __device__ __forceinline__ void chain_sweep_blocked(ChainPass& c, int stage, boo
         }
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+__device__ __forceinline__ void chain_sweep_blocked(ChainPass& c, int stage, bool run, int depth, float* row, float* hand,
+                                                    int n_full, int lane)
+{
+    const double z1o = c.z1, z2o = c.z2;
+    const int M = n_full / kChainBlock;
+    ExpRamp g = c.g;
+    const bool is_gain = stage == c.gain_lane;
+    if (!is_gain) { g.mem = 1.f; g.coef = 1.f; g.tc = 0.f; }     // y * 1.0f is exact: no select per sample
+    const bool last = stage == c.K - 1;
+    // wave-uniform: does any running lane need the select (a bypassed biquad) or a moving ramp?
+    const bool fussy = run && (!c.active || g.mem * g.coef + g.tc != g.mem);
+    if (__builtin_amdgcn_ballot_w64(fussy) == 0) chain_blocks<true>(c, g, stage, run, depth, last, row, hand, M, lane);
+    else chain_blocks<false>(c, g, stage, run, depth, last, row, hand, M, lane);
     if (is_gain) c.g = g;
     if (!run || !c.active) { c.z1 = z1o; c.z2 = z2o; }
 }

@@ -38,9 +38,11 @@ __host__ __device__ inline int convm_plane_stride(int max_hist, int n_frames)
 }
 __host__ __device__ inline size_t convm_lds_floats(const ConvDesc& d, int n_frames)
 {
-    return (size_t)d.channels * convm_plane_stride(d.max_hist, n_frames)       /* the activation plane      */
-         + 2 * (size_t)d.max_k_steps * kWave                                  /* B fragments + A offsets   */
-         + 16 + 4;                                                            /* Dense weights + bias      */
+    const size_t stage = 2 * (size_t)d.max_k_steps * kWave;                    /* B fragments + A offsets; the fused form's  */
+    return (size_t)d.channels * convm_plane_stride(d.max_hist, n_frames)       /* chain passes borrow it for their hand-over */
+         + (stage > (size_t)kChainHandFloats ? stage : (size_t)kChainHandFloats)
+         + 16 + 4                                                             /* Dense weights + bias      */
+         + 8;                                                                 /* fused form: what the chain prologue leaves for the epilogue */
 }
 
 // Workgroup barrier that orders LDS traffic only. __syncthreads() also drains vmcnt, i.e. it would wait for
@@ -51,6 +53,15 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// FUSED: the whole run() of the stream in this one launch (MODE_CHAIN only) — one wave of the workgroup runs the
+// pre pass (LPF, pre-gain, EQ-pre) on the audio row where layer 0 will read it, and the post pass (DC blocker, EQ-post,
+// master) on the row the Dense left, both in the blocked systolic form of k_chain. The chain is serial per stream
+// (~9 + ~10 us for 256 frames on a wave of its own), but two launches, two round trips of the block through HBM and
+// their gaps go away: BASELINE cfg4 86.4 -> 81.3 us. The four workgroups that share a CU start in step and run their
+// chain passes at the same time, each on its wave 0: the dispatcher rotates the SIMD a workgroup's first wave lands on
+// (scratch/uhwid.hip: of 1536 pairs of co-resident workgroups none had their waves 0 on one SIMD), so every chain wave
+// issues alone. (Picking the wave by HW_ID slot instead put two of them on one SIMD: 88.3 us.)
+template <bool FUSED>
 __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, ConvDesc d)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -59,18 +70,40 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = (int)a.n_frames;
     const int sg = blockIdx.x;
-    const int mode = a.mode;
-    if (n == 0) return;
-    if (mode == MODE_CHAIN) {
-        const uint32_t flags = a.ctl[sg].flags;
-        if (!(flags & CTL_ENABLED) || !(flags & CTL_NET_ON)) return;          // :607-619, :631-632 (uniform per workgroup)
+    const int mode = FUSED ? (int)MODE_CHAIN : a.mode;
+    if (!FUSED) {
+        if (n == 0) return;
+        if (mode == MODE_CHAIN) {
+            const uint32_t flags = a.ctl[sg].flags;
+            if (!(flags & CTL_ENABLED) || !(flags & CTL_NET_ON)) return;      // :607-619, :631-632 (uniform per workgroup)
+        }
     }
     const int C = d.channels;
     const int Hb = (d.max_hist + 3) & ~3;                    // plane index of frame 0
     const int F = convm_plane_stride(d.max_hist, n);
+    const size_t stage_floats = 2 * (size_t)d.max_k_steps * kWave;
     float* pl = smem;                                         // [C][F]: history | block, per channel
     float* wst = pl + (size_t)C * F;                          // [k_steps][64] records {B fragment value, A plane offset}
-    float* wdl = wst + 2 * (size_t)d.max_k_steps * kWave;     // Dense weights [16] + bias
+    float* wdl = wst + (stage_floats > (size_t)kChainHandFloats ? stage_floats : (size_t)kChainHandFloats);   // Dense weights [16] + bias
+    float* verdict = wdl + 20;                                // fused form: {stream live, model in circuit, ChainCtx}
+    constexpr int chain_wave = 0;
+
+    bool net = true;
+    if constexpr (FUSED) {
+        // channel 0's block part of the plane is the audio row: the pre pass leaves layer 0's input there
+        if (wave == chain_wave) {
+            const ChainCtx ctx = chain_prologue(a.ctl[sg], a.st[sg], a.in + (size_t)sg * n, a.out + (size_t)sg * n, pl + Hb, n, lane, wst);
+            if (lane == 0) {
+                // the context waits in LDS, not in six registers of every thread across the layer loop
+                verdict[0] = ctx.live ? 1.f : 0.f; verdict[1] = (ctx.live && (ctx.flags & CTL_NET_ON)) ? 1.f : 0.f;
+                verdict[2] = __builtin_bit_cast(float, ctx.flags); verdict[3] = __builtin_bit_cast(float, ctx.pending);
+                verdict[4] = ctx.pre_mem; verdict[5] = ctx.master_mem; verdict[6] = ctx.pre_tgt; verdict[7] = ctx.master_tgt;
+            }
+        }
+        lds_barrier();
+        if (verdict[0] == 0.f) return;                        // pre-run / hard bypass: the prologue did all there is to do
+        net = verdict[1] != 0.f;
+    }
 
     const float* W = a.wpack;
     float* hist_base = a.nn + (size_t)sg * a.nn_stride;
@@ -79,14 +112,14 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
 
     // layer-0 input: [history | x * in_gain | zeros up to the tile boundary]; x stays in a register for the skip
     float xg = 0.f;
-    {
+    if (net) {
         const ConvLayer& L0 = d.L[0];
         for (int c = 0; c < L0.in_ch; ++c)
             for (int j = tid; j < L0.hist; j += kConvmThreads)
                 pl[c * F + Hb - L0.hist + j] = hist_base[L0.state_off + c * L0.hist + j];
         for (int t = tid; t < n16; t += kConvmThreads) {
             float v = 0.f;
-            if (t < n) v = (mode == MODE_CHAIN ? row[t] : mode == MODE_NN_ONLY ? a.in[(size_t)t * a.input_size] : 0.f) * a.in_gain;
+            if (t < n) v = (FUSED ? pl[Hb + t] : mode == MODE_CHAIN ? row[t] : mode == MODE_NN_ONLY ? a.in[(size_t)t * a.input_size] : 0.f) * a.in_gain;
             pl[Hb + t] = v;
             xg = v;                                           // n <= 256: one frame per thread
         }
@@ -231,10 +264,11 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
         }
     };
 
+    const int ntiles = n16 / 16;
+    if (net) {
     fetch_frag(0);
     lds_barrier();                                            // layer 0's input is in the plane
     stage_frag(0);
-    const int ntiles = n16 / 16;
     for (int l = 0; l < d.n_layers; ++l) {
         const ConvLayer& L = d.L[l];
         const int Co = L.out_ch;
@@ -274,26 +308,56 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
         if (l + 1 < d.n_layers) { store_prefix(l + 1); stage_frag(l + 1); }
     }
     lds_barrier();
-    // Dense(C,1) + skip / output gain (:171-181), one thread per frame
+    // Dense(C,1) + skip / output gain (:171-181), one thread per frame. The fused form leaves the result where the
+    // audio row was: a thread reads column `tid` of every channel and then overwrites column `tid` of channel 0.
     if (mode != MODE_WARMUP && tid < n) {
         const int Cl = d.L[d.n_layers - 1].out_ch;
         float y = wdl[16];
         for (int o = 0; o < Cl; ++o) y = __builtin_fmaf(wdl[o], pl[(size_t)o * F + Hb + tid], y);
         float o2 = a.input_skip ? xg + y : y;
-        row[tid] = o2 * a.out_gain;
+        if constexpr (FUSED) pl[Hb + tid] = o2 * a.out_gain;
+        else row[tid] = o2 * a.out_gain;
+    }
+    }   // net
+    if constexpr (FUSED) {
+        lds_barrier();                                        // the row is complete, the staging area is free again
+        if (wave == chain_wave) {
+            ChainCtx ctx;
+            ctx.live = true;
+            ctx.flags = __builtin_bit_cast(uint32_t, verdict[2]); ctx.pending = __builtin_bit_cast(uint32_t, verdict[3]);
+            ctx.pre_mem = verdict[4]; ctx.master_mem = verdict[5]; ctx.pre_tgt = verdict[6]; ctx.master_tgt = verdict[7];
+            chain_epilogue(a.ctl[sg], a.st[sg], ctx, a.out + (size_t)sg * n, pl + Hb, n, lane, wst);
+        }
     }
 }
 
 size_t convm_lds_bytes(const ConvDesc& d, uint32_t n_frames) { return convm_lds_floats(d, (int)n_frames) * sizeof(float); }
 
-hipError_t launch_conv_mfma_kernel(const LaunchArgs& a, const ConvDesc& d, hipStream_t stream)
+// Streams (= workgroups) of the fused form that are resident at once on `device`: while a pool fits, its chain passes
+// cost their latency once; beyond, once per round of workgroups, and the packed k_chain launches are the cheaper form.
+int convm_resident_streams(const ConvDesc& d, uint32_t n_frames, int device)
 {
+    int per_cu = 0, cus = 0;
+    const size_t lds = convm_lds_bytes(d, n_frames);
+    const void* fn = reinterpret_cast<const void*>(k_conv_mfma<true>);
+    if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kConvmThreads, lds) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
+    return per_cu * cus;
+}
+
+// fused: the launch is the whole run() of every stream (a.mode must be MODE_CHAIN); otherwise applyModel only
+hipError_t launch_conv_mfma_kernel(const LaunchArgs& a, const ConvDesc& d, bool fused, hipStream_t stream)
+{
+    if (fused && a.mode != MODE_CHAIN) return hipErrorInvalidValue;
     const size_t lds = convm_lds_bytes(d, a.n_frames);
+    const void* fn = fused ? reinterpret_cast<const void*>(k_conv_mfma<true>) : reinterpret_cast<const void*>(k_conv_mfma<false>);
     if (lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_conv_mfma, dim3(a.n_streams), dim3(kConvmThreads), lds, stream, a, d);
+    if (fused) hipLaunchKernelGGL(k_conv_mfma<true>, dim3(a.n_streams), dim3(kConvmThreads), lds, stream, a, d);
+    else hipLaunchKernelGGL(k_conv_mfma<false>, dim3(a.n_streams), dim3(kConvmThreads), lds, stream, a, d);
     return hipGetLastError();
 }
 

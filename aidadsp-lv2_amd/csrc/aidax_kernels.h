@@ -44,7 +44,8 @@ size_t quad_lds_bytes(int hidden, uint32_t n_frames);
 hipError_t launch_quad_kernel(int cell, int hidden, const LaunchArgs& a, const QuadDesc& qd, hipStream_t stream);
 hipError_t launch_stack_kernel(const LaunchArgs& a, const StackDesc& d, hipStream_t stream);
 size_t convm_lds_bytes(const ConvDesc& d, uint32_t n_frames);
-hipError_t launch_conv_mfma_kernel(const LaunchArgs& a, const ConvDesc& d, hipStream_t stream);   // n_frames <= 256
+int convm_resident_streams(const ConvDesc& d, uint32_t n_frames, int device);                 // workgroups of the fused form resident at once
+hipError_t launch_conv_mfma_kernel(const LaunchArgs& a, const ConvDesc& d, bool fused, hipStream_t stream);   // n_frames <= 256; fused: whole run()
 hipError_t launch_conv_kernel(const LaunchArgs& a, const ConvDesc& d, hipStream_t stream);
 hipError_t launch_set_pending(StreamState* st, uint32_t n_streams, int32_t stream, uint32_t bits, hipStream_t q);
 hipError_t launch_init_streams(StreamState* st, uint32_t n, hipStream_t q);

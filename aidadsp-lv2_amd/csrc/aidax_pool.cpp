@@ -92,6 +92,7 @@ struct ModelSlot {
     MfmaDesc mdesc{};
     ConvDesc cdesc{};
     bool conv_mfma = false;          // conv stacks on the matrix cores (blocks of <= 256 frames), else k_conv
+    bool conv_fused = false;         // ... with the DSP chain inside the same launch (AIDAX_CONV_FUSED=0: packed k_chain launches around it)
     const KernelEntry* kernel = nullptr;
     int cell = 0, input_size = 1, input_skip = 0, hidden = 0;
     float in_gain = 1.f, out_gain = 1.f, model_sr = 48000.f;
@@ -196,7 +197,7 @@ struct aidax_pool {
         switch (m.kind) {
         case ModelSlot::TABLE: return chain_form(m) != 2;
         case ModelSlot::STACK: return true;
-        case ModelSlot::CONV: return !m.conv_mfma;
+        case ModelSlot::CONV: return !m.conv_mfma || m.conv_fused;
         default: return false;
         }
     }
@@ -306,9 +307,10 @@ struct aidax_pool {
         }
         if (m.has_model && m.kind == ModelSlot::STACK) return launch_stack_kernel(a, m.sdesc, s);
         if (m.has_model && m.kind == ModelSlot::CONV && m.conv_mfma) {
-            if (a.mode != MODE_CHAIN) return launch_conv_mfma_kernel(a, m.cdesc, s);
+            if (a.mode != MODE_CHAIN) return launch_conv_mfma_kernel(a, m.cdesc, false, s);
+            if (m.conv_fused) return launch_conv_mfma_kernel(a, m.cdesc, true, s);         // the whole run() in one launch
             hipError_t e = launch_chain_pass(true, a, s);
-            if (e == hipSuccess && a.n_frames != 0) e = launch_conv_mfma_kernel(a, m.cdesc, s);
+            if (e == hipSuccess && a.n_frames != 0) e = launch_conv_mfma_kernel(a, m.cdesc, false, s);
             if (e == hipSuccess) e = launch_chain_pass(false, a, s);
             return e;
         }
@@ -382,6 +384,12 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
         ms.kind = ModelSlot::CONV;
         wp = pack_conv(*m, &ms.cdesc, &state_floats);
         ms.conv_mfma = p.max_frames <= 256 && p.force_form != 4 && convm_lds_bytes(ms.cdesc, p.max_frames) <= 160 * 1024;
+        // chain passes inside the conv launch while every workgroup of the pool is resident at once (their serial
+        // latency is then paid once per block; in a second round of workgroups it would be paid again, and the packed
+        // k_chain launches around the kernel are cheaper). AIDAX_CONV_FUSED=1 / 0 forces the form.
+        const char* fused = std::getenv("AIDAX_CONV_FUSED");
+        ms.conv_fused = ms.conv_mfma && (fused ? fused[0] != '0'
+                                               : static_cast<int>(p.n_streams) <= convm_resident_streams(ms.cdesc, p.max_frames, p.device));
         if (!ms.conv_mfma && conv_lds_bytes(ms.cdesc, p.max_frames) > 160 * 1024)
             return fail(AIDAX_ERR_ARG, "conv model: pool max_frames too large for the LDS activation planes");
     } else if (m->n_rnn == 1 && find_kernel(m->cell, m->hidden) && p.quad_for_table_model(m->cell, m->hidden) &&
@@ -790,7 +798,7 @@ AIDAX_API const char* aidax_pool_kernel_name(const aidax_pool* p)
     if (m.kind == ModelSlot::STACK) return "k_stack";
     if (m.kind == ModelSlot::MFMA) return m.d_ring ? "k_chain+k_mfma_lp" : "k_chain+k_mfma";
     if (m.kind == ModelSlot::QUAD) return "k_chain+k_quad";
-    if (m.kind == ModelSlot::CONV) return m.conv_mfma ? "k_chain+k_conv_mfma" : "k_conv";
+    if (m.kind == ModelSlot::CONV) return m.conv_fused ? "k_conv_mfma" : m.conv_mfma ? "k_chain+k_conv_mfma" : "k_conv";
     const int form = p->chain_form(m);
     return form == 1 ? m.kernel->name_pipe : form == 2 ? m.kernel->name_split : m.kernel->name;
 }

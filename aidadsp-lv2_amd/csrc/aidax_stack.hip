@@ -23,53 +23,6 @@
 
 namespace aidax {
 
-// ------------------------------------------------------------ shared chain pieces
-// The per-stream prologue + pre pass of run() (:489-518, :607-630) executed by ONE wave on
-// an LDS block buffer; returns false when the stream early-outs (pre-run / disabled).
-struct ChainCtx {
-    uint32_t flags, pending;
-    float pre_mem, master_mem, pre_tgt, master_tgt;
-    bool live;
-};
-
-__device__ __forceinline__ ChainCtx chain_prologue(const StreamCtl& ctl, StreamState& st, const float* in_row,
-                                                   float* out_row, float* buf, int n, int lane)
-{
-    ChainCtx c;
-    c.flags = ctl.flags;
-    c.pending = st.pending;
-    c.pre_mem = st.pre_mem; c.master_mem = st.master_mem;
-    c.pre_tgt = st.pre_tgt; c.master_tgt = st.master_tgt;
-    if (c.pending & PEND_ACTIVATE) {
-        c.pre_mem = c.pre_tgt;
-        c.master_mem = c.master_tgt;
-        c.pending &= ~PEND_ACTIVATE;
-    }
-    c.pre_tgt = ctl.pre_target;
-    c.live = !(n == 0 || !(c.flags & CTL_ENABLED));
-    if (!c.live) {
-        if (n != 0 && out_row != in_row)
-            for (int i = lane; i < n; i += kWave) out_row[i] = in_row[i];
-        if (lane == 0) { st.pre_mem = c.pre_mem; st.master_mem = c.master_mem; st.pre_tgt = c.pre_tgt; st.pending = c.pending; }
-        return c;
-    }
-    load_block(buf, in_row, n, lane);
-    __builtin_amdgcn_wave_barrier();
-    ChainPass p;
-    const bool eq = c.flags & CTL_EQ_PRE;
-    p.K = eq ? 6 : 1;
-    p.gain_lane = 0;
-    const int k = lane < p.K ? lane : 0;
-    const int slot = pre_slot(k);
-    const bool act = k == 0 ? (c.flags & CTL_LPF_ON) != 0 : ((c.flags & CTL_EQ_BANDPASS) ? slot == BQ_MID : true);
-    chain_load(p, ctl, st, slot, act);
-    p.g.arm(c.pre_mem, c.pre_tgt, ctl.pre_coef);
-    chain_run(p, buf, buf, n, lane);
-    if (lane < p.K) { st.z[slot][0] = p.z1; st.z[slot][1] = p.z2; }
-    c.pre_mem = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p.g.mem), 0));
-    return c;
-}
-
 // PARAM1/2 ramps of one block (:634-640 + LinearValueSmoother::next), written to pq[t][2]
 __device__ __forceinline__ void param_ramps(const StreamCtl& ctl, StreamState& st, ChainCtx& c, float* pq, int n, int I, int lane)
 {
@@ -100,32 +53,6 @@ __device__ __forceinline__ void param_ramps(const StreamCtl& ctl, StreamState& s
         st.p_mem[0] = p_mem[0]; st.p_mem[1] = p_mem[1];
         st.p_tgt[0] = p_tgt[0]; st.p_tgt[1] = p_tgt[1];
         st.p_step[0] = p_step[0]; st.p_step[1] = p_step[1];
-    }
-}
-
-// post pass + store + state write-back (:645-655)
-__device__ __forceinline__ void chain_epilogue(const StreamCtl& ctl, StreamState& st, ChainCtx& c, float* out_row,
-                                               float* buf, int n, int lane)
-{
-    c.master_tgt = ctl.master_target;
-    ChainPass p;
-    const bool eq = c.flags & CTL_EQ_POST;
-    p.K = eq ? 6 : 1;
-    p.gain_lane = p.K - 1;
-    const int k = lane < p.K ? lane : 0;
-    const int slot = post_slot(k);
-    const bool act = k == 0 ? (c.flags & CTL_DC_ON) != 0 : ((c.flags & CTL_EQ_BANDPASS) ? slot == BQ_MID : true);
-    chain_load(p, ctl, st, slot, act);
-    p.g.arm(c.master_mem, c.master_tgt, ctl.master_coef);
-    chain_run(p, buf, buf, n, lane);
-    if (lane < p.K) { st.z[slot][0] = p.z1; st.z[slot][1] = p.z2; }
-    c.master_mem = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p.g.mem), p.K - 1));
-    __builtin_amdgcn_wave_barrier();
-    store_block(out_row, buf, n, lane);
-    if (lane == 0) {
-        st.pre_mem = c.pre_mem; st.master_mem = c.master_mem;
-        st.pre_tgt = c.pre_tgt; st.master_tgt = c.master_tgt;
-        st.pending = c.pending;
     }
 }
 

@@ -324,7 +324,7 @@ _EQ_POST = dict(bass_boost_db=4.0, mid_boost_db=-3.0, mid_q=1.2, treble_boost_db
 @pytest.mark.parametrize("name,kw,S,ckw,kernel", [
     ("cfg2", dict(kind="lstm", hidden=32, input_size=1, seed=32), 1024, {}, "k_lstm_pipe<32>"),
     ("cfg3", dict(kind="gru", hidden=64, input_size=3, seed=64), 4096, _EQ_POST, "k_chain+k_nn<gru64>"),
-    ("cfg4", dict(kind="conv", hidden=16, input_size=1, seed=1608), 1024, {}, "k_chain+k_conv_mfma"),
+    ("cfg4", dict(kind="conv", hidden=16, input_size=1, seed=1608), 1024, {}, "k_conv_mfma"),
     ("cfg5", dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2), 2048, {}, "k_chain+k_mfma_lp"),
     ("lstm80-2k", dict(kind="lstm", hidden=80, input_size=2, seed=80), 2048, dict(param1=0.7), "k_chain+k_quad"),
     ("lstm80-4k", dict(kind="lstm", hidden=80, input_size=2, seed=80), 4096, dict(param1=0.7), "k_chain+k_mfma"),
@@ -390,7 +390,7 @@ def test_device_resident_entry_point_matches_host_entry_point(tmp_path):
 
 # ------------------------------------------------- extensions (parity unpinned by the reference)
 
-@pytest.mark.parametrize("form", ["mfma", "valu"])
+@pytest.mark.parametrize("form", ["mfma", "valu", "split"])
 @pytest.mark.parametrize("kind,kw", [
     ("lstm96x2", dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2)),        # BASELINE cfg #5 model
     ("gru48x3", dict(kind="gru", hidden=48, input_size=2, seed=483, n_rnn=3)),
@@ -401,8 +401,13 @@ def test_extension_models_full_chain(kind, kw, form, tmp_path, monkeypatch):
     """Stacked recurrent layers and conv1d stacks through the full run() chain, 11 streams (not a
     multiple of the 8- or 16-stream workgroups), blocks shorter than the conv history, warm-up state.
     Both families run on their matrix-core kernel by default and on the VALU kernel with AIDAX_KERNEL=valu."""
+    conv = kw["kind"] == "conv"
     if form == "valu":
         monkeypatch.setenv("AIDAX_KERNEL", "valu")
+    if form == "split":                                       # conv stacks: packed k_chain launches around the conv kernel
+        if not conv:
+            pytest.skip("the stacked recurrent models have one matrix-core form")
+        monkeypatch.setenv("AIDAX_CONV_FUSED", "0")
     path, spec = _model_file(tmp_path, kind, **kw)
     m = ax.Model(path)
     S, n, block = 11, 1536, 64
@@ -411,8 +416,8 @@ def test_extension_models_full_chain(kind, kw, form, tmp_path, monkeypatch):
     cg, co = _ctl_pair(**ckw)
     pool = ax.Pool(S, 256)
     pool.set_model(m)
-    conv = kw["kind"] == "conv"
-    assert pool.kernel_name == (("k_conv" if conv else "k_stack") if form == "valu" else ("k_chain+k_conv_mfma" if conv else "k_chain+k_mfma_lp"))
+    mfma_name = ("k_chain+k_conv_mfma" if form == "split" else "k_conv_mfma") if conv else "k_chain+k_mfma_lp"
+    assert pool.kernel_name == (("k_conv" if conv else "k_stack") if form == "valu" else mfma_name)
     pool.set_controls(cg)
     got = _run_gpu(pool, x, block)
     want = O.run_streams(spec, co, x, block)
@@ -424,6 +429,37 @@ def test_extension_models_full_chain(kind, kw, form, tmp_path, monkeypatch):
     pool2.set_controls(cg)
     got2 = _run_gpu(pool2, x, 256)
     errlog.bound(np.abs(got2 - got).max(), 1e-7, "gpu_parity:406")
+
+
+def test_conv_fused_launch_is_bit_identical_to_split_launches(tmp_path, monkeypatch):
+    """The conv stack's one-launch form (chain passes inside k_conv_mfma) against packed k_chain launches around the
+    same kernel: same operations per sample in the same order, so every output sample and the carried state agree
+    to the bit — ragged blocks incl. 0 and 1 frames, per-stream disable / model bypass / EQ position / bandpass."""
+    path, _ = _model_file(tmp_path, "c16x8f", kind="conv", hidden=16, input_size=1, seed=78, in_skip=1, in_gain=-1.5, out_gain=2.0)
+    S = 37
+    sizes = [256, 1, 0, 37, 200, 16, 255, 129, 3, 256]
+    x = modelgen.signal(S, sum(sizes), seed=22)
+    kws = [dict(), dict(enabled=0.0), dict(net_bypass=1.0), dict(eq_position=1.0, bass_boost_db=5.0, mid_type=1.0),
+           dict(dc_blocker=0.0, in_lpf_pc=0.0, eq_bypass=1.0), dict(pregain_db=6.0, master_db=-6.0, treble_boost_db=4.0)]
+    outs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("AIDAX_CONV_FUSED", fused)
+        pool = ax.Pool(S, 256)
+        pool.set_model(ax.Model(path))
+        assert pool.kernel_name == ("k_conv_mfma" if fused == "1" else "k_chain+k_conv_mfma")
+        got = np.empty_like(x)
+        pos = 0
+        for bi, n in enumerate(sizes):
+            for s in range(S):
+                c = dict(kws[s % len(kws)])
+                if bi >= 4:
+                    c.update(master_db=-3.0, pregain_db=1.0)
+                pool.set_controls(ax.default_controls(**c), stream=s)
+            got[:, pos:pos + n] = pool.process(np.ascontiguousarray(x[:, pos:pos + n]))
+            pos += n
+        outs.append(got)
+        pool.close()
+    assert np.array_equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("name,kw", [
@@ -444,7 +480,7 @@ def test_matrix_core_form_ragged_blocks_and_per_stream_controls(name, kw, tmp_pa
     x = modelgen.signal(S, sum(sizes), seed=21)
     pool = ax.Pool(S, 256 if conv else 1024)
     pool.set_model(ax.Model(path))
-    assert pool.kernel_name == ("k_chain+k_conv_mfma" if conv else "k_chain+k_mfma_lp" if kw.get("n_rnn", 1) > 1 else "k_chain+k_mfma")
+    assert pool.kernel_name == ("k_conv_mfma" if conv else "k_chain+k_mfma_lp" if kw.get("n_rnn", 1) > 1 else "k_chain+k_mfma")
     kws = [dict(param1=0.3, param2=0.8), dict(enabled=0.0), dict(net_bypass=1.0), dict(eq_position=1.0, bass_boost_db=5.0, mid_type=1.0),
            dict(dc_blocker=0.0, in_lpf_pc=0.0, eq_bypass=1.0, param1=1.0), dict(pregain_db=6.0, master_db=-6.0, treble_boost_db=4.0, param2=0.1)]
     flip = dict(param1=0.9, param2=0.2, master_db=-3.0)                     # applied to every stream from the 5th block on

@@ -98,11 +98,25 @@ int push_controls(aidax_hub& h, uint32_t slot, bool off)
     return pool_park_stream(h.pool, slot, off);
 }
 
-// launch the period that is being collected (h.mu held): asynchronous, nothing in here waits for the GPU
+int launch_period(aidax_hub& h);
+
+// launch the period that is being collected (h.mu held): asynchronous, nothing in here waits for the GPU. A period
+// that cannot be launched is dropped (its instances read silence for it and the error is reported by their next
+// run()): the launcher must never find the same failing period waiting for it again.
 int flush_locked(aidax_hub& h)
 {
     h.flush_requested = false;
     if (h.n_submitted == 0) return AIDAX_OK;
+    const int rc = launch_period(h);
+    if (rc != AIDAX_OK) {
+        std::fill(h.submitted.begin(), h.submitted.end(), 0);
+        h.n_submitted = 0;
+    }
+    return rc;
+}
+
+int launch_period(aidax_hub& h)
+{
     const uint32_t n = h.period_frames;
     const uint32_t rows = h.hi_slot;
     for (uint32_t s = 0; s < rows; ++s) {
@@ -146,6 +160,16 @@ void launcher_main(aidax_hub* h)
         if (timed) h->cv.wait_until(lk, h->deadline);
         else h->cv.wait(lk);
     }
+}
+
+// counters read under the mutex: the launcher thread writes them
+template <class T, class F>
+T hub_read(const aidax_hub* h, F&& f)
+{
+    if (!h) return T{};
+    aidax_hub* m = const_cast<aidax_hub*>(h);
+    std::lock_guard<std::mutex> g(m->mu);
+    return f(*m);
 }
 
 }  // namespace
@@ -340,9 +364,9 @@ AIDAX_API int aidax_hub_flush(aidax_hub* h)
     return flush_locked(*h);
 }
 
-AIDAX_API uint32_t aidax_hub_latency_frames(const aidax_hub* h) { return h ? h->latency : 0; }
-AIDAX_API uint32_t aidax_hub_attached(const aidax_hub* h) { return h ? h->n_attached : 0; }
-AIDAX_API uint64_t aidax_hub_launches(const aidax_hub* h) { return h ? h->launches : 0; }
-AIDAX_API uint64_t aidax_hub_deadline_launches(const aidax_hub* h) { return h ? h->deadline_launches : 0; }
+AIDAX_API uint32_t aidax_hub_latency_frames(const aidax_hub* h) { return hub_read<uint32_t>(h, [](aidax_hub& x) { return x.latency; }); }
+AIDAX_API uint32_t aidax_hub_attached(const aidax_hub* h) { return hub_read<uint32_t>(h, [](aidax_hub& x) { return x.n_attached; }); }
+AIDAX_API uint64_t aidax_hub_launches(const aidax_hub* h) { return hub_read<uint64_t>(h, [](aidax_hub& x) { return x.launches; }); }
+AIDAX_API uint64_t aidax_hub_deadline_launches(const aidax_hub* h) { return hub_read<uint64_t>(h, [](aidax_hub& x) { return x.deadline_launches; }); }
 
 }  // extern "C"

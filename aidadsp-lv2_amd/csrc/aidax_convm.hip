@@ -76,6 +76,10 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
         if (mode == MODE_CHAIN) {
             const uint32_t flags = a.ctl[sg].flags;
             if (!(flags & CTL_ENABLED) || !(flags & CTL_NET_ON)) return;      // :607-619, :631-632 (uniform per workgroup)
+            if (tid == 0) {
+                StreamState& st = a.st[sg];
+                st.pending = param_targets(a.ctl[sg], st, st.pending);
+            }
         }
     }
     const int C = d.channels;
@@ -92,7 +96,12 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
     if constexpr (FUSED) {
         // channel 0's block part of the plane is the audio row: the pre pass leaves layer 0's input there
         if (wave == chain_wave) {
-            const ChainCtx ctx = chain_prologue(a.ctl[sg], a.st[sg], a.in + (size_t)sg * n, a.out + (size_t)sg * n, pl + Hb, n, lane, wst);
+            ChainCtx ctx = chain_prologue(a.ctl[sg], a.st[sg], a.in + (size_t)sg * n, a.out + (size_t)sg * n, pl + Hb, n, lane, wst);
+            if (ctx.live && (ctx.flags & CTL_NET_ON)) {
+                uint32_t pend = ctx.pending;
+                if (lane == 0) pend = param_targets(a.ctl[sg], a.st[sg], pend);
+                ctx.pending = (uint32_t)__builtin_amdgcn_readfirstlane((int)pend);
+            }
             if (lane == 0) {
                 // the context waits in LDS, not in six registers of every thread across the layer loop
                 verdict[0] = ctx.live ? 1.f : 0.f; verdict[1] = (ctx.live && (ctx.flags & CTL_NET_ON)) ? 1.f : 0.f;

@@ -360,6 +360,28 @@ __device__ __forceinline__ ChainCtx chain_prologue(const StreamCtl& ctl, StreamS
     return c;
 }
 
+// run() :634-640 for a model that takes no PARAM input (the conv stacks): the smoothers' targets still follow the
+// controls and the first run after a load still snaps them — what a model swapped in later inherits (:822-825).
+// Nothing calls next(), so the memories move only on that snap. One lane; returns `pending` with the flag cleared.
+__device__ __forceinline__ uint32_t param_targets(const StreamCtl& ctl, StreamState& st, uint32_t pending)
+{
+    float p_mem[2] = { st.p_mem[0], st.p_mem[1] };
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                        // LinearValueSmoother::setTargetValue (:209-216)
+        const float nt = ctl.p_target[i];
+        if (__builtin_fabsf(st.p_tgt[i] - nt) >= FLT_EPSILON) {
+            st.p_tgt[i] = nt;
+            st.p_step[i] = (nt - p_mem[i]) / ctl.p_den;
+        }
+    }
+    if (pending & PEND_PARAM_FIRST) {                    // paramFirstRun (:636-640)
+        pending &= ~PEND_PARAM_FIRST;
+        st.p_mem[0] = st.p_tgt[0];
+        st.p_mem[1] = st.p_tgt[1];
+    }
+    return pending;
+}
+
 // post pass + store + state write-back (:645-655)
 __device__ __forceinline__ void chain_epilogue(const StreamCtl& ctl, StreamState& st, ChainCtx& c, float* out_row,
                                                float* buf, int n, int lane, float* hand = nullptr)

@@ -323,6 +323,11 @@ __global__ __launch_bounds__(kStackThreads) void k_conv(LaunchArgs a, ConvDesc d
         } else {
             ctx = chain_prologue(a.ctl[sg], a.st[sg], a.in + (size_t)sg * n, a.out + (size_t)sg * n, buf, n, lane);
             net = ctx.live && (ctx.flags & CTL_NET_ON);
+            if (net) {
+                uint32_t pend = ctx.pending;
+                if (lane == 0) pend = param_targets(a.ctl[sg], a.st[sg], pend);
+                ctx.pending = (uint32_t)__builtin_amdgcn_readfirstlane((int)pend);
+            }
         }
         if (lane == 0) { shared_flag[0] = net ? 1.f : 0.f; shared_flag[1] = (bare || ctx.live) ? 1.f : 0.f; }
     }

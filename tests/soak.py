@@ -1,5 +1,5 @@
 # Soak: random block sizes, control flips, activates and model swaps for many blocks; three streams against the
-# oracle's plugin mirror. usage: AIDAX_KERNEL=<form> python tests/soak.py [blocks]
+# oracle's plugin mirror. usage: [SOAK_STREAMS=n] [AIDAX_KERNEL=<form>] python tests/soak.py [blocks]
 import importlib, os, sys, tempfile, threading
 sys.path.insert(0, os.getcwd())
 import numpy as np
@@ -10,13 +10,14 @@ blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 rs = np.random.RandomState(2026)
 d = tempfile.mkdtemp()
 models = []
-for kind, H, I, L in (("lstm", 32, 1, 1), ("gru", 16, 3, 1), ("lstm", 12, 2, 1), ("gru", 64, 1, 1), ("lstm", 32, 2, 2)):
-    # the last one is a stacked model (an extension): it runs on k_mfma_lp, so swaps also cross kernel families
+for kind, H, I, L in (("lstm", 32, 1, 1), ("gru", 16, 3, 1), ("lstm", 12, 2, 1), ("gru", 64, 1, 1), ("lstm", 32, 2, 2), ("conv", 16, 1, 1)):
+    # the last two are extensions — a stacked model (k_mfma_lp) and a conv stack (k_conv_mfma, chain passes inside the
+    # launch) — so swaps also cross kernel families
     j = modelgen.make_model(kind, H, I, seed=H + I, n_rnn=L)
     models.append((ax.Model(modelgen.write_model(j, os.path.join(d, f"{kind}{H}x{L}.json"))), O.parse_model(j)))
-S, MAXF = 70, 256
+S, MAXF = int(os.environ.get("SOAK_STREAMS", "70")), 256      # 70: the resident forms (pipe, lp, fused conv); ~4200: the many-streams forms
 pool = ax.Pool(S, MAXF)
-watch = [0, 33, 69]
+watch = [0, S // 2 - 2, S - 1]
 plugs = {s: O.OraclePlugin() for s in watch}
 cur = 0
 pool.set_model(models[cur][0])

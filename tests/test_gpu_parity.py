@@ -309,6 +309,51 @@ def test_activate_and_model_swap_semantics(tmp_path, bundled_models):
             errlog.bound(np.abs(got[s] - want).max(), 1.5e-6, "gpu_parity:289")
 
 
+@pytest.mark.parametrize("first,env", [
+    (dict(kind="lstm", hidden=16, input_size=1, seed=3), {}),                             # table kernel, no PARAM input
+    (dict(kind="conv", hidden=16, input_size=1, seed=4), {}),                             # k_conv_mfma, chain passes inside
+    (dict(kind="conv", hidden=16, input_size=1, seed=4), {"AIDAX_CONV_FUSED": "0"}),      # k_chain + k_conv_mfma + k_chain
+    (dict(kind="conv", hidden=16, input_size=1, seed=4), {"AIDAX_KERNEL": "valu"}),       # k_conv
+    (dict(kind="lstm", hidden=32, input_size=1, seed=5, n_rnn=2), {}),                    # k_mfma_lp
+])
+def test_param_targets_follow_the_controls_under_a_model_without_param_inputs(first, env, tmp_path, monkeypatch):
+    """run() sets the PARAM smoothers' targets and serves paramFirstRun for EVERY model (:634-640), also one whose
+    forward() takes the audio only; a conditioned model swapped in later starts its ramps from what the playing
+    model holds then (:822-825). PARAM1/2 move while the first model plays, then the swap: the second model's
+    first blocks ramp from those values (a stale target shows as a 0.1 s ramp error of ~1e-2)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    pa, spec_a = _model_file(tmp_path, "first", **first)
+    pb, spec_b = _model_file(tmp_path, "second", kind="gru", hidden=16, input_size=3, seed=6)
+    x = modelgen.signal(3, 1536, seed=10)
+    pool = ax.Pool(3, 128)
+    plugs = [O.OraclePlugin() for _ in range(3)]
+    pool.set_model(ax.Model(pa))
+    for p in plugs:
+        p.set_model(O.OracleModel(spec_a))
+    script = {1: dict(param1=0.8, param2=0.3), 3: "activate", 4: dict(param1=0.1, param2=0.9, net_bypass=1.0),
+              5: dict(param1=0.45, param2=0.65), 6: "swap", 9: dict(param1=0.7, param2=0.2)}
+    kw = {}
+    for bi, b in enumerate(range(0, 1536, 128)):
+        ev = script.get(bi)
+        if ev == "activate":
+            pool.activate()
+            for p in plugs:
+                p.activate()
+        elif ev == "swap":
+            pool.set_model(ax.Model(pb))
+            for p in plugs:
+                old = (p.model.ptr.contents.param1Coeff.target, p.model.ptr.contents.param2Coeff.target)
+                p.set_model(O.OracleModel(spec_b, old[0], old[1]))
+        elif ev is not None:
+            kw = ev
+        pool.set_controls(ax.default_controls(**kw))
+        got = pool.process(np.ascontiguousarray(x[:, b:b + 128]))
+        for s in range(3):
+            want = plugs[s].run(O.default_controls(**kw), x[s, b:b + 128])
+            errlog.bound(np.abs(got[s] - want).max(), 2e-6, "gpu_parity:param_targets")
+
+
 def test_long_run_drift_48000_samples(tmp_path):
     """One second of full-scale audio through LSTM-32: the fast sigmoid/tanh must hold
     1e-5 over >= 48000 recurrent steps (SURVEY §7 'Transcendentals at 1e-5')."""

@@ -1,6 +1,7 @@
 """Randomised soak (the reference has no such test; this is what a host does to a plugin): random
-block sizes incl. 0 and 1, control flips on random streams, activate(), model swaps between four models -
-three watched streams of 70 against the oracle's plugin mirror, in every launch form."""
+block sizes incl. 0 and 1, control flips on random streams, activate(), model swaps between six models (the two
+extension families included) - three watched streams against the oracle's plugin mirror, in every launch form, at 70
+streams (the resident forms) and at 4200 (the many-streams forms); and the hub under a host with a random life."""
 import os
 import subprocess
 import sys
@@ -20,3 +21,23 @@ def test_random_host_behaviour(form):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "soak.py"), "250"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "soak ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_random_host_behaviour_many_streams():
+    env = dict(os.environ)
+    env.pop("AIDAX_KERNEL", None)
+    env["SOAK_STREAMS"] = "4200"                        # k_quad, k_nn, k_mfma, k_chain + k_conv_mfma
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "soak.py"), "200"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "soak ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_random_hub_host():
+    """tests/soak_hub.py: attach / detach / skipped instances / block-size changes inside a period / model swaps of the
+    hub, every delivered block against the instance's own oracle plugin one period late, pass count against the
+    contract's."""
+    env = dict(os.environ)
+    env.pop("AIDAX_KERNEL", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "soak_hub.py"), "300"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "hub soak ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -41,3 +41,13 @@ def test_random_hub_host():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "soak_hub.py"), "300"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "hub soak ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_random_lv2_host():
+    """tests/soak_lv2.py: the plugin shell under the mock host — patch:Set / restore requests overlapping in flight, late
+    workers, late responses, failing loads, control moves, activate — against the oracle's plugin mirror."""
+    env = dict(os.environ)
+    env.pop("AIDAX_KERNEL", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "soak_lv2.py"), "400"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "lv2 soak ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -142,15 +142,14 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
     int kcb[kFragRegs];                        // (cin << 16 | frames back) of the contraction row behind fragment element j
     auto fetch_frag = [&](int l) {
         const ConvLayer& L = d.L[l];
-        const int* km = reinterpret_cast<const int*>(W + L.km_off);
+        const float2* recs = reinterpret_cast<const float2*>(W + L.wf_off);
 #pragma unroll
         for (int j = 0; j < kFragRegs; ++j) {
             if (j * kConvmThreads >= L.k_steps * kWave) break;
             const int i = tid + j * kConvmThreads;
-            const bool on = i < L.k_steps * kWave;
-            const int k = on ? 4 * (i >> 6) + ((i & 63) >> 4) : 0;
-            fr[j] = on ? W[L.wf_off + i] : 0.f;
-            kcb[j] = (km[2 * k] << 16) | km[2 * k + 1];
+            const float2 r = i < L.k_steps * kWave ? recs[i] : float2{ 0.f, 0.f };
+            fr[j] = r.x;
+            kcb[j] = __builtin_bit_cast(int, r.y);
         }
         bias_r = (lane & 15) < L.out_ch ? W[L.b_off + (lane & 15)] : 0.f;
     };
@@ -160,10 +159,9 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
         for (int j = 0; j < kFragRegs; ++j) {
             if (j * kConvmThreads >= L.k_steps * kWave) break;
             const int i = tid + j * kConvmThreads;
-            if (i < L.k_steps * kWave) {
-                wst[2 * i] = fr[j];
-                reinterpret_cast<int*>(wst)[2 * i + 1] = (kcb[j] >> 16) * F + Hb - (kcb[j] & 0xffff) + (i & 15);
-            }
+            if (i < L.k_steps * kWave)      // the A offset in BYTES: the k-loop adds it to the plane's base as it is
+                *reinterpret_cast<float2*>(wst + 2 * i) =
+                    float2{ fr[j], __builtin_bit_cast(float, 4 * ((kcb[j] >> 16) * F + Hb - (kcb[j] & 0xffff) + (i & 15))) };
         }
     };
     // history of a layer: [in_ch][hist] in HBM <-> plane[ch][Hb-hist .. Hb), walked flat (coalesced, hist*in_ch/256
@@ -289,14 +287,26 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
 #pragma unroll
         for (int j = 0; j < kConvmTiles; ++j) acc[j] = f32x4{bias, bias, bias, bias};
         if (wave < ntiles) {
-            for (int kk = 0; kk < L.k_steps; ++kk) {
-                const float2 rec = *reinterpret_cast<const float2*>(wst + 2 * (kk * kWave + lane));
-                const float b = rec.x;
-                const float* ap = pl + __builtin_bit_cast(int, rec.y) + 16 * wave;
+            const char* plw = reinterpret_cast<const char*>(pl + 16 * wave);
+            if (ntiles == 4 * kConvmTiles) {
+                // a full block: the four tiles of a wave sit at fixed distances — one address per k-step, the rest
+                // are the instruction's immediate offsets
+                for (int kk = 0; kk < L.k_steps; ++kk) {
+                    const float2 rec = *reinterpret_cast<const float2*>(wst + 2 * (kk * kWave + lane));
+                    const float* ap = reinterpret_cast<const float*>(plw + __builtin_bit_cast(int, rec.y));
 #pragma unroll
-                for (int j = 0; j < kConvmTiles; ++j) {
-                    const float av = ap[wave + 4 * j < ntiles ? 64 * j : 0];   // tiles past the block re-read the first
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc[j], 0, 0, 0);
+                    for (int j = 0; j < kConvmTiles; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[64 * j], rec.x, acc[j], 0, 0, 0);
+                }
+            } else {
+                for (int kk = 0; kk < L.k_steps; ++kk) {
+                    const float2 rec = *reinterpret_cast<const float2*>(wst + 2 * (kk * kWave + lane));
+                    const float* ap = reinterpret_cast<const float*>(plw + __builtin_bit_cast(int, rec.y));
+#pragma unroll
+                    for (int j = 0; j < kConvmTiles; ++j) {
+                        const float av = ap[wave + 4 * j < ntiles ? 64 * j : 0];   // tiles past the block re-read the first
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, rec.x, acc[j], 0, 0, 0);
+                    }
                 }
             }
         }

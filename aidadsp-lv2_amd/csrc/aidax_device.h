@@ -242,7 +242,7 @@ __device__ __forceinline__ void chain_blocks(ChainPass& c, ExpRamp& g, int stage
 }
 
 __device__ __forceinline__ void chain_sweep_blocked(ChainPass& c, int stage, bool run, int depth, float* row, float* hand,
-                                                    int n_full, int lane)
+                                                    int n_full, int lane, bool force_general = false)
 {
     const double z1o = c.z1, z2o = c.z2;
     const int M = n_full / kChainBlock;
@@ -252,7 +252,7 @@ __device__ __forceinline__ void chain_sweep_blocked(ChainPass& c, int stage, boo
     const bool last = stage == c.K - 1;
     // wave-uniform: does any running lane need the select (a bypassed biquad) or a moving ramp?
     const bool fussy = run && (!c.active || g.mem * g.coef + g.tc != g.mem);
-    if (__builtin_amdgcn_ballot_w64(fussy) == 0) chain_blocks<true>(c, g, stage, run, depth, last, row, hand, M, lane);
+    if (!force_general && __builtin_amdgcn_ballot_w64(fussy) == 0) chain_blocks<true>(c, g, stage, run, depth, last, row, hand, M, lane);
     else chain_blocks<false>(c, g, stage, run, depth, last, row, hand, M, lane);
     if (is_gain) c.g = g;
     if (!run || !c.active) { c.z1 = z1o; c.z2 = z2o; }

@@ -28,7 +28,8 @@ using Clock = std::chrono::steady_clock;
 // Staging buffers in rotation. One pass per period needs two (collect into one while the other's output is read); the
 // deadline may close a period in pieces (a host whose submissions span more than the deadline), and then an
 // instance's output of the last period sits in the buffer of the piece IT was part of, not in the most recent one —
-// so every slot remembers the pass that carried its last block, and a buffer is reused only kHubBuffers passes later.
+// so every slot remembers the pass that carried its last block, and a buffer is reused only kHubBuffers passes later
+// (its output stays readable for kHubBuffers - 2 further passes: not while it is being collected into again).
 constexpr int kHubBuffers = 4;
 
 struct aidax_hub {
@@ -100,7 +101,8 @@ int push_controls(aidax_hub& h, uint32_t slot, bool off)
 
 int launch_period(aidax_hub& h);
 
-// launch the period that is being collected (h.mu held): asynchronous, nothing in here waits for the GPU. A period
+// launch the period that is being collected (h.mu held): asynchronous, nothing in here waits for the GPU unless the
+// host has run kHubBuffers - 1 passes ahead of it. A period
 // that cannot be launched is dropped (its instances read silence for it and the error is reported by their next
 // run()): the launcher must never find the same failing period waiting for it again.
 int flush_locked(aidax_hub& h)
@@ -143,6 +145,11 @@ int launch_period(aidax_hub& h)
     h.n_submitted = 0;
     h.latency = n;
     h.cur = static_cast<int>((h.launches + 1) % kHubBuffers);
+    // The buffer that is collected into next was the staging of the pass kHubBuffers back: its rows must have left for
+    // the device before the instances overwrite them. A host that closes several short periods in a row (block-size
+    // changes, skipped instances) can run that far ahead of the GPU — found by tests/soak_hub.py as outputs computed from
+    // a later block's input. Normally that pass is long complete and this is one event query.
+    if (h.pass_id[h.cur] != 0 && hipEventQuery(h.done[h.cur]) != hipSuccess) HUB_TRY(hipEventSynchronize(h.done[h.cur]));
     return AIDAX_OK;
 }
 
@@ -338,7 +345,8 @@ AIDAX_API int aidax_hub_run(aidax_hub* h, int32_t slot, const float* in, float* 
         // the pass that carried this instance's previous block, if its buffer has not been reused since
         const uint64_t lp = h->last_pass[slot];
         const int pb = static_cast<int>(lp % kHubBuffers);
-        if (n_frames != 0 && lp != 0 && h->pass_id[pb] == lp && h->out_frames[pb] == n_frames) {
+        // (not from the buffer being collected into: the pass that closes this period will write its results there)
+        if (n_frames != 0 && lp != 0 && pb != h->cur && h->pass_id[pb] == lp && h->out_frames[pb] == n_frames) {
             prev_row = h->h_out[pb] + static_cast<size_t>(slot) * n_frames;
             prev_done = h->done[pb];
         }

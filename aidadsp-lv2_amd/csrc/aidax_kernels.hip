@@ -812,8 +812,8 @@ __global__ __launch_bounds__(kWave) void k_chain(LaunchArgs a)
         const int n_full = n & ~(kChainBlock - 1);
         // the longest cascade among the wave's running streams: without EQ on this side it is one stage, and the
         // sweep needs no fill / drain steps at all
-        const int depth = __builtin_amdgcn_ballot_w64(run && stage > 0) != 0 ? 6 : 1;
-        if (n_full != 0) chain_sweep_blocked(c, stage, run, depth, row, hand, n_full, lane);
+        const int depth = (a.tune & 8) || __builtin_amdgcn_ballot_w64(run && stage > 0) != 0 ? 6 : 1;
+        if (n_full != 0) chain_sweep_blocked(c, stage, run, depth, row, hand, n_full, lane, (a.tune & 8) != 0);
         if (n_full != n) chain_sweep<1>(c, stage, run, depth, row + n_full, row + n_full, n - n_full);
         // PRE: every valid row goes to out (a disabled stream's row is still the raw input: the hard
         // bypass copy of :612-619); POST: only rows that were processed

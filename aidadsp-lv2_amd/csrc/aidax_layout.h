@@ -186,11 +186,10 @@ struct ConvLayer {
     uint32_t w_off;        // K[ksize][in_ch][out_ch]
     uint32_t b_off;        // [out_ch]
     uint32_t state_off;    // history[in_ch][hist] in the stream's nn state
-    // k_conv_mfma: B fragments of v_mfma_f32_16x16x4_f32, [k_steps][64 lanes]: lane supplies
-    // K[tap][cin][cout = lane&15] for k = 4*kk + (lane>>4) = tap*in_ch + cin (zero past ksize*in_ch / out_ch)
+    // k_conv_mfma: [k_steps][64 lanes] records {B fragment value of v_mfma_f32_16x16x4_f32, (cin << 16 | frames back)}:
+    // lane supplies K[tap][cin][cout = lane&15] for k = 4*kk + (lane>>4) = tap*in_ch + cin (zero past ksize*in_ch / out_ch)
     uint32_t wf_off;
     int32_t k_steps;
-    uint32_t km_off;       // [4*k_steps][2] int32 bit patterns: (cin, frames back) of contraction row k
 };
 struct ConvDesc {
     int32_t n_layers, channels, max_hist, max_k_steps;

@@ -308,23 +308,21 @@ std::vector<float> pack_conv(const aidax_model& m, ConvDesc* d, uint32_t* state_
         const int K = C.ksize * C.in_ch;
         C.k_steps = (K + 3) / 4;
         if (C.k_steps > d->max_k_steps) d->max_k_steps = C.k_steps;
+        // one 8-byte record per (k-step, lane): the B fragment value K[tap][cin][cout = lane & 15] of contraction row
+        // k = 4*kk + (lane >> 4) = tap*in_ch + cin (zero past ksize*in_ch / out_ch), and where that row lives in the
+        // activation plane as (cin << 16 | frames back); padding rows (zero weights) point at row 0 so they read valid data
         while (out.size() % 4) out.push_back(0.f);
         C.wf_off = static_cast<uint32_t>(out.size());
         for (int kk = 0; kk < C.k_steps; ++kk)
             for (int lane = 0; lane < kWave; ++lane) {
                 const int k = 4 * kk + (lane >> 4), co = lane & 15;
                 out.push_back((k < K && co < C.out_ch) ? L.w0[(size_t)k * C.out_ch + co] : 0.f);   // w0 is [tap][cin][cout]
+                const int kc = k < K ? k : 0;
+                const int32_t where = ((kc % C.in_ch) << 16) | ((C.ksize - 1 - kc / C.in_ch) * C.dilation);
+                float f;
+                std::memcpy(&f, &where, 4);
+                out.push_back(f);
             }
-        // where row k of the contraction lives in the activation plane: (cin, frames back) per k, as int bit patterns;
-        // padding rows (zero weights) point at row 0 so they read valid data
-        C.km_off = static_cast<uint32_t>(out.size());
-        for (int k = 0; k < 4 * C.k_steps; ++k) {
-            const int kc = k < K ? k : 0;
-            const int32_t cin = kc % C.in_ch, back = (C.ksize - 1 - kc / C.in_ch) * C.dilation;
-            float f;
-            std::memcpy(&f, &cin, 4); out.push_back(f);
-            std::memcpy(&f, &back, 4); out.push_back(f);
-        }
     }
     const Layer& D = m.layers[m.n_rnn];
     d->wd_off = static_cast<uint32_t>(out.size());

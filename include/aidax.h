@@ -233,8 +233,11 @@ AIDAX_API const char* aidax_pool_kernel_name(const aidax_pool* p);
  * half the period after its first submission, aidax_hub_set_deadline_us), so an instance that stalls or
  * stops calling cannot hold the others: they keep their one period of latency, the straggler's stream simply
  * does not advance in that pass. An instance that comes around again before the period was closed, or a change
- * of block size, closes it on the spot. run() itself waits only for the event of the previous period's pass,
- * outside the hub's lock. Report aidax_hub_latency_frames() to the host as the plugin's latency. Thread-safe. */
+ * of block size, closes it on the spot. An instance reads the output of the pass that carried ITS previous block
+ * while that is at most two passes old and of the same length (a period that was closed in pieces), silence
+ * otherwise. run() itself waits only for the event of that pass, outside the hub's lock; the staging buffers
+ * rotate over four passes, and a host that closes periods faster than the GPU finishes them waits for the pass
+ * four back before its staging is reused. Report aidax_hub_latency_frames() to the host as the plugin's latency. Thread-safe. */
 typedef struct aidax_hub aidax_hub;
 
 AIDAX_API int  aidax_hub_create(uint32_t max_instances, uint32_t max_frames, double host_samplerate,

@@ -97,16 +97,20 @@ for b in range(blocks):
         for msg in h.work_queue:
             if int.from_bytes(msg[:4], "little") == 0:                # kWorkerLoad
                 spec = loadable(msg[4:].split(b"\0")[0].decode())
-                if spec is not None: answers.append((spec, msg[4:].split(b"\0")[0].decode())); last_in_size = spec.input_size
+                if spec is not None:
+                    # work() reads the PARAM targets of the model that plays NOW (:822-825), not of the one that plays
+                    # when the answer is delivered
+                    old = plug.model.ptr.contents if plug.model is not None else None
+                    answers.append((spec, old.param1Coeff.target if old else 0.0, old.param2Coeff.target if old else 0.0))
+                    last_in_size = spec.input_size
                 else: failed += 1
         h.pump_worker()
         assert len(h.responses) == len(answers)
     # ... and the host hands the answers over after some run(), not necessarily the next
     if h.responses and rs.rand() < 0.6:
         k = h.deliver_responses()
-        for spec, path in answers[:k]:
-            old = plug.model.ptr.contents if plug.model is not None else None
-            plug.set_model(O.OracleModel(spec, old.param1Coeff.target if old else 0.0, old.param2Coeff.target if old else 0.0))
+        for spec, p1, p2 in answers[:k]:
+            plug.set_model(O.OracleModel(spec, p1, p2))
             swaps += 1
         del answers[:k]
 h.close()

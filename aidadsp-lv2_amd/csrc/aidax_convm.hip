@@ -176,6 +176,10 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
     // (pack_conv aligns state_off, the plane geometry is a multiple of four).
     auto vec_hist = [&](const ConvLayer& L) { return (L.hist & 3) == 0 && (L.state_off & 3) == 0; };
     auto plane_index4 = [&](int i4, int hist4, float inv_hist4) {     // float4 index -> plane float offset of its first frame
+        if ((hist4 & (hist4 - 1)) == 0) {                              // dilations are powers of two as a rule: shift and mask
+            const int sh = 31 - __builtin_clz(hist4);
+            return (i4 >> sh) * F + Hb - 4 * hist4 + 4 * (i4 & (hist4 - 1));
+        }
         const int ch = (int)(((float)i4 + 0.5f) * inv_hist4);
         return ch * F + Hb - 4 * hist4 + 4 * (i4 - ch * hist4);
     };
@@ -291,6 +295,7 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
             if (ntiles == 4 * kConvmTiles) {
                 // a full block: the four tiles of a wave sit at fixed distances — one address per k-step, the rest
                 // are the instruction's immediate offsets
+                // (reading the next k-step's record ahead of this one's MFMAs was measured: 75.6 against 75.05 us)
                 for (int kk = 0; kk < L.k_steps; ++kk) {
                     const float2 rec = *reinterpret_cast<const float2*>(wst + 2 * (kk * kWave + lane));
                     const float* ap = reinterpret_cast<const float*>(plw + __builtin_bit_cast(int, rec.y));

@@ -264,3 +264,39 @@ def test_deadline_that_splits_a_period_loses_nothing(tmp_path, moving_split):
             prev[i] = plugs[i].run(c, x[i, p * n:(p + 1) * n])
     hub.flush()
     assert hub.launches >= 2 * periods - 1 and hub.deadline_launches >= periods
+
+
+def test_host_that_runs_ahead_of_the_gpu_keeps_its_staging_intact(tmp_path):
+    """Two instances called in turn without pause, every call with another block size than the call before it AND than
+    the same instance's previous call: every run() closes the other's period on the spot, and none of them reads a
+    block back (its previous output has another length), so nothing ever makes the host wait — it issues a pass every
+    few microseconds while a 256-frame pass of the stacked model takes a good part of a millisecond, and is soon many
+    passes ahead of the GPU. A pass's input staging (four buffers in rotation) must not be collected into again before
+    that pass has read it: a pass computed from a later block's input leaves the stream's state off the oracle's, which
+    the last round — same sizes twice, so it reads back — shows. The oracle's outputs are computed beforehand so that
+    nothing slows the host loop down. Found by tests/soak_hub.py; fails without the wait in flush_locked."""
+    m, spec = _model(tmp_path, kind="lstm", hidden=32, input_size=1, seed=321, n_rnn=2)
+    rounds = 41
+    size = lambda i, r: ((256, 128), (17, 64))[i][r % 2 if r < rounds - 1 else (rounds - 2) % 2]
+    c = O.default_controls()
+    rs = np.random.RandomState(5)
+    blocks = [[rs.uniform(-0.6, 0.6, size=size(i, r)).astype(np.float32) for r in range(rounds)] for i in range(2)]
+    want = []
+    for i in range(2):
+        plug = _oracle_instance(spec)
+        want.append([plug.run(c, b) for b in blocks[i]])
+    hub = ax.Hub(4, 256)
+    hub.set_model(m)
+    hub.set_deadline_us(0)
+    slots = [hub.attach() for _ in range(2)]
+    got = [[None] * rounds for _ in range(2)]
+    for r in range(rounds):
+        for i in range(2):
+            got[i][r] = hub.run(slots[i], blocks[i][r])
+    hub.flush()
+    assert hub.launches == 2 * rounds
+    for i in range(2):
+        for r in range(rounds - 1):
+            assert np.all(got[i][r] == 0.0), (i, r)                     # another length than the block before: silence
+        err = np.abs(got[i][rounds - 1] - want[i][rounds - 2]).max()
+        assert err < THR, (i, err)

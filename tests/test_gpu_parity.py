@@ -354,6 +354,85 @@ def test_param_targets_follow_the_controls_under_a_model_without_param_inputs(fi
             errlog.bound(np.abs(got[s] - want).max(), 2e-6, "gpu_parity:param_targets")
 
 
+def test_worker_thread_prepares_while_the_audio_thread_processes(tmp_path):
+    """The two-thread contract of a model swap with the threads REALLY concurrent: a worker thread prepares model after
+    model (pack, allocate, upload, warm up on the pool's worker stream) and frees what the swaps retire, while the
+    audio thread processes block after block and commits whatever the worker has ready at a block boundary — table
+    kernels, the stacked matrix-core kernel with its hand-over ring, the conv stack. PARAM controls rest, so what a
+    new model inherits does not depend on when its preparation ran; every block of every stream against the oracle."""
+    import queue
+    import threading
+    kinds = [dict(kind="lstm", hidden=16, input_size=1, seed=51), dict(kind="gru", hidden=24, input_size=2, seed=52),
+             dict(kind="lstm", hidden=32, input_size=1, seed=53, n_rnn=2), dict(kind="conv", hidden=16, input_size=1, seed=54)]
+    files = [_model_file(tmp_path, f"m{i}", **kw) for i, kw in enumerate(kinds)]
+    models = [ax.Model(p) for p, _ in files]
+    S, n, blocks = 6, 128, 160
+    x = modelgen.signal(S, n * blocks, seed=71)
+    ckw = dict(param1=0.35, pregain_db=2.0, bass_boost_db=3.0)
+    cg, co = _ctl_pair(**ckw)
+    pool = ax.Pool(S, n)
+    pool.set_model(models[0])
+    pool.set_controls(cg)
+    plugs = [O.OraclePlugin() for _ in range(S)]
+    for p in plugs:
+        p.set_model(O.OracleModel(files[0][1]))
+    ready, retired = queue.Queue(maxsize=1), queue.Queue()
+    stop = threading.Event()
+    failure = []
+
+    def worker():
+        try:
+            k = 0
+            while not stop.is_set():
+                while not retired.empty():
+                    pool.staged_free(retired.get())                 # waits for the passes that still read the old buffers
+                mi = (1, 2, 3, 0, 2, 1, 3)[k % 7]
+                sg = pool.prepare_model(models[mi])
+                k += 1
+                while not stop.is_set():
+                    try:
+                        ready.put((mi, sg), timeout=0.01)
+                        break
+                    except queue.Full:
+                        pass
+                else:
+                    pool.staged_free(sg)
+            while not retired.empty():
+                pool.staged_free(retired.get())
+        except Exception as e:                                      # pragma: no cover
+            failure.append(e)
+
+    t = threading.Thread(target=worker)
+    t.start()
+    swaps, names = 0, set()
+    try:
+        for b in range(blocks):
+            try:
+                mi, sg = ready.get_nowait()
+            except queue.Empty:
+                mi = None
+            if mi is not None:
+                pool.commit_model(sg)                               # audio side: no allocation, no wait
+                retired.put(sg)
+                swaps += 1
+                for p in plugs:
+                    old = p.model.ptr.contents
+                    p.set_model(O.OracleModel(files[mi][1], old.param1Coeff.target, old.param2Coeff.target))
+            blk = np.ascontiguousarray(x[:, b * n:(b + 1) * n])
+            got = pool.process(blk)
+            names.add(pool.kernel_name)
+            for s_ in range(S):
+                want = plugs[s_].run(co, blk[s_])
+                errlog.bound(np.abs(got[s_] - want).max(), 2e-6, "gpu_parity:concurrent_prepare")
+    finally:
+        stop.set()
+        t.join()
+        while not ready.empty():
+            pool.staged_free(ready.get()[1])
+    assert not failure, failure
+    assert swaps >= 8 and len(names) >= 3, (swaps, names)
+
+
 def test_long_run_drift_48000_samples(tmp_path):
     """One second of full-scale audio through LSTM-32: the fast sigmoid/tanh must hold
     1e-5 over >= 48000 recurrent steps (SURVEY §7 'Transcendentals at 1e-5')."""

@@ -13,12 +13,15 @@ models = []
 for kind, H, I, L in (("lstm", 32, 1, 1), ("gru", 16, 3, 1), ("lstm", 12, 2, 1), ("gru", 64, 1, 1), ("lstm", 32, 2, 2), ("conv", 16, 1, 1)):
     # the last two are extensions — a stacked model (k_mfma_lp) and a conv stack (k_conv_mfma, chain passes inside the
     # launch) — so swaps also cross kernel families
-    j = modelgen.make_model(kind, H, I, seed=H + I, n_rnn=L)
+    # the GRU-16 file carries a numeric samplerate: its PARAM smoothers run at the model's rate, not the host's (:1053-1060)
+    j = modelgen.make_model(kind, H, I, seed=H + I, n_rnn=L, samplerate=44100.0 if (kind, H) == ("gru", 16) else None,
+                            in_skip=1 if (kind, H) == ("lstm", 12) else None, in_gain=-2.0 if H == 12 else None, out_gain=1.5 if H == 12 else None)
     models.append((ax.Model(modelgen.write_model(j, os.path.join(d, f"{kind}{H}x{L}.json"))), O.parse_model(j)))
 S, MAXF = int(os.environ.get("SOAK_STREAMS", "70")), 256      # 70: the resident forms (pipe, lp, fused conv); ~4200: the many-streams forms
-pool = ax.Pool(S, MAXF)
+SR = float(os.environ.get("SOAK_SR", "48000"))                    # the host's rate: gain smoothers, filter designs
+pool = ax.Pool(S, MAXF, SR)
 watch = [0, S // 2 - 2, S - 1]
-plugs = {s: O.OraclePlugin() for s in watch}
+plugs = {s: O.OraclePlugin(SR) for s in watch}
 cur = 0
 pool.set_model(models[cur][0])
 for s in watch: plugs[s].set_model(O.OracleModel(models[cur][1]))

@@ -70,6 +70,7 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = (int)a.n_frames;
     const int sg = blockIdx.x;
+    const size_t rstride = a.row_stride ? a.row_stride : (size_t)n;      // a time slice of a longer block keeps the block's row pitch
     const int mode = FUSED ? (int)MODE_CHAIN : a.mode;
     if (!FUSED) {
         if (n == 0) return;
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
     if constexpr (FUSED) {
         // channel 0's block part of the plane is the audio row: the pre pass leaves layer 0's input there
         if (wave == chain_wave) {
-            ChainCtx ctx = chain_prologue(a.ctl[sg], a.st[sg], a.in + (size_t)sg * n, a.out + (size_t)sg * n, pl + Hb, n, lane, wst);
+            ChainCtx ctx = chain_prologue(a.ctl[sg], a.st[sg], a.in + (size_t)sg * rstride, a.out + (size_t)sg * rstride, pl + Hb, n, lane, wst);
             if (ctx.live && (ctx.flags & CTL_NET_ON)) {
                 uint32_t pend = ctx.pending;
                 if (lane == 0) pend = param_targets(a.ctl[sg], a.st[sg], pend);
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
 
     const float* W = a.wpack;
     float* hist_base = a.nn + (size_t)sg * a.nn_stride;
-    float* row = mode == MODE_CHAIN ? a.out + (size_t)sg * n : a.out;
+    float* row = mode == MODE_CHAIN ? a.out + (size_t)sg * rstride : a.out;
     const int n16 = (n + 15) & ~15;
 
     // layer-0 input: [history | x * in_gain | zeros up to the tile boundary]; x stays in a register for the skip
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
             ctx.live = true;
             ctx.flags = __builtin_bit_cast(uint32_t, verdict[2]); ctx.pending = __builtin_bit_cast(uint32_t, verdict[3]);
             ctx.pre_mem = verdict[4]; ctx.master_mem = verdict[5]; ctx.pre_tgt = verdict[6]; ctx.master_tgt = verdict[7];
-            chain_epilogue(a.ctl[sg], a.st[sg], ctx, a.out + (size_t)sg * n, pl + Hb, n, lane, wst);
+            chain_epilogue(a.ctl[sg], a.st[sg], ctx, a.out + (size_t)sg * rstride, pl + Hb, n, lane, wst);
         }
     }
 }

@@ -308,7 +308,21 @@ struct aidax_pool {
         if (m.has_model && m.kind == ModelSlot::STACK) return launch_stack_kernel(a, m.sdesc, s);
         if (m.has_model && m.kind == ModelSlot::CONV && m.conv_mfma) {
             if (a.mode != MODE_CHAIN) return launch_conv_mfma_kernel(a, m.cdesc, false, s);
-            if (m.conv_fused) return launch_conv_mfma_kernel(a, m.cdesc, true, s);         // the whole run() in one launch
+            if (m.conv_fused) {
+                // the whole run() in one launch; a block longer than the kernel's 256 frames goes through in time slices,
+                // each the whole run() of its slice (the rows keep the block's pitch)
+                const uint32_t chunk = ext_chunk();
+                if (a.n_frames <= chunk) return launch_conv_mfma_kernel(a, m.cdesc, true, s);
+                hipError_t e = hipSuccess;
+                for (uint32_t done = 0; done < a.n_frames && e == hipSuccess; done += chunk) {
+                    LaunchArgs b = a;
+                    b.in = a.in + done; b.out = a.out + done;
+                    b.n_frames = std::min(chunk, a.n_frames - done);
+                    b.row_stride = a.n_frames;
+                    e = launch_conv_mfma_kernel(b, m.cdesc, true, s);
+                }
+                return e;
+            }
             hipError_t e = launch_chain_pass(true, a, s);
             if (e == hipSuccess && a.n_frames != 0) e = launch_conv_mfma_kernel(a, m.cdesc, false, s);
             if (e == hipSuccess) e = launch_chain_pass(false, a, s);
@@ -383,13 +397,14 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
     if (is_conv_model(*m)) {
         ms.kind = ModelSlot::CONV;
         wp = pack_conv(*m, &ms.cdesc, &state_floats);
-        ms.conv_mfma = p.max_frames <= 256 && p.force_form != 4 && convm_lds_bytes(ms.cdesc, p.max_frames) <= 160 * 1024;
+        ms.conv_mfma = p.force_form != 4 && convm_lds_bytes(ms.cdesc, p.ext_chunk()) <= 160 * 1024;
         // chain passes inside the conv launch while every workgroup of the pool is resident at once (their serial
         // latency is then paid once per block; in a second round of workgroups it would be paid again, and the packed
         // k_chain launches around the kernel are cheaper). AIDAX_CONV_FUSED=1 / 0 forces the form.
         const char* fused = std::getenv("AIDAX_CONV_FUSED");
         ms.conv_fused = ms.conv_mfma && (fused ? fused[0] != '0'
-                                               : static_cast<int>(p.n_streams) <= convm_resident_streams(ms.cdesc, p.max_frames, p.device));
+                                               : static_cast<int>(p.n_streams) <= convm_resident_streams(ms.cdesc, p.ext_chunk(), p.device));
+        if (ms.conv_mfma && p.max_frames > 256) ms.conv_fused = true;      // long blocks go through in time slices: the one-launch form only
         if (!ms.conv_mfma && conv_lds_bytes(ms.cdesc, p.max_frames) > 160 * 1024)
             return fail(AIDAX_ERR_ARG, "conv model: pool max_frames too large for the LDS activation planes");
     } else if (m->n_rnn == 1 && find_kernel(m->cell, m->hidden) && p.quad_for_table_model(m->cell, m->hidden) &&

@@ -17,7 +17,9 @@ for kind, H, I, L in (("lstm", 32, 1, 1), ("gru", 16, 3, 1), ("lstm", 12, 2, 1),
     j = modelgen.make_model(kind, H, I, seed=H + I, n_rnn=L, samplerate=44100.0 if (kind, H) == ("gru", 16) else None,
                             in_skip=1 if (kind, H) == ("lstm", 12) else None, in_gain=-2.0 if H == 12 else None, out_gain=1.5 if H == 12 else None)
     models.append((ax.Model(modelgen.write_model(j, os.path.join(d, f"{kind}{H}x{L}.json"))), O.parse_model(j)))
-S, MAXF = int(os.environ.get("SOAK_STREAMS", "70")), 256      # 70: the resident forms (pipe, lp, fused conv); ~4200: the many-streams forms
+S, MAXF = int(os.environ.get("SOAK_STREAMS", "70")), int(os.environ.get("SOAK_MAXF", "256"))
+if MAXF > 512 and os.environ.get("AIDAX_KERNEL") == "valu":   # the VALU conv kernel keeps a whole block in two LDS planes
+    models = [m for m in models if m[1].rnn_type != "conv1d"]      # 70: the resident forms (pipe, lp, fused conv); ~4200: the many-streams forms
 SR = float(os.environ.get("SOAK_SR", "48000"))                    # the host's rate: gain smoothers, filter designs
 pool = ax.Pool(S, MAXF, SR)
 watch = [0, S // 2 - 2, S - 1]
@@ -59,7 +61,7 @@ for b in range(blocks):
         else: k["mid_type"] = float(rs.rand() > 0.5); k["mid_boost_db"] = float(rs.uniform(-8, 8)); k["in_lpf_pc"] = float(rs.choice([0.0, 30.0, 66.216, 100.0]))
         kw[s] = k
         pool.set_controls(ax.default_controls(**k), stream=s)
-    n = int(rs.choice([256, 256, 256, 128, 64, 17, 1, 0, 255, 200]))
+    n = int(rs.choice([256, 256, 256, 128, 64, 17, 1, 0, 255, 200] + ([MAXF, MAXF - 1, 1000, 513, 300] if MAXF > 256 else [])))
     x = (rs.uniform(-0.6, 0.6, size=(S, n))).astype(np.float32)
     got = pool.process(x)
     names.add(pool.kernel_name)

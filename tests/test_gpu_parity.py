@@ -555,6 +555,40 @@ def test_extension_models_full_chain(kind, kw, form, tmp_path, monkeypatch):
     errlog.bound(np.abs(got2 - got).max(), 1e-7, "gpu_parity:406")
 
 
+def test_conv_stack_on_a_pool_with_long_blocks(tmp_path):
+    """The matrix-core conv kernel carries 256 frames per launch; a pool created for longer host blocks sends a block
+    through in time slices, each the whole run() of its slice (rows keep the block's pitch). Ragged long blocks against
+    the oracle, and bit-identical to a pool that is handed the same audio in 256-frame blocks."""
+    path, spec = _model_file(tmp_path, "c16long", kind="conv", hidden=16, input_size=1, seed=79, in_skip=1, out_gain=1.5)
+    S = 5
+    sizes = [2048, 1000, 513, 256, 300, 1, 0, 257]
+    x = modelgen.signal(S, sum(sizes), seed=23)
+    cg, co = _ctl_pair(bass_boost_db=3.0, pregain_db=2.0, eq_position=1.0)
+    big = ax.Pool(S, 2048)
+    big.set_model(ax.Model(path))
+    assert big.kernel_name == "k_conv_mfma"
+    big.set_controls(cg)
+    got = np.empty_like(x)
+    pos = 0
+    for n in sizes:
+        got[:, pos:pos + n] = big.process(np.ascontiguousarray(x[:, pos:pos + n]))
+        pos += n
+    want = O.run_streams(spec, co, x, 256)
+    errlog.bound(np.abs(got - want).max(), 1.5e-6, "gpu_parity:conv_long_blocks")
+    small = ax.Pool(S, 256)
+    small.set_model(ax.Model(path))
+    small.set_controls(cg)
+    # the same slices: block boundaries of the long pool's launches (every `sizes` entry cut at multiples of 256)
+    ref = np.empty_like(x)
+    pos = 0
+    for n in sizes:
+        for d in range(0, max(n, 1), 256):
+            c = min(256, n - d)
+            ref[:, pos + d:pos + d + c] = small.process(np.ascontiguousarray(x[:, pos + d:pos + d + c]))
+        pos += n
+    assert np.array_equal(got, ref)
+
+
 def test_conv_fused_launch_is_bit_identical_to_split_launches(tmp_path, monkeypatch):
     """The conv stack's one-launch form (chain passes inside k_conv_mfma) against packed k_chain launches around the
     same kernel: same operations per sample in the same order, so every output sample and the carried state agree

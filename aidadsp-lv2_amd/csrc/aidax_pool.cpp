@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <sstream>
@@ -144,6 +146,12 @@ struct aidax_pool {
     float* hd_in = nullptr;          // device view of h_in / h_out (zero-copy passes)
     float* hd_out = nullptr;
     bool zero_copy = false;
+    // completion word of a pass in pinned host memory: the stream writes the pass number behind its last launch and the
+    // caller of aidax_pool_process polls it — no interrupt, no wake-up of a blocked thread (small pools: the plugin case)
+    uint32_t* h_done = nullptr;
+    uint32_t* hd_done = nullptr;
+    uint32_t done_seq = 0;
+    bool spin_wait = false;
 
     std::vector<aidax_controls> controls;
     std::vector<uint8_t> loading;
@@ -342,6 +350,7 @@ struct aidax_pool {
         if (cur.d_wpack) (void)hipFree(cur.d_wpack);
         if (cur.d_ring) (void)hipFree(cur.d_ring);
         if (cur.d_counters) (void)hipFree(cur.d_counters);
+        if (h_done) (void)hipHostFree(h_done);
         if (d_in) (void)hipFree(d_in);
         if (d_out) (void)hipFree(d_out);
         if (h_in) (void)hipHostFree(h_in);
@@ -576,6 +585,15 @@ AIDAX_API int aidax_pool_create(uint32_t n_streams, uint32_t max_frames, double 
                     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->hd_in), p->h_in, 0));
                     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->hd_out), p->h_out, 0));
                     p->zero_copy = true;
+                    const char* sp = std::getenv("AIDAX_SPIN_WAIT");
+                    int can = 0;
+                    (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device_id);
+                    if (can && !(sp && sp[0] == '0')) {
+                        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_done), 64, hipHostMallocDefault));
+                        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->hd_done), p->h_done, 0));
+                        *p->h_done = 0;
+                        p->spin_wait = true;
+                    }
                 }
             }
             for (int k = 0; k < kCtlRing; ++k) {
@@ -755,7 +773,26 @@ AIDAX_API int aidax_pool_process(aidax_pool* p, const float* in, float* out, uin
             if (rc != AIDAX_OK) return rc;
             if (bytes) HIP_TRY(hipMemcpyAsync(p->h_out, p->d_out, bytes, hipMemcpyDeviceToHost, p->q));
         }
-        HIP_TRY(hipStreamSynchronize(p->q));
+        if (p->spin_wait) {
+            // poll the completion word for up to ~2 ms (a block that takes longer is not a real-time block), then wait the usual way
+            const uint32_t seq = ++p->done_seq;
+            HIP_TRY(hipStreamWriteValue32(p->q, p->hd_done, seq, 0));
+            volatile uint32_t* w = p->h_done;
+            const auto t0 = std::chrono::steady_clock::now();
+            uint32_t polls = 0;
+            while (*w != seq) {
+                if ((++polls & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+                    HIP_TRY(hipStreamSynchronize(p->q));
+                    break;
+                }
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        } else {
+            HIP_TRY(hipStreamSynchronize(p->q));
+        }
         if (bytes) std::memcpy(out, p->h_out, bytes);
         return AIDAX_OK;
     });

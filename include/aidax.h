@@ -187,7 +187,9 @@ AIDAX_API int  aidax_pool_activate(aidax_pool* p, int32_t stream);
  * laid out [n_streams][n_frames] (in-place allowed). Blocking: waits for the pool's stream. n_frames == 0 is
  * the legal "pre-run" (:606-609) and only latches targets. The block travels through pinned staging that the
  * pool allocated at creation (blocks of <= 64 KiB — the one-instance plugin — are read and written by the
- * kernels in place in pinned host memory, no copy engine involved; AIDAX_ZEROCOPY=0 turns that off). */
+ * kernels in place in pinned host memory, no copy engine involved; AIDAX_ZEROCOPY=0 turns that off — and such
+ * a pool learns of the pass's end from a word the stream writes into pinned host memory, which the caller polls:
+ * no interrupt and no wake-up on the way back; AIDAX_SPIN_WAIT=0 waits with hipStreamSynchronize instead). */
 AIDAX_API int  aidax_pool_process(aidax_pool* p, const float* in, float* out, uint32_t n_frames);
 
 /* Same pass with device-resident buffers, asynchronous on `hip_stream`

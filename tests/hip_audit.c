@@ -14,12 +14,12 @@
 
 enum {
     A_MALLOC, A_FREE, A_HOST_MALLOC, A_HOST_FREE, A_DEVICE_SYNC, A_STREAM_SYNC, A_EVENT_SYNC, A_MEMCPY_SYNC,
-    A_STREAM_CREATE, A_EVENT_CREATE, A_MEMCPY_ASYNC, A_LAUNCH, A_EVENT_RECORD, A_STREAM_WAIT_EVENT, A_COUNT
+    A_STREAM_CREATE, A_EVENT_CREATE, A_MEMCPY_ASYNC, A_LAUNCH, A_EVENT_RECORD, A_STREAM_WAIT_EVENT, A_STREAM_WRITE_VALUE, A_COUNT
 };
 static const char* const kNames[A_COUNT] = {
     "hipMalloc", "hipFree", "hipHostMalloc", "hipHostFree", "hipDeviceSynchronize", "hipStreamSynchronize",
     "hipEventSynchronize", "hipMemcpy", "hipStreamCreate", "hipEventCreate", "hipMemcpyAsync", "launch",
-    "hipEventRecord", "hipStreamWaitEvent"
+    "hipEventRecord", "hipStreamWaitEvent", "hipStreamWriteValue32"
 };
 
 static __thread int t_on = 0;
@@ -74,3 +74,4 @@ int hipLaunchKernel(const void* f, dim3_t g, dim3_t b, void** args, size_t shmem
 }
 int hipEventRecord(void* e, void* q) { REAL("hipEventRecord", void*, void*); COUNT(A_EVENT_RECORD); return fn(e, q); }
 int hipStreamWaitEvent(void* q, void* e, unsigned f) { REAL("hipStreamWaitEvent", void*, void*, unsigned); COUNT(A_STREAM_WAIT_EVENT); return fn(q, e, f); }
+int hipStreamWriteValue32(void* q, void* p, uint32_t v, unsigned f) { REAL("hipStreamWriteValue32", void*, void*, uint32_t, unsigned); COUNT(A_STREAM_WRITE_VALUE); return fn(q, p, v, f); }

@@ -51,3 +51,15 @@ def test_random_lv2_host():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "soak_lv2.py"), "400"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "lv2 soak ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("model", ["lstm12", "stack"])
+def test_hub_under_real_time_pacing_with_threads(model):
+    """tests/soak_hub_rt.py: three host threads with jitter, dawdling and skipped periods, periods closed by the hub's
+    deadline: an instance only ever gets the oracle's output of its previous block or (rarely) silence."""
+    env = dict(os.environ)
+    env.pop("AIDAX_KERNEL", None)
+    env["SOAK_RT_MODEL"] = model
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "soak_hub_rt.py"), "400"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "hub rt soak ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -63,3 +63,14 @@ def test_hub_under_real_time_pacing_with_threads(model):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "soak_hub_rt.py"), "400"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "hub rt soak ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_abi_fuzz():
+    """tests/fuzz_abi.py: random sequences of C-ABI calls with valid and cleanly-invalid arguments (null handles and
+    buffers, streams / slots / sizes out of range, wrong modes, models a pool cannot host): a return code and a message,
+    never a crash, and the pool still matches the oracle afterwards."""
+    env = dict(os.environ)
+    env.pop("AIDAX_KERNEL", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_abi.py"), "25"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "abi fuzz ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

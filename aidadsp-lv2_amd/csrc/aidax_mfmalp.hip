@@ -62,7 +62,10 @@ __host__ __device__ constexpr size_t lp_ring_floats(int hidden, int waves, int m
 // Tiles per wave whose input half moves from the upper layer's workgroup to the lower one's. Two layers: the upper
 // has 8G k-steps per tile, the lower 4G + 1 — moving one tile's input half (4G MFMAs per wave) evens them out
 // (LSTM-96: 75 / 144 -> 99 / 120 MFMAs per wave and frame). Deeper stacks are bound by their last layer either way.
-__host__ __device__ constexpr int lp_moved_tiles(int n_layers, int tpw) { return (n_layers == 2 && tpw >= 2) ? 1 : 0; }
+// LSTM-96 (three tiles per wave): one moved tile still leaves 99 / 120; the waves of a workgroup's FIRST half move two
+// and those of the second half one (waves w and w + NW/2 share a SIMD, so every SIMD carries one of each): 111 / 108.
+// Returned as the LARGEST count a wave moves: 2 means "two for waves < NW/2, one for the others".
+__host__ __device__ constexpr int lp_moved_tiles(int n_layers, int tpw) { return n_layers != 2 ? 0 : tpw >= 3 ? 2 : tpw >= 2 ? 1 : 0; }
 constexpr int kLpCounterStride = 32;     // uint32 per (group, boundary): produced at [0], consumed at [16] (own cache lines)
 
 // the error word sits behind the counters of ALL the pool's groups; a one-stream view of the pool (reset_stream)
@@ -149,6 +152,7 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mw = M == 2 ? (wave < NW / 2 ? 2 : 1) : M;   // tiles THIS wave moves (M == 2: the first half of the waves two, the others one)
     const int n = (int)a.n_frames;
     const int NL = d.n_layers;
     const int Ht = d.hidden_true;
@@ -233,11 +237,13 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
 #pragma unroll
     for (int tl = 0; tl < TPW; ++tl)
         bias_r[tl] = *reinterpret_cast<const f32x4*>(W + L.b_off + 4 * (4 * (wave * TPW + tl) + (lane >> 4)));
-    f32x4 bias_up[MA];                                     // first layer, M > 0: the moved tiles start from the upper layer's bias
+    // One register set, two uses that exclude each other: on the first layer the bias rows the moved tiles start from
+    // (the upper layer's), on the others the started tiles of the NEXT frame on their way in from the ring.
+    f32x4 upx[MA];
 #pragma unroll
     for (int tl = 0; tl < MA; ++tl)
-        bias_up[tl] = (M > 0 && first) ? *reinterpret_cast<const f32x4*>(W + d.L[M > 0 ? 1 : 0].b_off + 4 * (4 * (wave * TPW + tl) + (lane >> 4)))
-                                        : f32x4{ 0.f, 0.f, 0.f, 0.f };
+        upx[tl] = (M > 0 && first) ? *reinterpret_cast<const f32x4*>(W + d.L[M > 0 ? 1 : 0].b_off + 4 * (4 * (wave * TPW + tl) + (lane >> 4)))
+                                    : f32x4{ 0.f, 0.f, 0.f, 0.f };
     // Dense(H,1) on the matrix cores (last layer): y = wd . h is one more 16-row tile whose row 0 is wd; its H/4
     // k-steps are dealt out TPW per wave, each wave leaves a partial sum per stream in LDS and wave 0 adds the NW
     // partials in a fixed order a tick later. (As VALU code — six LDS reads with bank conflicts, a DPP tree, twice per
@@ -298,11 +304,17 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
             if (first) {
                 f32x4 pacc[MA];
 #pragma unroll
-                for (int tl = 0; tl < M; ++tl) pacc[tl] = bias_up[tl];
-                lp_gates<TPW, G, 0, NRES, 0, M, MA>(pacc, wres, h_src, lane);
+                for (int tl = 0; tl < M; ++tl) pacc[tl] = upx[tl];
+                if constexpr (M == 2) {
+                    if (mw == 2) lp_gates<TPW, G, 0, NRES, 0, 2, MA>(pacc, wres, h_src, lane);
+                    else lp_gates<TPW, G, 0, NRES, 0, 1, MA>(pacc, wres, h_src, lane);
+                } else {
+                    lp_gates<TPW, G, 0, NRES, 0, M, MA>(pacc, wres, h_src, lane);
+                }
 #pragma unroll
                 for (int tl = 0; tl < M; ++tl)
-                    lp_store16(rs_out, slot_off + (uint32_t)(H * NS * sizeof(float)) + (uint32_t)(((wave * M + tl) * kWave + lane) * 16), pacc[tl]);
+                    if (tl < mw)
+                        lp_store16(rs_out, slot_off + (uint32_t)(H * NS * sizeof(float)) + (uint32_t)(((wave * M + tl) * kWave + lane) * 16), pacc[tl]);
             }
         }
     };
@@ -362,7 +374,7 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
         };
         constexpr int PER4 = (kHVec + NT - 1) / NT;        // f32x4 of a frame each thread moves
         f32x4 pre[PER4];
-        f32x4 ppre[MA], pcur[MA];                          // started tiles of the next / the current frame (layers >= 1, M > 0)
+        f32x4 pcur[MA] = {};                               // started tiles of the current frame (layers >= 1, M > 0); the next frame's: upx
         auto fetch_below = [&](int F) {                    // all threads: frame F of the launch -> registers
             const uint32_t slot_off = (uint32_t)(((base_in + (uint32_t)F) % kLpRing) * kSlot * sizeof(float));
 #pragma unroll
@@ -371,7 +383,8 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
             if constexpr (M > 0) {                         // ... and this wave's started tiles straight into registers
 #pragma unroll
                 for (int tl = 0; tl < M; ++tl)
-                    ppre[tl] = lp_load16(rs_in, slot_off + (uint32_t)(H * NS * sizeof(float)) + (uint32_t)(((wave * M + tl) * kWave + lane) * 16));
+                    if (tl < mw)
+                        upx[tl] = lp_load16(rs_in, slot_off + (uint32_t)(H * NS * sizeof(float)) + (uint32_t)(((wave * M + tl) * kWave + lane) * 16));
             }
         };
         auto stash_below = [&](int parity) {
@@ -388,7 +401,7 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
             fetch_below(done);
             stash_below(0);
 #pragma unroll
-            for (int tl = 0; tl < MA; ++tl) pcur[tl] = ppre[tl];
+            for (int tl = 0; tl < MA; ++tl) pcur[tl] = upx[tl];
         }
         __syncthreads();
 
@@ -460,9 +473,15 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
                 } else {
                     if constexpr (M > 0) {                 // the first M tiles arrive started (bias + input half), the others start here
 #pragma unroll
-                        for (int tl = 0; tl < M; ++tl) acc[tl] = pcur[tl];
+                        for (int tl = 0; tl < M; ++tl)
+                            if (tl < mw) acc[tl] = pcur[tl];
                     }
-                    lp_gates<TPW, G, 0, NRES, M, TPW>(acc, wres, below + (tick & 1) * H * NS, lane);
+                    if constexpr (M == 2) {
+                        if (mw == 2) lp_gates<TPW, G, 0, NRES, 2, TPW>(acc, wres, below + (tick & 1) * H * NS, lane);
+                        else lp_gates<TPW, G, 0, NRES, 1, TPW>(acc, wres, below + (tick & 1) * H * NS, lane);
+                    } else {
+                        lp_gates<TPW, G, 0, NRES, M, TPW>(acc, wres, below + (tick & 1) * H * NS, lane);
+                    }
                 }
                 lp_gates<TPW, G, G, NRES>(acc, wres, h_rd, lane);
 
@@ -487,7 +506,7 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
                 if (!first && more) {
                     stash_below((tick + 1) & 1);
 #pragma unroll
-                    for (int tl = 0; tl < MA; ++tl) pcur[tl] = ppre[tl];
+                    for (int tl = 0; tl < MA; ++tl) pcur[tl] = upx[tl];
                 }
                 if (!last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's ring stores have left before the barrier (G16)
             }
@@ -554,7 +573,7 @@ static LpFn lp_fn(int hidden, int n_layers)
 {
     switch (hidden) {
 #define AIDAX_LP_CASE(HID) case HID: { constexpr int T = HID / 4 / mfma_waves(HID), W_ = mfma_waves(HID);                         \
-        return lp_moved_tiles(2, T) == 1 && n_layers == 2 ? k_mfma_lp<T, W_, lp_moved_tiles(2, T)> : k_mfma_lp<T, W_, 0>; }
+        return lp_moved_tiles(2, T) > 0 && n_layers == 2 ? k_mfma_lp<T, W_, lp_moved_tiles(2, T)> : k_mfma_lp<T, W_, 0>; }
     AIDAX_LP_CASE(16) AIDAX_LP_CASE(32) AIDAX_LP_CASE(48) AIDAX_LP_CASE(64) AIDAX_LP_CASE(80) AIDAX_LP_CASE(96)
 #undef AIDAX_LP_CASE
     default: return nullptr;                               // wider stacks keep the fragment-streaming kernel

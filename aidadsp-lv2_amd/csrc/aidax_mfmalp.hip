@@ -65,7 +65,8 @@ __host__ __device__ constexpr size_t lp_ring_floats(int hidden, int waves, int m
 // LSTM-96 (three tiles per wave): one moved tile still leaves 99 / 120; the waves of a workgroup's FIRST half move two
 // and those of the second half one (waves w and w + NW/2 share a SIMD, so every SIMD carries one of each): 111 / 108.
 // Returned as the LARGEST count a wave moves: 2 means "two for waves < NW/2, one for the others".
-__host__ __device__ constexpr int lp_moved_tiles(int n_layers, int tpw) { return n_layers != 2 ? 0 : tpw >= 3 ? 2 : tpw >= 2 ? 1 : 0; }
+// (Only with eight waves: four waves sit on a SIMD each, and an uneven split would just make the slowest wave slower.)
+__host__ __device__ constexpr int lp_moved_tiles(int n_layers, int tpw, int nw) { return n_layers != 2 ? 0 : (nw == 8 && tpw == 3) ? 2 : tpw >= 2 ? 1 : 0; }
 constexpr int kLpCounterStride = 32;     // uint32 per (group, boundary): produced at [0], consumed at [16] (own cache lines)
 
 // the error word sits behind the counters of ALL the pool's groups; a one-stream view of the pool (reset_stream)
@@ -573,13 +574,13 @@ static LpFn lp_fn(int hidden, int n_layers)
 {
     switch (hidden) {
 #define AIDAX_LP_CASE(HID) case HID: { constexpr int T = HID / 4 / mfma_waves(HID), W_ = mfma_waves(HID);                         \
-        return lp_moved_tiles(2, T) > 0 && n_layers == 2 ? k_mfma_lp<T, W_, lp_moved_tiles(2, T)> : k_mfma_lp<T, W_, 0>; }
+        return lp_moved_tiles(2, T, W_) > 0 && n_layers == 2 ? k_mfma_lp<T, W_, lp_moved_tiles(2, T, W_)> : k_mfma_lp<T, W_, 0>; }
     AIDAX_LP_CASE(16) AIDAX_LP_CASE(32) AIDAX_LP_CASE(48) AIDAX_LP_CASE(64) AIDAX_LP_CASE(80) AIDAX_LP_CASE(96)
 #undef AIDAX_LP_CASE
     default: return nullptr;                               // wider stacks keep the fragment-streaming kernel
     }
 }
-static int lp_m(const MfmaDesc& d) { return lp_moved_tiles(d.n_layers, d.hidden / 4 / mfma_waves(d.hidden)); }
+static int lp_m(const MfmaDesc& d) { return lp_moved_tiles(d.n_layers, d.hidden / 4 / mfma_waves(d.hidden), mfma_waves(d.hidden)); }
 
 bool mfma_lp_serves(const MfmaDesc& d) { return d.n_layers >= 2 && lp_fn(d.hidden, d.n_layers) != nullptr; }
 size_t mfma_lp_lds_bytes(const MfmaDesc& d, uint32_t n_frames) { return lp_lds_floats(d.hidden, (int)n_frames) * sizeof(float); }

@@ -200,15 +200,20 @@ class ModelSpec:
         return int(self.layers[0]["shape"][-1])
 
     def descs(self):
+        """(LayerDesc array, count). The array points into numpy buffers that must outlive the C call that reads them:
+        they hang on the returned array itself (`arr.keep`), so two threads building models from one spec do not free
+        each other's."""
         n = len(self.layers)
         arr = (LayerDesc * n)()
-        self.arrays = []
+        arrays = []
+        arr.keep = arrays
+        self.arrays = arrays
         cur_in = self.input_size
         for i, l in enumerate(self.layers):
             t = l["type"]
             out = int(l["shape"][-1])
             w = [_f32(x) for x in l["weights"]]
-            self.arrays.extend(w)
+            arrays.extend(w)
             d = arr[i]
             d.in_size, d.out_size = cur_in, out
             d.activation = ACT[l.get("activation", "")]

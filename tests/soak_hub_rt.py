@@ -24,6 +24,13 @@ hub.set_model(m)
 if "SOAK_RT_DEADLINE_US" in os.environ:
     hub.set_deadline_us(int(os.environ["SOAK_RT_DEADLINE_US"]))
 slots = [hub.attach() for _ in range(N)]
+# the oracle plugins are built here, one after another: ModelSpec.descs() keeps the weight buffers of the LAST call
+# alive only, so building models from one spec on several threads at once would hand the C side freed memory
+all_plugs = []
+for i in range(N):
+    pl = O.OraclePlugin()
+    pl.set_model(O.OracleModel(spec)); pl.activate()
+    all_plugs.append(pl)
 stats = dict(blocks=0, delivered=0, silent=0, bad=0, worst=0.0)
 lock = threading.Lock()
 errors = []
@@ -33,9 +40,7 @@ start = time.perf_counter() + 0.05
 def host_thread(t):
     rs = np.random.RandomState(seed * 100 + t)
     mine = [i for i in range(N) if i % T == t]
-    plugs = {i: O.OraclePlugin() for i in mine}
-    for p in plugs.values():
-        p.set_model(O.OracleModel(spec)); p.activate()
+    plugs = {i: all_plugs[i] for i in mine}
     kw = {i: dict(param1=float(rs.rand()), pregain_db=float(rs.uniform(-6, 6))) for i in mine}
     for i in mine:
         hub.set_controls(slots[i], ax.default_controls(**kw[i]))

@@ -18,7 +18,10 @@
 // for the 16-channel model) — four workgroups per CU instead of two, all 1024 workgroups of BASELINE cfg4 resident at
 // once — and takes one of the three barriers out of a layer. Per-layer input history ((ksize-1)*dilation frames per
 // input channel) persists in HBM in the same layout as k_conv, so the two kernels are interchangeable mid-stream.
-// The DSP chain runs in the packed k_chain launches (split form); this kernel is applyModel only.
+// Two instantiations: k_conv_mfma<false> is applyModel only (warm-up, self-test, and MODE_CHAIN between two packed
+// k_chain launches — the form for pools with more streams than stay resident in one round); k_conv_mfma<true> is the
+// whole run() of its stream, chain passes included (see below). 256 frames per launch; a pool made for longer host
+// blocks sends them through in time slices (LaunchArgs::row_stride).
 #include "aidax_device.h"
 #include "aidax_kernels.h"
 #include "aidax_layout.h"

@@ -773,10 +773,16 @@ AIDAX_API int aidax_pool_process(aidax_pool* p, const float* in, float* out, uin
             if (rc != AIDAX_OK) return rc;
             if (bytes) HIP_TRY(hipMemcpyAsync(p->h_out, p->d_out, bytes, hipMemcpyDeviceToHost, p->q));
         }
+        uint32_t seq = 0;
+        if (p->spin_wait) {
+            seq = ++p->done_seq;
+            if (hipStreamWriteValue32(p->q, p->hd_done, seq, 0) != hipSuccess) {      // a runtime without stream memory operations
+                (void)hipGetLastError();
+                p->spin_wait = false;
+            }
+        }
         if (p->spin_wait) {
             // poll the completion word for up to ~2 ms (a block that takes longer is not a real-time block), then wait the usual way
-            const uint32_t seq = ++p->done_seq;
-            HIP_TRY(hipStreamWriteValue32(p->q, p->hd_done, seq, 0));
             volatile uint32_t* w = p->h_done;
             const auto t0 = std::chrono::steady_clock::now();
             uint32_t polls = 0;

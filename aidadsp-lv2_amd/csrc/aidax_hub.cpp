@@ -290,6 +290,12 @@ AIDAX_API int aidax_hub_set_controls(aidax_hub* h, int32_t slot, const aidax_con
     std::lock_guard<std::mutex> g(h->mu);
     if (slot < 0 || static_cast<uint32_t>(slot) >= h->cap || !h->attached[slot]) return fail(AIDAX_ERR_ARG, "slot not attached");
     if (std::memcmp(&h->ctl[slot], c, sizeof(*c)) == 0) return AIDAX_OK;
+    // the instance's last block may still wait for its pass (somebody else has not submitted yet): that block was
+    // played under the OLD controls, so its period is closed before the new ones go in
+    if (h->submitted[slot]) {
+        const int rc = flush_locked(*h);
+        if (rc != AIDAX_OK) return rc;
+    }
     h->ctl[slot] = *c;
     return aidax_pool_set_controls(h->pool, slot, c);      // the pool keeps the slot parked if it is
 }
@@ -299,6 +305,10 @@ AIDAX_API int aidax_hub_set_loading(aidax_hub* h, int32_t slot, int loading)
     if (!h) return fail(AIDAX_ERR_ARG, "null hub");
     std::lock_guard<std::mutex> g(h->mu);
     if (slot < 0 || static_cast<uint32_t>(slot) >= h->cap || !h->attached[slot]) return fail(AIDAX_ERR_ARG, "slot not attached");
+    if (h->submitted[slot]) {                               // as for the controls: what was submitted plays under what was in force
+        const int rc = flush_locked(*h);
+        if (rc != AIDAX_OK) return rc;
+    }
     return aidax_pool_set_loading(h->pool, slot, loading);
 }
 
@@ -307,6 +317,10 @@ AIDAX_API int aidax_hub_activate(aidax_hub* h, int32_t slot)
     if (!h) return fail(AIDAX_ERR_ARG, "null hub");
     std::lock_guard<std::mutex> g(h->mu);
     if (slot < 0 || static_cast<uint32_t>(slot) >= h->cap || !h->attached[slot]) return fail(AIDAX_ERR_ARG, "slot not attached");
+    if (h->submitted[slot]) {
+        const int rc = flush_locked(*h);
+        if (rc != AIDAX_OK) return rc;
+    }
     return aidax_pool_activate(h->pool, slot);
 }
 

@@ -239,7 +239,8 @@ AIDAX_API const char* aidax_pool_kernel_name(const aidax_pool* p);
  * while that is at most two passes old and of the same length (a period that was closed in pieces), silence
  * otherwise. run() itself waits only for the event of that pass, outside the hub's lock; the staging buffers
  * rotate over four passes, and a host that closes periods faster than the GPU finishes them waits for the pass
- * four back before its staging is reused. Report aidax_hub_latency_frames() to the host as the plugin's latency. Thread-safe. */
+ * four back before its staging is reused. Controls, the loading flag and activate() of an instance whose block still
+ * waits for its pass close the period first: a submitted block plays under what was in force when it was submitted. Report aidax_hub_latency_frames() to the host as the plugin's latency. Thread-safe. */
 typedef struct aidax_hub aidax_hub;
 
 AIDAX_API int  aidax_hub_create(uint32_t max_instances, uint32_t max_frames, double host_samplerate,

@@ -164,6 +164,16 @@ for p in range(periods):
             continue                        # the host skips this instance this period
         ni = n if rs.rand() > 0.04 or "nchange" in NO else int(rs.choice([256, 16 if "odd" in NO else 17]))
         run(s, rs.uniform(-0.6, 0.6, size=ni).astype(np.float32))
+        if rs.rand() < 0.05 and "midctl" not in NO:
+            # a control moves while the instance's block still waits for its pass: the block was played under the old
+            # value, so the hub closes the period first
+            it = insts[s]
+            new_kw = dict(it.kw, pregain_db=float(rs.uniform(-9, 9)), param1=float(rs.rand()))
+            if s in submitted:
+                mirror_flush()                                  # ... under the controls in force so far
+            it.kw = new_kw
+            hub.set_controls(s, ax.default_controls(**it.kw))
+            glog.append(f"period {p}: slot {s} controls (block pending) {it.kw}")
     if rs.rand() < 0.1 and order and "twice" not in NO:
         run(order[0], rs.uniform(-0.6, 0.6, size=n).astype(np.float32))      # the same instance twice: closes the period itself
     hub.flush()                             # the launcher thread may not have got to it yet: close the period here

@@ -74,3 +74,13 @@ def test_abi_fuzz():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_abi.py"), "25"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "abi fuzz ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_random_lv2_host_in_hub_mode():
+    """tests/soak_lv2_hub.py: four plugin instances of one process with AIDAX_HUB, moving between the hubs of four model
+    files by patch:Set with late workers and responses, controls moving while a block still waits for its pass."""
+    env = dict(os.environ)
+    env.pop("AIDAX_KERNEL", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "soak_lv2_hub.py"), "200"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "lv2 hub soak ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -57,6 +57,8 @@ RANGES = {"ANTIALIASING": (0, 100), "PREGAIN": (-12, 3), "NETBYPASS": (0, 1), "P
           "enabled": (0, 1)}
 TOGGLES = {"NETBYPASS", "EQBYPASS", "EQPOS", "MTYPE", "DCBLOCKER", "enabled"}
 answers = []            # specs of the loads work() has answered, in the order of h.responses
+answer_paths = []
+playing = None          # path of the model work_response() swapped in last
 worst, swaps, failed, last_in_size = 0.0, 0, 0, 0
 for b in range(blocks):
     r = rs.rand()
@@ -102,6 +104,7 @@ for b in range(blocks):
                     # when the answer is delivered
                     old = plug.model.ptr.contents if plug.model is not None else None
                     answers.append((spec, old.param1Coeff.target if old else 0.0, old.param2Coeff.target if old else 0.0))
+                    answer_paths.append(msg[4:].split(b"\0")[0].decode())
                     last_in_size = spec.input_size
                 else: failed += 1
         h.pump_worker()
@@ -112,6 +115,17 @@ for b in range(blocks):
         for spec, p1, p2 in answers[:k]:
             plug.set_model(O.OracleModel(spec, p1, p2))
             swaps += 1
-        del answers[:k]
+        playing = answer_paths[k - 1]
+        del answers[:k]; del answer_paths[:k]
+        # work_response() echoes the file now in use as a patch:Set on NOTIFY (:880-887); with several answers in one
+        # delivery the buffer holds one event per swap, the last one naming the model that plays from here on
+        notes = h.read_notify()
+        assert len(notes) == k and notes[-1][0].endswith("patch#Set"), notes
+        assert notes[-1][1]["http://lv2plug.in/ns/ext/patch#value"][1].rstrip(b"\0").decode() == playing
+    if rs.rand() < 0.05:
+        rc_, stored = h.save()                                        # :763-796: the playing model's path, abstract, as atom:Path
+        assert rc_ == 0
+        if playing is None: assert stored == []
+        else: assert len(stored) == 1 and stored[0][1].rstrip(b"\0").decode() == os.path.relpath(playing, bundle) and stored[0][2].endswith("atom#Path")
 h.close()
 print("lv2 soak ok:", blocks, "blocks,", swaps, "swaps,", failed, "failed loads, worst |err| =", worst)

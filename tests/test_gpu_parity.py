@@ -433,6 +433,45 @@ def test_worker_thread_prepares_while_the_audio_thread_processes(tmp_path):
     assert swaps >= 8 and len(names) >= 3, (swaps, names)
 
 
+def test_pools_of_one_process_on_several_threads(tmp_path):
+    """Four pools (four kernel families, different stream counts) of one process, each driven by a thread of its own at
+    full speed: nothing in the library is shared between pools but the device, so every pool must match its oracle
+    as if it were alone (error strings are per thread, function attributes are idempotent)."""
+    import threading
+    cases = [("t_pipe", dict(kind="lstm", hidden=16, input_size=2, seed=61), 9, 128),
+             ("t_split", dict(kind="gru", hidden=24, input_size=1, seed=62), 200, 64),
+             ("t_lp", dict(kind="lstm", hidden=32, input_size=1, seed=63, n_rnn=2), 20, 256),
+             ("t_conv", dict(kind="conv", hidden=16, input_size=1, seed=64), 6, 256)]
+    made = [(_model_file(tmp_path, name, **kw), S, n) for name, kw, S, n in cases]
+    failures, names = [], []
+    blocks = 40
+
+    def one(idx):
+        try:
+            (path, spec), S, n = made[idx]
+            pool = ax.Pool(S, n)
+            pool.set_model(ax.Model(path))
+            cg, co = _ctl_pair(param1=0.3, pregain_db=1.0 + idx, bass_boost_db=2.0)
+            pool.set_controls(cg)
+            x = modelgen.signal(S, n * blocks, seed=80 + idx)
+            got = _run_gpu(pool, x, n)
+            names.append(pool.kernel_name)
+            watch = [0, S // 2, S - 1]
+            want = O.run_streams(spec, co, x[watch], n)
+            err = float(np.abs(got[watch] - want).max())
+            if err > 2e-6:
+                failures.append((idx, err))
+            pool.close()
+        except Exception as e:                                      # pragma: no cover
+            failures.append((idx, repr(e)))
+
+    threads = [threading.Thread(target=one, args=(i,)) for i in range(len(cases))]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert not failures, failures
+    assert len(set(names)) == 4, names
+
+
 def test_long_run_drift_48000_samples(tmp_path):
     """One second of full-scale audio through LSTM-32: the fast sigmoid/tanh must hold
     1e-5 over >= 48000 recurrent steps (SURVEY §7 'Transcendentals at 1e-5')."""

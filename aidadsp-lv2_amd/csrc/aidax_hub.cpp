@@ -241,7 +241,8 @@ AIDAX_API int aidax_hub_set_model(aidax_hub* h, const aidax_model* m, int start_
     if (rc != AIDAX_OK) return rc;
     {
         std::lock_guard<std::mutex> g(h->mu);
-        rc = aidax_pool_commit_model(h->pool, sg);
+        rc = flush_locked(*h);                              // blocks submitted so far were played by the old model
+        if (rc == AIDAX_OK) rc = aidax_pool_commit_model(h->pool, sg);
     }
     aidax_staged_free(sg);
     return rc;

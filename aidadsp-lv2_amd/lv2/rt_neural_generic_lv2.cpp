@@ -132,7 +132,9 @@ bool hub_join(Plugin* self, const aidax_model* model, aidax_hub** hub_out, int32
         aidax_hub* hub = nullptr;
         const char* fr = std::getenv("AIDAX_HUB_FRAMES");
         const uint32_t max_frames = fr ? static_cast<uint32_t>(std::atoi(fr)) : 2048u;
-        if (aidax_hub_create(static_cast<uint32_t>(self->hub_capacity), max_frames, self->samplerate, self->device, &hub) != AIDAX_OK)
+        // twice the seats: an instance that reloads a file of this hub holds its old seat until the swap and the worker's
+        // kWorkerFree, so all of them may sit here twice for a moment
+        if (aidax_hub_create(2u * static_cast<uint32_t>(self->hub_capacity), max_frames, self->samplerate, self->device, &hub) != AIDAX_OK)
             return false;
         if (const char* dl = std::getenv("AIDAX_HUB_DEADLINE_US")) aidax_hub_set_deadline_us(hub, std::atoll(dl));
         if (aidax_hub_set_model(hub, model, AIDAX_START_WARMUP) != AIDAX_OK) { aidax_hub_destroy(hub); return false; }

@@ -357,6 +357,9 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the short cfg3/cfg4/cfg5 regions and the one-stream case")
     ap.add_argument("--dry-run", action="store_true", help="CPU stand-in for the rank plumbing (gloo, no GPU): tests only")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rank plumbing with the real kernels on a box with fewer GPUs than ranks: every rank runs on device 0, "
+                         "the reduction goes over gloo; the line says so and is no scaling measurement")
     args = ap.parse_args()
 
     if "RANK" not in os.environ and args.gpus > 1:
@@ -371,11 +374,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if args.share_device:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.share_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     ax = importlib.import_module("aidadsp-lv2_amd")
     W = ax.workloads
@@ -386,7 +394,7 @@ def main():
 
     m = measure(ax, W, torch, args.workload, S, args.steps, args.warmup, rank, world, local, not args.no_check, launch_stream)
     samples = float(S) * N_FRAMES * args.steps
-    elapsed_max, samples_all = reduce_results(m["elapsed"], samples, world)
+    elapsed_max, samples_all = reduce_results(m["elapsed"], samples, world, backend_device="cpu" if args.share_device else "cuda")
 
     if rank == 0:
         value = samples_all / elapsed_max
@@ -412,6 +420,9 @@ def main():
         }
         if wl["bound"] == "mfma":
             out["roofline_hbm"] = hbm
+        if args.share_device:
+            out["share_device"] = True                        # all ranks on device 0: the rank plumbing with real kernels, not a scaling number
+            out["config"]["note"] = f"{world} ranks share ONE GPU (--share-device): no scaling measurement"
         if world == 1 and not args.no_others:
             others = []
             for name in ("cfg3", "cfg4", "cfg5"):

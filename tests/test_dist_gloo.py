@@ -1,7 +1,9 @@
 """world_size-2 gloo test (CPU) of the only multi-rank logic on the path: contiguous
 stream sharding and the final MAX(elapsed)/SUM(samples) reduction of bench.py. The
 data path itself has no collective (streams are independent)."""
+import json
 import os
+import subprocess
 import socket
 import sys
 
@@ -95,3 +97,18 @@ def test_bench_single_rank_dry_run_needs_no_launcher_and_fails_loudly_when_a_ran
                              env=env, capture_output=True, text=True, timeout=300)
         assert run.returncode != 0
         assert not [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_two_ranks_with_the_real_kernels_on_one_gpu():
+    """`bench.py --gpus 2 --share-device`: the parent starts its two ranks, both run the real pool passes (on device 0:
+    a box with one GPU), the only collective — MAX(elapsed), SUM(samples) — goes over gloo, rank 0 prints the line and
+    marks it as no scaling measurement. The rank plumbing of SURVEY §8(e) end to end on hardware."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--steps", "40", "--warmup", "5",
+                        "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["share_device"] is True and j["steps"] == 40
+    assert j["value"] > 1e8 and j["max_abs_err"] < 1e-6
+    assert j["config"]["streams_per_gpu"] == 1024 and "no scaling measurement" in j["config"]["note"]

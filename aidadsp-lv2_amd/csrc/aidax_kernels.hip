@@ -187,7 +187,11 @@ struct LstmCell {
             }
             const float cn = __builtin_fmaf(gf, c[m], gi * gg);
             c[m] = cn;
+#ifdef AIDAX_TANHC_EXP
+            h[m] = go * tanh_exp(cn);                       // experiment: the exp form for tanh(c) only (scratch/ab_tanhc.sh)
+#else
             h[m] = go * tanh_rat(cn);
+#endif
         }
         publish_h(hout);
         __builtin_amdgcn_wave_barrier();

@@ -437,6 +437,15 @@ def main():
                                "unit": "samples/s", "roofline": c2 if WORKLOADS[name]["bound"] == "mfma" else h2,
                                "roofline_compute": c2, "max_abs_err": r["max_err"]})
             out["other_workloads"] = others
+            if args.workload == "cfg2":
+                # the same model with more streams per GPU than BASELINE's 1024: where the recurrent waves stop being alone
+                # on their SIMDs and throughput, not latency, is what is measured (the pool picks the form per size)
+                sweep = []
+                for So, steps in ((4096, 400), (16384, 120)):
+                    r = measure(ax, W, torch, "cfg2", So, steps, max(10, steps // 10), 0, 1, local, False, launch_stream, preroll_s=0.1)
+                    sweep.append({"streams": So, "kernel": r["kernel"], "steps": steps, "ms_per_step": r["elapsed"] / steps * 1e3,
+                                  "value": So * N_FRAMES * steps / r["elapsed"], "unit": "samples/s"})
+                out["stream_sweep"] = sweep
             out["realtime_case"] = realtime_case(ax, W, local)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, m["json"], args.workload)

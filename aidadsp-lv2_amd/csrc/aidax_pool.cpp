@@ -454,8 +454,8 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
     HIP_TRY(hipMalloc(&sg->d_pst, sizeof(StreamState) * p.n_streams));
     // Stacked model: one workgroup per (16 streams, layer), chained through a ring in global memory — where that adds
     // parallelism, i.e. while every (group, layer) workgroup gets a CU of its own (2048 streams for two layers on 256
-    // CUs: 1.7x over one workgroup per group; measured 0.85x beyond, where the CUs are full either way and the
-    // spinning consumers cost more than the resident weights save). AIDAX_MFMA_LP=1 / 0 forces it on / off.
+    // CUs: 1.9x over one workgroup per group; beyond, where the CUs are full either way, a second round of workgroups
+    // costs what the resident weights save: 4096 streams 2.49 against 2.45 ms). AIDAX_MFMA_LP=1 / 0 forces it on / off.
     const char* lp = std::getenv("AIDAX_MFMA_LP");
     int cus = 0;
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p.device));

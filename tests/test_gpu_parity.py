@@ -594,6 +594,94 @@ def test_extension_models_full_chain(kind, kw, form, tmp_path, monkeypatch):
     errlog.bound(np.abs(got2 - got).max(), 1e-7, "gpu_parity:406")
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_random_conv_architectures(seed, tmp_path, monkeypatch):
+    """Conv stacks drawn at random — 1..10 layers, 1..16 channels (all layers alike, as the kernels require), 1..8 taps,
+    dilations that are NOT powers of two as well (history lengths that are no multiple of four take the scalar history
+    path, the others the float4 one with shift or divide indexing), tanh / relu / sigmoid / linear layers, skip and
+    gains — through the one-launch form, the split form and the VALU kernel against the oracle, ragged blocks."""
+    rs = np.random.RandomState(900 + seed)
+    C_, nl, k = int(rs.randint(1, 17)), int(rs.randint(1, 11)), int(rs.randint(1, 9))
+    layers, cur = [], 1
+    for l in range(nl):
+        dil = int(rs.choice([1, 2, 3, 4, 5, 6, 8, 12, 16, 24, 32]))
+        while (k - 1) * dil > 256:                       # the kernels keep at most 256 frames of history per layer... stay inside
+            dil //= 2
+        layers.append(modelgen.conv_layer(rs, cur, C_, k, max(dil, 1), str(rs.choice(["tanh", "tanh", "relu", "sigmoid", ""]))))
+        cur = C_
+    layers.append(modelgen.dense_layer(rs, C_))
+    j = {"in_shape": [None, None, 1], "layers": layers, "metadata": {"name": f"random_conv_{seed}", "samplerate": "48000"},
+         "in_skip": int(rs.randint(2)), "in_gain": float(rs.uniform(-3, 3)), "out_gain": float(rs.uniform(-3, 3))}
+    path = modelgen.write_model(j, str(tmp_path / f"rc{seed}.json"))
+    spec = O.parse_model(j)
+    S = 5
+    sizes = [256, 100, 1, 255, 0, 64, 256]
+    x = modelgen.signal(S, sum(sizes), seed=300 + seed)
+    cg, co = _ctl_pair(pregain_db=1.5, bass_boost_db=-2.0)
+    want = O.run_streams(spec, co, x, 256)
+    for env, name in (({}, "k_conv_mfma"), ({"AIDAX_CONV_FUSED": "0"}, "k_chain+k_conv_mfma"), ({"AIDAX_KERNEL": "valu"}, "k_conv")):
+        for k_, v in (("AIDAX_CONV_FUSED", None), ("AIDAX_KERNEL", None)):
+            monkeypatch.delenv(k_, raising=False)
+        for k_, v in env.items():
+            monkeypatch.setenv(k_, v)
+        pool = ax.Pool(S, 256)
+        pool.set_model(ax.Model(path))
+        assert pool.kernel_name == name, (pool.kernel_name, name, C_, nl, k)
+        pool.set_controls(cg)
+        got = np.empty_like(x)
+        pos = 0
+        for n in sizes:
+            got[:, pos:pos + n] = pool.process(np.ascontiguousarray(x[:, pos:pos + n]))
+            pos += n
+        scale = max(1.0, float(np.abs(want).max()))
+        errlog.bound(np.abs(got - want).max() / scale, 3e-6, "gpu_parity:random_conv")
+        pool.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_recurrent_stacks(seed, tmp_path, monkeypatch):
+    """Stacked / wide recurrent models drawn at random — LSTM or GRU, 2..4 layers or one layer wider than the table,
+    widths that are multiples of four but not of sixteen too (they run zero-padded on the matrix cores), 1..3 inputs,
+    skip and gains — on the matrix-core kernel the pool picks and on the VALU kernel against the oracle, with PARAM
+    moves and ragged blocks."""
+    rs = np.random.RandomState(700 + seed)
+    kind = str(rs.choice(["lstm", "gru"]))
+    n_rnn = int(rs.choice([1, 2, 2, 3, 4]))
+    hidden = int(rs.choice([84, 96, 100, 112, 128])) if n_rnn == 1 else int(rs.choice([8, 12, 20, 24, 36, 44, 48, 64, 72, 96]))
+    I = int(rs.randint(1, 4))
+    j = modelgen.make_model(kind, hidden, I, seed=70 + seed, n_rnn=n_rnn, in_skip=int(rs.randint(2)),
+                            in_gain=float(rs.uniform(-2, 2)), out_gain=float(rs.uniform(-2, 2)))
+    path = modelgen.write_model(j, str(tmp_path / f"rs{seed}.json"))
+    spec = O.parse_model(j)
+    S = int(rs.choice([3, 17, 40]))
+    sizes = [256, 37, 0, 1, 200, 256]
+    x = modelgen.signal(S, sum(sizes), seed=500 + seed)
+    names = []
+    for env in ({}, {"AIDAX_KERNEL": "valu"}):
+        monkeypatch.delenv("AIDAX_KERNEL", raising=False)
+        for k_, v in env.items():
+            monkeypatch.setenv(k_, v)
+        pool = ax.Pool(S, 256)
+        pool.set_model(ax.Model(path))
+        names.append(pool.kernel_name)
+        plugs = [O.OraclePlugin() for _ in range(S)]
+        for p_ in plugs:
+            p_.set_model(O.OracleModel(spec))
+        worst, pos = 0.0, 0
+        for bi, n in enumerate(sizes):
+            kw = dict(param1=0.2 + 0.1 * bi, param2=0.9 - 0.15 * bi, pregain_db=1.0)
+            pool.set_controls(ax.default_controls(**kw))
+            got = pool.process(np.ascontiguousarray(x[:, pos:pos + n]))
+            for s_ in range(S):
+                want = plugs[s_].run(O.default_controls(**kw), x[s_, pos:pos + n])
+                if n:
+                    worst = max(worst, float(np.abs(got[s_] - want).max()) / max(1.0, float(np.abs(want).max())))
+            pos += n
+        errlog.bound(worst, 3e-6, "gpu_parity:random_stack")
+        pool.close()
+    assert names[0] != names[1], names
+
+
 def test_conv_stack_on_a_pool_with_long_blocks(tmp_path):
     """The matrix-core conv kernel carries 256 frames per launch; a pool created for longer host blocks sends a block
     through in time slices, each the whole run() of its slice (rows keep the block's pitch). Ragged long blocks against

@@ -225,3 +225,35 @@ def test_extension_fallback_kernels_for_long_blocks(kw, max_frames, kernel, tmp_
             want[s, pos:pos + n] = plugs[s].run(O.default_controls(), x[s, pos:pos + n])
         pos += n
     errlog.bound(np.abs(got - want).max(), 1e-6, "gpu_edges:224")
+
+
+def test_muted_tail_runs_through_the_denormals_bit_for_bit():
+    """A plugin that is muted (loading: master target 0) lets its master gain decay exponentially — through the fp32
+    denormal range, which the CPU reference (no -ffast-math, no flush-to-zero) keeps. 150 000 samples: a quarter of a
+    million denormal output samples, every block bit-identical to the oracle."""
+    import importlib
+    ax = importlib.import_module("aidadsp-lv2_amd")
+    S, n, blocks = 3, 256, 600
+    pool = ax.Pool(S, n)
+    pool.set_controls(ax.default_controls(master_db=6.0))
+    pool.activate()
+    plugs = [O.OraclePlugin() for _ in range(S)]
+    for p in plugs:
+        p.activate()
+    x = modelgen.signal(S, n * blocks, seed=3)
+    tiny = 0
+    for b in range(blocks):
+        blk = np.ascontiguousarray(x[:, b * n:(b + 1) * n])
+        if b == 2:                                    # the master ramp comes up ...
+            for p in plugs:
+                p.set_loading(False)
+            pool.set_loading(False)
+        if b == 40:                                   # ... and decays towards zero for the rest of the run
+            for p in plugs:
+                p.set_loading(True)
+            pool.set_loading(True)
+        got = pool.process(blk)
+        want = np.stack([plugs[s].run(O.default_controls(master_db=6.0), blk[s]) for s in range(S)])
+        tiny += int(((np.abs(want) > 0) & (np.abs(want) < 1.2e-38)).sum())
+        assert np.array_equal(got, want), b
+    assert tiny > 100000

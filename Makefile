@@ -33,13 +33,19 @@ $(OBJDIR)/%.o: $(SRC)/%.cpp $(HDRS)
 	@mkdir -p $(OBJDIR)
 	$(CXX) $(CXXFLAGS) -I$(ROCM)/include -D__HIP_PLATFORM_AMD__ -c $< -o $@
 
+# every kernel's register / scratch report is kept next to its object; the library is linked only after
+# tools/check_scratch.py has found no kernel with ScratchSize > 0
 $(OBJDIR)/%.o: $(SRC)/%.hip $(HDRS)
 	@mkdir -p $(OBJDIR)
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(@:.o=.remarks) || (cat $(@:.o=.remarks); exit 1)
 
-$(LIBDIR)/libaidax_hip.so: $(HOST_OBJS) $(KERN_OBJS)
+$(OBJDIR)/scratch.ok: $(KERN_OBJS) tools/check_scratch.py
+	python3 tools/check_scratch.py $(KERN_OBJS:.o=.remarks)
+	@touch $@
+
+$(LIBDIR)/libaidax_hip.so: $(HOST_OBJS) $(KERN_OBJS) $(OBJDIR)/scratch.ok
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $^
+	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(HOST_OBJS) $(KERN_OBJS)
 
 # The LV2 plugin shell (no lib prefix, like the reference's binary: rt-neural-generic/CMakeLists.txt:47)
 $(LV2SO): $(PKG)/lv2/rt_neural_generic_lv2.cpp $(PKG)/lv2/lv2_min.h include/aidax.h $(LIBDIR)/libaidax_hip.so
@@ -50,6 +56,15 @@ $(LV2SO): $(PKG)/lv2/rt_neural_generic_lv2.cpp $(PKG)/lv2/lv2_min.h include/aida
 bundle: $(LIBDIR)/libaidax_hip.so
 	python3 tools/make_bundle.py --out build
 
+# The host-only sources (json parser + loader, packers, control-rate DSP) under ASan + UBSan, driven by
+# tests/asan_harness.cpp over a corpus of model files (tests/test_asan.py). CPU only: never built or run on the GPU box.
+ASAN_SRCS := tests/asan_harness.cpp $(SRC)/aidax_model.cpp $(SRC)/aidax_pack.cpp $(SRC)/aidax_dsp_host.cpp
+build/asan/asan_harness: $(ASAN_SRCS) $(HDRS) $(SRC)/json_min.h
+	@mkdir -p build/asan
+	$(CXX) -O1 -g -std=c++17 -ffp-contract=off -fno-omit-frame-pointer -fsanitize=address,undefined -fno-sanitize-recover=undefined \
+	    -Wall -Wextra -Iinclude $(ASAN_SRCS) -o $@
+asan: build/asan/asan_harness
+
 oracle:
 	$(MAKE) -s -C oracle all
 	$(MAKE) -s -C oracle _ref
@@ -58,4 +73,4 @@ clean:
 	rm -rf build $(LIBDIR) $(LV2SO)
 	$(MAKE) -s -C oracle clean
 
-.PHONY: all oracle bundle clean
+.PHONY: all oracle bundle clean asan

@@ -119,6 +119,8 @@ def lib() -> C.CDLL:
     L.aidax_hub_latency_frames.restype = u32
     L.aidax_hub_attached.argtypes = [vp]
     L.aidax_hub_attached.restype = u32
+    L.aidax_hub_max_frames.argtypes = [vp]
+    L.aidax_hub_max_frames.restype = u32
     L.aidax_hub_launches.argtypes = [vp]
     L.aidax_hub_launches.restype = C.c_uint64
     L.aidax_hub_deadline_launches.argtypes = [vp]

@@ -51,6 +51,8 @@ struct aidax_hub {
     uint32_t hi_slot = 0;                        // rows [0, hi_slot) can be attached: what a pass moves and launches
     uint32_t latency = 0;
     uint64_t launches = 0, deadline_launches = 0;
+    uint64_t clean_upto = 0;                     // passes up to this id are known to carry no k_mfma_lp give-up
+    uint64_t bad_from = 1, bad_upto = 0;         // passes in [bad_from, bad_upto] may: their rows are delivered as silence
     int last_error = AIDAX_OK;
     float* h_in[kHubBuffers] = {};               // pinned staging, rows packed at the period's block length
     float* h_out[kHubBuffers] = {};
@@ -332,6 +334,8 @@ AIDAX_API int aidax_hub_run(aidax_hub* h, int32_t slot, const float* in, float* 
     if (n_frames != 0 && (!in || !out)) return fail(AIDAX_ERR_ARG, "null buffer");
     const float* prev_row = nullptr;
     hipEvent_t prev_done = nullptr;
+    uint64_t prev_pass = 0;
+    int prev_buf = 0;
     bool wake = false;
     {
         std::lock_guard<std::mutex> g(h->mu);
@@ -364,18 +368,35 @@ AIDAX_API int aidax_hub_run(aidax_hub* h, int32_t slot, const float* in, float* 
         if (n_frames != 0 && lp != 0 && pb != h->cur && h->pass_id[pb] == lp && h->out_frames[pb] == n_frames) {
             prev_row = h->h_out[pb] + static_cast<size_t>(slot) * n_frames;
             prev_done = h->done[pb];
+            prev_pass = lp;
+            prev_buf = pb;
         }
         if (h->n_submitted == h->n_attached) { h->flush_requested = true; wake = true; }
     }
     if (wake) h->cv.notify_one();
     // the previous period's output for this instance; its pass was launched a period ago
     if (n_frames != 0) {
+        bool delivered = false, lp_fault = false;
         if (prev_row) {
             if (hipEventQuery(prev_done) != hipSuccess) HUB_TRY(hipEventSynchronize(prev_done));
-            std::memcpy(out, prev_row, sizeof(float) * n_frames);
-        } else {
-            std::memset(out, 0, sizeof(float) * n_frames);
+            // The row is copied under the mutex, after checking that the buffer still holds that pass: while this thread
+            // waited, further periods may have closed (deadline, another instance's block size, set_controls, detach),
+            // and the pass kHubBuffers later is copied into this very buffer — a row read without the check could be
+            // half of each. (A thousand floats under the lock: a fraction of a microsecond.)
+            std::lock_guard<std::mutex> g(h->mu);
+            if (pool_take_lp_fault(h->pool)) {              // some pass in (clean_upto, launches] gave up a layer hand-over
+                h->bad_from = h->clean_upto + 1;
+                h->bad_upto = h->launches;
+            }
+            lp_fault = prev_pass >= h->bad_from && prev_pass <= h->bad_upto;
+            if (!lp_fault && prev_pass > h->clean_upto) h->clean_upto = prev_pass;     // its event has passed and nothing was reported
+            if (!lp_fault && h->pass_id[prev_buf] == prev_pass) {
+                std::memcpy(out, prev_row, sizeof(float) * n_frames);
+                delivered = true;
+            }
         }
+        if (!delivered) std::memset(out, 0, sizeof(float) * n_frames);
+        if (lp_fault) return fail(AIDAX_ERR_DEVICE, "hub: k_mfma_lp gave up a layer hand-over in the pass of this block (silence; the pool falls back to k_mfma)");
     }
     return AIDAX_OK;
 }
@@ -388,6 +409,7 @@ AIDAX_API int aidax_hub_flush(aidax_hub* h)
 }
 
 AIDAX_API uint32_t aidax_hub_latency_frames(const aidax_hub* h) { return hub_read<uint32_t>(h, [](aidax_hub& x) { return x.latency; }); }
+AIDAX_API uint32_t aidax_hub_max_frames(const aidax_hub* h) { return h ? h->max_frames : 0; }
 AIDAX_API uint32_t aidax_hub_attached(const aidax_hub* h) { return hub_read<uint32_t>(h, [](aidax_hub& x) { return x.n_attached; }); }
 AIDAX_API uint64_t aidax_hub_launches(const aidax_hub* h) { return hub_read<uint64_t>(h, [](aidax_hub& x) { return x.launches; }); }
 AIDAX_API uint64_t aidax_hub_deadline_launches(const aidax_hub* h) { return hub_read<uint64_t>(h, [](aidax_hub& x) { return x.deadline_launches; }); }

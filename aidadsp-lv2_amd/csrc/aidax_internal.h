@@ -54,6 +54,10 @@ int pool_process_prefix(aidax_pool* p, const float* d_in, float* d_out, uint32_t
 // park / unpark a stream (behaves disabled while parked; its controls stay what they are) — aidax_pool.cpp, used by the hub
 int pool_park_stream(aidax_pool* p, uint32_t stream, bool parked);
 
+// k_mfma_lp fault report of a pool (aidax_pool.cpp): true once per give-up; the pool then serves its model with k_mfma
+bool pool_take_lp_fault(aidax_pool* p);
+bool pool_lp_in_use(const aidax_pool* p);
+
 // weight packing (aidax_pack.cpp)
 std::vector<float> pack_weights(const aidax_model& m);
 // extension architectures: flat weight buffer + descriptor + per-stream state size (floats)

@@ -38,8 +38,8 @@ bool mfma_lp_serves(const MfmaDesc& d);
 size_t mfma_lp_lds_bytes(const MfmaDesc& d, uint32_t n_frames);
 size_t mfma_lp_ring_bytes(const MfmaDesc& d, uint32_t n_streams);
 size_t mfma_lp_counter_bytes(const MfmaDesc& d, uint32_t n_streams);
-size_t mfma_lp_error_offset(const MfmaDesc& d, uint32_t n_streams);      // uint32 index of the "a spin gave up" word in the counters
-hipError_t launch_mfma_lp_kernel(const LaunchArgs& a, const MfmaDesc& d, float* ring, uint32_t* counters, uint32_t pool_streams, hipStream_t stream);
+// `fault`: device view of a word in pinned host memory that a workgroup bumps when a hand-over wait timed out
+hipError_t launch_mfma_lp_kernel(const LaunchArgs& a, const MfmaDesc& d, float* ring, uint32_t* counters, uint32_t* fault, hipStream_t stream);
 size_t quad_lds_bytes(int hidden, uint32_t n_frames);
 hipError_t launch_quad_kernel(int cell, int hidden, const LaunchArgs& a, const QuadDesc& qd, hipStream_t stream);
 hipError_t launch_stack_kernel(const LaunchArgs& a, const StackDesc& d, hipStream_t stream);

@@ -1011,16 +1011,20 @@ __global__ void k_init_streams(StreamState* st, uint32_t n)
 }
 
 // work() reads the PARAM targets of the playing model (:822-825) for the model it is about to build. `live` is
-// being written by the audio side's passes while this runs on the worker's stream: a 4-byte read of a value
-// that only moves when a port moves, the same unsynchronised read the reference does.
+// being written by the audio side's passes while this runs on the worker's stream — the reference's worker reads
+// the audio thread's smoothers just as unsynchronised. Each target is ONE relaxed device-scope 4-byte load (served by
+// L2, never a torn or cached value): it is the target some run() before or during the prepare has set, which is all the
+// reference promises; the first run() after the swap sets the targets from the ports again and snaps (:634-640).
 __global__ void k_stage_params(const StreamState* live, StreamState* staged, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    StreamState s{};
-    s.p_tgt[0] = live[i].p_tgt[0];
-    s.p_tgt[1] = live[i].p_tgt[1];
-    staged[i] = s;
+    const float t0 = __hip_atomic_load(&live[i].p_tgt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float t1 = __hip_atomic_load(&live[i].p_tgt[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t* w = reinterpret_cast<uint32_t*>(&staged[i]);                  // an all-zero record but for the two targets
+    for (uint32_t k = 0; k < sizeof(StreamState) / 4; ++k) w[k] = 0u;
+    staged[i].p_tgt[0] = t0;
+    staged[i].p_tgt[1] = t1;
 }
 
 // work_response(): the per-stream members of the new DynamicModel (PARAM smoothers as prepared and warmed up,

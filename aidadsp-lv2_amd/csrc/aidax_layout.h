@@ -212,8 +212,8 @@ struct LaunchArgs {
     int32_t          input_skip;
     float            in_gain, out_gain;
     int32_t          tune;        // AIDAX_TUNE bit mask, measurement / test switches of the kernels (0 in production):
-                                  // 1 = no issue priority for the recurrent wave of k_*_pipe, 2 = k_mfma_lp with a group's layers on adjacent workgroup ids
-    uint32_t         ring_groups; // k_mfma_lp: stream groups the pool's ring / counter buffers were sized for
+                                  // 1 = no issue priority for the recurrent wave of k_*_pipe, 2 = k_mfma_lp with a group's layers on adjacent workgroup ids,
+                                  // 16 = k_mfma_lp reports a hand-over give-up that did not happen (tests of the fault path)
     uint32_t         row_stride;  // k_conv_mfma: frames between two streams' rows in `in` / `out` when a launch carries a
                                   // time slice of a longer block (0: rows are n_frames apart)
 };

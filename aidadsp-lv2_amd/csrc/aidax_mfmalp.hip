@@ -22,7 +22,9 @@
 // fits per CU), so EVERY workgroup of the grid becomes resident whatever the dispatch order, and a spinning consumer
 // can never keep its producer off the machine. (Forced on larger pools with AIDAX_MFMA_LP=1 — measurements only —
 // it leans on the dispatcher's observed id order: a layer's workgroup has a LOWER id than the layer above it, ids of
-// one group are 8 apart.) Every spin is bounded. Nothing depends on placement: ids of one group being equal modulo
+// one group are 8 apart.) Every spin is bounded in time. The premise also needs the grid to have the CUs to itself: the
+// pool lets ONE pool per device use this kernel, warms models up with k_mfma and never puts two of these grids in flight
+// (aidax_pool.cpp, lp_gate); what it cannot see (another process on the GPU) ends in a reported give-up. Nothing depends on placement: ids of one group being equal modulo
 // 8 puts them on one XCD under the observed b % 8 placement, a locality hint only.
 //
 // Same arithmetic as k_mfma (same fragments from pack_mfma, same accumulation order, same activations): the two
@@ -39,8 +41,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kLpChunk = 256;            // frames of audio staged in LDS at a time
 constexpr int kLpRing = 32;              // frames of h in flight between two layers
 constexpr int kLpBatch = 8;              // frames per counter update (a release costs ~2-6 us, an acquire ~1.7 us: MI355X_MICROARCH.md)
-constexpr uint32_t kLpSpinLimit = 1u << 20;   // polls before a waiting workgroup gives up (~1 s): a launch must end even if
-                                              // its partner never ran; the result is then wrong and the error word says so
+// A waiting workgroup gives up after kLpGiveUpTicks of the 100 MHz wall clock (250 ms: far beyond any wait that co-tenant
+// kernels can cause while the partner still gets a CU — a launch must end even if its partner never runs). The pass is then
+// wrong; the workgroup says so in the pool's fault word (pinned host memory), the pool reports AIDAX_ERR_DEVICE for it
+// and serves the model with k_mfma from then on (aidax_pool.cpp).
+constexpr uint64_t kLpGiveUpTicks = 25000000ull;
+__device__ __forceinline__ bool lp_timed_out(uint32_t& spins, uint64_t& t0)
+{
+    if (spins++ == 0) { t0 = wall_clock64(); return false; }
+    return (spins & 63u) == 0 && wall_clock64() - t0 > kLpGiveUpTicks;
+}
 
 __host__ __device__ inline size_t lp_lds_floats(int hidden, int n_frames)
 {
@@ -52,6 +62,7 @@ __host__ __device__ inline size_t lp_lds_floats(int hidden, int n_frames)
          + (size_t)hidden * kMfmaStreams                      /* cT[unit][n]                             */
          + (size_t)((hidden + 1 + 3) & ~3)                    /* Dense weights + bias (last layer)       */
          + kMfmaStreams                                       /* live flags                              */
+         + (size_t)4 * hidden                                 /* this layer's bias rows                  */
          + 2 * 8 * kMfmaStreams;                              /* Dense partial sums [parity][wave][n]    */
 }
 
@@ -68,10 +79,6 @@ __host__ __device__ constexpr size_t lp_ring_floats(int hidden, int waves, int m
 // (Only with eight waves: four waves sit on a SIMD each, and an uneven split would just make the slowest wave slower.)
 __host__ __device__ constexpr int lp_moved_tiles(int n_layers, int tpw, int nw) { return n_layers != 2 ? 0 : (nw == 8 && tpw == 3) ? 2 : tpw >= 2 ? 1 : 0; }
 constexpr int kLpCounterStride = 32;     // uint32 per (group, boundary): produced at [0], consumed at [16] (own cache lines)
-
-// the error word sits behind the counters of ALL the pool's groups; a one-stream view of the pool (reset_stream)
-// launches with a.n_streams == 1, so the pool's group count comes in separately (LaunchArgs::ring_groups)
-__device__ __forceinline__ int n_groups_alloc(const LaunchArgs& a, const MfmaDesc&) { return (int)a.ring_groups; }
 
 // 16-byte device-scope (sc0 sc1) accesses: write-through stores / L1-bypassing loads. Buffer instructions, so the
 // compiler keeps track of their completion (vmcnt) like of any other load.
@@ -138,11 +145,14 @@ __device__ __forceinline__ void lp_gates(f32x4 (&acc)[NACC], const f32x4 (&wres)
     }
 }
 
-// M: tiles per wave of the layer above whose input half the first layer computes (lp_moved_tiles; two-layer models)
-template <int TPW, int NW, int M>
-__global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d, float* ring, uint32_t* counters)
+// M: tiles per wave of the layer above whose input half the first layer computes (lp_moved_tiles; two-layer models).
+// FIRST / LAST: the role of this workgroup's layer, a compile-time constant of the body — the kernel branches once on the
+// layer index, so each role's registers are allocated for that role only (the first layer carries no fetched tiles, no
+// Dense fragments; the others no started-tile accumulators): LSTM-96 x2 fits its 256 registers without scratch.
+template <int TPW, int NW, int M, bool FIRST, bool LAST>
+__device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, float* ring, uint32_t* counters, uint32_t* fault,
+                                        float* smem, int grp, int l)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int H = 4 * TPW * NW;
     constexpr int NT = NW * kWave;
     constexpr int NS = kMfmaStreams;
@@ -159,16 +169,8 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
     const int Ht = d.hidden_true;
     const int I = a.input_size;
     const int mode = a.mode;
-    // workgroup id -> (group, layer): ids of one group are 8 apart, lower layers first
-    // (AIDAX_TUNE bit 2 lays a group's layers out on ADJACENT ids instead — different XCDs under b % 8 — so that the
-    // tests can exercise the cross-XCD hand-over too.)
     const int blk = (int)blockIdx.x;
-    const bool adjacent = (a.tune & 2) != 0;
-    const int grp = adjacent ? blk / NL : (blk / (8 * NL)) * 8 + (blk & 7);
-    const int l = adjacent ? blk % NL : (blk / 8) % NL;
-    const int n_groups = ((int)a.n_streams + NS - 1) / NS;
-    if (grp >= n_groups) return;
-    const bool first = l == 0, last = l == NL - 1;
+    constexpr bool first = FIRST, last = LAST;
     const int s_base = grp * NS;
     const int chunk = n < kLpChunk ? n : kLpChunk;
     const int nP = (chunk + 3) & ~3;
@@ -181,6 +183,7 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
     float* wdl   = cT + H * NS;                            // Dense weights, bias at [H]
     float* livef = wdl + ((H + 1 + 3) & ~3);               // [NS]
     float* dpart = livef + NS;                             // [2][NW][NS] Dense partial sums of the waves (last layer)
+    float* biasl = dpart + 2 * 8 * NS;                     // [4H] this layer's bias rows, as the accumulators take them
 
     const float* W = a.wpack;
     const MfmaLayer& L = d.L[l];
@@ -233,11 +236,10 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
         cT[i] = (valid && u < Ht && L.cell == 0) ? stp[Ht + u] : 0.f;
     }
 
-    // ---- this layer's bias rows (the accumulators start from them) and A fragments, resident for the launch
-    f32x4 bias_r[TPW];
-#pragma unroll
-    for (int tl = 0; tl < TPW; ++tl)
-        bias_r[tl] = *reinterpret_cast<const f32x4*>(W + L.b_off + 4 * (4 * (wave * TPW + tl) + (lane >> 4)));
+    // ---- this layer's bias rows (the accumulators start from them): parked in LDS and read back at the top of every
+    // tick — 4 TPW registers that the resident fragments need more (LSTM-96 x2: 256 registers, nothing spilled)
+    for (int i = tid; i < 4 * H; i += NT) biasl[i] = W[L.b_off + i];
+    const f32x4* bias_v = reinterpret_cast<const f32x4*>(biasl) + 4 * wave * TPW + (lane >> 4);
     // One register set, two uses that exclude each other: on the first layer the bias rows the moved tiles start from
     // (the upper layer's), on the others the started tiles of the NEXT frame on their way in from the ring.
     f32x4 upx[MA];
@@ -285,7 +287,8 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
     const __amdgpu_buffer_rsrc_t rs_in = lp_rsrc(first ? ring : ring_in, ring_bytes);
     uint32_t* cnt_out = last ? nullptr : counters + ((size_t)grp * (NL - 1) + l) * kLpCounterStride;
     uint32_t* cnt_in = first ? nullptr : counters + ((size_t)grp * (NL - 1) + (l - 1)) * kLpCounterStride;
-    uint32_t* counters_err = counters + (size_t)n_groups_alloc(a, d) * (NL - 1) * kLpCounterStride;   // spins that gave up
+    auto give_up = [&]() { __hip_atomic_fetch_add(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+    if ((a.tune & 16) && blk == 0 && tid == 0) give_up();      // test hook: report a give-up that did not happen
     // every thread needs the bases (they place a frame in the ring); the running counts are thread 0's business
     const uint32_t base_out = cnt_out ? __hip_atomic_load(cnt_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     const uint32_t base_in = cnt_in ? __hip_atomic_load(cnt_in + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
@@ -365,10 +368,11 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
         auto wait_below = [&](int frames_needed) {        // thread 0 only: until `frames_needed` frames of the launch exist
             if (frames_needed > n) frames_needed = n;
             uint32_t spins = 0;
+            uint64_t t0 = 0;
             while ((int)known_below < frames_needed) {
                 known_below = __hip_atomic_load(cnt_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base_in;
                 if ((int)known_below < frames_needed) {
-                    if (++spins > kLpSpinLimit) { __hip_atomic_fetch_add(counters_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); known_below = (uint32_t)n; break; }
+                    if (lp_timed_out(spins, t0)) { give_up(); known_below = (uint32_t)n; break; }
                     __builtin_amdgcn_s_sleep(8);
                 }
             }
@@ -429,11 +433,12 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
                 if (!first && tick + 2 < cnt) wait_below(F + 3);
                 if (!last && base + tick + 1 < n) {
                     uint32_t spins = 0;
+                    uint64_t t0 = 0;
                     while ((int)known_free < F + 2) {
                         const uint32_t consumed = __hip_atomic_load(cnt_out + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base_out;
                         known_free = consumed + kLpRing;
                         if ((int)known_free < F + 2) {
-                            if (++spins > kLpSpinLimit) { __hip_atomic_fetch_add(counters_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); known_free = (uint32_t)n + kLpRing; break; }
+                            if (lp_timed_out(spins, t0)) { give_up(); known_free = (uint32_t)n + kLpRing; break; }
                             __builtin_amdgcn_s_sleep(8);
                         }
                     }
@@ -466,7 +471,7 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
                 float* h_wr = hT + wr * H * NS;
                 f32x4 acc[TPW];
 #pragma unroll
-                for (int tl = 0; tl < TPW; ++tl) acc[tl] = bias_r[tl];
+                for (int tl = 0; tl < TPW; ++tl) acc[tl] = bias_v[4 * tl];
                 if (!last && F >= 1) ship_frame(h_rd, F - 1);          // h_rd = h(F-1)
                 if (first) {                               // the model inputs: one k-step (x, PARAM1, PARAM2, 0)
                     const float b = xin[(tick & 1) * 64 + lane];
@@ -570,8 +575,27 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
     }
 }
 
+template <int TPW, int NW, int M>
+__global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d, float* ring, uint32_t* counters, uint32_t* fault)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // workgroup id -> (group, layer): ids of one group are 8 apart, lower layers first
+    // (AIDAX_TUNE bit 2 lays a group's layers out on ADJACENT ids instead — different XCDs under b % 8 — so that the
+    // tests can exercise the cross-XCD hand-over too.)
+    const int NL = d.n_layers;
+    const int blk = (int)blockIdx.x;
+    const bool adjacent = (a.tune & 2) != 0;
+    const int grp = adjacent ? blk / NL : (blk / (8 * NL)) * 8 + (blk & 7);
+    const int l = adjacent ? blk % NL : (blk / 8) % NL;
+    const int n_groups = ((int)a.n_streams + kMfmaStreams - 1) / kMfmaStreams;
+    if (grp >= n_groups) return;
+    if (l == 0) lp_body<TPW, NW, M, true, false>(a, d, ring, counters, fault, smem, grp, l);
+    else if (l == NL - 1) lp_body<TPW, NW, M, false, true>(a, d, ring, counters, fault, smem, grp, l);
+    else lp_body<TPW, NW, M, false, false>(a, d, ring, counters, fault, smem, grp, l);
+}
+
 // ---------------------------------------------------------------- host side
-typedef void (*LpFn)(LaunchArgs, MfmaDesc, float*, uint32_t*);
+typedef void (*LpFn)(LaunchArgs, MfmaDesc, float*, uint32_t*, uint32_t*);
 static LpFn lp_fn(int hidden, int n_layers)
 {
     switch (hidden) {
@@ -594,19 +618,13 @@ size_t mfma_lp_ring_bytes(const MfmaDesc& d, uint32_t n_streams)
 size_t mfma_lp_counter_bytes(const MfmaDesc& d, uint32_t n_streams)
 {
     const size_t groups = (n_streams + kMfmaStreams - 1) / kMfmaStreams;
-    return (groups * (size_t)(d.n_layers - 1) + 1) * kLpCounterStride * sizeof(uint32_t);      // + the error word
-}
-size_t mfma_lp_error_offset(const MfmaDesc& d, uint32_t n_streams)
-{
-    return mfma_lp_counter_bytes(d, n_streams) / sizeof(uint32_t) - kLpCounterStride;
+    return groups * (size_t)(d.n_layers - 1) * kLpCounterStride * sizeof(uint32_t);
 }
 
-hipError_t launch_mfma_lp_kernel(const LaunchArgs& a0, const MfmaDesc& d, float* ring, uint32_t* counters, uint32_t pool_streams, hipStream_t stream)
+hipError_t launch_mfma_lp_kernel(const LaunchArgs& a, const MfmaDesc& d, float* ring, uint32_t* counters, uint32_t* fault, hipStream_t stream)
 {
-    LaunchArgs a = a0;
-    a.ring_groups = (pool_streams + kMfmaStreams - 1) / kMfmaStreams;
     LpFn fn = lp_fn(d.hidden, d.n_layers);
-    if (!fn || !ring || !counters) return hipErrorInvalidValue;
+    if (!fn || !ring || !counters || !fault) return hipErrorInvalidValue;
     const size_t lds = mfma_lp_lds_bytes(d, a.n_frames);
     if (lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -614,7 +632,7 @@ hipError_t launch_mfma_lp_kernel(const LaunchArgs& a0, const MfmaDesc& d, float*
     }
     const uint32_t groups = (a.n_streams + kMfmaStreams - 1) / kMfmaStreams;
     const uint32_t blocks = ((groups + 7) / 8) * 8 * (uint32_t)d.n_layers;
-    hipLaunchKernelGGL(fn, dim3(blocks), dim3(mfma_waves(d.hidden) * kWave), lds, stream, a, d, ring, counters);
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(mfma_waves(d.hidden) * kWave), lds, stream, a, d, ring, counters, fault);
     return hipGetLastError();
 }
 

@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <sstream>
 
 #include "aidax_internal.h"
@@ -56,6 +57,33 @@ ManyForm many_streams_form(int cell, int hidden, uint32_t n)
     // faster already at 64 streams, k_mfma takes over from 4096
     return n >= 4096 ? MANY_MFMA : MANY_QUAD;
 }
+
+// k_mfma_lp needs every workgroup of its grid resident at once, which the pool can promise only for ONE grid on the
+// device: one pool per device holds the right to use the kernel (a pool's staged model shares its own pool's hold), the
+// others serve their stacked models with k_mfma. Process-wide; another process on the same GPU is beyond its reach
+// and ends in a reported give-up (aidax_mfmalp.hip).
+struct LpGate {
+    std::mutex mu;
+    struct Hold { const void* owner = nullptr; int refs = 0; } dev[64];
+    bool acquire(int device, const void* owner)
+    {
+        if (device < 0 || device >= 64) return false;
+        std::lock_guard<std::mutex> g(mu);
+        Hold& h = dev[device];
+        if (h.refs != 0 && h.owner != owner) return false;
+        h.owner = owner;
+        ++h.refs;
+        return true;
+    }
+    void release(int device, const void* owner)
+    {
+        if (device < 0 || device >= 64) return;
+        std::lock_guard<std::mutex> g(mu);
+        Hold& h = dev[device];
+        if (h.owner == owner && h.refs > 0 && --h.refs == 0) h.owner = nullptr;
+    }
+};
+LpGate& lp_gate() { static LpGate g; return g; }
 
 struct HipFail : std::runtime_error { using std::runtime_error::runtime_error; };
 
@@ -105,6 +133,7 @@ struct ModelSlot {
     float* d_nn = nullptr;           // recurrent state [n_streams][nn_stride]
     float* d_ring = nullptr;         // k_mfma_lp: h of layer l-1 on its way to layer l, per stream group
     uint32_t* d_counters = nullptr;  // k_mfma_lp: frames produced / consumed per (group, layer boundary)
+    const void* lp_owner = nullptr;  // the pool whose hold on the device's LpGate this slot shares (d_ring != nullptr)
 
     float p_den() const { return 0.1f * model_sr; }      // LinearValueSmoother tau * sampleRate (:1053-1054)
 };
@@ -152,6 +181,22 @@ struct aidax_pool {
     uint32_t* hd_done = nullptr;
     uint32_t done_seq = 0;
     bool spin_wait = false;
+    // k_mfma_lp: a word in pinned host memory that a workgroup bumps when a layer hand-over timed out. The pass that did
+    // so is wrong; whoever notices reports it, and the pool serves the model with k_mfma from then on (lp_off).
+    uint32_t* h_lp_fault = nullptr;
+    uint32_t* hd_lp_fault = nullptr;
+    std::atomic<bool> lp_off{false};
+    std::atomic<uint32_t> lp_faults{0};
+    bool take_lp_fault()
+    {
+        if (!h_lp_fault) return false;
+        volatile uint32_t* w = h_lp_fault;
+        if (*w == 0) return false;
+        *w = 0;
+        lp_off.store(true, std::memory_order_relaxed);
+        lp_faults.fetch_add(1, std::memory_order_relaxed);
+        return true;
+    }
 
     std::vector<aidax_controls> controls;
     std::vector<uint8_t> loading;
@@ -209,6 +254,8 @@ struct aidax_pool {
         default: return false;
         }
     }
+
+    bool lp_in_use(const ModelSlot& m) const { return m.d_ring != nullptr && !lp_off.load(std::memory_order_relaxed); }
 
     static size_t lds_bytes(const ModelSlot& m, uint32_t n_frames)
     {
@@ -291,14 +338,18 @@ struct aidax_pool {
     uint32_t ext_chunk() const { return max_frames < 256 ? max_frames : 256; }
     uint32_t launch_chunk(const ModelSlot& m, uint32_t n) const
     {
-        return (m.kind == ModelSlot::STACK || m.kind == ModelSlot::CONV) ? std::min(ext_chunk(), n) : n;
+        // (MFMA: k_mfma takes any length, but a 2048-frame warm-up launch would hold its CUs for ~10 ms next to the passes)
+        return (m.kind == ModelSlot::STACK || m.kind == ModelSlot::CONV || m.kind == ModelSlot::MFMA) ? std::min(ext_chunk(), n) : n;
     }
     hipError_t launch(const ModelSlot& m, const LaunchArgs& a, hipStream_t s) const
     {
         if (m.has_model && m.kind == ModelSlot::MFMA) {
             // split form around the matrix-core kernel: packed chains in -> out, applyModel in place, packed chains
+            // k_mfma_lp only for the passes themselves: warm-ups (worker stream, next to the passes) and the bare-model
+            // modes run on k_mfma, which leaves bit-identical state — two of those grids must never be in flight together
             auto model_kernel = [&]() {
-                return m.d_ring ? launch_mfma_lp_kernel(a, m.mdesc, m.d_ring, m.d_counters, n_streams, s) : launch_mfma_kernel(a, m.mdesc, s);
+                return lp_in_use(m) && a.mode == MODE_CHAIN ? launch_mfma_lp_kernel(a, m.mdesc, m.d_ring, m.d_counters, hd_lp_fault, s)
+                                                            : launch_mfma_kernel(a, m.mdesc, s);
             };
             if (a.mode != MODE_CHAIN) return model_kernel();
             hipError_t e = launch_chain_pass(true, a, s);
@@ -350,6 +401,9 @@ struct aidax_pool {
         if (cur.d_wpack) (void)hipFree(cur.d_wpack);
         if (cur.d_ring) (void)hipFree(cur.d_ring);
         if (cur.d_counters) (void)hipFree(cur.d_counters);
+        if (cur.lp_owner) { lp_gate().release(device, cur.lp_owner); cur.lp_owner = nullptr; }
+        if (h_lp_fault) (void)hipHostFree(h_lp_fault);
+        h_lp_fault = nullptr;
         if (h_done) (void)hipHostFree(h_done);
         if (d_in) (void)hipFree(d_in);
         if (d_out) (void)hipFree(d_out);
@@ -380,6 +434,7 @@ void staged_release(aidax_staged* s)
     if (s->slot.d_nn) (void)hipFree(s->slot.d_nn);
     if (s->slot.d_ring) (void)hipFree(s->slot.d_ring);
     if (s->slot.d_counters) (void)hipFree(s->slot.d_counters);
+    if (s->slot.lp_owner) lp_gate().release(s->device, s->slot.lp_owner);
     if (s->d_pst) (void)hipFree(s->d_pst);
     if (s->fence) (void)hipEventDestroy(s->fence);
     delete s;
@@ -461,8 +516,9 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p.device));
     const size_t lp_groups = (p.n_streams + kMfmaStreams - 1) / kMfmaStreams;
     const bool lp_pays = lp ? lp[0] != '0' : lp_groups * static_cast<size_t>(ms.mdesc.n_layers) <= static_cast<size_t>(cus);
-    if (ms.kind == ModelSlot::MFMA && mfma_lp_serves(ms.mdesc) && lp_pays &&
-        mfma_lp_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024) {
+    if (ms.kind == ModelSlot::MFMA && mfma_lp_serves(ms.mdesc) && lp_pays && !p.lp_off.load() &&
+        mfma_lp_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024 && lp_gate().acquire(p.device, &p)) {
+        ms.lp_owner = &p;
         HIP_TRY(hipMalloc(&ms.d_ring, mfma_lp_ring_bytes(ms.mdesc, p.n_streams)));
         HIP_TRY(hipMalloc(&ms.d_counters, mfma_lp_counter_bytes(ms.mdesc, p.n_streams)));
         HIP_TRY(hipMemsetAsync(ms.d_counters, 0, mfma_lp_counter_bytes(ms.mdesc, p.n_streams), p.wq));
@@ -520,6 +576,9 @@ int pool_process_prefix(aidax_pool* p, const float* d_in, float* d_out, uint32_t
         hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : p->q;
         p->enter_stream(s);
         p->flush_ctl(s);
+        // a give-up of an earlier pass that nobody has collected yet: no further k_mfma_lp launch (its counters are out
+        // of step); the word stays for whoever reports it (aidax_pool_sync, the hub)
+        if (p->h_lp_fault && *static_cast<volatile uint32_t*>(p->h_lp_fault) != 0) p->lp_off.store(true, std::memory_order_relaxed);
         LaunchArgs a = p->args(p->cur, p->d_st, d_in, d_out, n_frames, MODE_CHAIN);
         a.n_streams = n_active;
         HIP_TRY(p->launch(p->cur, a, s));
@@ -541,6 +600,11 @@ int pool_park_stream(aidax_pool* p, uint32_t s, bool parked)
     p->mark_dirty(s, s);
     return AIDAX_OK;
 }
+
+// Did a k_mfma_lp pass since the last call give up a hand-over (its output is wrong)? Clears the report and retires the
+// kernel for this pool. The hub asks after a pass's event has passed.
+bool pool_take_lp_fault(aidax_pool* p) { return p->take_lp_fault(); }
+bool pool_lp_in_use(const aidax_pool* p) { return p->cur.has_model && p->lp_in_use(p->cur); }
 
 }  // namespace aidax
 
@@ -569,8 +633,14 @@ AIDAX_API int aidax_pool_create(uint32_t n_streams, uint32_t max_frames, double 
         if (const char* t = std::getenv("AIDAX_TUNE")) p->tune = std::atoi(t);
         try {
             HIP_TRY(hipSetDevice(device_id));
-            HIP_TRY(hipStreamCreateWithFlags(&p->q, hipStreamNonBlocking));
-            HIP_TRY(hipStreamCreateWithFlags(&p->wq, hipStreamNonBlocking));
+            // the audio side's stream outranks the worker's: a pass must not queue behind a warm-up for its CUs
+            int prio_least = 0, prio_greatest = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+            HIP_TRY(hipStreamCreateWithPriority(&p->q, hipStreamNonBlocking, prio_greatest));
+            HIP_TRY(hipStreamCreateWithPriority(&p->wq, hipStreamNonBlocking, prio_least));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_lp_fault), 64, hipHostMallocDefault));
+            HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->hd_lp_fault), p->h_lp_fault, 0));
+            *p->h_lp_fault = 0;
             HIP_TRY(hipEventCreateWithFlags(&p->ev_x, hipEventDisableTiming));
             HIP_TRY(hipMalloc(&p->d_ctl, sizeof(StreamCtl) * n_streams));
             HIP_TRY(hipMalloc(&p->d_st, sizeof(StreamState) * n_streams));
@@ -757,6 +827,10 @@ AIDAX_API int aidax_pool_process(aidax_pool* p, const float* in, float* out, uin
             if (rc != AIDAX_OK) return rc;
             if (bytes) HIP_TRY(hipMemcpyAsync(out, p->d_out, bytes, hipMemcpyDeviceToHost, p->q));
             HIP_TRY(hipStreamSynchronize(p->q));
+            if (p->take_lp_fault()) {
+                if (bytes) std::memset(out, 0, bytes);
+                return fail(AIDAX_ERR_DEVICE, "k_mfma_lp: a layer hand-over timed out (this block is silence; the pool falls back to k_mfma)");
+            }
             return AIDAX_OK;
         }
         if (bytes) std::memcpy(p->h_in, in, bytes);
@@ -799,6 +873,10 @@ AIDAX_API int aidax_pool_process(aidax_pool* p, const float* in, float* out, uin
         } else {
             HIP_TRY(hipStreamSynchronize(p->q));
         }
+        if (p->take_lp_fault()) {                           // the pass is wrong: silence, and k_mfma from the next one on
+            if (bytes) std::memset(out, 0, bytes);
+            return fail(AIDAX_ERR_DEVICE, "k_mfma_lp: a layer hand-over timed out (this block is silence; the pool falls back to k_mfma)");
+        }
         if (bytes) std::memcpy(out, p->h_out, bytes);
         return AIDAX_OK;
     });
@@ -811,11 +889,8 @@ AIDAX_API int aidax_pool_sync(aidax_pool* p)
         HIP_TRY(hipSetDevice(p->device));
         if (p->last_stream && p->last_stream != p->q) HIP_TRY(hipStreamSynchronize(p->last_stream));
         HIP_TRY(hipStreamSynchronize(p->q));
-        if (p->cur.d_counters) {                           // k_mfma_lp: did a layer hand-over give up waiting?
-            uint32_t gave_up = 0;
-            HIP_TRY(hipMemcpy(&gave_up, p->cur.d_counters + mfma_lp_error_offset(p->cur.mdesc, p->n_streams), sizeof(gave_up), hipMemcpyDeviceToHost));
-            if (gave_up != 0) return fail(AIDAX_ERR_DEVICE, "k_mfma_lp: a layer hand-over timed out (results of that pass are invalid)");
-        }
+        // k_mfma_lp: did a layer hand-over of a pass since the last report give up waiting?
+        if (p->take_lp_fault()) return fail(AIDAX_ERR_DEVICE, "k_mfma_lp: a layer hand-over timed out (a pass since the last sync is invalid; the pool falls back to k_mfma)");
         return AIDAX_OK;
     });
 }
@@ -854,7 +929,7 @@ AIDAX_API const char* aidax_pool_kernel_name(const aidax_pool* p)
     if (!(p && p->cur.has_model)) return "k_nomodel";
     const ModelSlot& m = p->cur;
     if (m.kind == ModelSlot::STACK) return "k_stack";
-    if (m.kind == ModelSlot::MFMA) return m.d_ring ? "k_chain+k_mfma_lp" : "k_chain+k_mfma";
+    if (m.kind == ModelSlot::MFMA) return p->lp_in_use(m) ? "k_chain+k_mfma_lp" : "k_chain+k_mfma";
     if (m.kind == ModelSlot::QUAD) return "k_chain+k_quad";
     if (m.kind == ModelSlot::CONV) return m.conv_fused ? "k_conv_mfma" : m.conv_mfma ? "k_chain+k_conv_mfma" : "k_conv";
     const int form = p->chain_form(m);

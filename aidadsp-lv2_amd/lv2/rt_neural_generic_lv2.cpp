@@ -411,7 +411,18 @@ void run(LV2_Handle instance, uint32_t n_samples)
             done += cnt;
         } while (rc == AIDAX_OK && done < n_samples);
     } else if (self->hub) {
-        rc = aidax_hub_run(self->hub, self->slot, self->in, self->out_1, n_samples);
+        // A host block longer than the hub's blocks (offline renders: 4096, 8192 frames) goes through in slices; coming
+        // around again closes the period per slice, so each slice returns the result of the slice before it. Equal
+        // slices where the length divides (the hub hands a block's result back only for a block of the same length).
+        const uint32_t cap = aidax_hub_max_frames(self->hub);
+        if (n_samples <= cap || cap == 0) {
+            rc = aidax_hub_run(self->hub, self->slot, self->in, self->out_1, n_samples);
+        } else {
+            const uint32_t k = (n_samples + cap - 1) / cap;
+            const uint32_t slice = n_samples % k == 0 ? n_samples / k : cap;
+            for (uint32_t done = 0; done < n_samples && rc == AIDAX_OK; done += slice)
+                rc = aidax_hub_run(self->hub, self->slot, self->in + done, self->out_1 + done, std::min(slice, n_samples - done));
+        }
     } else if (n_samples != 0) {
         // hub mode before the first model: the master gain rests at 0 (:306-310), a disabled plugin copies (:612-619)
         if (self->last_controls.enabled > 0.5f) std::memset(self->out_1, 0, sizeof(float) * n_samples);

@@ -22,12 +22,17 @@ Prints ONE json line (rank 0) with the driver's contract keys plus
                     SURVEY §8(d)) over the average launch duration measured with HIP events on the launch stream
   roofline_compute  the same pass against the fp32 peak from ALGORITHMIC flops — the roofline
                     that actually binds this path (1064 flop/B against a machine balance of ~20)
-  other_workloads   short timed regions of the other single-GPU BASELINE configs (cfg3, cfg4, cfg5 at their
-                    per-GPU sizes) in the same process, each with its rooflines and max-abs error (N = 1 only)
+  other_workloads   short timed regions of the other BASELINE configs at their per-GPU sizes in the same process,
+                    each with its rooflines, max-abs error and its own cpu_baseline (N = 1: cfg3, cfg4, cfg5; N > 1:
+                    cfg4 and cfg5 — BASELINE's 8-GPU workloads — on every rank, reduced like the headline)
+  ranks             world size, collective backend and every rank's own elapsed time of the headline region
   realtime_case     the LV2 case of SURVEY §8(d): ONE stream, 256-frame blocks — wall time per
                     aidax_pool_process call (pinned staging + launch + wait) next to the CPU oracle on one thread
   cpu_baseline      the CPU oracle (a port, not RTNeural) timed on this host's cores on a bounded sample of
                     the same workload (N=1, rank 0 only)
+  roofline.traffic  HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE: two child runs of this
+                    script under the profiler, N = 1 only); when the profiler is not usable, the committed profile of
+                    the same kernel sources (hash-checked), else null
 """
 import argparse
 import importlib
@@ -141,20 +146,88 @@ def usable_cores() -> int:
     return n
 
 
+def kernel_sources_sha16() -> str:
+    """Hash of everything the device code is built from (csrc/*.hip, csrc/*.h, the Makefile's flags): a committed
+    counter profile describes the benchmarked kernel only if it was taken on the same sources."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "aidadsp-lv2_amd", "csrc")
+    for fn in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.h")) + [os.path.join(ROOT, "Makefile")]):
+        h.update(os.path.basename(fn).encode())
+        h.update(open(fn, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def lib_sha16(ax) -> str:
+    import hashlib
+    return hashlib.sha256(open(ax.lib_path(), "rb").read()).hexdigest()[:16]
+
+
+def _kernel_matches(kernel_name: str, text: str) -> bool:
+    """`k_lstm_pipe<32>` against a (possibly namespaced, templated) kernel name of a profile"""
+    if "<" not in kernel_name:
+        return kernel_name in text
+    base, arg = kernel_name.split("<", 1)
+    return base + "<" in text and arg in text
+
+
+def measure_traffic_live(workload: str, kernel_name: str, wide_read_bytes: float, timeout_s: float = 150.0):
+    """HBM bytes per launch of the benchmarked kernel, measured now: two short child runs of this script under
+    `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE do not fit one pass; counters are collected without any trace
+    domain). Units and the gfx950 correction as MI355X_MICROARCH.md prescribes: both counters are KB; FETCH_SIZE
+    reports exactly half of the bytes of a wide coalesced streaming read (16 B/lane) and narrower reads at face value,
+    so the pass's one wide read — the audio block, `wide_read_bytes` — is added back once. None when the profiler
+    cannot be run here."""
+    import csv
+    import glob
+    import shutil
+    prof = shutil.which("rocprofv3")
+    if not prof:
+        return None
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="aidax_pmc_")
+        cmd = [prof, "--output-format", "csv", "--pmc", ctr, "-d", d, "-o", "r", "--", sys.executable, os.path.abspath(__file__),
+               "--workload", workload, "--steps", "200", "--warmup", "20", "--no-cpu-baseline", "--no-check", "--no-others", "--no-traffic"]
+        env = dict(os.environ, TMPDIR="/tmp")
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+        except Exception:
+            return None
+        if r.returncode != 0:
+            return None
+        got = []
+        for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(fn)):
+                if row.get("Counter_Name") == ctr and _kernel_matches(kernel_name, row.get("Kernel_Name", "")):
+                    got.append(float(row["Counter_Value"]))
+        shutil.rmtree(d, ignore_errors=True)
+        if len(got) < 20:
+            return None
+        got.sort()
+        vals[ctr] = got[len(got) // 2]
+    return {"bytes": vals["FETCH_SIZE"] * 1024.0 + 0.5 * wide_read_bytes + vals["WRITE_SIZE"] * 1024.0,
+            "fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
+            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two child runs of this command (200 steps each), median per launch"}
+
+
 def pmc_traffic_bytes(kernel_name: str, wide_read_bytes: float):
-    """HBM bytes per launch of the benchmarked kernel from the COMMITTED rocprofv3 PMC passes
-    (profiles/*_pmc_summary.txt, latest round that has this kernel). FETCH_SIZE / WRITE_SIZE are KB; on gfx950
-    FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read (16 B/lane) and narrower reads at
-    face value (MI355X_MICROARCH.md, HBM section), so the kernel's one wide read — the audio block, `wide_read_bytes`
-    — is added back once: fetched = FETCH_SIZE + wide/2. Counters cannot be read from inside a timed run; the source
-    file is named next to the value. None if no profile."""
+    """Fallback: the same figure from the COMMITTED rocprofv3 PMC passes (profiles/*_pmc_summary.txt, latest round
+    that has this kernel) — only if that profile was taken on the kernel sources this library was built from
+    (`kernel_src_sha16=` line of the summary); a profile of other sources says nothing about this build. None then."""
     import glob
     import re
     best = None
+    mine = kernel_sources_sha16()
     for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.txt"))):
         fetch = write = None
-        for line in open(fn):
-            if "<" not in kernel_name or kernel_name.split("<")[0] + "<" not in line or kernel_name.split("<")[1] not in line:
+        text = open(fn).read()
+        m = re.search(r"kernel_src_sha16=([0-9a-f]{16})", text)
+        if not m or m.group(1) != mine:
+            continue
+        for line in text.splitlines():
+            if not _kernel_matches(kernel_name, line):
                 continue
             m = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+n=\s*\d+ median=([0-9.e+]+)", line)
             if m and m.group(1) == "FETCH_SIZE":
@@ -168,16 +241,20 @@ def pmc_traffic_bytes(kernel_name: str, wide_read_bytes: float):
 
 
 def cpu_baseline(W, j, name: str = "cfg2", target_s: float = 12.0):
-    """The CPU oracle on all host cores over a bounded sample of the workload."""
+    """The CPU oracle on all host cores over a bounded sample of the workload: up to 1024 of its streams (fewer for
+    the heavy models, a multiple of the core count) over as many 256-frame blocks as fit `target_s`."""
     from oracle import oracle as O
     spec = O.parse_model(j)
     cores = usable_cores()
-    streams = 1024                            # 1024 of the workload's streams; the sample is bounded in blocks
-    x = W.signal(streams, N_FRAMES)
     c = O.default_controls(**WORKLOADS[name]["controls"])
-    secs, _ = O.cpu_bench(spec, c, x, n_blocks=2, warm_blocks=1, n_threads=cores, fast=True)
-    per_block = secs / 2
-    blocks = int(max(4, min(20000, target_s / max(per_block, 1e-6))))
+    probe = 4 * cores
+    secs, _ = O.cpu_bench(spec, c, W.signal(probe, N_FRAMES), n_blocks=1, warm_blocks=1, n_threads=cores, fast=True)
+    per_stream_block = max(secs, 1e-6) / probe
+    streams = 1024                            # the sample is bounded in blocks ...
+    while streams > probe and 4 * streams * per_stream_block > target_s:
+        streams //= 2                         # ... and, where four blocks of 1024 streams would not fit, in streams
+    x = W.signal(streams, N_FRAMES)
+    blocks = int(max(4, min(20000, target_s / (streams * per_stream_block))))
     secs, _ = O.cpu_bench(spec, c, x, n_blocks=blocks, warm_blocks=1, n_threads=cores, fast=True)
     sps = streams * N_FRAMES * blocks / secs
     return {"value": sps, "unit": "samples/s", "cores": cores, "kind": "port",
@@ -356,6 +433,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the short cfg3/cfg4/cfg5 regions and the one-stream case")
+    ap.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic (the two rocprofv3 --pmc child runs)")
     ap.add_argument("--dry-run", action="store_true", help="CPU stand-in for the rank plumbing (gloo, no GPU): tests only")
     ap.add_argument("--share-device", action="store_true",
                     help="rank plumbing with the real kernels on a box with fewer GPUs than ranks: every rank runs on device 0, "
@@ -394,17 +472,44 @@ def main():
 
     m = measure(ax, W, torch, args.workload, S, args.steps, args.warmup, rank, world, local, not args.no_check, launch_stream)
     samples = float(S) * N_FRAMES * args.steps
-    elapsed_max, samples_all = reduce_results(m["elapsed"], samples, world, backend_device="cpu" if args.share_device else "cuda")
+    red_dev = "cpu" if args.share_device else "cuda"
+    elapsed_max, samples_all = reduce_results(m["elapsed"], samples, world, backend_device=red_dev)
+    rank_elapsed = [m["elapsed"]]
+    if world > 1:
+        mine = torch.tensor([m["elapsed"]], dtype=torch.float64, device=red_dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_elapsed = [float(t.item()) for t in every]
+
+    # N > 1: BASELINE's 8-GPU workloads (cfg4: 1024 streams per GPU, cfg5: 2048) on EVERY rank, each region bracketed
+    # and reduced like the headline (not with --share-device: ranks that share one GPU are rank plumbing, and two
+    # processes cannot both hold the CUs k_mfma_lp needs)
+    multi_others = []
+    if world > 1 and not args.no_others and not args.share_device:
+        for name in ("cfg4", "cfg5"):
+            if name == args.workload:
+                continue
+            So, steps = WORKLOADS[name]["streams"], OTHER_STEPS[name]
+            r = measure(ax, W, torch, name, So, steps, max(10, steps // 10), rank, world, local, not args.no_check, launch_stream,
+                        preroll_s=0.15)
+            e_max, n_all = reduce_results(r["elapsed"], float(So) * N_FRAMES * steps, world, backend_device=red_dev)
+            multi_others.append((name, So, steps, r, e_max, n_all))
 
     if rank == 0:
         value = samples_all / elapsed_max
         hbm, comp = rooflines(args.workload, S, m["kernel_ms"], m["kernel"])
-        traffic = pmc_traffic_bytes(m["kernel"], 4.0 * S * N_FRAMES) if (args.workload == "cfg2" and S == wl["streams"]) else None
+        traffic, how = None, None
+        if args.workload == "cfg2" and S == wl["streams"] and not args.no_traffic and "+" not in m["kernel"]:
+            if world == 1:
+                traffic, how = measure_traffic_live(args.workload, m["kernel"], 4.0 * S * N_FRAMES), "measured by this run"
+            if traffic is None:
+                traffic, how = pmc_traffic_bytes(m["kernel"], 4.0 * S * N_FRAMES), "committed profile of the same kernel sources, not measured in this run"
+        hbm["kernel_src_sha16"], hbm["lib_sha16"] = kernel_sources_sha16(), lib_sha16(ax)
         if traffic:
             hbm["traffic"] = traffic["bytes"]
-            hbm["traffic_source"] = (f"committed profile {traffic['source']} (rocprofv3 --pmc passes, not measured in this run): "
-                                     f"FETCH_SIZE {traffic['fetch_size_kb']:.0f} KB + half of the 16 B/lane audio read it under-reports + "
-                                     f"WRITE_SIZE {traffic['write_size_kb']:.0f} KB; algorithmic 8 B/sample + per-stream control/state/NN records = 3.28 MB")
+            hbm["traffic_source"] = (f"{how}: {traffic['source']}; FETCH_SIZE {traffic['fetch_size_kb']:.0f} KB + half of the 16 B/lane "
+                                     f"audio read it under-reports + WRITE_SIZE {traffic['write_size_kb']:.0f} KB; algorithmic 8 B/sample + "
+                                     f"per-stream control/state/NN records = 3.28 MB")
         out = {
             "metric": "audio samples/sec (48 kHz mono, many streams)",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -417,6 +522,8 @@ def main():
             "roofline_compute": comp,
             "preroll_ms": m["preroll_ms"],
             "max_abs_err": m["max_err"],
+            "ranks": {"world_size": world, "backend": ("gloo" if args.share_device else "nccl (RCCL)") if world > 1 else None,
+                      "elapsed_s": rank_elapsed, "collective": "all_reduce MAX(elapsed) + SUM(samples), all_gather(elapsed): after the timed region only"},
         }
         if wl["bound"] == "mfma":
             out["roofline_hbm"] = hbm
@@ -436,6 +543,8 @@ def main():
                                "ms_per_step": r["elapsed"] / steps * 1e3, "value": So * N_FRAMES * steps / r["elapsed"],
                                "unit": "samples/s", "roofline": c2 if WORKLOADS[name]["bound"] == "mfma" else h2,
                                "roofline_compute": c2, "max_abs_err": r["max_err"]})
+                if not args.no_cpu_baseline:
+                    others[-1]["cpu_baseline"] = cpu_baseline(W, r["json"], name, target_s=3.0)
             out["other_workloads"] = others
             if args.workload == "cfg2":
                 # the same model with more streams per GPU than BASELINE's 1024: where the recurrent waves stop being alone
@@ -449,6 +558,14 @@ def main():
             out["realtime_case"] = realtime_case(ax, W, local)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, m["json"], args.workload)
+        if multi_others:
+            out["other_workloads"] = []
+            for name, So, steps, r, e_max, n_all in multi_others:
+                h2, c2 = rooflines(name, So, r["kernel_ms"], r["kernel"])
+                out["other_workloads"].append({"workload": WORKLOADS[name]["text"], "streams_per_gpu": So, "n_gpus": world, "kernel": r["kernel"],
+                                               "steps": steps, "ms_per_step": e_max / steps * 1e3, "value": n_all / e_max, "unit": "samples/s",
+                                               "scaling": "weak", "roofline": c2 if WORKLOADS[name]["bound"] == "mfma" else h2,
+                                               "roofline_compute": c2, "max_abs_err": r["max_err"]})
 
     if world > 1:
         dist.destroy_process_group()       # RCCL prints its banner on teardown: keep the JSON line last

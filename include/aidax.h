@@ -199,6 +199,10 @@ AIDAX_API int  aidax_pool_process(aidax_pool* p, const float* in, float* out, ui
  * until a later call names another one (or NULL), or the pool is destroyed. */
 AIDAX_API int  aidax_pool_process_device(aidax_pool* p, const float* d_in, float* d_out,
                                          uint32_t n_frames, void* hip_stream);
+/* Waits for the pool's passes. AIDAX_ERR_DEVICE also when a pass since the last report went wrong on the device:
+ * the stacked-model kernel k_mfma_lp runs a stream group's layers on separate workgroups that wait for each other, and
+ * gives a wait up after 250 ms (another process holding the GPU's CUs); the blocking aidax_pool_process reports the same
+ * for its own block and returns silence. The pool serves the model with the one-workgroup-per-group kernel from then on. */
 AIDAX_API int  aidax_pool_sync(aidax_pool* p);
 
 /* testModel() (:900-955) on the GPU: input_batch through the bare model from
@@ -264,6 +268,8 @@ AIDAX_API int  aidax_hub_set_deadline_us(aidax_hub* h, int64_t microseconds);
 AIDAX_API int  aidax_hub_flush(aidax_hub* h);
 AIDAX_API uint32_t aidax_hub_latency_frames(const aidax_hub* h);
 AIDAX_API uint32_t aidax_hub_attached(const aidax_hub* h);
+/* the longest block aidax_hub_run accepts (callers slice longer host blocks: the LV2 shell does) */
+AIDAX_API uint32_t aidax_hub_max_frames(const aidax_hub* h);
 /* number of pool passes launched so far (tests, statistics) */
 AIDAX_API uint64_t aidax_hub_launches(const aidax_hub* h);
 /* ... of which were launched by the deadline with somebody missing */

@@ -29,6 +29,11 @@ def main(prof, out):
                 lines.append(f"{os.path.basename(d):10s} {ctr:22s} n={len(v):4d} median={med:.6g} mean={sum(v)/len(v):.6g} min={v2[0]:.6g} max={v2[-1]:.6g}  {kern[:60]}")
             for kern, m in meta.items():
                 lines.append(f"{os.path.basename(d):10s} dispatch: grid={m[0]} wg={m[1]} lds={m[2]} vgpr={m[3]} agpr={m[4]} sgpr={m[5]} scratch={m[6]}  {kern[:60]}")
+    # which kernel sources these counters describe (bench.py only quotes a committed profile of the sources it runs)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    lines.insert(0, f"kernel_src_sha16={bench.kernel_sources_sha16()}  (csrc/*.hip, csrc/*.h, Makefile at the time of the summary)")
     with open(out + "_pmc_summary.txt", "w") as g:
         g.write("\n".join(lines) + "\n")
     print("\n".join(lines))

@@ -1,0 +1,89 @@
+// asan_harness.cpp — the host-only half of the library (json parser, loader, weight packers, control-rate DSP design)
+// under AddressSanitizer + UndefinedBehaviorSanitizer. CPU test infrastructure: built by `make asan` from the
+// product's own sources (aidax_model.cpp + json_min.h, aidax_pack.cpp, aidax_dsp_host.cpp), never shipped, never run
+// on the GPU box. Usage: asan_harness <model files...>; every file is loaded (a clean error code is fine), and what
+// loads goes through every packer the pool would pick for it; then the biquad designs and the control reduction run
+// over a grid of control values. Exit code 0 unless a sanitizer aborts the process.
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+#include "../aidadsp-lv2_amd/csrc/aidax_internal.h"
+
+namespace aidax {
+// the pool's predicate lives next to the HIP code; here every architecture the loader can parse goes on to the packers
+bool model_supported(const aidax_model&) { return true; }
+}  // namespace aidax
+
+using namespace aidax;
+
+static bool table_width(int h)
+{
+    for (int w : { 8, 12, 16, 20, 24, 32, 40, 64, 80 })
+        if (w == h) return true;
+    return false;
+}
+
+int main(int argc, char** argv)
+{
+    int loaded = 0, rejected = 0, packed = 0, refused = 0;
+    double sink = 0.0;
+    for (int i = 1; i < argc; ++i) {
+        aidax_model* m = nullptr;
+        const int rc = aidax_model_load(argv[i], &m);
+        if (rc != AIDAX_OK || !m) {
+            if (!aidax_last_error() || !aidax_last_error()[0]) { std::fprintf(stderr, "%s: error code %d without a message\n", argv[i], rc); return 2; }
+            ++rejected;
+            continue;
+        }
+        ++loaded;
+        aidax_model_info_t info{};
+        (void)aidax_model_info(m, &info);
+        std::vector<float> gi(static_cast<size_t>(info.n_golden) + 1), go(static_cast<size_t>(info.n_golden) + 1);
+        (void)aidax_model_golden(m, gi.data(), go.data(), static_cast<uint32_t>(info.n_golden));
+        auto use = [&](const std::vector<float>& w) { for (float v : w) sink += v; ++packed; };
+        try {
+            uint32_t st = 0, a = 0, b = 0;
+            if (is_conv_model(*m)) {
+                bool ok = m->input_size == 1 && m->hidden <= 16 && m->n_rnn <= kMaxConvLayers;
+                for (int l = 0; ok && l < m->n_rnn; ++l) ok = m->layers[l].out_size == m->hidden && m->layers[l].ksize <= 8;
+                if (ok) { ConvDesc d{}; use(pack_conv(*m, &d, &st)); }
+            } else {
+                if (m->n_rnn == 1 && table_width(m->hidden)) { use(pack_weights(*m)); use(pack_quad(*m, &a, &b)); }
+                if (mfma_form_fits(*m)) { MfmaDesc d{}; use(pack_mfma(*m, &d, &st)); }
+                if (is_stack_model(*m) && m->n_rnn <= kMaxStackLayers && m->hidden <= 128 && m->hidden % 4 == 0) { StackDesc d{}; use(pack_stack(*m, &d, &st)); }
+            }
+        } catch (const std::exception&) {
+            ++refused;                                      // a packer may refuse a shape; it must not corrupt memory doing so
+        }
+        aidax_model_free(m);
+    }
+    // control-rate host code: every filter type over a grid, and the per-stream record for a sweep of control values
+    for (int type = 0; type < 7; ++type)
+        for (double fc : { 0.0007, 0.01, 0.125, 0.3, 0.495 })
+            for (double q : { 0.2, 0.707, 5.0 })
+                for (double g : { -20.0, -0.5, 0.0, 6.0, 20.0 }) {
+                    double c[5];
+                    design_biquad(type, fc, q, g, c);
+                    sink += c[0] + c[4];
+                }
+    aidax_controls c{};
+    aidax_controls_default(&c);
+    const float sweep[] = { -200.f, -96.f, -1.f, 0.f, 0.5f, 1.f, 25.f, 100.f, 20000.f };
+    float* fields = reinterpret_cast<float*>(&c);
+    const size_t nf = sizeof(aidax_controls) / sizeof(float);
+    for (size_t f = 0; f < nf; ++f)
+        for (float v : sweep) {
+            aidax_controls k = c;
+            reinterpret_cast<float*>(&k)[f] = v;
+            for (double sr : { 8000.0, 44100.0, 48000.0, 192000.0 }) {
+                StreamCtl o{};
+                build_stream_ctl(k, sr, (f & 1) != 0, (f & 2) != 0, exp_smoother_coef(static_cast<float>(sr), 0.1f), 0.1f * 48000.f, &o);
+                sink += o.pre_target + o.bq[0][0];
+            }
+        }
+    (void)fields;
+    std::printf("asan_harness: %d loaded, %d rejected, %d packs, %d refused (sink %g)\n", loaded, rejected, packed, refused, sink);
+    return 0;
+}

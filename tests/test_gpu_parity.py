@@ -514,6 +514,7 @@ def test_full_size_properties(name, kw, S, ckw, kernel, tmp_path):
         grp = got[idx == k]
         assert np.all(grp == grp[0]), (name, k)
     perm = np.random.RandomState(0).permutation(S)
+    pool.close()                                              # (one pool per device holds k_mfma_lp: the second must get the same kernel)
     pool2 = ax.Pool(S, block)
     pool2.set_model(m)
     pool2.set_controls(cg)

@@ -248,8 +248,8 @@ AIDAX_API int aidax_model_golden(const aidax_model* m, float* in, float* out, ui
 {
     if (!m) return fail(AIDAX_ERR_ARG, "null argument");
     const size_t n = m->golden_in.size() < cap ? m->golden_in.size() : cap;
-    if (in) std::memcpy(in, m->golden_in.data(), n * sizeof(float));
-    if (out) std::memcpy(out, m->golden_out.data(), n * sizeof(float));
+    if (in && n) std::memcpy(in, m->golden_in.data(), n * sizeof(float));       // (a model without goldens: data() may be null)
+    if (out && n) std::memcpy(out, m->golden_out.data(), n * sizeof(float));
     return static_cast<int>(n);
 }
 

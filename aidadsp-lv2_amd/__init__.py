@@ -9,7 +9,7 @@ The directory name carries a hyphen, so import it with
 ``importlib.import_module("aidadsp-lv2_amd")``.
 """
 from .binding import (  # noqa: F401
-    AidaxError, Controls, Hub, Model, ModelInfo, Pool, lib, lib_path, default_controls,
+    AidaxError, Controls, StreamDsp, Hub, Model, ModelInfo, Pool, lib, lib_path, default_controls,
     biquad_design, db_to_coeff, lpf_fc, declared_symbols,
     ALL_STREAMS, START_WARMUP, START_RESET,
 )

@@ -36,6 +36,11 @@ CONTROL_FIELDS = ("in_lpf_pc", "pregain_db", "net_bypass", "param1", "param2", "
                   "presence_boost_db", "dc_blocker", "master_db", "enabled")
 
 
+class StreamDsp(C.Structure):
+    _fields_ = [("z", (C.c_double * 2) * 7), ("pre_mem", C.c_float), ("master_mem", C.c_float), ("pre_target", C.c_float),
+                ("master_target", C.c_float), ("param_target", C.c_float * 2)]
+
+
 class Controls(C.Structure):
     _fields_ = [(n, C.c_float) for n in CONTROL_FIELDS]
 
@@ -121,6 +126,10 @@ def lib() -> C.CDLL:
     L.aidax_hub_attached.restype = u32
     L.aidax_hub_max_frames.argtypes = [vp]
     L.aidax_hub_max_frames.restype = u32
+    L.aidax_hub_attach_successor.argtypes = [vp, vp, C.c_int32, C.POINTER(C.c_int32)]
+    L.aidax_hub_adopt.argtypes = [vp, C.c_int32, vp, C.c_int32]
+    L.aidax_pool_export_stream_dsp.argtypes = [vp, u32, C.POINTER(StreamDsp)]
+    L.aidax_pool_import_stream_dsp.argtypes = [vp, u32, C.POINTER(StreamDsp)]
     L.aidax_hub_launches.argtypes = [vp]
     L.aidax_hub_launches.restype = C.c_uint64
     L.aidax_hub_deadline_launches.argtypes = [vp]
@@ -276,6 +285,14 @@ class Pool:
     def sync(self):
         _check(lib().aidax_pool_sync(self.h))
 
+    def export_stream_dsp(self, stream: int) -> "StreamDsp":
+        d = StreamDsp()
+        _check(lib().aidax_pool_export_stream_dsp(self.h, stream, C.byref(d)))
+        return d
+
+    def import_stream_dsp(self, stream: int, d: "StreamDsp"):
+        _check(lib().aidax_pool_import_stream_dsp(self.h, stream, C.byref(d)))
+
     def reset_stream(self, stream: int, start_mode: int = START_WARMUP):
         _check(lib().aidax_pool_reset_stream(self.h, stream, start_mode))
 
@@ -318,6 +335,14 @@ class Hub:
 
     def detach(self, slot: int):
         _check(lib().aidax_hub_detach(self.h, slot))
+
+    def attach_successor(self, prev: "Hub", prev_slot: int) -> int:
+        slot = C.c_int32(-1)
+        _check(lib().aidax_hub_attach_successor(self.h, prev.h if prev is not None else None, prev_slot, C.byref(slot)))
+        return slot.value
+
+    def adopt(self, slot: int, prev: "Hub", prev_slot: int):
+        _check(lib().aidax_hub_adopt(self.h, slot, prev.h, prev_slot))
 
     def set_controls(self, slot: int, c: Controls):
         _check(lib().aidax_hub_set_controls(self.h, slot, C.byref(c)))

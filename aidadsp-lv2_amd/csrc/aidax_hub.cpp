@@ -60,6 +60,9 @@ struct aidax_hub {
     float* d_out = nullptr;
     hipStream_t q = nullptr;
     hipEvent_t done[kHubBuffers] = {};
+    StreamState* h_peek = nullptr;               // pinned: one seat's record on its way to a worker thread (attach_successor)
+    hipEvent_t peek_ev = nullptr;
+    std::mutex peek_mu;                          // one reader at a time
     int cur = 1;                                 // the buffer being collected into: always (id of the next pass) % kHubBuffers
 
     ~aidax_hub()
@@ -77,6 +80,8 @@ struct aidax_hub {
             if (h_out[i]) (void)hipHostFree(h_out[i]);
             if (done[i]) (void)hipEventDestroy(done[i]);
         }
+        if (h_peek) (void)hipHostFree(h_peek);
+        if (peek_ev) (void)hipEventDestroy(peek_ev);
         if (d_in) (void)hipFree(d_in);
         if (d_out) (void)hipFree(d_out);
         if (q) (void)hipStreamDestroy(q);
@@ -212,6 +217,8 @@ AIDAX_API int aidax_hub_create(uint32_t max_instances, uint32_t max_frames, doub
         good = ok(hipHostMalloc(reinterpret_cast<void**>(&h->h_in[i]), bytes, hipHostMallocDefault), "hipHostMalloc") &&
                ok(hipHostMalloc(reinterpret_cast<void**>(&h->h_out[i]), bytes, hipHostMallocDefault), "hipHostMalloc") &&
                ok(hipEventCreateWithFlags(&h->done[i], hipEventDisableTiming), "hipEventCreate");
+    good = good && ok(hipHostMalloc(reinterpret_cast<void**>(&h->h_peek), sizeof(StreamState), hipHostMallocDefault), "hipHostMalloc") &&
+           ok(hipEventCreateWithFlags(&h->peek_ev, hipEventDisableTiming), "hipEventCreate");
     if (!good) { delete h; return AIDAX_ERR_DEVICE; }
     // nobody is attached yet: every stream rests disabled
     for (uint32_t s = 0; s < max_instances; ++s)
@@ -250,15 +257,15 @@ AIDAX_API int aidax_hub_set_model(aidax_hub* h, const aidax_model* m, int start_
     return rc;
 }
 
-AIDAX_API int aidax_hub_attach(aidax_hub* h, int32_t* slot)
+namespace {
+
+int attach_locked(aidax_hub* h, int32_t* slot, const float* p_targets)
 {
-    if (!h || !slot) return fail(AIDAX_ERR_ARG, "null argument");
-    std::lock_guard<std::mutex> g(h->mu);
     for (uint32_t s = 0; s < h->cap; ++s) {
         if (h->attached[s]) continue;
         // a fresh instance in this slot: a handful of asynchronous launches on the pool's stream, ordered
         // against the passes by the pool's stream edges — nothing here waits for the GPU
-        int rc = aidax_pool_reset_stream(h->pool, s, AIDAX_START_WARMUP);
+        int rc = pool_reset_stream_inherit(h->pool, s, AIDAX_START_WARMUP, p_targets);
         if (rc != AIDAX_OK) return rc;
         rc = aidax_pool_activate(h->pool, static_cast<int32_t>(s));
         if (rc != AIDAX_OK) return rc;
@@ -273,6 +280,72 @@ AIDAX_API int aidax_hub_attach(aidax_hub* h, int32_t* slot)
         return AIDAX_OK;
     }
     return fail(AIDAX_ERR_STATE, "hub is full");
+}
+
+}  // namespace
+
+AIDAX_API int aidax_hub_attach(aidax_hub* h, int32_t* slot)
+{
+    if (!h || !slot) return fail(AIDAX_ERR_ARG, "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    return attach_locked(h, slot, nullptr);
+}
+
+// Worker thread of an instance that plays on (prev, prev_slot) and has loaded another model file: a seat in `h` whose
+// fresh DynamicModel is built around the PARAM targets its playing model holds (work(), :822-825, :1053-1061 — they
+// are also the conditioning inputs of the 2048-zero warm-up). The predecessor's pending block is launched first, the
+// read waits for it outside every lock.
+AIDAX_API int aidax_hub_attach_successor(aidax_hub* h, aidax_hub* prev, int32_t prev_slot, int32_t* slot)
+{
+    if (!h || !slot) return fail(AIDAX_ERR_ARG, "null argument");
+    float targets[2] = { 0.f, 0.f };                         // no predecessor / no model there: work() passes 0 / 0
+    if (prev) {
+        std::lock_guard<std::mutex> one(prev->peek_mu);
+        bool reading = false;
+        {
+            std::lock_guard<std::mutex> g(prev->mu);
+            if (prev_slot >= 0 && static_cast<uint32_t>(prev_slot) < prev->cap && prev->attached[prev_slot] && pool_has_model(prev->pool)) {
+                if (prev->submitted[prev_slot]) {
+                    const int rc = flush_locked(*prev);
+                    if (rc != AIDAX_OK) return rc;
+                }
+                const int rc = pool_peek_stream_state(prev->pool, static_cast<uint32_t>(prev_slot), prev->h_peek, prev->peek_ev);
+                if (rc != AIDAX_OK) return rc;
+                reading = true;
+            }
+        }
+        if (reading) {
+            HUB_TRY(hipEventSynchronize(prev->peek_ev));
+            targets[0] = prev->h_peek->p_tgt[0];
+            targets[1] = prev->h_peek->p_tgt[1];
+        }
+    }
+    std::lock_guard<std::mutex> g(h->mu);
+    return attach_locked(h, slot, targets);
+}
+
+// Audio thread, work_response() of that instance (:859-893): from its next block on it plays on (h, slot). The
+// plugin's own DSP members — the seven biquads' memories and both gain smoothers (rt-neural-generic.h:311-317), which
+// the reference keeps across a model swap (:868-875) — move with it: the predecessor's pending block is launched, and a
+// device-side copy ordered behind it fills the new seat's record. No wait, no allocation.
+AIDAX_API int aidax_hub_adopt(aidax_hub* h, int32_t slot, aidax_hub* prev, int32_t prev_slot)
+{
+    if (!h || !prev) return fail(AIDAX_ERR_ARG, "null argument");
+    auto body = [&]() -> int {
+        if (slot < 0 || static_cast<uint32_t>(slot) >= h->cap || !h->attached[slot]) return fail(AIDAX_ERR_ARG, "slot not attached");
+        if (prev_slot < 0 || static_cast<uint32_t>(prev_slot) >= prev->cap || !prev->attached[prev_slot]) return fail(AIDAX_ERR_ARG, "predecessor not attached");
+        if (prev->submitted[prev_slot]) {                    // its last block belongs to the stream the new seat continues
+            const int rc = flush_locked(*prev);
+            if (rc != AIDAX_OK) return rc;
+        }
+        return pool_adopt_stream_dsp(h->pool, static_cast<uint32_t>(slot), prev->pool, static_cast<uint32_t>(prev_slot));
+    };
+    if (h == prev) {
+        std::lock_guard<std::mutex> g(h->mu);
+        return body();
+    }
+    std::scoped_lock g(h->mu, prev->mu);
+    return body();
 }
 
 AIDAX_API int aidax_hub_detach(aidax_hub* h, int32_t slot)

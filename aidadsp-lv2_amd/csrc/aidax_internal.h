@@ -54,6 +54,13 @@ int pool_process_prefix(aidax_pool* p, const float* d_in, float* d_out, uint32_t
 // park / unpark a stream (behaves disabled while parked; its controls stay what they are) — aidax_pool.cpp, used by the hub
 int pool_park_stream(aidax_pool* p, uint32_t stream, bool parked);
 
+// a stream that continues another plugin instance's life (hub mode; aidax_pool.cpp)
+int  pool_reset_stream_inherit(aidax_pool* p, uint32_t stream, int start_mode, const float* p_targets);
+int  pool_adopt_stream_dsp(aidax_pool* dst, uint32_t ds, aidax_pool* src, uint32_t ss);
+int  pool_read_stream_state(aidax_pool* p, uint32_t stream, StreamState* out);
+bool pool_has_model(const aidax_pool* p);
+int  pool_peek_stream_state(aidax_pool* p, uint32_t stream, StreamState* pinned_out, void* done_event);
+
 // k_mfma_lp fault report of a pool (aidax_pool.cpp): true once per give-up; the pool then serves its model with k_mfma
 bool pool_take_lp_fault(aidax_pool* p);
 bool pool_lp_in_use(const aidax_pool* p);

@@ -51,6 +51,8 @@ hipError_t launch_set_pending(StreamState* st, uint32_t n_streams, int32_t strea
 hipError_t launch_init_streams(StreamState* st, uint32_t n, hipStream_t q);
 hipError_t launch_stage_params(const StreamState* live, StreamState* staged, uint32_t n, hipStream_t q);
 hipError_t launch_install_params(StreamState* live, const StreamState* staged, uint32_t n, hipStream_t q);
+hipError_t launch_set_param_targets(StreamState* st, float t0, float t1, hipStream_t q);
+hipError_t launch_adopt_dsp(StreamState* dst, const StreamState* src, hipStream_t q);
 hipError_t launch_reset_for_model(StreamState* st, float* nn, uint32_t n_streams, uint32_t nn_stride, float p_den, hipStream_t q);
 
 }  // namespace aidax

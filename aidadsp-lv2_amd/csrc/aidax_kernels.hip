@@ -1041,6 +1041,27 @@ __global__ void k_install_params(StreamState* live, const StreamState* staged, u
     live[i].pending |= PEND_PARAM_FIRST;
 }
 
+// A fresh stream that continues another one's plugin instance (hub mode: an instance moves to the hub of its new model
+// file): the DynamicModel it is about to get is built around the PARAM targets of the model that plays now (:822-825).
+__global__ void k_set_param_targets(StreamState* st, float t0, float t1)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->p_tgt[0] = t0; st->p_tgt[1] = t1; }
+}
+
+// ... and at the swap (work_response, :868-875) the plugin's own DSP members stay what they are: the seven biquads'
+// z1 / z2 and both gain smoothers (rt-neural-generic.h:311-317) travel from the old stream's record to the new one's.
+// The PARAM smoothers belong to the new model and stay; activate() was not called by a swap.
+__global__ void k_adopt_dsp(StreamState* dst, const StreamState* src)
+{
+    const int i = threadIdx.x;
+    if (i < BQ_COUNT * 2) (&dst->z[0][0])[i] = (&src->z[0][0])[i];
+    if (i == 0) {
+        dst->pre_mem = src->pre_mem; dst->master_mem = src->master_mem;
+        dst->pre_tgt = src->pre_tgt; dst->master_tgt = src->master_tgt;
+        dst->pending &= ~PEND_ACTIVATE;
+    }
+}
+
 // ------------------------------------------------------------ host dispatch
 #define AIDAX_LSTM(H) { 0, H, k_lstm<H>, k_lstm_pipe<H>, k_nn<LstmCell<H>>, LstmCell<H>::PACK, LstmCell<H>::STATE, "k_lstm<" #H ">", "k_lstm_pipe<" #H ">", "k_chain+k_nn<lstm" #H ">" }
 // LSTM-64 / LSTM-80: the helper waves' share of the register file (pipe) resp. the Dense ring (split, H = 80) push the
@@ -1162,6 +1183,18 @@ hipError_t launch_stage_params(const StreamState* live, StreamState* staged, uin
 hipError_t launch_install_params(StreamState* live, const StreamState* staged, uint32_t n, hipStream_t q)
 {
     hipLaunchKernelGGL(k_install_params, dim3((n + 255) / 256), dim3(256), 0, q, live, staged, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_set_param_targets(StreamState* st, float t0, float t1, hipStream_t q)
+{
+    hipLaunchKernelGGL(k_set_param_targets, dim3(1), dim3(64), 0, q, st, t0, t1);
+    return hipGetLastError();
+}
+
+hipError_t launch_adopt_dsp(StreamState* dst, const StreamState* src, hipStream_t q)
+{
+    hipLaunchKernelGGL(k_adopt_dsp, dim3(1), dim3(64), 0, q, dst, src);
     return hipGetLastError();
 }
 

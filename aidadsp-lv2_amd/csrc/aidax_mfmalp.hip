@@ -589,7 +589,8 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
     const int l = adjacent ? blk % NL : (blk / 8) % NL;
     const int n_groups = ((int)a.n_streams + kMfmaStreams - 1) / kMfmaStreams;
     if (grp >= n_groups) return;
-    if (l == 0) lp_body<TPW, NW, M, true, false>(a, d, ring, counters, fault, smem, grp, l);
+    if (NL == 1) lp_body<TPW, NW, M, true, true>(a, d, ring, counters, fault, smem, grp, l);      // one layer: no ring, nobody waits
+    else if (l == 0) lp_body<TPW, NW, M, true, false>(a, d, ring, counters, fault, smem, grp, l);
     else if (l == NL - 1) lp_body<TPW, NW, M, false, true>(a, d, ring, counters, fault, smem, grp, l);
     else lp_body<TPW, NW, M, false, false>(a, d, ring, counters, fault, smem, grp, l);
 }
@@ -608,17 +609,18 @@ static LpFn lp_fn(int hidden, int n_layers)
 }
 static int lp_m(const MfmaDesc& d) { return lp_moved_tiles(d.n_layers, d.hidden / 4 / mfma_waves(d.hidden), mfma_waves(d.hidden)); }
 
-bool mfma_lp_serves(const MfmaDesc& d) { return d.n_layers >= 2 && lp_fn(d.hidden, d.n_layers) != nullptr; }
+// (one-layer models too: a workgroup per 16 streams with the layer's fragments resident in registers — no ring, no waits)
+bool mfma_lp_serves(const MfmaDesc& d) { return d.n_layers >= 1 && lp_fn(d.hidden, d.n_layers) != nullptr; }
 size_t mfma_lp_lds_bytes(const MfmaDesc& d, uint32_t n_frames) { return lp_lds_floats(d.hidden, (int)n_frames) * sizeof(float); }
 size_t mfma_lp_ring_bytes(const MfmaDesc& d, uint32_t n_streams)
 {
     const size_t groups = (n_streams + kMfmaStreams - 1) / kMfmaStreams;
-    return groups * (size_t)(d.n_layers - 1) * lp_ring_floats(d.hidden, mfma_waves(d.hidden), lp_m(d)) * sizeof(float);
+    return 256 + groups * (size_t)(d.n_layers - 1) * lp_ring_floats(d.hidden, mfma_waves(d.hidden), lp_m(d)) * sizeof(float);
 }
 size_t mfma_lp_counter_bytes(const MfmaDesc& d, uint32_t n_streams)
 {
     const size_t groups = (n_streams + kMfmaStreams - 1) / kMfmaStreams;
-    return groups * (size_t)(d.n_layers - 1) * kLpCounterStride * sizeof(uint32_t);
+    return 256 + groups * (size_t)(d.n_layers - 1) * kLpCounterStride * sizeof(uint32_t);
 }
 
 hipError_t launch_mfma_lp_kernel(const LaunchArgs& a, const MfmaDesc& d, float* ring, uint32_t* counters, uint32_t* fault, hipStream_t stream)

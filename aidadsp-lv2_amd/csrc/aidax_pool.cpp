@@ -164,6 +164,7 @@ struct aidax_pool {
     hipStream_t q = nullptr;         // the audio side's stream
     hipStream_t wq = nullptr;        // the worker side's stream (prepare)
     hipEvent_t ev_x = nullptr;       // edge between two streams that carry passes one after the other
+    hipEvent_t ev_adopt = nullptr;   // "everything this pool has issued so far": what a stream of ANOTHER pool waits for before it adopts one of ours
     hipStream_t last_stream = nullptr;
 
     StreamCtl* d_ctl = nullptr;
@@ -255,7 +256,7 @@ struct aidax_pool {
         }
     }
 
-    bool lp_in_use(const ModelSlot& m) const { return m.d_ring != nullptr && !lp_off.load(std::memory_order_relaxed); }
+    bool lp_in_use(const ModelSlot& m) const { return m.d_ring != nullptr && !(m.mdesc.n_layers >= 2 && lp_off.load(std::memory_order_relaxed)); }
 
     static size_t lds_bytes(const ModelSlot& m, uint32_t n_frames)
     {
@@ -415,6 +416,8 @@ struct aidax_pool {
             ctl_ring[k] = nullptr; ctl_ev[k] = nullptr;
         }
         if (ev_x) (void)hipEventDestroy(ev_x);
+        if (ev_adopt) (void)hipEventDestroy(ev_adopt);
+        ev_adopt = nullptr;
         if (q) (void)hipStreamDestroy(q);
         if (wq) (void)hipStreamDestroy(wq);
         d_ctl = nullptr; d_st = nullptr; cur.d_nn = nullptr; cur.d_wpack = nullptr; d_in = nullptr; d_out = nullptr;
@@ -516,9 +519,11 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p.device));
     const size_t lp_groups = (p.n_streams + kMfmaStreams - 1) / kMfmaStreams;
     const bool lp_pays = lp ? lp[0] != '0' : lp_groups * static_cast<size_t>(ms.mdesc.n_layers) <= static_cast<size_t>(cus);
-    if (ms.kind == ModelSlot::MFMA && mfma_lp_serves(ms.mdesc) && lp_pays && !p.lp_off.load() &&
-        mfma_lp_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024 && lp_gate().acquire(p.device, &p)) {
-        ms.lp_owner = &p;
+    // (a one-layer model has no hand-over and nothing to wait for: no hold on the device's gate needed)
+    const bool lp_chained = ms.mdesc.n_layers >= 2;
+    if (ms.kind == ModelSlot::MFMA && mfma_lp_serves(ms.mdesc) && lp_pays && !(lp_chained && p.lp_off.load()) &&
+        mfma_lp_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024 && (!lp_chained || lp_gate().acquire(p.device, &p))) {
+        if (lp_chained) ms.lp_owner = &p;
         HIP_TRY(hipMalloc(&ms.d_ring, mfma_lp_ring_bytes(ms.mdesc, p.n_streams)));
         HIP_TRY(hipMalloc(&ms.d_counters, mfma_lp_counter_bytes(ms.mdesc, p.n_streams)));
         HIP_TRY(hipMemsetAsync(ms.d_counters, 0, mfma_lp_counter_bytes(ms.mdesc, p.n_streams), p.wq));
@@ -642,6 +647,7 @@ AIDAX_API int aidax_pool_create(uint32_t n_streams, uint32_t max_frames, double 
             HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->hd_lp_fault), p->h_lp_fault, 0));
             *p->h_lp_fault = 0;
             HIP_TRY(hipEventCreateWithFlags(&p->ev_x, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&p->ev_adopt, hipEventDisableTiming));
             HIP_TRY(hipMalloc(&p->d_ctl, sizeof(StreamCtl) * n_streams));
             HIP_TRY(hipMalloc(&p->d_st, sizeof(StreamState) * n_streams));
             const size_t block_bytes = sizeof(float) * n_streams * static_cast<size_t>(max_frames);
@@ -733,6 +739,17 @@ AIDAX_API int aidax_pool_set_model(aidax_pool* p, const aidax_model* m, int star
 
 AIDAX_API int aidax_pool_reset_stream(aidax_pool* p, uint32_t stream, int start_mode)
 {
+    return aidax::pool_reset_stream_inherit(p, stream, start_mode, nullptr);
+}
+
+}  // extern "C"
+
+namespace aidax {
+
+// aidax_pool_reset_stream for a stream that continues another plugin instance's life: the fresh DynamicModel is built
+// around `p_targets` (the PARAM targets of the model that instance plays now, :822-825) instead of the 0 / 0 of a first load.
+int pool_reset_stream_inherit(aidax_pool* p, uint32_t stream, int start_mode, const float* p_targets)
+{
     if (!p) return fail(AIDAX_ERR_ARG, "null pool");
     if (stream >= p->n_streams) return fail(AIDAX_ERR_ARG, "stream out of range");
     if (start_mode != AIDAX_START_WARMUP && start_mode != AIDAX_START_RESET) return fail(AIDAX_ERR_ARG, "bad start_mode");
@@ -741,6 +758,7 @@ AIDAX_API int aidax_pool_reset_stream(aidax_pool* p, uint32_t stream, int start_
         p->enter_stream(p->q);
         const ModelSlot& m = p->cur;
         HIP_TRY(launch_init_streams(p->d_st + stream, 1, p->q));      // instantiate(), :283-321
+        if (p_targets) HIP_TRY(launch_set_param_targets(p->d_st + stream, p_targets[0], p_targets[1], p->q));
         if (m.has_model) {
             // a fresh DynamicModel for this stream only: the launch arguments view the pool as one stream
             HIP_TRY(launch_reset_for_model(p->d_st + stream, m.d_nn + static_cast<size_t>(stream) * m.nn_stride, 1,
@@ -757,6 +775,95 @@ AIDAX_API int aidax_pool_reset_stream(aidax_pool* p, uint32_t stream, int start_
         }
         p->loading[stream] = m.has_model ? 0 : 1;
         p->refresh_ctl(stream);
+        return AIDAX_OK;
+    });
+}
+
+// Stream `ds` of `dst` takes over the plugin-owned DSP members (biquad states, gain smoothers) of stream `ss` of `src`,
+// as they are once everything `src` has issued so far has run: an event on src's latest stream, a wait on dst's own,
+// one tiny kernel. Nothing waits on the host: this is work_response() of an instance that moves between hubs. The
+// caller serialises access to both pools (the hubs' locks).
+int pool_adopt_stream_dsp(aidax_pool* dst, uint32_t ds, aidax_pool* src, uint32_t ss)
+{
+    if (!dst || !src || ds >= dst->n_streams || ss >= src->n_streams) return fail(AIDAX_ERR_ARG, "adopt: stream out of range");
+    if (dst->device != src->device) return fail(AIDAX_ERR_ARG, "adopt: pools on different devices");
+    return guarded([&]() -> int {
+        HIP_TRY(hipSetDevice(dst->device));
+        hipStream_t from = src->last_stream ? src->last_stream : src->q;
+        HIP_TRY(hipEventRecord(src->ev_adopt, from));
+        dst->enter_stream(dst->q);
+        HIP_TRY(hipStreamWaitEvent(dst->q, src->ev_adopt, 0));
+        HIP_TRY(launch_adopt_dsp(dst->d_st + ds, src->d_st + ss, dst->q));
+        if (src != dst) {                                   // src must not overwrite the record before the copy has read it:
+            HIP_TRY(hipEventRecord(dst->ev_adopt, dst->q));  // its next operation waits for the copy (the stream is parked or
+            src->enter_stream(src->q);                       // detached by then, but a later occupant of the seat is reset on src->q)
+            HIP_TRY(hipStreamWaitEvent(src->q, dst->ev_adopt, 0));
+        }
+        return AIDAX_OK;
+    });
+}
+
+// One stream's record as it is once the pool's issued work has run (waits: worker / test side only).
+int pool_read_stream_state(aidax_pool* p, uint32_t stream, StreamState* out)
+{
+    if (!p || !out || stream >= p->n_streams) return fail(AIDAX_ERR_ARG, "stream out of range");
+    return guarded([&]() -> int {
+        HIP_TRY(hipSetDevice(p->device));
+        if (p->last_stream && p->last_stream != p->q) HIP_TRY(hipStreamSynchronize(p->last_stream));
+        HIP_TRY(hipStreamSynchronize(p->q));
+        HIP_TRY(hipMemcpy(out, p->d_st + stream, sizeof(StreamState), hipMemcpyDeviceToHost));
+        return AIDAX_OK;
+    });
+}
+
+bool pool_has_model(const aidax_pool* p) { return p->cur.has_model; }
+
+// The same read without a wait inside: the copy (into pinned memory of the caller) and `done` are put behind what the
+// pool has issued so far; the caller waits for `done` wherever it may.
+int pool_peek_stream_state(aidax_pool* p, uint32_t stream, StreamState* pinned_out, void* done_event)
+{
+    if (!p || !pinned_out || stream >= p->n_streams) return fail(AIDAX_ERR_ARG, "stream out of range");
+    return guarded([&]() -> int {
+        HIP_TRY(hipSetDevice(p->device));
+        p->enter_stream(p->q);
+        HIP_TRY(hipMemcpyAsync(pinned_out, p->d_st + stream, sizeof(StreamState), hipMemcpyDeviceToHost, p->q));
+        HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(done_event), p->q));
+        return AIDAX_OK;
+    });
+}
+
+}  // namespace aidax
+
+extern "C" {
+
+AIDAX_API int aidax_pool_export_stream_dsp(aidax_pool* p, uint32_t stream, aidax_stream_dsp* out)
+{
+    if (!p || !out) return fail(AIDAX_ERR_ARG, "null argument");
+    StreamState st{};
+    const int rc = aidax::pool_read_stream_state(p, stream, &st);
+    if (rc != AIDAX_OK) return rc;
+    std::memcpy(out->z, st.z, sizeof(out->z));
+    out->pre_mem = st.pre_mem; out->master_mem = st.master_mem;
+    out->pre_target = st.pre_tgt; out->master_target = st.master_tgt;
+    out->param_target[0] = p->cur.has_model ? st.p_tgt[0] : 0.f;           // no model: work() passes 0 / 0 (:815-816)
+    out->param_target[1] = p->cur.has_model ? st.p_tgt[1] : 0.f;
+    return AIDAX_OK;
+}
+
+AIDAX_API int aidax_pool_import_stream_dsp(aidax_pool* p, uint32_t stream, const aidax_stream_dsp* in)
+{
+    if (!p || !in) return fail(AIDAX_ERR_ARG, "null argument");
+    if (stream >= p->n_streams) return fail(AIDAX_ERR_ARG, "stream out of range");
+    return guarded([&]() -> int {
+        HIP_TRY(hipSetDevice(p->device));
+        StreamState st{};
+        const int rc = aidax::pool_read_stream_state(p, stream, &st);     // waits for the pool's passes: not an audio-thread call
+        if (rc != AIDAX_OK) return rc;
+        std::memcpy(st.z, in->z, sizeof(st.z));
+        st.pre_mem = in->pre_mem; st.master_mem = in->master_mem;
+        st.pre_tgt = in->pre_target; st.master_tgt = in->master_target;
+        st.pending &= ~static_cast<uint32_t>(PEND_ACTIVATE);
+        HIP_TRY(hipMemcpy(p->d_st + stream, &st, sizeof(StreamState), hipMemcpyHostToDevice));
         return AIDAX_OK;
     });
 }

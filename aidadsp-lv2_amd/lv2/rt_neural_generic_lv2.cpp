@@ -141,7 +141,8 @@ bool hub_join(Plugin* self, const aidax_model* model, aidax_hub** hub_out, int32
         it = g_hubs.emplace(key, HubRef{ hub, 0 }).first;
     }
     int32_t slot = -1;
-    if (aidax_hub_attach(it->second.hub, &slot) != AIDAX_OK) {
+    // the seat continues the stream of the one this instance plays on now (PARAM targets for the new DynamicModel, :822-825)
+    if (aidax_hub_attach_successor(it->second.hub, self->hub, self->slot, &slot) != AIDAX_OK) {
         if (it->second.refs == 0) { aidax_hub_destroy(it->second.hub); g_hubs.erase(it); }
         return false;
     }
@@ -564,6 +565,10 @@ LV2_Worker_Status work_response(LV2_Handle instance, uint32_t, const void* data)
             return LV2_WORKER_SUCCESS;
         }
     } else {
+        // the plugin's own members (biquads, gain smoothers: rt-neural-generic.h:311-317) stay what they are across a
+        // swap: the new seat adopts them from the old one, on the device, behind the old seat's last block
+        if (self->hub && aidax_hub_adopt(apply->hub, apply->slot, self->hub, self->slot) != AIDAX_OK)
+            plog(self, self->uris.log_Error, "aidax: %s\n", aidax_last_error());
         self->hub = apply->hub;
         self->slot = apply->slot;
         self->last_loading = false;                           // a freshly attached stream is not loading

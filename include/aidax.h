@@ -171,6 +171,21 @@ AIDAX_API int  aidax_pool_set_model(aidax_pool* p, const aidax_model* m, int sta
  * model. Used when a host attaches a new instance to a running pool (aidax_hub below). */
 AIDAX_API int  aidax_pool_reset_stream(aidax_pool* p, uint32_t stream, int start_mode);
 
+/* The plugin-owned DSP members of one stream — what RtNeuralGeneric keeps in itself rather than in its DynamicModel
+ * (rt-neural-generic.h:311-317: seven Biquads, preGain, masterGain) and therefore keeps across a model swap (:868-875) —
+ * plus the PARAM targets of the playing model, which work() hands to the next one (:822-825). */
+typedef struct {
+    double z[7][2];            /* Biquad z1, z2 (common/Biquad.h:50): in_lpf, dc_blocker, depth, bass, mid, treble, presence */
+    float  pre_mem, master_mem, pre_target, master_target;     /* ExponentialValueSmoother mem / target as last set */
+    float  param_target[2];    /* LinearValueSmoother targets of the playing model (0 / 0 without one) */
+} aidax_stream_dsp;
+
+/* Read / write those members of one stream. Both wait for the pool's passes (worker / main thread, tests); the
+ * audio-thread way of moving a plugin instance between pools is aidax_hub_adopt below. import leaves the PARAM
+ * smoothers alone (they belong to the pool's model) and, like a model swap, arms no activate(). */
+AIDAX_API int  aidax_pool_export_stream_dsp(aidax_pool* p, uint32_t stream, aidax_stream_dsp* out);
+AIDAX_API int  aidax_pool_import_stream_dsp(aidax_pool* p, uint32_t stream, const aidax_stream_dsp* in);
+
 /* The `loading` flag (:318, :576, :889): while set, the master gain target is 0. */
 AIDAX_API int  aidax_pool_set_loading(aidax_pool* p, int32_t stream, int loading);
 
@@ -254,6 +269,18 @@ AIDAX_API void aidax_hub_destroy(aidax_hub* h);
 AIDAX_API int  aidax_hub_set_model(aidax_hub* h, const aidax_model* m, int start_mode);
 /* a new instance: *slot receives its index; its stream starts from instantiate() + warm-up state */
 AIDAX_API int  aidax_hub_attach(aidax_hub* h, int32_t* slot);
+/* An instance that plays on (prev, prev_slot) and changes its model file moves to the hub of the new file — a model
+ * swap of the reference (work() :807-836, work_response() :859-893) spread over two hubs:
+ *   aidax_hub_attach_successor   worker thread: a seat in `h` whose fresh DynamicModel is built (and warmed up) around
+ *                                the PARAM targets the predecessor's model holds (:822-825); launches the
+ *                                predecessor's pending block and waits for it, outside the hubs' locks. prev may be
+ *                                NULL (first load: plain attach).
+ *   aidax_hub_adopt              audio thread, at the swap: the new seat takes over the plugin's own DSP members
+ *                                (aidax_stream_dsp: biquad memories, gain smoothers) by a device-side copy ordered
+ *                                behind the predecessor's last pass. No wait, no allocation. The predecessor's seat
+ *                                is detached afterwards (worker), as the old DynamicModel is freed there (:838-840). */
+AIDAX_API int  aidax_hub_attach_successor(aidax_hub* h, aidax_hub* prev, int32_t prev_slot, int32_t* slot);
+AIDAX_API int  aidax_hub_adopt(aidax_hub* h, int32_t slot, aidax_hub* prev, int32_t prev_slot);
 AIDAX_API int  aidax_hub_detach(aidax_hub* h, int32_t slot);
 AIDAX_API int  aidax_hub_set_controls(aidax_hub* h, int32_t slot, const aidax_controls* c);
 /* the instance's `loading` flag and activate(), as aidax_pool_set_loading / aidax_pool_activate for its stream */

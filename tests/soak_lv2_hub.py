@@ -1,8 +1,10 @@
 # LV2 shell in hub mode (AIDAX_HUB): several plugin instances of one process under the mock host, sharing one pool pass
 # per period with the other instances that play the same model file. Random patch:Set requests move instances between
-# hubs (a new seat starts like a new plugin instance: documented difference from the one-pool mode), workers and
-# responses come late, controls move. An instance must only ever deliver the oracle's output of its previous block on
-# its current seat, or silence (first block on a seat, a pass too old) — and silence must stay rare.
+# hubs: like a model swap of the reference (rt-neural-generic.cpp:868-875) the instance keeps its biquad memories and
+# gain smoothers (the new seat adopts them on the device, behind the old seat's last block) and the new DynamicModel is
+# built around the PARAM targets of the playing one (:822-825) — the mirror is ONE oracle plugin per instance for its
+# whole life. Workers and responses come late, controls move. An instance must only ever deliver the oracle's output of
+# its previous block, or silence (first block on a seat, a pass too old) — and silence must stay rare.
 # usage: python tests/soak_lv2_hub.py [periods]
 import os, shutil, sys, tempfile
 os.environ["AIDAX_HUB"] = "4"
@@ -37,6 +39,7 @@ class Mirror:
     def __init__(self):
         self.plug = O.OraclePlugin()
         self.prev = None
+        self.seated = False
         self.answers = []                 # specs work() has answered, in the order of the host's response queue
         self.log = []
 
@@ -78,18 +81,23 @@ for p in range(periods):
             for msg in h.work_queue:
                 if int.from_bytes(msg[:4], "little") == 0:
                     spec = specs.get(msg[4:].split(b"\0")[0].decode())
-                    if spec is not None: m.answers.append(spec)
+                    if spec is not None:
+                        # work() reads the playing model's PARAM targets now (:822-825)
+                        old = m.plug.model.ptr.contents if m.plug.model is not None else None
+                        m.answers.append((spec, old.param1Coeff.target if old else 0.0, old.param2Coeff.target if old else 0.0))
                     else: stats["failed"] += 1
             h.pump_worker()
             m.log.append((p, "pumped", len(m.answers)))
             assert len(h.responses) == len(m.answers)
         if h.responses and rs.rand() < 0.7:
             k = h.deliver_responses()
-            for spec in m.answers[:k]:
-                m.plug = O.OraclePlugin()                          # a new seat: a new stream from instantiate() on
-                m.plug.set_model(O.OracleModel(spec, 0.0, 0.0))
-                m.plug.activate()
-                m.prev = None
+            for spec, p1, p2 in m.answers[:k]:
+                if not m.seated:                                   # the first model: the instance gets its first seat, a stream
+                    m.plug = O.OraclePlugin()                      # from instantiate() + activate() on (before it, hub mode keeps none)
+                    m.plug.activate()
+                    m.seated = True
+                m.plug.set_model(O.OracleModel(spec, p1, p2))      # the swap of :868-875: the plugin's own members stay
+                m.prev = None                                      # (the hub's one period of latency starts over on the new seat)
                 m.log.append((p, "seat change"))
                 stats["swaps"] += 1
             del m.answers[:k]

@@ -490,7 +490,7 @@ _EQ_POST = dict(bass_boost_db=4.0, mid_boost_db=-3.0, mid_q=1.2, treble_boost_db
     ("cfg4", dict(kind="conv", hidden=16, input_size=1, seed=1608), 1024, {}, "k_conv_mfma"),
     ("cfg5", dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2), 2048, {}, "k_chain+k_mfma_lp"),
     ("lstm80-2k", dict(kind="lstm", hidden=80, input_size=2, seed=80), 2048, dict(param1=0.7), "k_chain+k_quad"),
-    ("lstm80-4k", dict(kind="lstm", hidden=80, input_size=2, seed=80), 4096, dict(param1=0.7), "k_chain+k_mfma"),
+    ("lstm80-4k", dict(kind="lstm", hidden=80, input_size=2, seed=80), 4096, dict(param1=0.7), "k_chain+k_mfma_lp"),
     ("gru16-4k", dict(kind="gru", hidden=16, input_size=3, seed=16), 4096, dict(param1=0.2, param2=0.9), "k_chain+k_quad"),
 ])
 def test_full_size_properties(name, kw, S, ckw, kernel, tmp_path):

@@ -303,3 +303,83 @@ def test_host_that_runs_ahead_of_the_gpu_keeps_its_staging_intact(tmp_path):
             assert np.all(got[i][r] == 0.0), (i, r)                     # another length than the block before: silence
         err = np.abs(got[i][rounds - 1] - want[i][rounds - 2]).max()
         assert err < THR, (i, err)
+
+
+def test_an_instance_that_moves_between_hubs_keeps_its_filter_and_gain_memories(tmp_path):
+    """A model-file change in hub mode (the reference's swap, rt-neural-generic.cpp:868-875, spread over two hubs): the
+    worker attaches a successor seat in the hub of the new file (fresh DynamicModel around the playing model's PARAM
+    targets, :822-825), the audio thread adopts — the plugin's biquad memories and gain smoothers travel on the device,
+    behind the old seat's last block. ONE oracle plugin per instance for its whole life is the reference: with the
+    network bypassed the audio after the move is bit-exact (the filters ring on, the gains keep ramping), with it the
+    reference's tolerance holds. A second instance stays on the first hub and must not notice."""
+    ja = modelgen.make_model(kind="gru", hidden=16, input_size=3, seed=41)
+    jb = modelgen.make_model(kind="lstm", hidden=20, input_size=2, seed=42)
+    pa, pb = str(tmp_path / "a.json"), str(tmp_path / "b.json")
+    modelgen.write_model(ja, pa); modelgen.write_model(jb, pb)
+    sa, sb = O.parse_model(ja), O.parse_model(jb)
+    n = 128
+    for bypass in (1.0, 0.0):
+        hub_a, hub_b = ax.Hub(4, 256), ax.Hub(4, 256)
+        hub_a.set_model(ax.Model(pa)); hub_b.set_model(ax.Model(pb))
+        hub_a.set_deadline_us(0); hub_b.set_deadline_us(0)
+        ckw = dict(net_bypass=bypass, param1=0.6, param2=0.2, pregain_db=4.0, master_db=-3.0, bass_boost_db=5.0, treble_boost_db=-4.0,
+                   eq_position=1.0, in_lpf_pc=40.0)
+        cg, co = ax.default_controls(**ckw), O.default_controls(**ckw)
+        mover, stayer = hub_a.attach(), hub_a.attach()
+        pm, ps = _oracle_instance(sa), _oracle_instance(sa)
+        x = modelgen.signal(2, n * 24, seed=77)
+        hub, slot, prev_m, prev_s = hub_a, mover, None, None
+        for b in range(24):
+            blk = [np.ascontiguousarray(x[i, b * n:(b + 1) * n]) for i in range(2)]
+            hub.set_controls(slot, cg)
+            got_m = hub.run(slot, blk[0])
+            hub_a.set_controls(stayer, cg)
+            got_s = hub_a.run(stayer, blk[1])
+            for got, prev, who in ((got_m, prev_m, "mover"), (got_s, prev_s, "stayer")):
+                if prev is None:
+                    assert not got.any(), (b, who)
+                elif bypass:
+                    assert np.array_equal(got, prev), (b, who, np.abs(got - prev).max())
+                else:
+                    assert np.abs(got - prev).max() < THR * 2, (b, who, np.abs(got - prev).max())
+            prev_m, prev_s = pm.run(co, blk[0]), ps.run(co, blk[1])
+            if b in (7, 15):                                         # the instance's worker has loaded the other file ...
+                new_hub, spec = (hub_b, sb) if hub is hub_a else (hub_a, sa)
+                old = pm.model.ptr.contents
+                p1, p2 = old.param1Coeff.target, old.param2Coeff.target
+                new_slot = new_hub.attach_successor(hub, slot)
+                new_hub.adopt(new_slot, hub, slot)                   # ... and the host delivers work_response()
+                hub.detach(slot)                                     # kWorkerFree
+                hub, slot = new_hub, new_slot
+                pm.set_model(O.OracleModel(spec, p1, p2))
+                prev_m = None                                        # one period of latency starts over on the new seat
+        hub_a.close(); hub_b.close()
+
+
+def test_export_and_import_of_a_streams_dsp_members(tmp_path):
+    """aidax_pool_export_stream_dsp / _import_stream_dsp: the biquad states and gain smoothers of a running stream
+    planted into a fresh pool make it continue bit for bit (network bypassed) where the first one stands."""
+    m, spec = _model(tmp_path, kind="lstm", hidden=12, input_size=1, seed=5)
+    ckw = dict(net_bypass=1.0, pregain_db=-5.0, master_db=2.0, mid_boost_db=6.0, mid_q=2.0, depth_boost_db=3.0)
+    cg, co = ax.default_controls(**ckw), O.default_controls(**ckw)
+    n = 96
+    x = modelgen.signal(1, n * 12, seed=12)
+    pool = ax.Pool(3, n)
+    pool.set_model(m); pool.set_controls(cg)
+    plug = _oracle_instance(spec)
+    for b in range(6):
+        blk = np.ascontiguousarray(x[:, b * n:(b + 1) * n])
+        got = pool.process(np.repeat(blk, 3, axis=0))
+        assert np.array_equal(got[1], plug.run(co, blk[0]))
+    d = pool.export_stream_dsp(1)
+    assert d.pre_target == pytest.approx(10 ** (-5.0 / 20), rel=1e-6) and any(abs(d.z[k][0]) > 0 for k in range(7))
+    pool2 = ax.Pool(2, n)
+    pool2.set_model(m); pool2.set_controls(cg)
+    pool2.import_stream_dsp(0, d)
+    for b in range(6, 12):
+        blk = np.ascontiguousarray(x[:, b * n:(b + 1) * n])
+        got = pool2.process(np.repeat(blk, 2, axis=0))
+        want = plug.run(co, blk[0])
+        assert np.array_equal(got[0], want), b
+        assert not np.array_equal(got[1], want)                      # the untouched stream started from instantiate()
+    pool.close(); pool2.close()

@@ -102,6 +102,8 @@ def lib() -> C.CDLL:
     L.aidax_pool_set_controls.argtypes = [vp, i32, C.POINTER(Controls)]
     L.aidax_pool_activate.argtypes = [vp, i32]
     L.aidax_pool_process.argtypes = [vp, _fp, _fp, u32]
+    L.aidax_pool_submit.argtypes = [vp, _fp, u32]
+    L.aidax_pool_collect.argtypes = [vp, _fp, u32]
     L.aidax_pool_process_device.argtypes = [vp, vp, vp, u32, vp]
     L.aidax_pool_sync.argtypes = [vp]
     L.aidax_model_self_test.argtypes = [vp, C.c_int, C.POINTER(i32), _fp, _fp]
@@ -275,6 +277,17 @@ class Pool:
         assert x.ndim == 2 and x.shape[0] == self.n_streams
         out = np.empty_like(x)
         _check(lib().aidax_pool_process(self.h, x.ctypes.data_as(_fp), out.ctypes.data_as(_fp), x.shape[1]))
+        return out
+
+    def submit(self, x: np.ndarray):
+        x = _f32(x)
+        assert x.ndim == 2 and x.shape[0] == self.n_streams
+        _check(lib().aidax_pool_submit(self.h, x.ctypes.data_as(_fp), x.shape[1]))
+
+    def collect(self, n_frames: int, out: Optional[np.ndarray] = None) -> np.ndarray:
+        if out is None:
+            out = np.empty((self.n_streams, n_frames), np.float32)
+        _check(lib().aidax_pool_collect(self.h, out.ctypes.data_as(_fp), n_frames))
         return out
 
     def process_device(self, d_in: int, d_out: int, n_frames: int, stream: int = 0):

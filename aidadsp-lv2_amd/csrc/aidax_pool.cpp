@@ -199,6 +199,17 @@ struct aidax_pool {
         return true;
     }
 
+    // aidax_pool_submit / aidax_pool_collect: two staging sets and two copy streams, so that the upload of block k+1
+    // and the download of block k-1 run under the pass of block k (allocated by the first submit)
+    struct Pipeline {
+        bool ready = false;
+        float* h_in[2] = {}; float* h_out[2] = {}; float* d_in[2] = {}; float* d_out[2] = {};
+        hipEvent_t ev_up[2] = {}, ev_pass[2] = {}, ev_down[2] = {};
+        hipStream_t q_up = nullptr, q_down = nullptr;
+        uint32_t frames[2] = {};
+        uint64_t submitted = 0, collected = 0;
+    } pipe;
+
     std::vector<aidax_controls> controls;
     std::vector<uint8_t> loading;
     std::vector<uint8_t> forced_off;                     // the hub parks a stream (raw copy, state does not move) without touching its controls
@@ -405,6 +416,18 @@ struct aidax_pool {
         if (cur.lp_owner) { lp_gate().release(device, cur.lp_owner); cur.lp_owner = nullptr; }
         if (h_lp_fault) (void)hipHostFree(h_lp_fault);
         h_lp_fault = nullptr;
+        for (int k = 0; k < 2; ++k) {
+            if (pipe.h_in[k]) (void)hipHostFree(pipe.h_in[k]);
+            if (pipe.h_out[k]) (void)hipHostFree(pipe.h_out[k]);
+            if (pipe.d_in[k]) (void)hipFree(pipe.d_in[k]);
+            if (pipe.d_out[k]) (void)hipFree(pipe.d_out[k]);
+            if (pipe.ev_up[k]) (void)hipEventDestroy(pipe.ev_up[k]);
+            if (pipe.ev_pass[k]) (void)hipEventDestroy(pipe.ev_pass[k]);
+            if (pipe.ev_down[k]) (void)hipEventDestroy(pipe.ev_down[k]);
+        }
+        if (pipe.q_up) (void)hipStreamDestroy(pipe.q_up);
+        if (pipe.q_down) (void)hipStreamDestroy(pipe.q_down);
+        pipe = Pipeline{};
         if (h_done) (void)hipHostFree(h_done);
         if (d_in) (void)hipFree(d_in);
         if (d_out) (void)hipFree(d_out);
@@ -703,6 +726,8 @@ AIDAX_API void aidax_pool_destroy(aidax_pool* p)
     if (p->last_stream && p->last_stream != p->q) (void)hipStreamSynchronize(p->last_stream);
     if (p->q) (void)hipStreamSynchronize(p->q);
     if (p->wq) (void)hipStreamSynchronize(p->wq);
+    if (p->pipe.q_up) (void)hipStreamSynchronize(p->pipe.q_up);
+    if (p->pipe.q_down) (void)hipStreamSynchronize(p->pipe.q_down);
     p->release();
     delete p;
 }
@@ -989,6 +1014,72 @@ AIDAX_API int aidax_pool_process(aidax_pool* p, const float* in, float* out, uin
     });
 }
 
+// ---- the pipelined host-buffer path. One caller thread (the audio side); at most two blocks between submit and collect.
+AIDAX_API int aidax_pool_submit(aidax_pool* p, const float* in, uint32_t n_frames)
+{
+    if (!p) return fail(AIDAX_ERR_ARG, "null pool");
+    if (n_frames == 0 || n_frames > p->max_frames) return fail(AIDAX_ERR_ARG, "n_frames out of range");
+    if (!in) return fail(AIDAX_ERR_ARG, "null buffer");
+    return guarded([&]() -> int {
+        HIP_TRY(hipSetDevice(p->device));
+        auto& pl = p->pipe;
+        if (!pl.ready) {                                    // first call: the second staging set (not a real-time call)
+            const size_t cap = sizeof(float) * p->n_streams * static_cast<size_t>(p->max_frames);
+            HIP_TRY(hipStreamCreateWithFlags(&pl.q_up, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&pl.q_down, hipStreamNonBlocking));
+            for (int k = 0; k < 2; ++k) {
+                HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&pl.h_in[k]), cap, hipHostMallocDefault));
+                HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&pl.h_out[k]), cap, hipHostMallocDefault));
+                HIP_TRY(hipMalloc(&pl.d_in[k], cap));
+                HIP_TRY(hipMalloc(&pl.d_out[k], cap));
+                HIP_TRY(hipEventCreateWithFlags(&pl.ev_up[k], hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&pl.ev_pass[k], hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&pl.ev_down[k], hipEventDisableTiming));
+            }
+            pl.ready = true;
+        }
+        if (pl.submitted - pl.collected >= 2) return fail(AIDAX_ERR_STATE, "two blocks are in flight: collect one first");
+        const int s = static_cast<int>(pl.submitted & 1);
+        const size_t bytes = sizeof(float) * p->n_streams * static_cast<size_t>(n_frames);
+        std::memcpy(pl.h_in[s], in, bytes);
+        // set s was last used by block k-2, which has been collected: its pass and both its copies are complete
+        HIP_TRY(hipMemcpyAsync(pl.d_in[s], pl.h_in[s], bytes, hipMemcpyHostToDevice, pl.q_up));
+        HIP_TRY(hipEventRecord(pl.ev_up[s], pl.q_up));
+        p->enter_stream(p->q);
+        HIP_TRY(hipStreamWaitEvent(p->q, pl.ev_up[s], 0));
+        const int rc = pool_process_prefix(p, pl.d_in[s], pl.d_out[s], n_frames, p->q, p->n_streams);
+        if (rc != AIDAX_OK) return rc;
+        HIP_TRY(hipEventRecord(pl.ev_pass[s], p->q));
+        HIP_TRY(hipStreamWaitEvent(pl.q_down, pl.ev_pass[s], 0));
+        HIP_TRY(hipMemcpyAsync(pl.h_out[s], pl.d_out[s], bytes, hipMemcpyDeviceToHost, pl.q_down));
+        HIP_TRY(hipEventRecord(pl.ev_down[s], pl.q_down));
+        pl.frames[s] = n_frames;
+        ++pl.submitted;
+        return AIDAX_OK;
+    });
+}
+
+AIDAX_API int aidax_pool_collect(aidax_pool* p, float* out, uint32_t n_frames)
+{
+    if (!p || !out) return fail(AIDAX_ERR_ARG, "null argument");
+    return guarded([&]() -> int {
+        auto& pl = p->pipe;
+        if (!pl.ready || pl.collected == pl.submitted) return fail(AIDAX_ERR_STATE, "nothing was submitted");
+        const int s = static_cast<int>(pl.collected & 1);
+        if (pl.frames[s] != n_frames) return fail(AIDAX_ERR_ARG, "n_frames differs from the submitted block's");
+        HIP_TRY(hipSetDevice(p->device));
+        if (hipEventQuery(pl.ev_down[s]) != hipSuccess) HIP_TRY(hipEventSynchronize(pl.ev_down[s]));
+        ++pl.collected;
+        const size_t bytes = sizeof(float) * p->n_streams * static_cast<size_t>(n_frames);
+        if (p->take_lp_fault()) {
+            std::memset(out, 0, bytes);
+            return fail(AIDAX_ERR_DEVICE, "k_mfma_lp: a layer hand-over timed out (this block is silence; the pool falls back to k_mfma)");
+        }
+        std::memcpy(out, pl.h_out[s], bytes);
+        return AIDAX_OK;
+    });
+}
+
 AIDAX_API int aidax_pool_sync(aidax_pool* p)
 {
     if (!p) return fail(AIDAX_ERR_ARG, "null pool");
@@ -996,6 +1087,7 @@ AIDAX_API int aidax_pool_sync(aidax_pool* p)
         HIP_TRY(hipSetDevice(p->device));
         if (p->last_stream && p->last_stream != p->q) HIP_TRY(hipStreamSynchronize(p->last_stream));
         HIP_TRY(hipStreamSynchronize(p->q));
+        if (p->pipe.q_down) HIP_TRY(hipStreamSynchronize(p->pipe.q_down));
         // k_mfma_lp: did a layer hand-over of a pass since the last report give up waiting?
         if (p->take_lp_fault()) return fail(AIDAX_ERR_DEVICE, "k_mfma_lp: a layer hand-over timed out (a pass since the last sync is invalid; the pool falls back to k_mfma)");
         return AIDAX_OK;

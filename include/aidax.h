@@ -207,6 +207,15 @@ AIDAX_API int  aidax_pool_activate(aidax_pool* p, int32_t stream);
  * no interrupt and no wake-up on the way back; AIDAX_SPIN_WAIT=0 waits with hipStreamSynchronize instead). */
 AIDAX_API int  aidax_pool_process(aidax_pool* p, const float* in, float* out, uint32_t n_frames);
 
+/* The same pass for a host that streams blocks: submit() stages block k (pinned copy, upload on a copy stream, the
+ * pass, download on another copy stream) and returns; collect() waits for the OLDEST submitted block and copies it
+ * out. With one block kept in flight — submit(k+1) before collect(k) — the upload of k+1 and the download of k-1 run
+ * under the pass of k. At most two blocks between submit and collect (AIDAX_ERR_STATE beyond); collect's n_frames is
+ * the submitted block's. One caller thread. The first submit allocates the second staging set: make it before going
+ * real-time. */
+AIDAX_API int  aidax_pool_submit(aidax_pool* p, const float* in, uint32_t n_frames);
+AIDAX_API int  aidax_pool_collect(aidax_pool* p, float* out, uint32_t n_frames);
+
 /* Same pass with device-resident buffers, asynchronous on `hip_stream`
  * (a hipStream_t; NULL = the pool's own stream). No host sync inside. The pool's control pokes (activate,
  * reset_stream, commit_model) run on its own stream; when consecutive operations sit on different streams the

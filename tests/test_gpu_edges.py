@@ -257,3 +257,38 @@ def test_muted_tail_runs_through_the_denormals_bit_for_bit():
         tiny += int(((np.abs(want) > 0) & (np.abs(want) < 1.2e-38)).sum())
         assert np.array_equal(got, want), b
     assert tiny > 100000
+
+
+def test_pipelined_host_buffer_path_is_the_blocking_path_bit_for_bit(tmp_path):
+    """aidax_pool_submit / aidax_pool_collect with a block kept in flight (the upload of block k+1 and the download of
+    k-1 run under the pass of k) against aidax_pool_process on an identical pool: same bits, block for block, with
+    controls that move between blocks and block lengths that change; the calling rules are enforced."""
+    path = str(tmp_path / "p.json")
+    modelgen.write_model(modelgen.make_model(kind="gru", hidden=24, input_size=2, seed=19), path)
+    m = ax.Model(path)
+    S, sizes = 70, [128, 128, 64, 256, 256, 1, 200, 128, 128, 128]
+    x = modelgen.signal(S, sum(sizes), seed=15)
+    a, b = ax.Pool(S, 256), ax.Pool(S, 256)
+    a.set_model(m); b.set_model(m)
+    L = ax.lib()
+    out = np.empty((S, 256), np.float32)
+    assert L.aidax_pool_collect(b.h, out.ctypes.data_as(C.POINTER(C.c_float)), 128) == -6        # AIDAX_ERR_STATE: nothing submitted
+    blocks, pos = [], 0
+    for n in sizes:
+        blocks.append(np.ascontiguousarray(x[:, pos:pos + n])); pos += n
+    ctl = lambda k: ax.default_controls(param1=0.1 * k, pregain_db=float(k % 3), bass_boost_db=2.0 * (k % 2))
+    want = []
+    for k, blk in enumerate(blocks):
+        a.set_controls(ctl(k))
+        want.append(a.process(blk))
+    b.set_controls(ctl(0))
+    b.submit(blocks[0])
+    for k in range(1, len(blocks)):
+        b.set_controls(ctl(k))                                   # applies to the block submitted next, not to the one in flight
+        b.submit(blocks[k])
+        if k == 3:
+            assert L.aidax_pool_submit(b.h, blocks[k].ctypes.data_as(C.POINTER(C.c_float)), sizes[k]) == -6   # two in flight already
+        got = b.collect(sizes[k - 1])
+        assert np.array_equal(got, want[k - 1]), k
+    assert np.array_equal(b.collect(sizes[-1]), want[-1])
+    a.close(); b.close()

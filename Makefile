@@ -22,7 +22,7 @@ HIPFLAGS := --offload-arch=$(ARCH) $(CXXFLAGS) -fno-slp-vectorize
 
 HOST_SRCS := $(SRC)/aidax_model.cpp $(SRC)/aidax_dsp_host.cpp $(SRC)/aidax_pack.cpp $(SRC)/aidax_pool.cpp $(SRC)/aidax_hub.cpp
 HOST_OBJS := $(patsubst $(SRC)/%.cpp,$(OBJDIR)/%.o,$(HOST_SRCS))
-KERN_OBJS := $(OBJDIR)/aidax_kernels.o $(OBJDIR)/aidax_stack.o $(OBJDIR)/aidax_mfma.o $(OBJDIR)/aidax_mfmalp.o $(OBJDIR)/aidax_convm.o $(OBJDIR)/aidax_quad.o
+KERN_OBJS := $(OBJDIR)/aidax_kernels.o $(OBJDIR)/aidax_stack.o $(OBJDIR)/aidax_mfma.o $(OBJDIR)/aidax_mfmalp.o $(OBJDIR)/aidax_convm.o $(OBJDIR)/aidax_quad.o $(OBJDIR)/aidax_q4.o
 HDRS      := $(wildcard $(SRC)/*.h) include/aidax.h
 
 LV2SO := $(PKG)/lv2/rt-neural-generic.so

@@ -74,6 +74,7 @@ std::vector<float> pack_stack(const aidax_model& m, StackDesc* d, uint32_t* stat
 bool mfma_form_fits(const aidax_model& m);    // recurrent layers of one width, a multiple of 16 and <= 128
 std::vector<float> pack_mfma(const aidax_model& m, MfmaDesc* d, uint32_t* state_floats);
 std::vector<float> pack_quad(const aidax_model& m, uint32_t* bias_off, uint32_t* dense_off);   // table models only
+std::vector<float> pack_q4(const aidax_model& m);       // LSTM-32, one input: the record k_lstm_q4 reads
 std::vector<float> pack_conv(const aidax_model& m, ConvDesc* d, uint32_t* state_floats);
 
 }  // namespace aidax

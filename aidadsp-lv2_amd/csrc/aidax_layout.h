@@ -153,6 +153,10 @@ struct StackDesc {
 //   k-steps come in groups of 4:  [wave][group][lane][4 k-steps][TPW]   -> TPW float4 per lane and group;
 //   a wave's groups run [h of the layer below | own h(t-1)]; layer 0's 1..3 inputs are one k-step on
 //   their own, [wave][lane][TPW]; the bias is a plain [unit][4 rows] table the accumulators start from.
+// k_lstm_q4 (aidax_q4.hip): registers per lane and cell wave of its weight record — 17 k-step weights, 4 accumulator
+// start values (the bias rows, on the lanes of the first K-half)
+constexpr int kQ4Regs = 21;
+
 constexpr int kMfmaStreams = 16;
 #ifndef AIDAX_MFMA_WIDE
 #define AIDAX_MFMA_WIDE 1

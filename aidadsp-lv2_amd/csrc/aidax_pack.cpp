@@ -284,6 +284,37 @@ std::vector<float> pack_quad(const aidax_model& m, uint32_t* bias_off, uint32_t*
     return out;
 }
 
+// k_lstm_q4 (aidax_q4.hip): LSTM-32 for v_mfma_f32_4x4x1_16b_f32 with the contraction split in two halves over the
+// instruction's 16 blocks. Cell wave w owns units 8w..8w+7; lane l = 4 b + row: block b = (K-half b >> 3, unit 8w + (b & 7)),
+// row = gate i, f, g, o (json column blocks i|f|c|o).
+//   [wave][reg][64 lanes]:  reg 0       weight of the model input x (first K-half; 0 on the second)
+//                           reg 1..16   recurrent weight of column 16 * half + reg - 1
+//                           reg 17..20  what the accumulator rows start from on the lane as COLUMN j = l & 3 of block b:
+//                                       the bias of gate (reg - 17) of the block's unit (first K-half; 0 on the second)
+//   then the Dense weights [32] and bias.
+std::vector<float> pack_q4(const aidax_model& m)
+{
+    const Layer& L = m.layers[0];
+    const Layer& D = m.layers[m.n_rnn];
+    const int H = 32, R = 4 * H;
+    if (L.type != Layer::LSTM || m.hidden != H || L.in_size != 1 || m.n_rnn != 1) throw std::runtime_error("pack_q4: LSTM-32 with one input only");
+    const float* W = L.w0.data();      // [1][R]
+    const float* U = L.w1.data();      // [H][R]
+    const float* b = L.w2.data();      // [R]
+    std::vector<float> out(static_cast<size_t>(4) * kQ4Regs * kWave, 0.f);
+    for (int w = 0; w < 4; ++w)
+        for (int lane = 0; lane < kWave; ++lane) {
+            const int blk = lane >> 2, row = lane & 3, half = blk >> 3, u = 8 * w + (blk & 7);
+            auto reg = [&](int r) -> float& { return out[(static_cast<size_t>(w) * kQ4Regs + r) * kWave + lane]; };
+            reg(0) = half == 0 ? W[row * H + u] : 0.f;
+            for (int k = 0; k < 16; ++k) reg(1 + k) = U[static_cast<size_t>(16 * half + k) * R + row * H + u];
+            for (int g = 0; g < 4; ++g) reg(17 + g) = half == 0 ? b[g * H + u] : 0.f;
+        }
+    out.insert(out.end(), D.w0.begin(), D.w0.end());
+    out.push_back(D.w1[0]);
+    return out;
+}
+
 std::vector<float> pack_conv(const aidax_model& m, ConvDesc* d, uint32_t* state_floats)
 {
     std::vector<float> out;

@@ -129,6 +129,8 @@ struct ModelSlot {
     uint32_t nn_stride = 0;
     int pipe_capacity = 0;           // streams the 3-wave pipeline keeps resident at once (0 = never use it)
     bool split_pays = false;         // the lean recurrent kernel keeps the occupancy of the one-wave kernel
+    float* d_wq4 = nullptr;          // k_lstm_q4's weight record (LSTM-32 snapshot models), next to the table kernels' d_wpack
+    int q4_capacity = 0;             // streams that form serves: one workgroup of four streams per CU
     float* d_wpack = nullptr;        // weights in the kernel's layout
     float* d_nn = nullptr;           // recurrent state [n_streams][nn_stride]
     float* d_ring = nullptr;         // k_mfma_lp: h of layer l-1 on its way to layer l, per stream group
@@ -225,10 +227,12 @@ struct aidax_pool {
     int force_form = 0;              // AIDAX_KERNEL=wave|pipe|split|valu|mfma|quad overrides the heuristic (A/B testing)
 
     // Form of a MODE_CHAIN pass of a TABLE slot: 0 one wave per stream, 1 three-wave pipeline (all streams resident at
-    // once: latency-bound regime), 2 split launches with packed chains (many streams: issue-bound regime)
+    // once: latency-bound regime), 2 split launches with packed chains (many streams: issue-bound regime), 3 four
+    // streams per workgroup with the cell on the matrix cores (k_lstm_q4: about four streams per CU or fewer)
     int chain_form(const ModelSlot& m) const
     {
         if (m.kind != ModelSlot::TABLE && m.has_model) return 0;
+        if (m.has_model && m.d_wq4 && force_form == 7) return 3;      // opt-in only (AIDAX_KERNEL=q4): measured slower than the pipeline, see aidax_q4.hip
         if (force_form == 1) return 0;
         if (force_form == 2) return (m.has_model && m.kernel && m.kernel->fn_pipe) ? 1 : 0;
         const bool packed_fits = chain_lds_bytes(max_frames) <= kChainLdsLimit;      // packed chains keep 8 blocks in LDS
@@ -401,6 +405,11 @@ struct aidax_pool {
         }
         if (m.has_model && m.kind == ModelSlot::CONV) return launch_conv_kernel(a, m.cdesc, s);
         const int form = a.mode == MODE_CHAIN ? chain_form(m) : 0;
+        if (form == 3) {
+            LaunchArgs b = a;
+            b.wpack = m.d_wq4;
+            return launch_q4_kernel(m.hidden, b, s);
+        }
         if (form == 1) return launch_pipe_kernel(m.kernel, a, s);
         if (form == 2) return launch_split_kernels(m.has_model ? m.kernel : nullptr, a, s);
         return launch_stream_kernel(m.has_model ? m.kernel : nullptr, a, lds_bytes(m, a.mode == MODE_CHAIN ? a.n_frames : 0), s);
@@ -411,6 +420,8 @@ struct aidax_pool {
         if (d_st) (void)hipFree(d_st);
         if (cur.d_nn) (void)hipFree(cur.d_nn);
         if (cur.d_wpack) (void)hipFree(cur.d_wpack);
+        if (cur.d_wq4) (void)hipFree(cur.d_wq4);
+        cur.d_wq4 = nullptr;
         if (cur.d_ring) (void)hipFree(cur.d_ring);
         if (cur.d_counters) (void)hipFree(cur.d_counters);
         if (cur.lp_owner) { lp_gate().release(device, cur.lp_owner); cur.lp_owner = nullptr; }
@@ -457,6 +468,7 @@ void staged_release(aidax_staged* s)
     (void)hipSetDevice(s->device);
     if (s->fenced) (void)hipEventSynchronize(s->fence);         // passes that still read the retired buffers
     if (s->slot.d_wpack) (void)hipFree(s->slot.d_wpack);
+    if (s->slot.d_wq4) (void)hipFree(s->slot.d_wq4);
     if (s->slot.d_nn) (void)hipFree(s->slot.d_nn);
     if (s->slot.d_ring) (void)hipFree(s->slot.d_ring);
     if (s->slot.d_counters) (void)hipFree(s->slot.d_counters);
@@ -552,6 +564,16 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
         HIP_TRY(hipMemsetAsync(ms.d_counters, 0, mfma_lp_counter_bytes(ms.mdesc, p.n_streams), p.wq));
     }
     HIP_TRY(hipMemcpyAsync(ms.d_wpack, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice, p.wq));
+    std::vector<float> wq4;                                // (lives until the stream has been waited for below)
+    if (ms.kind == ModelSlot::TABLE && q4_serves(m->cell, m->hidden, m->input_size) && p.force_form == 7 &&
+        q4_lds_bytes(m->hidden, p.max_frames) <= 64 * 1024) {
+        // AIDAX_KERNEL=q4 (A/B runs and tests only): LSTM-32 snapshot models, four streams per workgroup with the cell on the
+        // matrix cores; the table kernels' record stays for warm-ups and the bare-model modes
+        wq4 = pack_q4(*m);
+        HIP_TRY(hipMalloc(&ms.d_wq4, wq4.size() * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(ms.d_wq4, wq4.data(), wq4.size() * sizeof(float), hipMemcpyHostToDevice, p.wq));
+        ms.q4_capacity = std::min(q4_resident_streams(m->hidden, p.max_frames, p.device), 4 * cus);
+    }
     // fresh DynamicModel per stream: reset() + param smoothers around the targets the playing model holds now
     // (:822-825, :1035, :1053-1061) ...
     HIP_TRY(launch_stage_params(p.d_st, sg->d_pst, p.n_streams, p.wq));
@@ -657,7 +679,7 @@ AIDAX_API int aidax_pool_create(uint32_t n_streams, uint32_t max_frames, double 
         p->host_sr = host_samplerate;
         p->gain_coef = exp_smoother_coef(static_cast<float>(host_samplerate), 0.1f);
         if (const char* f = std::getenv("AIDAX_KERNEL"))
-            p->force_form = std::strcmp(f, "wave") == 0 ? 1 : std::strcmp(f, "pipe") == 0 ? 2 : std::strcmp(f, "split") == 0 ? 3 : std::strcmp(f, "valu") == 0 ? 4 : std::strcmp(f, "mfma") == 0 ? 5 : std::strcmp(f, "quad") == 0 ? 6 : 0;
+            p->force_form = std::strcmp(f, "wave") == 0 ? 1 : std::strcmp(f, "pipe") == 0 ? 2 : std::strcmp(f, "split") == 0 ? 3 : std::strcmp(f, "valu") == 0 ? 4 : std::strcmp(f, "mfma") == 0 ? 5 : std::strcmp(f, "quad") == 0 ? 6 : std::strcmp(f, "q4") == 0 ? 7 : 0;
         if (const char* t = std::getenv("AIDAX_TUNE")) p->tune = std::atoi(t);
         try {
             HIP_TRY(hipSetDevice(device_id));
@@ -1132,7 +1154,7 @@ AIDAX_API const char* aidax_pool_kernel_name(const aidax_pool* p)
     if (m.kind == ModelSlot::QUAD) return "k_chain+k_quad";
     if (m.kind == ModelSlot::CONV) return m.conv_fused ? "k_conv_mfma" : m.conv_mfma ? "k_chain+k_conv_mfma" : "k_conv";
     const int form = p->chain_form(m);
-    return form == 1 ? m.kernel->name_pipe : form == 2 ? m.kernel->name_split : m.kernel->name;
+    return form == 3 ? "k_lstm_q4<32>" : form == 1 ? m.kernel->name_pipe : form == 2 ? m.kernel->name_split : m.kernel->name;
 }
 
 AIDAX_API int aidax_model_forward(const aidax_model* m, int device_id, const float* X, float* y, uint32_t n, int unit_gains)

@@ -844,7 +844,7 @@ def test_stacked_model_state_readback(tmp_path):
 
 # ------------------------------------------------------------ the launch forms of the chain
 
-@pytest.mark.parametrize("form", ["wave", "pipe", "split", "mfma", "quad"])
+@pytest.mark.parametrize("form", ["wave", "pipe", "split", "mfma", "quad", "q4"])
 def test_every_kernel_form_passes_the_same_chain_cases(form, tmp_path, monkeypatch, bundled_models):
     """AIDAX_KERNEL pins one form: one wave per stream, the 3-wave pipeline, the split launches (packed
     chain kernels around the lean recurrent kernel), or the split launches around the matrix-core
@@ -863,7 +863,7 @@ def test_every_kernel_form_passes_the_same_chain_cases(form, tmp_path, monkeypat
            dict(dc_blocker=0.0, in_lpf_pc=0.0, eq_bypass=1.0), dict(pregain_db=6.0, master_db=-6.0, treble_boost_db=4.0)]
     for s in range(S):
         pool.set_controls(ax.default_controls(**kws[s % len(kws)]), stream=s)
-    assert pool.kernel_name.startswith({"wave": "k_lstm<", "pipe": "k_lstm_pipe<", "split": "k_chain+k_nn<", "mfma": "k_chain+k_mfma", "quad": "k_chain+k_quad"}[form])
+    assert pool.kernel_name.startswith({"wave": "k_lstm<", "pipe": "k_lstm_pipe<", "split": "k_chain+k_nn<", "mfma": "k_chain+k_mfma", "quad": "k_chain+k_quad", "q4": "k_lstm_q4<"}[form])
     got = np.empty_like(x)
     pos = 0
     for n in sizes:

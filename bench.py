@@ -172,7 +172,7 @@ def _kernel_matches(kernel_name: str, text: str) -> bool:
     return base + "<" in text and arg in text
 
 
-def measure_traffic_live(workload: str, kernel_name: str, wide_read_bytes: float, timeout_s: float = 150.0):
+def measure_traffic_live(workload: str, kernel_name: str, wide_read_bytes: float, timeout_s: float = 100.0):
     """HBM bytes per launch of the benchmarked kernel, measured now: two short child runs of this script under
     `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE do not fit one pass; counters are collected without any trace
     domain). Units and the gfx950 correction as MI355X_MICROARCH.md prescribes: both counters are KB; FETCH_SIZE

@@ -65,6 +65,14 @@ __device__ __forceinline__ float fast_sigmoid(float v)
     return __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// The same for a pre-activation that already carries the factor -log2(e): the table kernels' packers fold it into the
+// sigmoid rows' weights and biases (aidax_pack.cpp), which takes the multiply off the recurrence's critical path.
+constexpr float kNegLog2e = -1.44269504088896340736f;
+__device__ __forceinline__ float sigmoid_pre(float v_scaled)
+{
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v_scaled));
+}
+
 // tanh as an odd rational x*P(x^2)/Q(x^2), P of degree 6 and Q of degree 3 in x^2, fitted for
 // this kernel (scratch: Lawson-weighted least squares on [0,9], relative error 6.6e-9 in fp64).
 // In fp32 with FMAs: <= 3.6e-7 relative everywhere, exact odd symmetry, |y| <= 1 with the

@@ -41,9 +41,12 @@ namespace aidax {
 
 // --------------------------------------------------------------- LSTM cell
 // Lane mapping per aidax_layout.h. Gate index g = part + S*e; json column order
-// i|f|c|o (pinned by the bundled goldens). After the dot products every lane of
-// a unit holds all four gate activations (permlane swaps), so c and h are kept
-// redundantly in the S lanes of the unit and no lane idles in the update.
+// i|f|c|o (pinned by the bundled goldens). The packer folds the activations' input scales into the rows
+// (-log2 e for a sigmoid evaluated as 1/(1+2^v), 0.5 - exact - for one evaluated as 0.5*tanh(0.5 v)+0.5).
+// S = 4: after the dot products every lane of a unit gets all four gate activations (permlane swaps) and c, h are
+// kept redundantly. S = 2 (part 0: i, g; part 1: f, o): part 0 sends i*g over with ONE swap and the cell state lives in
+// part 1 only (c, h of the part-0 lanes are scratch; they publish into a spare slot) — three instructions instead of six
+// on the recurrence's critical path.
 template <int H>
 struct LstmCell {
     static constexpr LaneMap M = lstm_map(H);
@@ -55,9 +58,10 @@ struct LstmCell {
     float wx[NU][GPL][kMaxInputs];
     float bias[NU][GPL];
     float wd[NU], bd;
-    float amul[GPL], aka[GPL], akb[GPL];
+    float aka[GPL], akb[GPL];
     float c[NU], h[NU];
     int part, slot;
+    static constexpr int kStatePart = S == 2 ? 1 : 0;      // the lanes whose c / h are the cell's
 
     __device__ __forceinline__ void load(const float* __restrict__ wp, const float* __restrict__ st, int lane)
     {
@@ -80,9 +84,8 @@ struct LstmCell {
 #pragma unroll
         for (int e = 0; e < GPL; ++e) {
             // row positions whose gate type differs between lanes are evaluated in the common
-            // form ka*tanh(ms*v)+kb: tanh (1,1,0), sigmoid (0.5,0.5,0.5)
+            // form ka*tanh(v)+kb: tanh (1,0), sigmoid (0.5,0.5) on a row the packer scaled by 0.5
             const bool is_tanh = (part + S * e) == 2;       // the candidate ("c") gate
-            amul[e] = is_tanh ? 1.f : 0.5f;
             aka[e] = is_tanh ? 1.f : 0.5f;
             akb[e] = is_tanh ? 0.f : 0.5f;
         }
@@ -99,22 +102,27 @@ struct LstmCell {
 #pragma unroll
         for (int m = 0; m < NU; ++m) {
             const int j = slot + m * SLOTS;
-            if (part == 0 && j < H) { st[j] = h[m]; st[H + j] = c[m]; }
+            if (part == kStatePart && j < H) { st[j] = h[m]; st[H + j] = c[m]; }
         }
     }
 
+    // hbuf: H floats + at least one spare (rows of the kernels' LDS buffers are H + 4 long)
     __device__ __forceinline__ void publish_h(float* hbuf) const
     {
 #pragma unroll
         for (int m = 0; m < NU; ++m) {
             const int j = slot + m * SLOTS;
-            if (j < H) hbuf[j] = h[m];       // the S lanes of a unit hold the same h: same address, same data
+            if constexpr (S == 2) {
+                if (j < H) hbuf[part == kStatePart ? j : H] = h[m];     // part 0's h is scratch: into the spare slot, no branch
+            } else {
+                if (j < H) hbuf[j] = h[m];   // the S lanes of a unit hold the same h: same address, same data
+            }
         }
     }
 
     static constexpr int HID = H;
 
-    // Dense(H,1) contribution of this lane for the h it holds (0 outside part 0 / j >= H)
+    // Dense(H,1) contribution of this lane for the h it holds (0 outside the state part / j >= H)
     __device__ __forceinline__ float dense_partial() const
     {
         float d = 0.f;
@@ -165,20 +173,33 @@ struct LstmCell {
 #pragma unroll
             for (int e = 0; e < GPL; ++e) {
                 if constexpr (S == 1) {                     // gate = e, known at compile time
-                    act[e] = e == 2 ? tanh_rat(acc[m][e]) : fast_sigmoid(acc[m][e]);
+                    act[e] = e == 2 ? tanh_rat(acc[m][e]) : sigmoid_pre(acc[m][e]);
                 } else if (S == 2 && e == 0) {              // (i | f): sigmoid in both halves
-                    act[e] = fast_sigmoid(acc[m][e]);
+                    act[e] = sigmoid_pre(acc[m][e]);
                 } else {
-                    act[e] = __builtin_fmaf(tanh_rat(acc[m][e] * amul[e]), aka[e], akb[e]);
+                    act[e] = __builtin_fmaf(tanh_rat(acc[m][e]), aka[e], akb[e]);
                 }
+            }
+            if constexpr (S == 2) {
+                // part 0 holds (i, g), part 1 (f, o): i*g crosses over with one swap (the register it lands in is a dead
+                // accumulator), and c' = f*c + i*g, h = o*tanh(c') happen where f and o are — in part 1
+                const float ig = act[0] * act[1];
+                const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, acc[m][1]), __builtin_bit_cast(unsigned, ig), false, false);
+                const unsigned r0 = r[0];
+                const float cn = __builtin_fmaf(act[0], c[m], __builtin_bit_cast(float, r0));
+                c[m] = cn;
+#ifdef AIDAX_TANHC_EXP
+                h[m] = act[1] * tanh_exp(cn);
+#else
+                h[m] = act[1] * tanh_rat(cn);
+#endif
+                continue;
             }
             float gi, gf, gg, go;
             if constexpr (S == 1) {
                 gi = act[0]; gf = act[1]; gg = act[2]; go = act[3];
             } else if constexpr (S == 2) {
-                // part 0 holds (i, g), part 1 holds (f, o); a 32-lane half swap shares them
-                const Pair a0 = share_halves(act[0]), a1 = share_halves(act[1]);
-                gi = a0.lo; gf = a0.hi; gg = a1.lo; go = a1.hi;
+                gi = gf = gg = go = 0.f;                    // (handled above)
             } else {
                 // part q holds gate q: rows (v0,v1,v2,v3) -> (v0,v1,v0,v1),(v2,v3,v2,v3) -> each broadcast
                 const Pair p = share_halves(act[0]);
@@ -323,8 +344,8 @@ struct GruCell {
             const float zp = unit_sum(ax[m][0] + ar[m][0]);
             const float rp = unit_sum(ax[m][1] + ar[m][1]);
             const float nh = unit_sum(ar[m][2]);
-            const float z = fast_sigmoid(zp);
-            const float r = fast_sigmoid(rp);
+            const float z = sigmoid_pre(zp);               // the packer scaled the z and r rows by -log2 e
+            const float r = sigmoid_pre(rp);
             const float pre = __builtin_fmaf(r, nh, ax[m][2]);
             const float n = tanh_rat(pre);
             h[m] = __builtin_fmaf(z, h[m] - n, n);          // (1-z)*n + z*h
@@ -1131,7 +1152,7 @@ bool split_form_pays(const KernelEntry* e, uint32_t n_frames)
 {
     if (!e->fn_nn) return false;
     int occ_wave = 0, occ_nn = 0;
-    const size_t lds_wave = ((size_t)((n_frames + 3) & ~3u) + (size_t)e->hidden) * sizeof(float);
+    const size_t lds_wave = ((size_t)((n_frames + 3) & ~3u) + (size_t)e->hidden + 4) * sizeof(float);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_wave, e->fn, kWave, lds_wave) != hipSuccess) return false;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_nn, e->fn_nn, kWave, nn_lds_floats(e->hidden, (int)n_frames) * sizeof(float)) != hipSuccess) return false;
     hipFuncAttributes aw{}, an{};

@@ -21,6 +21,12 @@ struct Packer {
     }
 };
 
+// The activations' input scales are folded into the gate rows (weights and bias), so the kernels' recurrence carries no
+// multiply for them (LstmCell / GruCell, aidax_kernels.hip): a sigmoid evaluated as 1 / (1 + 2^v) takes its row times
+// -log2(e); a sigmoid that shares its instruction stream with a tanh row (S >= 2) is evaluated as 0.5 tanh(0.5 v) + 0.5 and
+// takes its row times 0.5, which is exact; tanh rows stay as they are.
+constexpr float kNegLog2e = -1.44269504088896340736f;
+
 std::vector<float> pack_lstm(const aidax_model& m)
 {
     const Layer& L = m.layers[0];
@@ -28,6 +34,13 @@ std::vector<float> pack_lstm(const aidax_model& m)
     const int H = L.out_size, I = L.in_size, G = 4 * H;
     const LaneMap M = lstm_map(H);
     Packer p(lstm_pack_regs(H));
+    auto row_scale = [&](int part, int e) {
+        const int gate = part + M.S * e;                            // i, f, g (the candidate, tanh), o
+        if (M.S == 1) return gate == 2 ? 1.f : kNegLog2e;
+        if (M.S == 2 && e == 0) return kNegLog2e;                   // (i | f): a sigmoid in both halves
+        return gate == 2 ? 1.f : 0.5f;                              // rows evaluated in the common tanh form
+    };
+    const int state_part = M.S == 2 ? 1 : 0;                        // the lanes that keep c and h (LstmCell::kStatePart)
     for (int lane = 0; lane < kWave; ++lane) {
         const int part = lane / M.slots, slot = lane % M.slots;
         int r = 0;
@@ -36,14 +49,15 @@ std::vector<float> pack_lstm(const aidax_model& m)
             const bool live = j < H;
             for (int e = 0; e < M.GPL; ++e) {
                 const int col = (part + M.S * e) * H + j;           // gate-major column of the json matrices
-                for (int k = 0; k < H; ++k) p.put(r++, lane, live ? L.w1[static_cast<size_t>(k) * G + col] : 0.f);
-                for (int i = 0; i < kMaxInputs; ++i) p.put(r++, lane, (live && i < I) ? L.w0[static_cast<size_t>(i) * G + col] : 0.f);
-                p.put(r++, lane, live ? L.w2[col] : 0.f);
+                const float sc = row_scale(part, e);
+                for (int k = 0; k < H; ++k) p.put(r++, lane, live ? sc * L.w1[static_cast<size_t>(k) * G + col] : 0.f);
+                for (int i = 0; i < kMaxInputs; ++i) p.put(r++, lane, (live && i < I) ? sc * L.w0[static_cast<size_t>(i) * G + col] : 0.f);
+                p.put(r++, lane, live ? sc * L.w2[col] : 0.f);
             }
         }
         for (int mm = 0; mm < M.NU; ++mm) {
             const int j = slot + mm * M.slots;
-            p.put(r++, lane, (part == 0 && j < H) ? D.w0[j] : 0.f);
+            p.put(r++, lane, (part == state_part && j < H) ? D.w0[j] : 0.f);
         }
         p.put(r++, lane, D.w1[0]);
     }
@@ -70,13 +84,14 @@ std::vector<float> pack_gru(const aidax_model& m)
             const bool live = j < H;
             for (int e = 0; e < 3; ++e) {
                 const int col = e * H + j;
+                const float sc = e < 2 ? kNegLog2e : 1.f;           // z, r: sigmoids as 1 / (1 + 2^v)
                 // this lane's K slice of the recurrent row
-                for (int k = 0; k < KS; ++k) p.put(r++, lane, live ? L.w1[static_cast<size_t>(part * KS + k) * G + col] : 0.f);
+                for (int k = 0; k < KS; ++k) p.put(r++, lane, live ? sc * L.w1[static_cast<size_t>(part * KS + k) * G + col] : 0.f);
                 // z, r: input weights and (b0+b1) ride on part 0 and reach the others through the partial-sum
                 // exchange; candidate: every part keeps the input side whole (it is not summed), b1 sits under r*( )
                 const bool owns_input = e == 2 || part == 0;
-                for (int i = 0; i < kMaxInputs; ++i) p.put(r++, lane, (live && owns_input && i < I) ? L.w0[static_cast<size_t>(i) * G + col] : 0.f);
-                p.put(r++, lane, (live && owns_input) ? (e < 2 ? b0[col] + b1[col] : b0[col]) : 0.f);
+                for (int i = 0; i < kMaxInputs; ++i) p.put(r++, lane, (live && owns_input && i < I) ? sc * L.w0[static_cast<size_t>(i) * G + col] : 0.f);
+                p.put(r++, lane, (live && owns_input) ? (e < 2 ? sc * (b0[col] + b1[col]) : b0[col]) : 0.f);
             }
         }
         for (int mm = 0; mm < M.NU; ++mm) {

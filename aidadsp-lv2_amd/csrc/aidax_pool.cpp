@@ -275,7 +275,7 @@ struct aidax_pool {
 
     static size_t lds_bytes(const ModelSlot& m, uint32_t n_frames)
     {
-        return (static_cast<size_t>((n_frames + 3) & ~3u) + static_cast<size_t>(m.hidden > 0 ? m.hidden : 4)) * sizeof(float);
+        return (static_cast<size_t>((n_frames + 3) & ~3u) + static_cast<size_t>(m.hidden > 0 ? m.hidden + 4 : 4)) * sizeof(float);   // block + h row + spare slot
     }
 
     void mark_dirty(uint32_t lo, uint32_t hi)

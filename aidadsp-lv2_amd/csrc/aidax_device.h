@@ -35,6 +35,16 @@ __device__ __forceinline__ float wave_sum(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// acc += w * (h of the lane N places to the left in its 16-lane row, cyclically): the cross-lane read rides on the FMA
+// itself (v_fmac_f32_dpp). The compiler's DPP combine does not fold v_mov_dpp into a following fmac here, so the
+// instruction is spelled out; `h` must have been written at least two instructions earlier (DPP read hazard).
+template <int N>
+__device__ __forceinline__ void fmac_row_ror(float& acc, float h, float w)
+{
+    static_assert(N >= 1 && N <= 15, "rotation within a row of 16 lanes");
+    asm volatile("v_fmac_f32_dpp %0, %1, %2 row_ror:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(h), "v"(w), "n"(N));
+}
+
 // Cross-lane shares on the permlane swap network. (The swapped pair is copied to
 // scalars before the float bit_cast: __builtin_bit_cast applied directly to an
 // ext-vector element reads element 0 on ROCm 7.2's clang.)

@@ -62,6 +62,12 @@ struct LstmCell {
     float c[NU], h[NU];
     int part, slot;
     static constexpr int kStatePart = S == 2 ? 1 : 0;      // the lanes whose c / h are the cell's
+    // H = 32 (two full 16-lane rows of units): half of a row's recurrent FMAs take h(t-1) straight out of the
+    // neighbours' registers — the lane's own unit plus 15 rotations within its row (v_fmac_f32_dpp) — while the reads of the
+    // other 16 units are still on their way back from LDS: the write -> read turn-around of h, ~100 cycles per frame on
+    // the recurrence's critical path, is covered by work, and four of the eight broadcast reads are gone. The packer
+    // stores a lane's recurrent weights in the order they are used: [own row's units by rotation | the other row's].
+    static constexpr bool ROT = S == 2 && H == 32;
 
     __device__ __forceinline__ void load(const float* __restrict__ wp, const float* __restrict__ st, int lane)
     {
@@ -112,7 +118,7 @@ struct LstmCell {
 #pragma unroll
         for (int m = 0; m < NU; ++m) {
             const int j = slot + m * SLOTS;
-            if constexpr (S == 2) {
+            if constexpr (S == 2 && !ROT) {
                 if (j < H) hbuf[part == kStatePart ? j : H] = h[m];     // part 0's h is scratch: into the spare slot, no branch
             } else {
                 if (j < H) hbuf[j] = h[m];   // the S lanes of a unit hold the same h: same address, same data
@@ -149,6 +155,29 @@ struct LstmCell {
                 if constexpr (NI >= 3) a = __builtin_fmaf(wx[m][e][2], x2, a);
                 acc[m][e] = a;
             }
+        if constexpr (ROT) {
+            // the other row's 16 units through LDS (issued first), this row's 16 out of the neighbours' registers
+            const float4* hv = reinterpret_cast<const float4*>(hprev + 16 * (1 - ((slot >> 4) & 1)));
+            const float4 q0 = hv[0], q1 = hv[1], q2 = hv[2], q3 = hv[3];
+            __builtin_amdgcn_sched_barrier(0);
+            const float hr = h[0];                          // h(t-1) of this lane's unit: every lane holds its unit's
+            float a0 = acc[0][0], a1 = acc[0][1];
+            a0 = __builtin_fmaf(w[0][0][0], hr, a0);
+            a1 = __builtin_fmaf(w[0][1][0], hr, a1);
+#define AIDAX_ROT(N) fmac_row_ror<N>(a0, hr, w[0][0][N]); fmac_row_ror<N>(a1, hr, w[0][1][N]);
+            AIDAX_ROT(1) AIDAX_ROT(2) AIDAX_ROT(3) AIDAX_ROT(4) AIDAX_ROT(5) AIDAX_ROT(6) AIDAX_ROT(7) AIDAX_ROT(8)
+            AIDAX_ROT(9) AIDAX_ROT(10) AIDAX_ROT(11) AIDAX_ROT(12) AIDAX_ROT(13) AIDAX_ROT(14) AIDAX_ROT(15)
+#undef AIDAX_ROT
+            const float4 qs[4] = { q0, q1, q2, q3 };
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                a0 = __builtin_fmaf(w[0][0][16 + 4 * k4 + 0], qs[k4].x, a0); a1 = __builtin_fmaf(w[0][1][16 + 4 * k4 + 0], qs[k4].x, a1);
+                a0 = __builtin_fmaf(w[0][0][16 + 4 * k4 + 1], qs[k4].y, a0); a1 = __builtin_fmaf(w[0][1][16 + 4 * k4 + 1], qs[k4].y, a1);
+                a0 = __builtin_fmaf(w[0][0][16 + 4 * k4 + 2], qs[k4].z, a0); a1 = __builtin_fmaf(w[0][1][16 + 4 * k4 + 2], qs[k4].z, a1);
+                a0 = __builtin_fmaf(w[0][0][16 + 4 * k4 + 3], qs[k4].w, a0); a1 = __builtin_fmaf(w[0][1][16 + 4 * k4 + 3], qs[k4].w, a1);
+            }
+            acc[0][0] = a0; acc[0][1] = a1;
+        } else {
         const float4* hv = reinterpret_cast<const float4*>(hprev);
 #pragma unroll
         for (int k4 = 0; k4 < H / 4; ++k4) {
@@ -165,6 +194,7 @@ struct LstmCell {
                     acc[m][e] = a;
                 }
             if constexpr (WINDOW > 0) { if ((k4 + 1) % WINDOW == 0) __builtin_amdgcn_sched_barrier(0); }
+        }
         }
         __builtin_amdgcn_wave_barrier();                    // all reads of h(t-1) precede the publish below
 #pragma unroll
@@ -189,10 +219,12 @@ struct LstmCell {
                 const float cn = __builtin_fmaf(act[0], c[m], __builtin_bit_cast(float, r0));
                 c[m] = cn;
 #ifdef AIDAX_TANHC_EXP
-                h[m] = act[1] * tanh_exp(cn);
+                const float hn = act[1] * tanh_exp(cn);
 #else
-                h[m] = act[1] * tanh_rat(cn);
+                const float hn = act[1] * tanh_rat(cn);
 #endif
+                if constexpr (ROT) h[m] = share_halves(hn).hi;      // the (f, o) half's h into both halves: the rotations read it
+                else h[m] = hn;
                 continue;
             }
             float gi, gf, gg, go;

@@ -50,7 +50,17 @@ std::vector<float> pack_lstm(const aidax_model& m)
             for (int e = 0; e < M.GPL; ++e) {
                 const int col = (part + M.S * e) * H + j;           // gate-major column of the json matrices
                 const float sc = row_scale(part, e);
-                for (int k = 0; k < H; ++k) p.put(r++, lane, live ? sc * L.w1[static_cast<size_t>(k) * G + col] : 0.f);
+                for (int kk = 0; kk < H; ++kk) {
+                    // LstmCell::ROT (S = 2, H = 32): a lane's recurrent weights in the order the kernel uses them — the 16
+                    // units of its own 16-lane row by rotation (row_ror:n delivers the lane n places to the left, cyclically),
+                    // then the other row's 16 in natural order
+                    int k = kk;
+                    if (M.S == 2 && H == 32) {
+                        const int own = 16 * ((slot >> 4) & 1), pos = slot & 15;
+                        k = kk < 16 ? own + ((pos - kk) & 15) : (16 - own) + (kk - 16);
+                    }
+                    p.put(r++, lane, live ? sc * L.w1[static_cast<size_t>(k) * G + col] : 0.f);
+                }
                 for (int i = 0; i < kMaxInputs; ++i) p.put(r++, lane, (live && i < I) ? sc * L.w0[static_cast<size_t>(i) * G + col] : 0.f);
                 p.put(r++, lane, live ? sc * L.w2[col] : 0.f);
             }

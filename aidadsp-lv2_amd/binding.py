@@ -46,7 +46,8 @@ class Controls(C.Structure):
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "lib", "libaidax_hip.so")
+    # AIDAX_LIB: another build of the library (A/B measurements of two builds in one gpurun call)
+    return os.environ.get("AIDAX_LIB") or os.path.join(_HERE, "lib", "libaidax_hip.so")
 
 
 _lib: Optional[C.CDLL] = None

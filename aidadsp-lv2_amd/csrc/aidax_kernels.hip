@@ -47,7 +47,7 @@ namespace aidax {
 // kept redundantly. S = 2 (part 0: i, g; part 1: f, o): part 0 sends i*g over with ONE swap and the cell state lives in
 // part 1 only (c, h of the part-0 lanes are scratch; they publish into a spare slot) — three instructions instead of six
 // on the recurrence's critical path.
-template <int H>
+template <int H, bool ROTP = true>
 struct LstmCell {
     static constexpr LaneMap M = lstm_map(H);
     static constexpr int S = M.S, SLOTS = M.slots, NU = M.NU, GPL = M.GPL;
@@ -67,10 +67,13 @@ struct LstmCell {
     // other 16 units are still on their way back from LDS: the write -> read turn-around of h, ~100 cycles per frame on
     // the recurrence's critical path, is covered by work, and four of the eight broadcast reads are gone. The packer
     // stores a lane's recurrent weights in the order they are used: [own row's units by rotation | the other row's].
-    static constexpr bool ROT = S == 2 && H == 32;
+    static constexpr bool ROT = ROTP && lstm_has_alt_pack(H);
+    // where this instantiation's lane records start in the model's weight buffer (ROTP = false: the natural-order copy)
+    static constexpr int kPackOffset = (!ROTP && lstm_has_alt_pack(H)) ? lstm_alt_pack_offset(H) : 0;
 
-    __device__ __forceinline__ void load(const float* __restrict__ wp, const float* __restrict__ st, int lane)
+    __device__ __forceinline__ void load(const float* __restrict__ wbase, const float* __restrict__ st, int lane)
     {
+        const float* __restrict__ wp = wbase + kPackOffset;
         part = lane / SLOTS;
         slot = lane % SLOTS;
         int r = 0;
@@ -1116,7 +1119,7 @@ __global__ void k_adopt_dsp(StreamState* dst, const StreamState* src)
 }
 
 // ------------------------------------------------------------ host dispatch
-#define AIDAX_LSTM(H) { 0, H, k_lstm<H>, k_lstm_pipe<H>, k_nn<LstmCell<H>>, LstmCell<H>::PACK, LstmCell<H>::STATE, "k_lstm<" #H ">", "k_lstm_pipe<" #H ">", "k_chain+k_nn<lstm" #H ">" }
+#define AIDAX_LSTM(H) { 0, H, k_lstm<H>, k_lstm_pipe<H>, k_nn<LstmCell<H, false>>, LstmCell<H>::PACK, LstmCell<H>::STATE, "k_lstm<" #H ">", "k_lstm_pipe<" #H ">", "k_chain+k_nn<lstm" #H ">" }
 // LSTM-64 / LSTM-80: the helper waves' share of the register file (pipe) resp. the Dense ring (split, H = 80) push the
 // 4H-row cell past 512 registers — those forms would spill, so they do not exist; the pool serves these cells
 // with k_quad / k_mfma, or the one-wave kernel when neither fits (pools with long blocks).

@@ -113,6 +113,13 @@ constexpr int lstm_pack_regs(int H)
     const LaneMap L = lstm_map(H);
     return L.NU * L.GPL * (H + kMaxInputs + 1) + L.NU + 1;
 }
+// LSTM-32's record comes twice: [lane records, recurrent weights in rotation order | Dense tail | lane records in natural
+// order]. The latency-bound forms (one wave per stream, the pipeline) take half of h out of the neighbours' registers
+// (LstmCell::ROT); the throughput-bound k_nn, where the dearer DPP FMAs cost more than the LDS latency they hide, reads
+// the second copy with broadcast LDS reads as before.
+constexpr bool lstm_has_alt_pack(int H) { return lstm_map(H).S == 2 && H == 32; }
+constexpr int lstm_alt_pack_offset(int H) { return lstm_pack_regs(H) * kWave + H + 1; }      // floats from the record's start
+
 constexpr int gru_pack_regs(int H)
 {
     const LaneMap L = gru_map(H);

@@ -27,7 +27,24 @@ struct Packer {
 // takes its row times 0.5, which is exact; tanh rows stay as they are.
 constexpr float kNegLog2e = -1.44269504088896340736f;
 
+static std::vector<float> pack_lstm_records(const aidax_model& m, bool rotation_order);
+
+// [lane records | Dense weights + bias in natural order (the pipeline's output wave)] and, for LSTM-32, the lane records
+// once more with the recurrent weights in natural order (lstm_has_alt_pack, aidax_layout.h)
 std::vector<float> pack_lstm(const aidax_model& m)
+{
+    const int H = m.layers[0].out_size;
+    std::vector<float> out = pack_lstm_records(m, lstm_has_alt_pack(H));
+    if (lstm_has_alt_pack(H)) {
+        std::vector<float> alt = pack_lstm_records(m, false);
+        alt.resize(static_cast<size_t>(lstm_pack_regs(H)) * kWave);          // without its Dense tail
+        if (static_cast<int>(out.size()) != lstm_alt_pack_offset(H)) throw std::logic_error("pack_lstm: record size");
+        out.insert(out.end(), alt.begin(), alt.end());
+    }
+    return out;
+}
+
+static std::vector<float> pack_lstm_records(const aidax_model& m, bool rotation_order)
 {
     const Layer& L = m.layers[0];
     const Layer& D = m.layers[1];
@@ -55,7 +72,7 @@ std::vector<float> pack_lstm(const aidax_model& m)
                     // units of its own 16-lane row by rotation (row_ror:n delivers the lane n places to the left, cyclically),
                     // then the other row's 16 in natural order
                     int k = kk;
-                    if (M.S == 2 && H == 32) {
+                    if (rotation_order) {
                         const int own = 16 * ((slot >> 4) & 1), pos = slot & 15;
                         k = kk < 16 ? own + ((pos - kk) & 15) : (16 - own) + (kk - 16);
                     }

@@ -51,10 +51,12 @@ template <int H, bool ROTP = true>
 struct LstmCell {
     static constexpr LaneMap M = lstm_map(H);
     static constexpr int S = M.S, SLOTS = M.slots, NU = M.NU, GPL = M.GPL;
-    static constexpr int PACK = lstm_pack_regs(H);
+    static constexpr int PACK = lstm_pack_regs(H);         // of the model's primary record (the Dense tail sits behind it)
     static constexpr int STATE = 2 * H;
+    static constexpr bool ROT4 = ROTP && lstm_rot4(H);     // S = 4, H <= 16: every recurrent FMA by row rotation, no LDS read
+    static constexpr int KW = lstm_row_weights(H, ROT4);   // recurrent weights per gate row in this instantiation's record
 
-    float w[NU][GPL][H];
+    float w[NU][GPL][KW];
     float wx[NU][GPL][kMaxInputs];
     float bias[NU][GPL];
     float wd[NU], bd;
@@ -67,7 +69,7 @@ struct LstmCell {
     // other 16 units are still on their way back from LDS: the write -> read turn-around of h, ~100 cycles per frame on
     // the recurrence's critical path, is covered by work, and four of the eight broadcast reads are gone. The packer
     // stores a lane's recurrent weights in the order they are used: [own row's units by rotation | the other row's].
-    static constexpr bool ROT = ROTP && lstm_has_alt_pack(H);
+    static constexpr bool ROT = ROTP && lstm_rot2(H);
     // where this instantiation's lane records start in the model's weight buffer (ROTP = false: the natural-order copy)
     static constexpr int kPackOffset = (!ROTP && lstm_has_alt_pack(H)) ? lstm_alt_pack_offset(H) : 0;
 
@@ -82,7 +84,7 @@ struct LstmCell {
 #pragma unroll
             for (int e = 0; e < GPL; ++e) {
 #pragma unroll
-                for (int k = 0; k < H; ++k) w[m][e][k] = wp[(r++) * kWave + lane];
+                for (int k = 0; k < KW; ++k) w[m][e][k] = wp[(r++) * kWave + lane];
 #pragma unroll
                 for (int i = 0; i < kMaxInputs; ++i) wx[m][e][i] = wp[(r++) * kWave + lane];
                 bias[m][e] = wp[(r++) * kWave + lane];
@@ -158,7 +160,17 @@ struct LstmCell {
                 if constexpr (NI >= 3) a = __builtin_fmaf(wx[m][e][2], x2, a);
                 acc[m][e] = a;
             }
-        if constexpr (ROT) {
+        if constexpr (ROT4) {
+            // a 16-lane row is one gate of all the units: h(t-1) of every unit is a rotation away, nothing comes from LDS
+            const float hr = h[0];
+            float a0 = __builtin_fmaf(w[0][0][0], hr, acc[0][0]);
+#define AIDAX_ROT(N) fmac_row_ror<N>(a0, hr, w[0][0][N]);
+            AIDAX_ROT(1) AIDAX_ROT(2) AIDAX_ROT(3) AIDAX_ROT(4) AIDAX_ROT(5) AIDAX_ROT(6) AIDAX_ROT(7) AIDAX_ROT(8)
+            AIDAX_ROT(9) AIDAX_ROT(10) AIDAX_ROT(11) AIDAX_ROT(12) AIDAX_ROT(13) AIDAX_ROT(14) AIDAX_ROT(15)
+#undef AIDAX_ROT
+            acc[0][0] = a0;
+            (void)hprev;
+        } else if constexpr (ROT) {
             // the other row's 16 units through LDS (issued first), this row's 16 out of the neighbours' registers
             const float4* hv = reinterpret_cast<const float4*>(hprev + 16 * (1 - ((slot >> 4) & 1)));
             const float4 q0 = hv[0], q1 = hv[1], q2 = hv[2], q3 = hv[3];

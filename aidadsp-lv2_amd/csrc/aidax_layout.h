@@ -108,16 +108,22 @@ constexpr LaneMap gru_map(int H)
 //   GRU only: + for m: bias_n1 (recurrent bias of the candidate row, kept apart)
 //   then for m in [0,NU): dense weight of unit (0 outside part 0 / j >= H)
 //   then 1: dense bias
-constexpr int lstm_pack_regs(int H)
+// Cells whose units fill whole 16-lane rows read h(t-1) out of the neighbours' registers (row rotations, LstmCell::ROT /
+// ROT4) in the latency-bound forms — one wave per stream, the pipeline: LSTM-32 (S = 2: two rows of units, half of the
+// recurrent FMAs) and LSTM-8 / 12 / 16 (S = 4: one row of units per gate, all of them; a row then carries 16 weights, zeros
+// for units beyond H). Their record comes twice: [lane records, recurrent weights in rotation order | Dense tail | lane
+// records in natural order] — the throughput-bound k_nn, where the dearer DPP FMAs cost more than the LDS latency they hide,
+// reads the second copy with broadcast LDS reads as before.
+constexpr bool lstm_rot4(int H) { return lstm_map(H).S == 4 && lstm_map(H).NU == 1; }
+constexpr bool lstm_rot2(int H) { return lstm_map(H).S == 2 && H == 32; }
+constexpr bool lstm_has_alt_pack(int H) { return lstm_rot2(H) || lstm_rot4(H); }
+constexpr int lstm_row_weights(int H, bool rotation_order) { return (rotation_order && lstm_rot4(H)) ? 16 : H; }
+constexpr int lstm_pack_regs(int H, bool rotation_order)
 {
     const LaneMap L = lstm_map(H);
-    return L.NU * L.GPL * (H + kMaxInputs + 1) + L.NU + 1;
+    return L.NU * L.GPL * (lstm_row_weights(H, rotation_order) + kMaxInputs + 1) + L.NU + 1;
 }
-// LSTM-32's record comes twice: [lane records, recurrent weights in rotation order | Dense tail | lane records in natural
-// order]. The latency-bound forms (one wave per stream, the pipeline) take half of h out of the neighbours' registers
-// (LstmCell::ROT); the throughput-bound k_nn, where the dearer DPP FMAs cost more than the LDS latency they hide, reads
-// the second copy with broadcast LDS reads as before.
-constexpr bool lstm_has_alt_pack(int H) { return lstm_map(H).S == 2 && H == 32; }
+constexpr int lstm_pack_regs(int H) { return lstm_pack_regs(H, lstm_has_alt_pack(H)); }       // the first (primary) record
 constexpr int lstm_alt_pack_offset(int H) { return lstm_pack_regs(H) * kWave + H + 1; }      // floats from the record's start
 
 constexpr int gru_pack_regs(int H)

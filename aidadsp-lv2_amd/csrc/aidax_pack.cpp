@@ -37,7 +37,7 @@ std::vector<float> pack_lstm(const aidax_model& m)
     std::vector<float> out = pack_lstm_records(m, lstm_has_alt_pack(H));
     if (lstm_has_alt_pack(H)) {
         std::vector<float> alt = pack_lstm_records(m, false);
-        alt.resize(static_cast<size_t>(lstm_pack_regs(H)) * kWave);          // without its Dense tail
+        alt.resize(static_cast<size_t>(lstm_pack_regs(H, false)) * kWave);   // without its Dense tail
         if (static_cast<int>(out.size()) != lstm_alt_pack_offset(H)) throw std::logic_error("pack_lstm: record size");
         out.insert(out.end(), alt.begin(), alt.end());
     }
@@ -50,7 +50,8 @@ static std::vector<float> pack_lstm_records(const aidax_model& m, bool rotation_
     const Layer& D = m.layers[1];
     const int H = L.out_size, I = L.in_size, G = 4 * H;
     const LaneMap M = lstm_map(H);
-    Packer p(lstm_pack_regs(H));
+    Packer p(lstm_pack_regs(H, rotation_order));
+    const int KW = lstm_row_weights(H, rotation_order);
     auto row_scale = [&](int part, int e) {
         const int gate = part + M.S * e;                            // i, f, g (the candidate, tanh), o
         if (M.S == 1) return gate == 2 ? 1.f : kNegLog2e;
@@ -67,16 +68,16 @@ static std::vector<float> pack_lstm_records(const aidax_model& m, bool rotation_
             for (int e = 0; e < M.GPL; ++e) {
                 const int col = (part + M.S * e) * H + j;           // gate-major column of the json matrices
                 const float sc = row_scale(part, e);
-                for (int kk = 0; kk < H; ++kk) {
-                    // LstmCell::ROT (S = 2, H = 32): a lane's recurrent weights in the order the kernel uses them — the 16
-                    // units of its own 16-lane row by rotation (row_ror:n delivers the lane n places to the left, cyclically),
-                    // then the other row's 16 in natural order
+                for (int kk = 0; kk < KW; ++kk) {
+                    // rotation order: a lane's recurrent weights in the order the kernel uses them — the 16 units of its own
+                    // 16-lane row by rotation (row_ror:n delivers the lane n places to the left, cyclically), then (LSTM-32)
+                    // the other row's 16 in natural order. S = 4: a row is all the units; those beyond H weigh nothing.
                     int k = kk;
                     if (rotation_order) {
                         const int own = 16 * ((slot >> 4) & 1), pos = slot & 15;
                         k = kk < 16 ? own + ((pos - kk) & 15) : (16 - own) + (kk - 16);
                     }
-                    p.put(r++, lane, live ? sc * L.w1[static_cast<size_t>(k) * G + col] : 0.f);
+                    p.put(r++, lane, (live && k < H) ? sc * L.w1[static_cast<size_t>(k) * G + col] : 0.f);
                 }
                 for (int i = 0; i < kMaxInputs; ++i) p.put(r++, lane, (live && i < I) ? sc * L.w0[static_cast<size_t>(i) * G + col] : 0.f);
                 p.put(r++, lane, live ? sc * L.w2[col] : 0.f);

@@ -527,7 +527,7 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
         ms.kind = ModelSlot::TABLE;
         ms.kernel = find_kernel(m->cell, m->hidden);
         wp = pack_weights(*m);
-        const int alt = (m->cell == AIDAX_CELL_LSTM && lstm_has_alt_pack(m->hidden)) ? ms.kernel->pack_regs * kWave : 0;      // LSTM-32: a second copy for k_nn
+        const int alt = (m->cell == AIDAX_CELL_LSTM && lstm_has_alt_pack(m->hidden)) ? lstm_pack_regs(m->hidden, false) * kWave : 0;   // a natural-order copy for k_nn
         if (static_cast<int>(wp.size()) != ms.kernel->pack_regs * kWave + m->hidden + 1 + alt) return fail(AIDAX_ERR_STATE, "weight pack size mismatch");
         state_floats = static_cast<uint32_t>(ms.kernel->state_floats);
     }

@@ -185,6 +185,8 @@ def measure_traffic_live(workload: str, kernel_name: str, wide_read_bytes: float
     prof = shutil.which("rocprofv3")
     if not prof:
         return None
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ):
+        return None                                # this run is being profiled itself: no profiler under a profiler
     vals = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="aidax_pmc_")

@@ -11,15 +11,16 @@ out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
-bench="$root/bench.py --workload $wl --steps $steps --warmup 50 --no-cpu-baseline --no-check --no-others"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o r -- python3 $bench > "$out/trace.log" 2>&1
-rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$out/pmc_fetch" -o r -- python3 $bench > "$out/pmc_fetch.log" 2>&1
-rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$out/pmc_write" -o r -- python3 $bench > "$out/pmc_write.log" 2>&1
+py=$(command -v python3)
+bench="$root/bench.py --workload $wl --steps $steps --warmup 50 --no-cpu-baseline --no-check --no-others --no-traffic"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o r -- $py $bench > "$out/trace.log" 2>&1
+rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$out/pmc_fetch" -o r -- $py $bench > "$out/pmc_fetch.log" 2>&1
+rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$out/pmc_write" -o r -- $py $bench > "$out/pmc_write.log" 2>&1
 rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU \
-    -d "$out/pmc_sq" -o r -- python3 $bench > "$out/pmc_sq.log" 2>&1
+    -d "$out/pmc_sq" -o r -- $py $bench > "$out/pmc_sq.log" 2>&1
 if [ "$wl" = "cfg5" ] || [ "$wl" = "cfg4" ]; then
     rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
-        -d "$out/pmc_mfma" -o r -- python3 $bench > "$out/pmc_mfma.log" 2>&1
+        -d "$out/pmc_mfma" -o r -- $py $bench > "$out/pmc_mfma.log" 2>&1
 fi
 cd "$root"
 find "$out" -name "*.csv" | head -20

@@ -637,6 +637,9 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
     float pre_tgt = 0.f, master_tgt = 0.f;
     Cell cell;
     float* nnst = a.nn + (size_t)s * a.nn_stride;
+    float q_carry = 0.f;                  // Q: this lane's last cascade output (lane + 1 reads it by row shift), across stages
+    int q_done = 0;                       // Q: samples of the block already stored
+    double q_z1o = 0.0, q_z2o = 0.0;      // Q: the biquad state at the start of the block
 
     if (wave == 0) {                      // ---- P prologue
         load_block(inbuf, in_row, n, lane);
@@ -686,6 +689,7 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
         const float master_mem = (pending0 & PEND_ACTIVATE) ? st.master_tgt : st.master_mem;
         master_tgt = ctl.master_target;
         cp.g.arm(master_mem, master_tgt, ctl.master_coef);
+        q_z1o = cp.z1; q_z2o = cp.z2;
         if (net_on) {
             const float* wd_nat = a.wpack + (size_t)Cell::PACK * kWave;     // [H] Dense weights then bias
             for (int i = lane; i < H + 1; i += kWave) wdl[i] = wd_nat[i];
@@ -773,10 +777,36 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
                 }
                 if (lane < cnt) qb[lane] = o;
                 __builtin_amdgcn_wave_barrier();
-                chain_run<1>(cp, qb, qb, cnt, lane);
-                __builtin_amdgcn_wave_barrier();
-                if (lane < cnt) out_row[base + lane] = qb[lane];
-                __builtin_amdgcn_wave_barrier();
+                // The post pass is ONE cascade over the whole block, not one per stage: lane k works on sample g - k at global
+                // step g, whatever stage g falls in, so its K - 1 steps of fill and drain are paid once per block instead of once
+                // per 16 frames, and every stage but the first and the last runs the steady-state step (no range tests). The
+                // last cascade stage writes sample idx to inbuf[idx] — the input block, which wave P has long consumed that far
+                // (it runs two stages ahead) — and what a stage completes leaves for HBM at its end.
+                const bool first_stage = p == 2, last_stage = p == n_sub + 1;
+                const bool q_run = lane < cp.K, q_writer = lane == cp.K - 1;
+                if (first_stage) {                          // lanes k > 0 start k steps late: range tests
+                    for (int t = 0; t < cnt; ++t) {
+                        chain_step<1, true>(cp, lane, q_run, q_writer, qb[t], q_carry, inbuf, base + t, n);
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                } else {                                    // every lane of the cascade has a sample in range: the lean step
+                    float head_next = qb[0];
+                    for (int t = 0; t < cnt; ++t) {
+                        const float head = head_next;
+                        head_next = qb[t + 1 < cnt ? t + 1 : t];
+                        chain_step<1, false>(cp, lane, q_run, q_writer, head, q_carry, inbuf, base + t, n);
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                if (last_stage)                             // the cascade's last K - 1 samples drain
+                    for (int t = cnt; t < cnt + cp.K - 1; ++t) {
+                        chain_step<1, true>(cp, lane, q_run, q_writer, 0.f, q_carry, inbuf, base + t, n);
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                // samples that have left the cascade: everything up to K - 1 behind the stage's last frame (all, at the end)
+                const int hi = last_stage ? n : base + cnt - (cp.K - 1);
+                for (int i = q_done + lane; i < hi; i += kWave) out_row[i] = inbuf[i];
+                if (hi > q_done) q_done = hi;
             }
         }
         __syncthreads();
@@ -798,6 +828,7 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
     } else if (wave == 1) {
         if (net_on) cell.store(nnst);
     } else {
+        if (lane >= cp.K || !cp.active) { cp.z1 = q_z1o; cp.z2 = q_z2o; }      // a bypassed biquad keeps its state (:646)
         if (lane < cp.K) { st.z[slot][0] = cp.z1; st.z[slot][1] = cp.z2; }
         if (lane == cp.K - 1) { st.master_mem = cp.g.mem; st.master_tgt = master_tgt; }
     }

@@ -60,6 +60,8 @@ struct aidax_hub {
     float* d_out = nullptr;
     hipStream_t q = nullptr;
     hipEvent_t done[kHubBuffers] = {};
+    bool guard[kHubBuffers] = {};                // the buffer's previous pass may still be reading its input staging: whoever
+                                                 // stages into it next waits for done[b] first — outside the lock (aidax_hub_run)
     StreamState* h_peek = nullptr;               // pinned: one seat's record on its way to a worker thread (attach_successor)
     hipEvent_t peek_ev = nullptr;
     std::mutex peek_mu;                          // one reader at a time
@@ -155,8 +157,9 @@ int launch_period(aidax_hub& h)
     // The buffer that is collected into next was the staging of the pass kHubBuffers back: its rows must have left for
     // the device before the instances overwrite them. A host that closes several short periods in a row (block-size
     // changes, skipped instances) can run that far ahead of the GPU — found by tests/soak_hub.py as outputs computed from
-    // a later block's input. Normally that pass is long complete and this is one event query.
-    if (h.pass_id[h.cur] != 0 && hipEventQuery(h.done[h.cur]) != hipSuccess) HUB_TRY(hipEventSynchronize(h.done[h.cur]));
+    // a later block's input. Normally that pass is long complete and this is one event query; otherwise the buffer is
+    // marked and the first run() that stages into it waits for the event, with the lock released.
+    h.guard[h.cur] = h.pass_id[h.cur] != 0 && hipEventQuery(h.done[h.cur]) != hipSuccess;
     return AIDAX_OK;
 }
 
@@ -411,18 +414,31 @@ AIDAX_API int aidax_hub_run(aidax_hub* h, int32_t slot, const float* in, float* 
     int prev_buf = 0;
     bool wake = false;
     {
-        std::lock_guard<std::mutex> g(h->mu);
-        if (slot < 0 || static_cast<uint32_t>(slot) >= h->cap || !h->attached[slot]) return fail(AIDAX_ERR_ARG, "slot not attached");
-        if (h->last_error != AIDAX_OK) {                     // a pass the launcher could not issue
-            const int rc = h->last_error;
-            h->last_error = AIDAX_OK;
-            return fail(rc, "hub: a pool pass failed to launch");
-        }
-        // this instance is back before the period was closed (somebody was skipped and the launcher has not
-        // got to it yet), or the host changed the block size: close the period here
-        if (h->submitted[slot] || (h->n_submitted != 0 && n_frames != h->period_frames)) {
-            const int rc = flush_locked(*h);
-            if (rc != AIDAX_OK) return rc;
+        std::unique_lock<std::mutex> g(h->mu);
+        for (;;) {
+            if (slot < 0 || static_cast<uint32_t>(slot) >= h->cap || !h->attached[slot]) return fail(AIDAX_ERR_ARG, "slot not attached");
+            if (h->last_error != AIDAX_OK) {                 // a pass the launcher could not issue
+                const int rc = h->last_error;
+                h->last_error = AIDAX_OK;
+                return fail(rc, "hub: a pool pass failed to launch");
+            }
+            // this instance is back before the period was closed (somebody was skipped and the launcher has not
+            // got to it yet), or the host changed the block size: close the period here
+            if (h->submitted[slot] || (h->n_submitted != 0 && n_frames != h->period_frames)) {
+                const int rc = flush_locked(*h);
+                if (rc != AIDAX_OK) return rc;
+            }
+            // the staging buffer of the period being collected: if the pass that last used it (kHubBuffers back) has not
+            // read its rows yet — a host far ahead of the GPU — wait for it WITHOUT the lock (the others keep running),
+            // then look at everything again
+            const int gb = h->cur;
+            if (!h->guard[gb]) break;
+            if (hipEventQuery(h->done[gb]) == hipSuccess) { h->guard[gb] = false; break; }
+            hipEvent_t ev = h->done[gb];
+            g.unlock();
+            const hipError_t we = hipEventSynchronize(ev);
+            g.lock();
+            if (we != hipSuccess) return fail(AIDAX_ERR_DEVICE, "hub: waiting for a pass failed");
         }
         if (h->n_submitted == 0) {                           // first of a new period: block length and deadline
             h->period_frames = n_frames;

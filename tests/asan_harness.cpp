@@ -50,7 +50,36 @@ int main(int argc, char** argv)
                 for (int l = 0; ok && l < m->n_rnn; ++l) ok = m->layers[l].out_size == m->hidden && m->layers[l].ksize <= 8;
                 if (ok) { ConvDesc d{}; use(pack_conv(*m, &d, &st)); }
             } else {
-                if (m->n_rnn == 1 && table_width(m->hidden)) { use(pack_weights(*m)); use(pack_quad(*m, &a, &b)); }
+                if (m->n_rnn == 1 && table_width(m->hidden)) {
+                    const std::vector<float> wp = pack_weights(*m);
+                    use(wp);
+                    use(pack_quad(*m, &a, &b));
+                    // LSTM records that come twice (rotation order for the latency-bound kernels, natural order for k_nn:
+                    // aidax_layout.h) must hold the same weights: entry kk of a lane's rotation-order row is the natural
+                    // row's entry for unit own + ((pos - kk) & 15) resp. the other row's unit, zeros beyond H
+                    if (m->cell == AIDAX_CELL_LSTM && lstm_has_alt_pack(m->hidden)) {
+                        const int H = m->hidden;
+                        const LaneMap M = lstm_map(H);
+                        const int KW = lstm_row_weights(H, true), row_r = KW + kMaxInputs + 1, row_n = H + kMaxInputs + 1;
+                        const float* rot = wp.data();
+                        const float* nat = wp.data() + lstm_alt_pack_offset(H);
+                        if (wp.size() != static_cast<size_t>(lstm_alt_pack_offset(H)) + static_cast<size_t>(lstm_pack_regs(H, false)) * kWave) {
+                            std::fprintf(stderr, "%s: pack size\n", argv[i]); return 3;
+                        }
+                        for (int lane = 0; lane < kWave; ++lane) {
+                            const int slot = lane % M.slots, own = 16 * ((slot >> 4) & 1), pos = slot & 15;
+                            for (int e = 0; e < M.GPL; ++e)
+                                for (int kk = 0; kk < KW; ++kk) {
+                                    const int k = kk < 16 ? own + ((pos - kk) & 15) : (16 - own) + (kk - 16);
+                                    const float want = k < H ? nat[(e * row_n + k) * kWave + lane] : 0.f;
+                                    if (rot[(e * row_r + kk) * kWave + lane] != want) { std::fprintf(stderr, "%s: rotation-order record differs at lane %d row %d entry %d\n", argv[i], lane, e, kk); return 3; }
+                                }
+                            for (int e = 0; e < M.GPL; ++e)
+                                for (int t = 0; t < kMaxInputs + 1; ++t)          // input weights and bias ride along unchanged
+                                    if (rot[(e * row_r + KW + t) * kWave + lane] != nat[(e * row_n + H + t) * kWave + lane]) { std::fprintf(stderr, "%s: input / bias entries differ\n", argv[i]); return 3; }
+                        }
+                    }
+                }
                 if (mfma_form_fits(*m)) { MfmaDesc d{}; use(pack_mfma(*m, &d, &st)); }
                 if (is_stack_model(*m) && m->n_rnn <= kMaxStackLayers && m->hidden <= 128 && m->hidden % 4 == 0) { StackDesc d{}; use(pack_stack(*m, &d, &st)); }
             }

@@ -322,6 +322,11 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
             }
         }
     };
+    // the cell state of this lane's (unit, stream) pairs — one per tile — lives in registers for the launch (cT is only how
+    // it travels between the state records and the lanes)
+    float creg[TPW];
+#pragma unroll
+    for (int tl = 0; tl < TPW; ++tl) creg[tl] = cT[(wave * TPW + tl) * 64 + lane];
     // frames [0, total) of this launch as the ring sees them
     int par = 0;                                           // parity of hT the next frame reads
     int done = 0;                                          // frames finished before this chunk
@@ -500,8 +505,8 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
                     if (L.cell == 0) {
                         const float gi = fast_sigmoid(acc[tl].x), gf = fast_sigmoid(acc[tl].y);
                         const float gg = tanh_rat(acc[tl].z), go = fast_sigmoid(acc[tl].w);
-                        const float cn = __builtin_fmaf(gf, cT[e], gi * gg);
-                        cT[e] = cn;
+                        const float cn = __builtin_fmaf(gf, creg[tl], gi * gg);
+                        creg[tl] = cn;
                         hn = go * tanh_rat(cn);
                     } else {
                         const float gz = fast_sigmoid(acc[tl].x), gr = fast_sigmoid(acc[tl].y);
@@ -558,6 +563,9 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
     }
 
     // ---- recurrent state and smoother memories back to HBM for the streams that ran
+#pragma unroll
+    for (int tl = 0; tl < TPW; ++tl) cT[(wave * TPW + tl) * 64 + lane] = creg[tl];
+    __syncthreads();
     for (int i = tid; i < H * NS; i += NT) {
         const int u = i / NS, sn = i % NS, sg = s_base + sn;
         if (sg < (int)a.n_streams && u < Ht && livef[sn] != 0.f) {

@@ -240,6 +240,10 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
     // tick — 4 TPW registers that the resident fragments need more (LSTM-96 x2: 256 registers, nothing spilled)
     for (int i = tid; i < 4 * H; i += NT) biasl[i] = W[L.b_off + i];
     const f32x4* bias_v = reinterpret_cast<const f32x4*>(biasl) + 4 * wave * TPW + (lane >> 4);
+    __syncthreads();
+    f32x4 bias_r[TPW];
+#pragma unroll
+    for (int tl = 0; tl < TPW; ++tl) bias_r[tl] = bias_v[4 * tl];
     // One register set, two uses that exclude each other: on the first layer the bias rows the moved tiles start from
     // (the upper layer's), on the others the started tiles of the NEXT frame on their way in from the ring.
     f32x4 upx[MA];
@@ -476,7 +480,7 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
                 float* h_wr = hT + wr * H * NS;
                 f32x4 acc[TPW];
 #pragma unroll
-                for (int tl = 0; tl < TPW; ++tl) acc[tl] = bias_v[4 * tl];
+                for (int tl = 0; tl < TPW; ++tl) acc[tl] = bias_r[tl];
                 if (!last && F >= 1) ship_frame(h_rd, F - 1);          // h_rd = h(F-1)
                 if (first) {                               // the model inputs: one k-step (x, PARAM1, PARAM2, 0)
                     const float b = xin[(tick & 1) * 64 + lane];

@@ -62,7 +62,6 @@ __host__ __device__ inline size_t lp_lds_floats(int hidden, int n_frames)
          + (size_t)hidden * kMfmaStreams                      /* cT[unit][n]                             */
          + (size_t)((hidden + 1 + 3) & ~3)                    /* Dense weights + bias (last layer)       */
          + kMfmaStreams                                       /* live flags                              */
-         + (size_t)4 * hidden                                 /* this layer's bias rows                  */
          + 2 * 8 * kMfmaStreams;                              /* Dense partial sums [parity][wave][n]    */
 }
 
@@ -183,7 +182,6 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
     float* wdl   = cT + H * NS;                            // Dense weights, bias at [H]
     float* livef = wdl + ((H + 1 + 3) & ~3);               // [NS]
     float* dpart = livef + NS;                             // [2][NW][NS] Dense partial sums of the waves (last layer)
-    float* biasl = dpart + 2 * 8 * NS;                     // [4H] this layer's bias rows, as the accumulators take them
 
     const float* W = a.wpack;
     const MfmaLayer& L = d.L[l];
@@ -236,14 +234,11 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
         cT[i] = (valid && u < Ht && L.cell == 0) ? stp[Ht + u] : 0.f;
     }
 
-    // ---- this layer's bias rows (the accumulators start from them): parked in LDS and read back at the top of every
-    // tick — 4 TPW registers that the resident fragments need more (LSTM-96 x2: 256 registers, nothing spilled)
-    for (int i = tid; i < 4 * H; i += NT) biasl[i] = W[L.b_off + i];
-    const f32x4* bias_v = reinterpret_cast<const f32x4*>(biasl) + 4 * wave * TPW + (lane >> 4);
-    __syncthreads();
+    // ---- this layer's bias rows (the accumulators start from them) and A fragments, resident for the launch
     f32x4 bias_r[TPW];
 #pragma unroll
-    for (int tl = 0; tl < TPW; ++tl) bias_r[tl] = bias_v[4 * tl];
+    for (int tl = 0; tl < TPW; ++tl)
+        bias_r[tl] = *reinterpret_cast<const f32x4*>(W + L.b_off + 4 * (4 * (wave * TPW + tl) + (lane >> 4)));
     // One register set, two uses that exclude each other: on the first layer the bias rows the moved tiles start from
     // (the upper layer's), on the others the started tiles of the NEXT frame on their way in from the ring.
     f32x4 upx[MA];

@@ -37,7 +37,10 @@ __device__ __forceinline__ float wave_sum(float v)
 
 // acc += w * (h of the lane N places to the left in its 16-lane row, cyclically): the cross-lane read rides on the FMA
 // itself (v_fmac_f32_dpp). The compiler's DPP combine does not fold v_mov_dpp into a following fmac here, so the
-// instruction is spelled out; `h` must have been written at least two instructions earlier (DPP read hazard).
+// instruction is spelled out. The hazard recognizer does not look into inline asm: `h` must have been written at least
+// two instructions before the first rotation (VALU write -> DPP read needs two wait states) — in LstmCell it is the
+// previous frame's result, with the publish, the LDS reads and the input FMAs in between; an explicit s_nop costs an
+// issue slot of the lone wave per use (measured: cfg2 73.4 -> 75.4 us) and is not needed there.
 template <int N>
 __device__ __forceinline__ void fmac_row_ror(float& acc, float h, float w)
 {

@@ -23,6 +23,17 @@ int main(int argc, char** argv)
     printf("lpf=%.3f master=%.1f enabled=%.0f\n", c.in_lpf_pc, c.master_db, c.enabled);
     if (aidax_biquad_design(0, 0.25, 0.707, 0.0, bq) != AIDAX_OK) return 1;
     printf("lowpass a0=%.6f\n", bq[0]);
+    {   /* the round-3 entry points from plain C: null handles are argument errors, never crashes */
+        aidax_stream_dsp dsp;
+        float blk[4] = { 0.f, 0.f, 0.f, 0.f };
+        int32_t slot = -1;
+        memset(&dsp, 0, sizeof dsp);
+        printf("null handles: submit=%d collect=%d export=%d import=%d successor=%d adopt=%d hub_frames=%u\n",
+               aidax_pool_submit(NULL, blk, 4), aidax_pool_collect(NULL, blk, 4), aidax_pool_export_stream_dsp(NULL, 0, &dsp),
+               aidax_pool_import_stream_dsp(NULL, 0, &dsp), aidax_hub_attach_successor(NULL, NULL, -1, &slot),
+               aidax_hub_adopt(NULL, 0, NULL, 0), aidax_hub_max_frames(NULL));
+        printf("sizeof(aidax_stream_dsp)=%u\n", (unsigned)sizeof dsp);
+    }
     rc = aidax_pool_create(1, 256, 48000.0, 0, &pool);
     printf("pool_create rc=%d pool=%s\n", rc, pool ? "set" : "null");
     if (pool) aidax_pool_destroy(pool);

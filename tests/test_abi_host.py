@@ -167,6 +167,8 @@ def test_header_is_plain_c_and_a_c_program_links(tmp_path, bundled_models):
     run = subprocess.run([exe, model], capture_output=True, text=True)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "cell=0 hidden=12 inputs=1 layers=1" in run.stdout
+    assert "null handles: submit=-1 collect=-1 export=-1 import=-1 successor=-1 adopt=-1 hub_frames=0" in run.stdout
+    assert "sizeof(aidax_stream_dsp)=136" in run.stdout          # 7 x 2 doubles + 6 floats: the binding's ctypes mirror
     import torch
     if not torch.cuda.is_available():
         assert "pool_create rc=-5 pool=null" in run.stdout

@@ -225,41 +225,32 @@ struct LstmCell {
                     act[e] = __builtin_fmaf(tanh_rat(acc[m][e]), aka[e], akb[e]);
                 }
             }
-            if constexpr (S == 2) {
+            // c' = f*c + i*g, h = o*tanh(c') — where the four gates of a unit come together:
+            float gi_gg, gf, go;
+            if constexpr (S == 1) {                         // one lane holds all four
+                gi_gg = act[0] * act[2]; gf = act[1]; go = act[3];
+            } else if constexpr (S == 2) {
                 // part 0 holds (i, g), part 1 (f, o): i*g crosses over with one swap (the register it lands in is a dead
-                // accumulator), and c' = f*c + i*g, h = o*tanh(c') happen where f and o are — in part 1
+                // accumulator), and the update happens where f and o are — in part 1; part 0's c and h are scratch
                 const float ig = act[0] * act[1];
                 const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, acc[m][1]), __builtin_bit_cast(unsigned, ig), false, false);
                 const unsigned r0 = r[0];
-                const float cn = __builtin_fmaf(act[0], c[m], __builtin_bit_cast(float, r0));
-                c[m] = cn;
-#ifdef AIDAX_TANHC_EXP
-                const float hn = act[1] * tanh_exp(cn);
-#else
-                const float hn = act[1] * tanh_rat(cn);
-#endif
-                if constexpr (ROT) h[m] = share_halves(hn).hi;      // the (f, o) half's h into both halves: the rotations read it
-                else h[m] = hn;
-                continue;
-            }
-            float gi, gf, gg, go;
-            if constexpr (S == 1) {
-                gi = act[0]; gf = act[1]; gg = act[2]; go = act[3];
-            } else if constexpr (S == 2) {
-                gi = gf = gg = go = 0.f;                    // (handled above)
+                gi_gg = __builtin_bit_cast(float, r0); gf = act[0]; go = act[1];
             } else {
-                // part q holds gate q: rows (v0,v1,v2,v3) -> (v0,v1,v0,v1),(v2,v3,v2,v3) -> each broadcast
+                // part q holds gate q: rows (v0,v1,v2,v3) -> (v0,v1,v0,v1),(v2,v3,v2,v3) -> each broadcast; every lane updates
                 const Pair p = share_halves(act[0]);
                 const Pair lo = share_rows(p.lo), hi = share_rows(p.hi);
-                gi = lo.lo; gf = lo.hi; gg = hi.lo; go = hi.hi;
+                gi_gg = lo.lo * hi.lo; gf = lo.hi; go = hi.hi;
             }
-            const float cn = __builtin_fmaf(gf, c[m], gi * gg);
+            const float cn = __builtin_fmaf(gf, c[m], gi_gg);
             c[m] = cn;
 #ifdef AIDAX_TANHC_EXP
-            h[m] = go * tanh_exp(cn);                       // experiment: the exp form for tanh(c) only (scratch/ab_tanhc.sh)
+            const float hn = go * tanh_exp(cn);             // experiment: the exp form for tanh(c) only (scratch/ab_tanhc.sh)
 #else
-            h[m] = go * tanh_rat(cn);
+            const float hn = go * tanh_rat(cn);
 #endif
+            if constexpr (ROT) h[m] = share_halves(hn).hi;  // the (f, o) half's h into both halves: the rotations read it
+            else h[m] = hn;
         }
         publish_h(hout);
         __builtin_amdgcn_wave_barrier();

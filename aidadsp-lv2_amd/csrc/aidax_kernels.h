@@ -43,7 +43,6 @@ hipError_t launch_mfma_lp_kernel(const LaunchArgs& a, const MfmaDesc& d, float* 
 // k_lstm_q4 (aidax_q4.hip): LSTM-32 snapshot models, four streams per workgroup, the whole run() in one launch
 bool q4_serves(int cell, int hidden, int input_size);
 size_t q4_lds_bytes(int hidden, uint32_t n_frames);
-int q4_resident_streams(int hidden, uint32_t n_frames, int device);
 hipError_t launch_q4_kernel(int hidden, const LaunchArgs& a, hipStream_t stream);     // a.wpack = the pack_q4 record
 size_t quad_lds_bytes(int hidden, uint32_t n_frames);
 hipError_t launch_quad_kernel(int cell, int hidden, const LaunchArgs& a, const QuadDesc& qd, hipStream_t stream);

@@ -130,7 +130,6 @@ struct ModelSlot {
     int pipe_capacity = 0;           // streams the 3-wave pipeline keeps resident at once (0 = never use it)
     bool split_pays = false;         // the lean recurrent kernel keeps the occupancy of the one-wave kernel
     float* d_wq4 = nullptr;          // k_lstm_q4's weight record (LSTM-32 snapshot models), next to the table kernels' d_wpack
-    int q4_capacity = 0;             // streams that form serves: one workgroup of four streams per CU
     float* d_wpack = nullptr;        // weights in the kernel's layout
     float* d_nn = nullptr;           // recurrent state [n_streams][nn_stride]
     float* d_ring = nullptr;         // k_mfma_lp: h of layer l-1 on its way to layer l, per stream group
@@ -573,7 +572,6 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
         wq4 = pack_q4(*m);
         HIP_TRY(hipMalloc(&ms.d_wq4, wq4.size() * sizeof(float)));
         HIP_TRY(hipMemcpyAsync(ms.d_wq4, wq4.data(), wq4.size() * sizeof(float), hipMemcpyHostToDevice, p.wq));
-        ms.q4_capacity = std::min(q4_resident_streams(m->hidden, p.max_frames, p.device), 4 * cus);
     }
     // fresh DynamicModel per stream: reset() + param smoothers around the targets the playing model holds now
     // (:822-825, :1035, :1053-1061) ...

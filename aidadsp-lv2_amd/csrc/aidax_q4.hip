@@ -374,14 +374,4 @@ hipError_t launch_q4_kernel(int hidden, const LaunchArgs& a, hipStream_t stream)
     return hipGetLastError();
 }
 
-// workgroups of this form resident at once on the device
-int q4_resident_streams(int hidden, uint32_t n_frames, int device)
-{
-    int per_cu = 0, cus = 0;
-    if (hidden != 32) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lstm_q4<32>, kQ4Waves * kWave, q4_lds_bytes(hidden, n_frames)) != hipSuccess) return 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
-    return per_cu * cus * kQ4Streams;
-}
-
 }  // namespace aidax

@@ -14,7 +14,8 @@ PKG     := aidadsp-lv2_amd
 SRC     := $(PKG)/csrc
 LIBDIR  := $(PKG)/lib
 OBJDIR  := build/obj
-CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wall -Wextra -Iinclude
+# EXTRA: measurement builds only (scratch/: e.g. EXTRA=-DAIDAX_LP_TRACE into another LIBDIR / OBJDIR)
+CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wall -Wextra -Iinclude $(EXTRA)
 # -fno-slp-vectorize: clang's SLP pass pairs scalar fp32 FMAs/adds into v_pk_fma_f32 / v_pk_add_f32, which
 # cost as much as the two scalar instructions on gfx950 plus the moves that build the pairs (measured:
 # GRU-24 pipeline 88.5 -> 84.1 us, cfg3 478 -> 464 us, nothing slower by more than noise)

@@ -225,41 +225,46 @@ constexpr int kChainBlock = AIDAX_CHAIN_BLOCK;
 // (mem * coef + tc == mem, so next() returns the same value for the rest of the block): the per-sample select
 // and the two ramp instructions drop out — 12 instructions per sample and stage instead of 15, same values.
 template <bool PLAIN>
+__device__ __forceinline__ void chain_macro_step(ChainPass& c, ExpRamp& g, int stage, bool run, bool last,
+                                                 float* row, float* hand, int M, int m, int lane)
+{
+    const int j = m - stage;
+    if (run && j >= 0 && j < M) {
+        const float g_fixed = g.mem;
+        const float* src = stage == 0 ? row + kChainBlock * j : hand + (((m - 1) & 1) * kWave + lane - 1) * kChainBlock;
+        float* dst = last ? row + kChainBlock * j : hand + ((m & 1) * kWave + lane) * kChainBlock;
+        float v[kChainBlock];
+#pragma unroll
+        for (int q = 0; q < kChainBlock / 4; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(src + 4 * q);
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+#pragma unroll
+        for (int i = 0; i < kChainBlock; ++i) {
+            const float x = v[i];
+            const double xd = x;                            // Biquad::process, Biquad.h:53-58
+            const double yd = xd * c.a0 + c.z1;
+            c.z1 = xd * c.a1 + c.z2 - c.b1 * yd;
+            c.z2 = xd * c.a2 - c.b2 * yd;
+            if constexpr (PLAIN) {
+                v[i] = (float)yd * g_fixed;
+            } else {
+                const float y = c.active ? (float)yd : x;
+                v[i] = y * g.next();
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kChainBlock / 4; ++q)
+            *reinterpret_cast<float4*>(dst + 4 * q) = float4{ v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3] };
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <bool PLAIN>
 __device__ __forceinline__ void chain_blocks(ChainPass& c, ExpRamp& g, int stage, bool run, int depth, bool last,
                                              float* row, float* hand, int M, int lane)
 {
-    const float g_fixed = g.mem;
-    for (int m = 0; m < M + depth - 1; ++m) {
-        const int j = m - stage;
-        if (run && j >= 0 && j < M) {
-            const float* src = stage == 0 ? row + kChainBlock * j : hand + (((m - 1) & 1) * kWave + lane - 1) * kChainBlock;
-            float* dst = last ? row + kChainBlock * j : hand + ((m & 1) * kWave + lane) * kChainBlock;
-            float v[kChainBlock];
-#pragma unroll
-            for (int q = 0; q < kChainBlock / 4; ++q) {
-                const float4 t = *reinterpret_cast<const float4*>(src + 4 * q);
-                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
-            }
-#pragma unroll
-            for (int i = 0; i < kChainBlock; ++i) {
-                const float x = v[i];
-                const double xd = x;                            // Biquad::process, Biquad.h:53-58
-                const double yd = xd * c.a0 + c.z1;
-                c.z1 = xd * c.a1 + c.z2 - c.b1 * yd;
-                c.z2 = xd * c.a2 - c.b2 * yd;
-                if constexpr (PLAIN) {
-                    v[i] = (float)yd * g_fixed;
-                } else {
-                    const float y = c.active ? (float)yd : x;
-                    v[i] = y * g.next();
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < kChainBlock / 4; ++q)
-                *reinterpret_cast<float4*>(dst + 4 * q) = float4{ v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3] };
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
+    for (int m = 0; m < M + depth - 1; ++m) chain_macro_step<PLAIN>(c, g, stage, run, last, row, hand, M, m, lane);
 }
 
 __device__ __forceinline__ void chain_sweep_blocked(ChainPass& c, int stage, bool run, int depth, float* row, float* hand,
@@ -277,6 +282,42 @@ __device__ __forceinline__ void chain_sweep_blocked(ChainPass& c, int stage, boo
     else chain_blocks<false>(c, g, stage, run, depth, last, row, hand, M, lane);
     if (is_gain) c.g = g;
     if (!run || !c.active) { c.z1 = z1o; c.z2 = z2o; }
+}
+
+// The blocked pass as a RESUMABLE job: begin, one macro-step (eight frames per stage) at a time, end — for a wave that
+// has other duties between the steps (the helper waves of k_mfma_lp's one-launch form run the pre pass ahead of the
+// frame loop and the post pass behind it, a step per tick). Same operations per sample and stage as chain_sweep_blocked.
+struct ChainJob {
+    ExpRamp g;
+    double z1o, z2o;
+    int M, m;
+    bool last, is_gain, plain;
+};
+__device__ __forceinline__ void chain_job_begin(ChainJob& r, const ChainPass& c, int stage, bool run, int n_full, bool force_general)
+{
+    r.z1o = c.z1; r.z2o = c.z2;
+    r.M = n_full / kChainBlock;
+    r.m = 0;
+    r.g = c.g;
+    r.is_gain = stage == c.gain_lane;
+    if (!r.is_gain) { r.g.mem = 1.f; r.g.coef = 1.f; r.g.tc = 0.f; }
+    r.last = stage == c.K - 1;
+    const bool fussy = run && (!c.active || r.g.mem * r.g.coef + r.g.tc != r.g.mem);
+    r.plain = !force_general && __builtin_amdgcn_ballot_w64(fussy) == 0;
+}
+__device__ __forceinline__ bool chain_job_pending(const ChainJob& r, int depth) { return r.M != 0 && r.m < r.M + depth - 1; }
+// frames the FIRST stage needs in the row for the next step (an input that arrives over time: the post pass)
+__device__ __forceinline__ int chain_job_needs(const ChainJob& r) { return r.m < r.M ? kChainBlock * (r.m + 1) : 0; }
+__device__ __forceinline__ void chain_job_step(ChainJob& r, ChainPass& c, int stage, bool run, float* row, float* hand, int lane)
+{
+    if (r.plain) chain_macro_step<true>(c, r.g, stage, run, r.last, row, hand, r.M, r.m, lane);
+    else chain_macro_step<false>(c, r.g, stage, run, r.last, row, hand, r.M, r.m, lane);
+    ++r.m;
+}
+__device__ __forceinline__ void chain_job_end(const ChainJob& r, ChainPass& c, bool run)
+{
+    if (r.is_gain) c.g = r.g;
+    if (!run || !c.active) { c.z1 = r.z1o; c.z2 = r.z2o; }
 }
 
 template <int DST_STRIDE = 1>

@@ -35,11 +35,12 @@ hipError_t launch_chain_pass(bool pre, const LaunchArgs& a, hipStream_t stream);
 hipError_t launch_mfma_kernel(const LaunchArgs& a, const MfmaDesc& d, hipStream_t stream);
 // k_mfma_lp (aidax_mfmalp.hip): stacked models, one workgroup per (16 streams, layer), layers chained through a global ring
 bool mfma_lp_serves(const MfmaDesc& d);
-size_t mfma_lp_lds_bytes(const MfmaDesc& d, uint32_t n_frames);
+size_t mfma_lp_lds_bytes(const MfmaDesc& d, uint32_t n_frames, bool fused = false);
+bool mfma_lp_fused_serves(const MfmaDesc& d);       // one-layer models: the DSP chain inside the same launch (helper waves)
 size_t mfma_lp_ring_bytes(const MfmaDesc& d, uint32_t n_streams);
 size_t mfma_lp_counter_bytes(const MfmaDesc& d, uint32_t n_streams);
 // `fault`: device view of a word in pinned host memory that a workgroup bumps when a hand-over wait timed out
-hipError_t launch_mfma_lp_kernel(const LaunchArgs& a, const MfmaDesc& d, float* ring, uint32_t* counters, uint32_t* fault, hipStream_t stream);
+hipError_t launch_mfma_lp_kernel(const LaunchArgs& a, const MfmaDesc& d, float* ring, uint32_t* counters, uint32_t* fault, hipStream_t stream, bool fused = false);
 // k_lstm_q4 (aidax_q4.hip): LSTM-32 snapshot models, four streams per workgroup, the whole run() in one launch
 bool q4_serves(int cell, int hidden, int input_size);
 size_t q4_lds_bytes(int hidden, uint32_t n_frames);

@@ -52,7 +52,7 @@ __device__ __forceinline__ bool lp_timed_out(uint32_t& spins, uint64_t& t0)
     return (spins & 63u) == 0 && wall_clock64() - t0 > kLpGiveUpTicks;
 }
 
-__host__ __device__ inline size_t lp_lds_floats(int hidden, int n_frames)
+__host__ __device__ inline size_t lp_lds_floats(int hidden, int n_frames, int n_helpers = 0)
 {
     const size_t nP = (size_t)(((n_frames < kLpChunk ? n_frames : kLpChunk) + 3) & ~3);
     return (size_t)kMfmaStreams * nP                          /* xb: audio rows (first and last layer)   */
@@ -62,7 +62,12 @@ __host__ __device__ inline size_t lp_lds_floats(int hidden, int n_frames)
          + (size_t)hidden * kMfmaStreams                      /* cT[unit][n]                             */
          + (size_t)((hidden + 1 + 3) & ~3)                    /* Dense weights + bias (last layer)       */
          + kMfmaStreams                                       /* live flags                              */
-         + 2 * 8 * kMfmaStreams;                              /* Dense partial sums [parity][wave][n]    */
+         + 2 * 8 * kMfmaStreams                               /* Dense partial sums [parity][wave][n]    */
+         + (size_t)n_helpers * 2 * kChainHandFloats           /* one-launch form: hand-over slots of the helper waves' pre and post pass */
+#ifdef AIDAX_LP_TRACE
+         + 2048                                               /* scratch/lp_trace.py: time stamps of eight ticks, 12 waves, 8 stamps (u64) needs 1536 floats */
+#endif
+         ;
 }
 
 // one frame in the ring: h [unit][stream], then (M > 0) the pre-activations of the first M tiles of every wave of the
@@ -144,11 +149,210 @@ __device__ __forceinline__ void lp_gates(f32x4 (&acc)[NACC], const f32x4 (&wres)
     }
 }
 
+#ifdef AIDAX_LP_TRACE
+#define LP_STAMP(k) do { if (blockIdx.x == 0 && tick >= kTraceT0 && tick < kTraceT0 + 8) {                         \
+        __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = clock64(); __builtin_amdgcn_sched_barrier(0); \
+        if ((threadIdx.x & 63) == 0) trace[((tick - kTraceT0) * 12 + (threadIdx.x >> 6)) * 8 + (k)] = t_; } } while (0)
+#else
+#define LP_STAMP(k) do {} while (0)
+#endif
+
+// ---------------------------------------------------------------- one-launch form: the helper waves
+// One-layer models whose main waves leave room for a third wave per SIMD (lp_helpers) run their whole run() in this
+// launch: NHELP extra waves, each the keeper of 16 / NHELP streams of the group in 8-lane groups like k_chain's. A helper
+//   * runs the PRE pass (LPF -> pre-gain ramp -> EQ-pre) on its streams' rows in LDS ahead of the frame loop — six
+//     macro-steps of eight frames before the first tick, one more per tick until the chunk is done;
+//   * writes the model inputs of the next frame (x * in_gain, the PARAM smoothers' samples) and finishes the Dense of
+//     the frame before last (partial sums, bias, skip, output gain) — what lane < 16 of wave 0 did at the head of every
+//     tick while seven waves waited (scratch/lp_trace.py: 2 100 cycles against 460);
+//   * runs the POST pass (DC blocker -> EQ-post -> master ramp) over the finished frames, one macro-step whenever eight
+//     more are there, the rest after the last tick, and stores the rows.
+// The passes are k_chain's own (chain_macro_step): same operations per sample and stage, bit-identical state. The helper
+// meets the main waves at every barrier of lp_body — their barrier sequences must stay the same.
+template <int H, int NW, int NHELP>
+__device__ __forceinline__ void lp_helper(const LaunchArgs& a, float* xb, float* xin, const float* wdl, float* livef,
+                                          const float* dpart, float* hands, int grp, int nP)
+{
+    constexpr int NS = kMfmaStreams;
+    constexpr int SPH = NS / NHELP;                        // streams per helper wave
+    static_assert(SPH * NHELP == NS && SPH <= 8, "eight lanes per stream");
+    if (!(a.tune & 1024)) __builtin_amdgcn_s_setprio(3);   // (measurement: AIDAX_TUNE bit 1024 leaves the helpers at the main waves' priority)
+    const int lane = threadIdx.x & 63;
+    const int hw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) - NW;
+    const int gl = lane >> 3, stage = lane & 7;
+    const int n = (int)a.n_frames;
+    const int I = a.input_size;
+    const int s_base = grp * NS;
+    const bool slot_ok = gl < SPH;                         // this lane group stands for stream slot `sl` of the group
+    const int sl = hw * SPH + (slot_ok ? gl : 0);
+    const bool valid = slot_ok && s_base + sl < (int)a.n_streams;
+    const int sg = valid ? s_base + sl : s_base;           // the others shadow the group's first stream and never store
+    const bool keeper = slot_ok && stage == 0;             // the lane that does the per-stream scalar work
+
+    const StreamCtl& ctl = a.ctl[sg];
+    StreamState& st = a.st[sg];
+    const uint32_t flags = ctl.flags;
+    const uint32_t pending0 = st.pending;
+    const bool live = valid && n != 0 && (flags & CTL_ENABLED);                 // :607-619
+    const bool net = live && (flags & CTL_NET_ON);                             // :631-632
+
+    float p_mem[2] = { st.p_mem[0], st.p_mem[1] }, p_tgt[2] = { st.p_tgt[0], st.p_tgt[1] }, p_step[2] = { st.p_step[0], st.p_step[1] };
+    uint32_t pending = pending0 & ~PEND_ACTIVATE;
+    if (net) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                      // LinearValueSmoother::setTargetValue (:209-216)
+            const float nt = ctl.p_target[i];
+            if (__builtin_fabsf(p_tgt[i] - nt) >= FLT_EPSILON) {
+                p_tgt[i] = nt;
+                p_step[i] = (p_tgt[i] - p_mem[i]) / ctl.p_den;
+            }
+        }
+        if (pending & PEND_PARAM_FIRST) {                  // paramFirstRun (:636-640)
+            pending &= ~PEND_PARAM_FIRST;
+            p_mem[0] = p_tgt[0];
+            p_mem[1] = p_tgt[1];
+        }
+    }
+    if (keeper) livef[sl] = net ? 1.f : 0.f;
+
+    // the two passes of this lane's stage, set up like k_chain<true> / k_chain<false>
+    ChainPass P, Q;
+    float pre_mem0, pre_tgt, master_mem0, master_tgt;
+    int slot_p, slot_q;
+    {
+        const bool eq = flags & CTL_EQ_PRE;
+        P.K = eq ? 6 : 1;
+        P.gain_lane = 0;
+        const int k = stage < P.K ? stage : 0;
+        slot_p = pre_slot(k);
+        const bool act = k == 0 ? (flags & CTL_LPF_ON) != 0 : ((flags & CTL_EQ_BANDPASS) ? slot_p == BQ_MID : true);
+        chain_load(P, ctl, st, slot_p, act);
+        pre_mem0 = st.pre_mem; pre_tgt = st.pre_tgt;
+        if (pending0 & PEND_ACTIVATE) pre_mem0 = pre_tgt;  // activate(): clearToTargetValue (:341-342)
+        pre_tgt = ctl.pre_target;                          // :513, before every early-out
+        P.g.arm(pre_mem0, pre_tgt, ctl.pre_coef);
+    }
+    {
+        const bool eq = flags & CTL_EQ_POST;
+        Q.K = eq ? 6 : 1;
+        Q.gain_lane = Q.K - 1;
+        const int k = stage < Q.K ? stage : 0;
+        slot_q = post_slot(k);
+        const bool act = k == 0 ? (flags & CTL_DC_ON) != 0 : ((flags & CTL_EQ_BANDPASS) ? slot_q == BQ_MID : true);
+        chain_load(Q, ctl, st, slot_q, act);
+        master_mem0 = st.master_mem; master_tgt = st.master_tgt;
+        if (pending0 & PEND_ACTIVATE) master_mem0 = master_tgt;
+        if (live) master_tgt = ctl.master_target;          // :654, only on the DSP path
+        Q.g.arm(master_mem0, master_tgt, ctl.master_coef);
+    }
+    const bool run_p = live && stage < P.K, run_q = live && stage < Q.K;
+    const bool general = (a.tune & 8) != 0;
+    const int depth_p = general || __builtin_amdgcn_ballot_w64(run_p && stage > 0) != 0 ? 6 : 1;
+    const int depth_q = general || __builtin_amdgcn_ballot_w64(run_q && stage > 0) != 0 ? 6 : 1;
+    float* row = xb + sl * nP;
+    float* hand_p = hands + (size_t)(2 * hw) * kChainHandFloats;
+    float* hand_q = hand_p + kChainHandFloats;
+#ifdef AIDAX_LP_TRACE
+    unsigned long long* trace = reinterpret_cast<unsigned long long*>(hands + NHELP * 2 * kChainHandFloats);
+    constexpr int kTraceT0 = 96;
+#endif
+    __syncthreads();                                       // (1) set-up
+
+    auto write_xin = [&](int parity, int f) {              // x * in_gain, PARAM1, PARAM2 of frame f (:171-181, :195-231)
+        float q1 = 0.f, q2 = 0.f;
+        if (I >= 2) q1 = lin_next(p_mem[0], p_tgt[0], p_step[0]);
+        if (I >= 3) q2 = lin_next(p_mem[1], p_tgt[1], p_step[1]);
+        if (keeper) {
+            float* col = xin + parity * 64;
+            col[sl] = net ? row[f] * a.in_gain : 0.f;
+            col[NS + sl] = q1;
+            col[2 * NS + sl] = q2;
+            col[3 * NS + sl] = 0.f;
+        }
+    };
+
+    for (int base = 0; base < n; base += kLpChunk) {
+        const int cnt = n - base < kLpChunk ? n - base : kLpChunk;
+        const int n_full = cnt & ~(kChainBlock - 1);
+        __syncthreads();                                   // (2) the chunk's rows are in LDS
+        ChainJob jp, jq;
+        chain_job_begin(jp, P, stage, run_p, n_full, general);
+        bool p_open = true;
+        auto pre_work = [&](int steps) {                   // the ragged tail right behind the last whole block
+            for (int k = 0; k < steps && chain_job_pending(jp, depth_p); ++k) chain_job_step(jp, P, stage, run_p, row, hand_p, lane);
+            if (p_open && !chain_job_pending(jp, depth_p)) {
+                chain_job_end(jp, P, run_p);
+                if (n_full != cnt) chain_sweep<1>(P, stage, run_p, depth_p, row + n_full, row + n_full, cnt - n_full);
+                p_open = false;
+            }
+        };
+        pre_work(6);                                       // frames 0..7 (and what a short chunk has) are final
+        chain_job_begin(jq, Q, stage, run_q, n_full, general);
+        write_xin(0, 0);
+        __syncthreads();                                   // (3)
+        const int ticks = cnt + 2;
+        for (int tick = 0; tick < ticks; ++tick) {
+            LP_STAMP(0);
+            if (tick >= 2 && keeper) {                     // Dense of frame tick-2: the waves' partial sums, bias, skip, gain
+                const int fd = tick - 2;
+                float y = wdl[H];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) y += dpart[(((tick - 1) & 1) * NW + w) * NS + sl];
+                const float x = row[fd] * a.in_gain;
+                float o = a.input_skip ? x + y : y;
+                o = o * a.out_gain;
+                if (net) row[fd] = o;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // frames 0 .. tick-2 of the rows are model output now: a post-pass step when eight more are there
+            if (chain_job_pending(jq, depth_q) && chain_job_needs(jq) <= tick - 1) chain_job_step(jq, Q, stage, run_q, row, hand_q, lane);
+            pre_work(1);
+            if (tick + 1 < cnt) write_xin((tick + 1) & 1, tick + 1);
+            LP_STAMP(4);
+            __syncthreads();                               // the tick's barrier
+            LP_STAMP(5);
+        }
+        while (chain_job_pending(jq, depth_q)) chain_job_step(jq, Q, stage, run_q, row, hand_q, lane);
+        chain_job_end(jq, Q, run_q);
+        if (n_full != cnt) chain_sweep<1>(Q, stage, run_q, depth_q, row + n_full, row + n_full, cnt - n_full);
+        __builtin_amdgcn_wave_barrier();
+        // every valid row goes out: processed, or — a disabled stream — the raw input (the hard bypass copy of :612-619)
+        for (int g = 0; g < SPH; ++g) {
+            const int s2 = s_base + hw * SPH + g;
+            if (s2 >= (int)a.n_streams) continue;
+            if ((a.ctl[s2].flags & CTL_ENABLED) || a.out != a.in) {
+                float* dst = a.out + (size_t)s2 * n + base;
+                const float* src = xb + (hw * SPH + g) * nP;
+                if (((n | base) & 3) == 0) store_block(dst, src, cnt, lane);
+                else for (int t = lane; t < cnt; t += kWave) dst[t] = src[t];
+            }
+        }
+        __syncthreads();                                   // (4) the rows may be overwritten
+    }
+#ifdef AIDAX_LP_TRACE
+    if (blockIdx.x == 0) __syncthreads();
+#endif
+    __syncthreads();                                       // (5)
+    if (!valid) return;
+    if (run_p) { st.z[slot_p][0] = P.z1; st.z[slot_p][1] = P.z2; }
+    if (run_q) { st.z[slot_q][0] = Q.z1; st.z[slot_q][1] = Q.z2; }
+    if (stage == 0) { st.pre_mem = live ? P.g.mem : pre_mem0; st.pre_tgt = pre_tgt; }
+    if (stage == Q.gain_lane) { st.master_mem = live ? Q.g.mem : master_mem0; st.master_tgt = master_tgt; }
+    if (keeper) {
+        st.pending = pending;
+        if (net) {
+            st.p_mem[0] = p_mem[0]; st.p_mem[1] = p_mem[1];
+            st.p_tgt[0] = p_tgt[0]; st.p_tgt[1] = p_tgt[1];
+            st.p_step[0] = p_step[0]; st.p_step[1] = p_step[1];
+        }
+    }
+}
+
 // M: tiles per wave of the layer above whose input half the first layer computes (lp_moved_tiles; two-layer models).
 // FIRST / LAST: the role of this workgroup's layer, a compile-time constant of the body — the kernel branches once on the
 // layer index, so each role's registers are allocated for that role only (the first layer carries no fetched tiles, no
 // Dense fragments; the others no started-tile accumulators): LSTM-96 x2 fits its 256 registers without scratch.
-template <int TPW, int NW, int M, bool FIRST, bool LAST>
+template <int TPW, int NW, int M, bool FIRST, bool LAST, int NHELP = 0>
 __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, float* ring, uint32_t* counters, uint32_t* fault,
                                         float* smem, int grp, int l)
 {
@@ -159,6 +363,8 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
     constexpr int NRES = 2 * G * TPW;                      // f32x4 of resident A fragments: [h below | own h]
     constexpr int MA = M > 0 ? M : 1;                      // array extent of the moved-tile registers
     constexpr size_t kSlot = lp_slot_floats(H, NW, M);     // floats of one ring frame
+    static_assert(NHELP == 0 || (FIRST && LAST), "helper waves serve one-layer models");
+    constexpr bool fused = NHELP > 0;                      // the whole run() in this launch: a.in -> a.out, MODE_CHAIN only
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -182,7 +388,18 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
     float* wdl   = cT + H * NS;                            // Dense weights, bias at [H]
     float* livef = wdl + ((H + 1 + 3) & ~3);               // [NS]
     float* dpart = livef + NS;                             // [2][NW][NS] Dense partial sums of the waves (last layer)
+#ifdef AIDAX_LP_TRACE
+    // measurement build only (scratch/lp_trace.py): workgroup 0 stamps the shader clock at six points of ticks 96..103
+    unsigned long long* trace = reinterpret_cast<unsigned long long*>(dpart + 2 * 8 * NS + NHELP * 2 * kChainHandFloats);
+    constexpr int kTraceT0 = 96;
+#endif
 
+    if constexpr (fused) {
+        if (wave >= NW) {
+            lp_helper<H, NW, NHELP>(a, xb, xin, wdl, livef, dpart, dpart + 2 * 8 * NS, grp, nP);
+            return;
+        }
+    }
     const float* W = a.wpack;
     const MfmaLayer& L = d.L[l];
 
@@ -190,7 +407,7 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
     float p_mem[2] = { 0.f, 0.f }, p_tgt[2] = { 0.f, 0.f }, p_step[2] = { 0.f, 0.f };
     uint32_t pending = 0;
     bool mine_live = false;
-    if (tid < NS) {
+    if (!fused && tid < NS) {
         const int sg = s_base + tid;
         const bool valid = sg < (int)a.n_streams;
         if (valid) {
@@ -335,9 +552,13 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
         if (first || last) {
             for (int sl = wave; sl < NS; sl += NW) {
                 const int sg = s_base + sl;
-                const bool lv = livef[sl] != 0.f;
+                const bool lv = fused ? sg < (int)a.n_streams : livef[sl] != 0.f;     // one-launch form: every row, the chains run on net-off streams too
                 float* row = xb + sl * nP;
-                if (lv && mode == MODE_CHAIN) {
+                if (fused) {
+                    const float* src = a.in + (size_t)(lv ? sg : 0) * n + base;
+                    if (lv && ((n | base) & 3) == 0) load_block(row, src, cnt, lane);
+                    else for (int t = lane; t < cnt; t += kWave) row[t] = lv ? src[t] : 0.f;
+                } else if (lv && mode == MODE_CHAIN) {
                     const float* src = a.out + (size_t)sg * n + base;
                     if (((n | base) & 3) == 0) load_block(row, src, cnt, lane);
                     else for (int t = lane; t < cnt; t += kWave) row[t] = src[t];
@@ -403,7 +624,7 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
         };
 
         if (first) {
-            if (tid < NS) write_xin(0, 0);
+            if (!fused && tid < NS) write_xin(0, 0);
         } else {
             if (tid == 0) wait_below(done + 2);            // frame 0 of the chunk for now, frame 1 for tick 0's prefetch
             __syncthreads();
@@ -420,10 +641,11 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
             const bool body = tick < cnt;
             const bool more = tick + 1 < cnt;              // another frame of this chunk follows
             const int F = done + tick;                     // frame of the launch this tick computes
+            LP_STAMP(0);
             // ---- the next frame's input on its way: model inputs (first layer) / h of the layer below into
             // registers (others; thread 0 made sure of its existence before the previous barrier)
             if (first) {
-                if (tid < NS && more) write_xin((tick + 1) & 1, tick + 1);
+                if (!fused && tid < NS && more) write_xin((tick + 1) & 1, tick + 1);
             } else if (more) {
                 fetch_below(F + 1);
             }
@@ -449,7 +671,10 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
                 }
             }
 
-            // ---- Dense(H,1) of frame tick-1: this wave's k-steps against h(tick-1) (= hT[rd], stable for the whole tick)
+            // ---- Dense(H,1) of frame tick-1: this wave's k-steps against h(tick-1) (= hT[rd], stable for the whole tick).
+            // At the head of the tick on purpose: its LDS reads and two MFMAs run while the gates' first operands are still on
+            // their way from LDS. (Issued behind the gates, with the partial sum leaving after the cell update: cfg5 1 130 ->
+            // 1 156 us, GRU-64 446 -> 466 us.)
             if (last && tick >= 1 && tick <= cnt) {
                 f32x4 dacc = f32x4{ 0.f, 0.f, 0.f, 0.f };
                 const float* hv = hT + rd * H * NS;
@@ -459,7 +684,7 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
                 if (lane < NS) dpart[((tick & 1) * NW + wave) * NS + lane] = dacc.x;      // row 0, column = stream `lane`
             }
             // ---- ... and of frame tick-2: the NW partial sums, bias, skip, output gain (wave 0, one lane per stream)
-            if (last && tick >= 2 && wave == 0 && lane < NS) {
+            if (!fused && last && tick >= 2 && wave == 0 && lane < NS) {
                 const int fd = tick - 2;
                 float y = wdl[H];
 #pragma unroll
@@ -470,6 +695,7 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
                 if (livef[lane] != 0.f) xb[lane * nP + fd] = o;
             }
 
+            LP_STAMP(1);
             if (body) {
                 float* h_rd = hT + rd * H * NS;
                 float* h_wr = hT + wr * H * NS;
@@ -495,7 +721,9 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
                         lp_gates<TPW, G, 0, NRES, M, TPW>(acc, wres, below + (tick & 1) * H * NS, lane);
                     }
                 }
+                LP_STAMP(2);
                 lp_gates<TPW, G, G, NRES>(acc, wres, h_rd, lane);
+                LP_STAMP(3);
 
 #pragma unroll
                 for (int tl = 0; tl < TPW; ++tl) {
@@ -515,6 +743,7 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
                     h_wr[e] = hn;
                 }
                 par = wr;
+                LP_STAMP(4);
                 if (!first && more) {
                     stash_below((tick + 1) & 1);
 #pragma unroll
@@ -523,6 +752,7 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
                 if (!last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's ring stores have left before the barrier (G16)
             }
             __syncthreads();                               // h(t) in LDS, the next frame's input in LDS, ring stores of this frame done
+            LP_STAMP(5);
             // ---- counters, by thread 0 after the barrier: every kLpBatch frames and at the end of the launch
             if (body && tid == 0) {
                 if (!last) {
@@ -541,7 +771,7 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
         }
         done += cnt;
         // ---- results of this chunk back to HBM (last layer)
-        if (last) {
+        if (last && !fused) {
             for (int sl = wave; sl < NS; sl += NW) {
                 const int sg = s_base + sl;
                 if (livef[sl] == 0.f || mode == MODE_WARMUP) continue;
@@ -561,6 +791,9 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
         if (tid == 0) __hip_atomic_store(cnt_out, base_out + (uint32_t)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
+#ifdef AIDAX_LP_TRACE
+    if (blockIdx.x == 0) { __syncthreads(); for (int i = tid; i < 2 * 768; i += NT) fault[16 + i] = reinterpret_cast<const uint32_t*>(trace)[i]; }
+#endif
     // ---- recurrent state and smoother memories back to HBM for the streams that ran
 #pragma unroll
     for (int tl = 0; tl < TPW; ++tl) cT[(wave * TPW + tl) * 64 + lane] = creg[tl];
@@ -573,7 +806,7 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
             if (L.cell == 0) stp[Ht + u] = cT[i];
         }
     }
-    if (first && tid < NS && mine_live && mode == MODE_CHAIN) {
+    if (!fused && first && tid < NS && mine_live && mode == MODE_CHAIN) {
         StreamState& st = a.st[s_base + tid];
         st.p_mem[0] = p_mem[0]; st.p_mem[1] = p_mem[1];
         st.p_tgt[0] = p_tgt[0]; st.p_tgt[1] = p_tgt[1];
@@ -582,10 +815,15 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
     }
 }
 
-template <int TPW, int NW, int M>
-__global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d, float* ring, uint32_t* counters, uint32_t* fault)
+template <int TPW, int NW, int M, int NHELP = 0>
+__global__ __launch_bounds__((NW + NHELP) * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d, float* ring, uint32_t* counters, uint32_t* fault)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if constexpr (NHELP > 0) {                             // one layer, the whole run() of its streams: workgroup = stream group
+        const int n_groups = ((int)a.n_streams + kMfmaStreams - 1) / kMfmaStreams;
+        if ((int)blockIdx.x < n_groups) lp_body<TPW, NW, 0, true, true, NHELP>(a, d, ring, counters, fault, smem, (int)blockIdx.x, 0);
+        return;
+    }
     // workgroup id -> (group, layer): ids of one group are 8 apart, lower layers first
     // (AIDAX_TUNE bit 2 lays a group's layers out on ADJACENT ids instead — different XCDs under b % 8 — so that the
     // tests can exercise the cross-XCD hand-over too.)
@@ -604,6 +842,19 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d
 
 // ---------------------------------------------------------------- host side
 typedef void (*LpFn)(LaunchArgs, MfmaDesc, float*, uint32_t*, uint32_t*);
+// Helper waves of the one-launch form: a third wave per SIMD must fit next to the main waves' registers (512 per SIMD
+// lane: H <= 64 at <= 160 registers; H = 80 / 96 hold 256 / 233 and keep the three-launch form).
+constexpr int kLpHelpers = 4;
+static int lp_helpers(int hidden) { return hidden == 16 || hidden == 32 || hidden == 48 || hidden == 64 ? kLpHelpers : 0; }
+static LpFn lp_fn_fused(int hidden)
+{
+    switch (hidden) {
+#define AIDAX_LP_FUSED_CASE(HID) case HID: { constexpr int T = HID / 4 / mfma_waves(HID), W_ = mfma_waves(HID); return k_mfma_lp<T, W_, 0, kLpHelpers>; }
+    AIDAX_LP_FUSED_CASE(16) AIDAX_LP_FUSED_CASE(32) AIDAX_LP_FUSED_CASE(48) AIDAX_LP_FUSED_CASE(64)
+#undef AIDAX_LP_FUSED_CASE
+    default: return nullptr;
+    }
+}
 static LpFn lp_fn(int hidden, int n_layers)
 {
     switch (hidden) {
@@ -618,7 +869,12 @@ static int lp_m(const MfmaDesc& d) { return lp_moved_tiles(d.n_layers, d.hidden 
 
 // (one-layer models too: a workgroup per 16 streams with the layer's fragments resident in registers — no ring, no waits)
 bool mfma_lp_serves(const MfmaDesc& d) { return d.n_layers >= 1 && lp_fn(d.hidden, d.n_layers) != nullptr; }
-size_t mfma_lp_lds_bytes(const MfmaDesc& d, uint32_t n_frames) { return lp_lds_floats(d.hidden, (int)n_frames) * sizeof(float); }
+size_t mfma_lp_lds_bytes(const MfmaDesc& d, uint32_t n_frames, bool fused)
+{
+    return lp_lds_floats(d.hidden, (int)n_frames, fused ? lp_helpers(d.hidden) : 0) * sizeof(float);
+}
+// the whole run() in the one launch (a.in -> a.out, MODE_CHAIN): one-layer models with room for the helper waves
+bool mfma_lp_fused_serves(const MfmaDesc& d) { return d.n_layers == 1 && lp_helpers(d.hidden) > 0; }
 size_t mfma_lp_ring_bytes(const MfmaDesc& d, uint32_t n_streams)
 {
     const size_t groups = (n_streams + kMfmaStreams - 1) / kMfmaStreams;
@@ -630,18 +886,20 @@ size_t mfma_lp_counter_bytes(const MfmaDesc& d, uint32_t n_streams)
     return 256 + groups * (size_t)(d.n_layers - 1) * kLpCounterStride * sizeof(uint32_t);
 }
 
-hipError_t launch_mfma_lp_kernel(const LaunchArgs& a, const MfmaDesc& d, float* ring, uint32_t* counters, uint32_t* fault, hipStream_t stream)
+hipError_t launch_mfma_lp_kernel(const LaunchArgs& a, const MfmaDesc& d, float* ring, uint32_t* counters, uint32_t* fault, hipStream_t stream, bool fused)
 {
-    LpFn fn = lp_fn(d.hidden, d.n_layers);
+    if (fused && (!mfma_lp_fused_serves(d) || a.mode != MODE_CHAIN || a.n_frames == 0)) return hipErrorInvalidValue;
+    LpFn fn = fused ? lp_fn_fused(d.hidden) : lp_fn(d.hidden, d.n_layers);
     if (!fn || !ring || !counters || !fault) return hipErrorInvalidValue;
-    const size_t lds = mfma_lp_lds_bytes(d, a.n_frames);
+    const size_t lds = mfma_lp_lds_bytes(d, a.n_frames, fused);
     if (lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     const uint32_t groups = (a.n_streams + kMfmaStreams - 1) / kMfmaStreams;
     const uint32_t blocks = ((groups + 7) / 8) * 8 * (uint32_t)d.n_layers;
-    hipLaunchKernelGGL(fn, dim3(blocks), dim3(mfma_waves(d.hidden) * kWave), lds, stream, a, d, ring, counters, fault);
+    const int waves = mfma_waves(d.hidden) + (fused ? lp_helpers(d.hidden) : 0);
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(waves * kWave), lds, stream, a, d, ring, counters, fault);
     return hipGetLastError();
 }
 

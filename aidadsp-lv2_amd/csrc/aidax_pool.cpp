@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <atomic>
 #include <chrono>
@@ -46,10 +47,17 @@ constexpr uint32_t kMaxFrames = 8192;           // LDS block buffer bound (32 Ki
 // k_mfma (16 streams per workgroup on mfma_16x16x4) takes over for the wide cells from 4096-8192 streams
 // (LSTM-80 @ 16384: 2.3 ms against 4.3 ms for k_quad and 8.4 ms for the one-wave kernel). GRU-64 ties with
 // its register kernel up to 8192 streams and stays there.
+// Round 3 (scratch/perf_lp1.py, profiles/r03_cfg3_forms.txt): the one-launch form of k_mfma_lp (one workgroup per 16
+// streams, the DSP chain on its helper waves) costs the same whatever the stream count while its workgroups fit the
+// machine in one round, and beats every other form when that round is (nearly) full — LSTM-32 209 us against 231,
+// GRU-32 197 / 211, LSTM-40 338 / 346, GRU-64 434 / 468 at 4096 streams on 256 CUs; at 3072 streams the others win.
 enum ManyForm { MANY_NONE = 0, MANY_QUAD = 1, MANY_MFMA = 2 };
-ManyForm many_streams_form(int cell, int hidden, uint32_t n)
+ManyForm many_streams_form(int cell, int hidden, uint32_t n, int cus)
 {
     const bool lstm = cell == AIDAX_CELL_LSTM;
+    const uint32_t groups = (n + kMfmaStreams - 1) / kMfmaStreams;
+    const bool full_round = cus > 0 && groups <= static_cast<uint32_t>(cus) && groups * 8 > static_cast<uint32_t>(cus) * 7;
+    if (full_round && (hidden == 32 || hidden == 64 || (hidden == 40 && lstm))) return MANY_MFMA;
     if (hidden <= 32) return n >= 4096 ? MANY_QUAD : MANY_NONE;
     if (hidden == 40) return n >= 8192 ? MANY_MFMA : n >= (lstm ? 512u : 4096u) ? MANY_QUAD : MANY_NONE;
     if (hidden == 64 && !lstm) return n >= 16384 ? MANY_MFMA : n <= 1024 ? MANY_QUAD : MANY_NONE;
@@ -135,6 +143,7 @@ struct ModelSlot {
     float* d_ring = nullptr;         // k_mfma_lp: h of layer l-1 on its way to layer l, per stream group
     uint32_t* d_counters = nullptr;  // k_mfma_lp: frames produced / consumed per (group, layer boundary)
     const void* lp_owner = nullptr;  // the pool whose hold on the device's LpGate this slot shares (d_ring != nullptr)
+    bool lp_fused = false;           // k_mfma_lp runs the DSP chain too (one-layer models, helper waves): one launch per block
 
     float p_den() const { return 0.1f * model_sr; }      // LinearValueSmoother tau * sampleRate (:1053-1054)
 };
@@ -223,6 +232,7 @@ struct aidax_pool {
 
     ModelSlot cur;
     int tune = 0;                    // AIDAX_TUNE (measurement switches, see LaunchArgs)
+    int cus = 0;                     // compute units of the device (form selection)
     int force_form = 0;              // AIDAX_KERNEL=wave|pipe|split|valu|mfma|quad overrides the heuristic (A/B testing)
 
     // Form of a MODE_CHAIN pass of a TABLE slot: 0 one wave per stream, 1 three-wave pipeline (all streams resident at
@@ -244,12 +254,12 @@ struct aidax_pool {
     bool quad_for_table_model(int cell_kind, int hidden_units) const
     {
         if (force_form == 6) return true;
-        return force_form == 0 && many_streams_form(cell_kind, hidden_units, n_streams) == MANY_QUAD;
+        return force_form == 0 && many_streams_form(cell_kind, hidden_units, n_streams, cus) == MANY_QUAD;
     }
     bool mfma_for_table_model(int cell_kind, int hidden_units) const
     {
         if (force_form == 5) return true;
-        return force_form == 0 && many_streams_form(cell_kind, hidden_units, n_streams) == MANY_MFMA;
+        return force_form == 0 && many_streams_form(cell_kind, hidden_units, n_streams, cus) == MANY_MFMA;
     }
     bool use_pipe(const ModelSlot& m) const
     {
@@ -367,6 +377,8 @@ struct aidax_pool {
                                                             : launch_mfma_kernel(a, m.mdesc, s);
             };
             if (a.mode != MODE_CHAIN) return model_kernel();
+            if (m.lp_fused && lp_in_use(m) && a.n_frames != 0)
+                return launch_mfma_lp_kernel(a, m.mdesc, m.d_ring, m.d_counters, hd_lp_fault, s, true);
             hipError_t e = launch_chain_pass(true, a, s);
             if (e == hipSuccess && a.n_frames != 0) e = model_kernel();
             if (e == hipSuccess) e = launch_chain_pass(false, a, s);
@@ -424,6 +436,11 @@ struct aidax_pool {
         if (cur.d_ring) (void)hipFree(cur.d_ring);
         if (cur.d_counters) (void)hipFree(cur.d_counters);
         if (cur.lp_owner) { lp_gate().release(device, cur.lp_owner); cur.lp_owner = nullptr; }
+#ifdef AIDAX_LP_TRACE
+        if (h_lp_fault)
+            if (const char* f = std::getenv("AIDAX_LP_TRACE_FILE"))
+                if (FILE* fp = std::fopen(f, "wb")) { std::fwrite(h_lp_fault + 16, 4, 1536, fp); std::fclose(fp); }
+#endif
         if (h_lp_fault) (void)hipHostFree(h_lp_fault);
         h_lp_fault = nullptr;
         for (int k = 0; k < 2; ++k) {
@@ -562,6 +579,8 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
         HIP_TRY(hipMalloc(&ms.d_ring, mfma_lp_ring_bytes(ms.mdesc, p.n_streams)));
         HIP_TRY(hipMalloc(&ms.d_counters, mfma_lp_counter_bytes(ms.mdesc, p.n_streams)));
         HIP_TRY(hipMemsetAsync(ms.d_counters, 0, mfma_lp_counter_bytes(ms.mdesc, p.n_streams), p.wq));
+        const char* fu = std::getenv("AIDAX_LP_FUSED");      // (=0: packed k_chain launches around the kernel, A/B runs)
+        ms.lp_fused = mfma_lp_fused_serves(ms.mdesc) && !(fu && fu[0] == '0') && mfma_lp_lds_bytes(ms.mdesc, p.max_frames, true) <= 160 * 1024;
     }
     HIP_TRY(hipMemcpyAsync(ms.d_wpack, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice, p.wq));
     std::vector<float> wq4;                                // (lives until the stream has been waited for below)
@@ -682,12 +701,17 @@ AIDAX_API int aidax_pool_create(uint32_t n_streams, uint32_t max_frames, double 
         if (const char* t = std::getenv("AIDAX_TUNE")) p->tune = std::atoi(t);
         try {
             HIP_TRY(hipSetDevice(device_id));
+            HIP_TRY(hipDeviceGetAttribute(&p->cus, hipDeviceAttributeMultiprocessorCount, device_id));
             // the audio side's stream outranks the worker's: a pass must not queue behind a warm-up for its CUs
             int prio_least = 0, prio_greatest = 0;
             HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
             HIP_TRY(hipStreamCreateWithPriority(&p->q, hipStreamNonBlocking, prio_greatest));
             HIP_TRY(hipStreamCreateWithPriority(&p->wq, hipStreamNonBlocking, prio_least));
+#ifdef AIDAX_LP_TRACE
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_lp_fault), 8192, hipHostMallocDefault));     // + the time stamps of scratch/lp_trace.py
+#else
             HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_lp_fault), 64, hipHostMallocDefault));
+#endif
             HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->hd_lp_fault), p->h_lp_fault, 0));
             *p->h_lp_fault = 0;
             HIP_TRY(hipEventCreateWithFlags(&p->ev_x, hipEventDisableTiming));
@@ -1149,7 +1173,7 @@ AIDAX_API const char* aidax_pool_kernel_name(const aidax_pool* p)
     if (!(p && p->cur.has_model)) return "k_nomodel";
     const ModelSlot& m = p->cur;
     if (m.kind == ModelSlot::STACK) return "k_stack";
-    if (m.kind == ModelSlot::MFMA) return p->lp_in_use(m) ? "k_chain+k_mfma_lp" : "k_chain+k_mfma";
+    if (m.kind == ModelSlot::MFMA) return !p->lp_in_use(m) ? "k_chain+k_mfma" : m.lp_fused ? "k_mfma_lp" : "k_chain+k_mfma_lp";
     if (m.kind == ModelSlot::QUAD) return "k_chain+k_quad";
     if (m.kind == ModelSlot::CONV) return m.conv_fused ? "k_conv_mfma" : m.conv_mfma ? "k_chain+k_conv_mfma" : "k_conv";
     const int form = p->chain_form(m);

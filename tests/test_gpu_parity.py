@@ -486,7 +486,7 @@ _EQ_POST = dict(bass_boost_db=4.0, mid_boost_db=-3.0, mid_q=1.2, treble_boost_db
 
 @pytest.mark.parametrize("name,kw,S,ckw,kernel", [
     ("cfg2", dict(kind="lstm", hidden=32, input_size=1, seed=32), 1024, {}, "k_lstm_pipe<32>"),
-    ("cfg3", dict(kind="gru", hidden=64, input_size=3, seed=64), 4096, _EQ_POST, "k_chain+k_nn<gru64>"),
+    ("cfg3", dict(kind="gru", hidden=64, input_size=3, seed=64), 4096, _EQ_POST, "k_mfma_lp"),                    # one launch: the chain on the helper waves
     ("cfg4", dict(kind="conv", hidden=16, input_size=1, seed=1608), 1024, {}, "k_conv_mfma"),
     ("cfg5", dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2), 2048, {}, "k_chain+k_mfma_lp"),
     ("lstm80-2k", dict(kind="lstm", hidden=80, input_size=2, seed=80), 2048, dict(param1=0.7), "k_chain+k_quad"),
@@ -844,14 +844,16 @@ def test_stacked_model_state_readback(tmp_path):
 
 # ------------------------------------------------------------ the launch forms of the chain
 
-@pytest.mark.parametrize("form", ["wave", "pipe", "split", "mfma", "quad", "q4"])
+@pytest.mark.parametrize("form", ["wave", "pipe", "split", "mfma", "mfma_split", "quad", "q4"])
 def test_every_kernel_form_passes_the_same_chain_cases(form, tmp_path, monkeypatch, bundled_models):
     """AIDAX_KERNEL pins one form: one wave per stream, the 3-wave pipeline, the split launches (packed
-    chain kernels around the lean recurrent kernel), or the split launches around the matrix-core
-    kernel (16 streams per workgroup). Same inputs, same oracle, same bars:
-    ragged block sizes incl. the pre-run, per-stream controls with bypass/disable, conditioned GRU
+    chain kernels around the lean recurrent kernel), the matrix-core kernel (16 streams per workgroup) with
+    the DSP chain on its helper waves (one launch) or between the packed chain launches. Same inputs, same oracle,
+    same bars: ragged block sizes incl. the pre-run, per-stream controls with bypass/disable, conditioned GRU
     with ramping params, model swap and activate."""
-    monkeypatch.setenv("AIDAX_KERNEL", form)
+    monkeypatch.setenv("AIDAX_KERNEL", form.split("_")[0])
+    if form == "mfma_split":
+        monkeypatch.setenv("AIDAX_LP_FUSED", "0")
     # (1) ragged blocks, 70 streams (not a multiple of the 8-stream chain waves), LSTM-32 with skip + gains
     path, spec = _model_file(tmp_path, "f1", kind="lstm", hidden=32, input_size=1, seed=5, in_skip=1, in_gain=-2.0, out_gain=3.0)
     S = 70
@@ -863,7 +865,7 @@ def test_every_kernel_form_passes_the_same_chain_cases(form, tmp_path, monkeypat
            dict(dc_blocker=0.0, in_lpf_pc=0.0, eq_bypass=1.0), dict(pregain_db=6.0, master_db=-6.0, treble_boost_db=4.0)]
     for s in range(S):
         pool.set_controls(ax.default_controls(**kws[s % len(kws)]), stream=s)
-    assert pool.kernel_name.startswith({"wave": "k_lstm<", "pipe": "k_lstm_pipe<", "split": "k_chain+k_nn<", "mfma": "k_chain+k_mfma", "quad": "k_chain+k_quad", "q4": "k_lstm_q4<"}[form])
+    assert pool.kernel_name.startswith({"wave": "k_lstm<", "pipe": "k_lstm_pipe<", "split": "k_chain+k_nn<", "mfma": "k_mfma_lp", "mfma_split": "k_chain+k_mfma", "quad": "k_chain+k_quad", "q4": "k_lstm_q4<"}[form])
     got = np.empty_like(x)
     pos = 0
     for n in sizes:

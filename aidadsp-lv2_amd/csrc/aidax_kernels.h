@@ -40,6 +40,10 @@ bool mfma_lp_fused_serves(const MfmaDesc& d);       // one-layer models: the DSP
 size_t mfma_lp_ring_bytes(const MfmaDesc& d, uint32_t n_streams);
 size_t mfma_lp_counter_bytes(const MfmaDesc& d, uint32_t n_streams);
 // `fault`: device view of a word in pinned host memory that a workgroup bumps when a hand-over wait timed out
+// k_gru_gm (aidax_mfmalp.hip): one-layer GRU on gate-major tiles, the whole run() in one launch (MODE_CHAIN, n_frames > 0)
+bool gru_gm_serves(const MfmaDesc& d);
+size_t gru_gm_lds_bytes(const MfmaDesc& d, uint32_t n_frames);
+hipError_t launch_gru_gm_kernel(const LaunchArgs& a, const MfmaDesc& d, hipStream_t stream);
 hipError_t launch_mfma_lp_kernel(const LaunchArgs& a, const MfmaDesc& d, float* ring, uint32_t* counters, uint32_t* fault, hipStream_t stream, bool fused = false);
 // k_lstm_q4 (aidax_q4.hip): LSTM-32 snapshot models, four streams per workgroup, the whole run() in one launch
 bool q4_serves(int cell, int hidden, int input_size);

@@ -186,7 +186,9 @@ struct MfmaLayer {
 };
 struct MfmaDesc {
     int32_t n_layers, hidden, tpw, waves;      // hidden = the kernel's width: the model's rounded up to 16 (zero rows / columns)
-    int32_t hidden_true, pad[3];               // the model's width: layout of the recurrent state in HBM (h[.] then c[.])
+    int32_t hidden_true;                       // the model's width: layout of the recurrent state in HBM (h[.] then c[.])
+    uint32_t gm_off;                           // one-layer GRU: offset of the gate-major record k_gru_gm reads (0: none), see pack_mfma
+    int32_t pad[2];
     MfmaLayer L[kMaxStackLayers];
     uint32_t wd_off, bd_off;
 };

@@ -840,6 +840,163 @@ __global__ __launch_bounds__((NW + NHELP) * kWave) void k_mfma_lp(LaunchArgs a, 
     else lp_body<TPW, NW, M, false, false>(a, d, ring, counters, fault, smem, grp, l);
 }
 
+// ================================================================ k_gru_gm: one-layer GRU, gate-major tiles
+// The tiles of k_mfma / k_mfma_lp hold four gate rows per unit; a GRU has three that contract over h (z, r and the
+// candidate's recurrent half) and one that only sees the model inputs, so a quarter of the recurrent MFMAs multiply zeros.
+// Here a wave owns 16 units as three recurrent tiles of their own (z, r, recurrent half: H/4 k-steps each) plus the
+// input half as a fourth accumulator that takes the input k-step only: 3 H/4 + 3 MFMAs per wave and frame instead of
+// 4 (H/4 + 1) — GRU-64: 51 against 68 per SIMD. A lane then holds the four gates of FOUR units (rows 4q .. 4q+3 of each
+// tile) for its stream, their h(t-1) stays in registers, and one main wave per SIMD does it (H / 16 of them) next to
+// one helper wave (lp_helper: the DSP chain, the model inputs, the Dense's tail — the whole run() in this launch).
+// Same weights and the same accumulation order per row as pack_mfma's other record: the recurrent state is
+// bit-identical to k_mfma's (which warms the model up) and k_mfma_lp's.
+__host__ __device__ inline size_t gm_lds_floats(int hidden, int n_frames, int n_helpers)
+{
+    const size_t nP = (size_t)(((n_frames < kLpChunk ? n_frames : kLpChunk) + 3) & ~3);
+    return (size_t)kMfmaStreams * nP + 2 * 64 + (size_t)2 * hidden * kMfmaStreams + (size_t)((hidden + 1 + 3) & ~3) + kMfmaStreams
+         + 2 * 8 * kMfmaStreams + (size_t)n_helpers * 2 * kChainHandFloats
+#ifdef AIDAX_LP_TRACE
+         + 2048                                             /* the helpers' time stamps land here (not dumped for this kernel) */
+#endif
+         ;
+}
+
+template <int UT, int NHELP>
+__global__ __launch_bounds__((UT + NHELP) * kWave) void k_gru_gm(LaunchArgs a, MfmaDesc d)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int H = 16 * UT, NW = UT, NS = kMfmaStreams, KS = H / 4, NT = NW * kWave;
+    constexpr int DK = KS / NW;                             // Dense k-steps per wave (= 4)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = (int)a.n_frames;
+    const int grp = (int)blockIdx.x;
+    const int s_base = grp * NS;
+    const int Ht = d.hidden_true;
+    const int chunk = n < kLpChunk ? n : kLpChunk;
+    const int nP = (chunk + 3) & ~3;
+    float* xb    = smem;                                    // [NS][nP] audio rows
+    float* xin   = xb + NS * nP;                            // [2][4][NS] model inputs of a frame
+    float* hT    = xin + 2 * 64;                            // [2][H][NS]
+    float* wdl   = hT + 2 * H * NS;                         // Dense weights, bias at [H]
+    float* livef = wdl + ((H + 1 + 3) & ~3);                // [NS]
+    float* dpart = livef + NS;                              // [2][8][NS] Dense partial sums of the waves
+    float* hands = dpart + 2 * 8 * NS;
+    if (wave >= NW) {
+        lp_helper<H, NW, NHELP>(a, xb, xin, wdl, livef, dpart, hands, grp, nP);
+        return;
+    }
+    const float* W = a.wpack;
+    const MfmaLayer& L = d.L[0];
+    const int q = lane >> 4, c = lane & 15;
+    for (int i = tid; i < H + 1; i += NT) wdl[i] = W[d.wd_off + i];
+    // this wave's record (pack_mfma: gate-major)
+    const float* rec = W + d.gm_off + (size_t)wave * kWave * (3 + 3 * KS + 16);
+    float w_in[3], w_rec[KS][3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) w_in[g] = rec[g * kWave + lane];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) w_rec[kk][g] = rec[(3 + 3 * kk + g) * kWave + lane];
+    f32x4 bias[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias[g] = *reinterpret_cast<const f32x4*>(rec + (3 + 3 * KS) * kWave + (g * kWave + lane) * 4);
+    float dfrag[DK];
+#pragma unroll
+    for (int i = 0; i < DK; ++i) dfrag[i] = c == 0 ? W[d.wd_off + 4 * (wave * DK + i) + q] : 0.f;
+    // h(t-1) of this lane's four units (16 wave + 4q + e) of stream s_base + c: registers for the launch, LDS for the others
+    const int sg = s_base + c;
+    const bool valid = sg < (int)a.n_streams;
+    const float* stp = a.nn + (size_t)(valid ? sg : 0) * a.nn_stride + L.state_off;
+    float hreg[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int u = 16 * wave + 4 * q + e;
+        hreg[e] = (valid && u < Ht) ? stp[u] : 0.f;         // padded units rest at 0
+        hT[u * NS + c] = hreg[e];
+    }
+    __syncthreads();                                        // (1)
+
+    int par = 0;
+    for (int base = 0; base < n; base += kLpChunk) {
+        const int cnt = n - base < kLpChunk ? n - base : kLpChunk;
+        for (int sl = wave; sl < NS; sl += NW) {            // every valid row: the chains run on net-off streams too
+            const int s2 = s_base + sl;
+            const bool lv = s2 < (int)a.n_streams;
+            float* row = xb + sl * nP;
+            const float* src = a.in + (size_t)(lv ? s2 : 0) * n + base;
+            if (lv && ((n | base) & 3) == 0) load_block(row, src, cnt, lane);
+            else for (int t = lane; t < cnt; t += kWave) row[t] = lv ? src[t] : 0.f;
+        }
+        __syncthreads();                                    // (2)
+        __syncthreads();                                    // (3) the helpers have run the head of the pre pass and written frame 0's inputs
+        const int ticks = cnt + 2;
+        for (int tick = 0; tick < ticks; ++tick) {
+            const float* h_rd = hT + par * H * NS;
+            float* h_wr = hT + (par ^ 1) * H * NS;
+            if (tick >= 1 && tick <= cnt) {                 // Dense of frame tick-1: this wave's k-steps against h(tick-1)
+                f32x4 dacc = f32x4{ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+                for (int i = 0; i < DK; ++i)
+                    dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(dfrag[i], h_rd[64 * (wave * DK + i) + lane], dacc, 0, 0, 0);
+                if (lane < NS) dpart[((tick & 1) * NW + wave) * NS + lane] = dacc.x;
+            }
+            if (tick < cnt) {
+                f32x4 az = bias[0], ar = bias[1], an = bias[2], ax = bias[3];
+                const float bx = xin[(tick & 1) * 64 + lane];
+                az = __builtin_amdgcn_mfma_f32_16x16x4f32(w_in[0], bx, az, 0, 0, 0);
+                ar = __builtin_amdgcn_mfma_f32_16x16x4f32(w_in[1], bx, ar, 0, 0, 0);
+                ax = __builtin_amdgcn_mfma_f32_16x16x4f32(w_in[2], bx, ax, 0, 0, 0);
+                // h k-steps, the B values a group of four ahead of the MFMAs that use them
+                float b0[4], b1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b0[j] = h_rd[64 * j + lane];
+#pragma unroll
+                for (int g = 0; g < KS / 4; ++g) {
+                    if (g + 1 < KS / 4) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) (g & 1 ? b0 : b1)[j] = h_rd[64 * (4 * (g + 1) + j) + lane];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float bh = (g & 1 ? b1 : b0)[j];
+                        az = __builtin_amdgcn_mfma_f32_16x16x4f32(w_rec[4 * g + j][0], bh, az, 0, 0, 0);
+                        ar = __builtin_amdgcn_mfma_f32_16x16x4f32(w_rec[4 * g + j][1], bh, ar, 0, 0, 0);
+                        an = __builtin_amdgcn_mfma_f32_16x16x4f32(w_rec[4 * g + j][2], bh, an, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gz = fast_sigmoid(az[e]), gr = fast_sigmoid(ar[e]);
+                    const float nn = tanh_rat(__builtin_fmaf(gr, an[e], ax[e]));
+                    const float hn = __builtin_fmaf(gz, hreg[e] - nn, nn);
+                    hreg[e] = hn;
+                    h_wr[(16 * wave + 4 * q + e) * NS + c] = hn;
+                }
+                par ^= 1;
+            }
+            __syncthreads();                                // the tick's barrier
+        }
+        __syncthreads();                                    // (4) the helpers have stored the rows
+    }
+#ifdef AIDAX_LP_TRACE
+    if (blockIdx.x == 0) __syncthreads();                   // (lp_helper's extra barrier of the measurement build)
+#endif
+    __syncthreads();                                        // (5)
+    if (valid && livef[c] != 0.f) {
+        float* dst = a.nn + (size_t)sg * a.nn_stride + L.state_off;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int u = 16 * wave + 4 * q + e;
+            if (u < Ht) dst[u] = hreg[e];
+        }
+    }
+}
+
 // ---------------------------------------------------------------- host side
 typedef void (*LpFn)(LaunchArgs, MfmaDesc, float*, uint32_t*, uint32_t*);
 // Helper waves of the one-launch form: a third wave per SIMD must fit next to the main waves' registers (512 per SIMD
@@ -900,6 +1057,34 @@ hipError_t launch_mfma_lp_kernel(const LaunchArgs& a, const MfmaDesc& d, float* 
     const uint32_t blocks = ((groups + 7) / 8) * 8 * (uint32_t)d.n_layers;
     const int waves = mfma_waves(d.hidden) + (fused ? lp_helpers(d.hidden) : 0);
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(waves * kWave), lds, stream, a, d, ring, counters, fault);
+    return hipGetLastError();
+}
+
+// k_gru_gm: one-layer GRU models with three or four main waves (48 / 64 units after rounding up to 16). Narrower ones would
+// leave SIMDs without a main wave — GRU-32 at 4096 streams: 245 us here against 197 us on k_mfma_lp's one-launch form,
+// whose eight waves share one tile row each.
+typedef void (*GmFn)(LaunchArgs, MfmaDesc);
+static GmFn gm_fn(int hidden)
+{
+    switch (hidden) {
+    case 48: return k_gru_gm<3, kLpHelpers>;
+    case 64: return k_gru_gm<4, kLpHelpers>;
+    default: return nullptr;
+    }
+}
+bool gru_gm_serves(const MfmaDesc& d) { return d.n_layers == 1 && d.L[0].cell == 1 && d.gm_off != 0 && gm_fn(d.hidden) != nullptr; }
+size_t gru_gm_lds_bytes(const MfmaDesc& d, uint32_t n_frames) { return gm_lds_floats(d.hidden, (int)n_frames, kLpHelpers) * sizeof(float); }
+hipError_t launch_gru_gm_kernel(const LaunchArgs& a, const MfmaDesc& d, hipStream_t stream)
+{
+    GmFn fn = gm_fn(d.hidden);
+    if (!fn || !gru_gm_serves(d) || a.mode != MODE_CHAIN || a.n_frames == 0) return hipErrorInvalidValue;
+    const size_t lds = gru_gm_lds_bytes(d, a.n_frames);
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const uint32_t groups = (a.n_streams + kMfmaStreams - 1) / kMfmaStreams;
+    hipLaunchKernelGGL(fn, dim3(groups), dim3((d.hidden / 16 + kLpHelpers) * kWave), lds, stream, a, d);
     return hipGetLastError();
 }
 

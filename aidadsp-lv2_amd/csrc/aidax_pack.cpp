@@ -234,6 +234,39 @@ std::vector<float> pack_mfma(const aidax_model& m, MfmaDesc* d, uint32_t* state_
     out.resize(out.size() + (H - Ht), 0.f);          // padded units carry zero Dense weights
     d->bd_off = static_cast<uint32_t>(out.size());
     out.push_back(D.w1[0]);
+    // One-layer GRU: a second, GATE-MAJOR record for k_gru_gm. Above, a 16-row tile is four units x (z, r, candidate's
+    // recurrent half, candidate's input half), and the fourth row meets 4-column blocks of zeros in every recurrent k-step:
+    // a quarter of the matrix-core work. Here wave w owns units 16w .. 16w+15 as three recurrent tiles (z, r, recurrent
+    // half: H/4 k-steps each) and the input half as a fourth that sees the input k-step only. Same weights, same
+    // accumulation order per row, so the state is bit-identical to the record above. Per wave: [3][64] input k-step
+    // (z, r, input half), [H/4][3][64] recurrent k-steps, [4][64][4] bias rows as the accumulators' start values.
+    if (m.n_rnn == 1 && m.layers[0].type != Layer::LSTM) {
+        while (out.size() % 4) out.push_back(0.f);
+        d->gm_off = static_cast<uint32_t>(out.size());
+        const Layer& L = m.layers[0];
+        const int R = 3 * Ht, I = L.in_size;
+        const float* W = L.w0.data();
+        const float* U = L.w1.data();
+        const float* b = L.w2.data();
+        auto col = [&](int g, int u) { return (g == 0 ? 0 : g == 1 ? Ht : 2 * Ht) + u; };     // g: 0 z, 1 r, 2 recurrent half, 3 input half
+        auto w_in = [&](int u, int g, int k) { return (u < Ht && g != 2 && k < I) ? W[(size_t)k * R + col(g, u)] : 0.f; };
+        auto w_rec = [&](int u, int g, int k) { return (u < Ht && g != 3 && k < Ht) ? U[(size_t)k * R + col(g, u)] : 0.f; };
+        auto bias = [&](int u, int g) {
+            if (u >= Ht) return 0.f;
+            if (g <= 1) return b[col(g, u)] + b[R + col(g, u)];
+            return g == 2 ? b[R + col(g, u)] : b[col(g, u)];
+        };
+        for (int w = 0; w < H / 16; ++w) {
+            for (int g : { 0, 1, 3 })
+                for (int lane = 0; lane < kWave; ++lane) out.push_back(w_in(16 * w + (lane & 15), g, lane >> 4));
+            for (int kk = 0; kk < H / 4; ++kk)
+                for (int g = 0; g < 3; ++g)
+                    for (int lane = 0; lane < kWave; ++lane) out.push_back(w_rec(16 * w + (lane & 15), g, 4 * kk + (lane >> 4)));
+            for (int g = 0; g < 4; ++g)
+                for (int lane = 0; lane < kWave; ++lane)
+                    for (int e = 0; e < 4; ++e) out.push_back(bias(16 * w + 4 * (lane >> 4) + e, g));
+        }
+    }
     *state_floats = st;
     return out;
 }

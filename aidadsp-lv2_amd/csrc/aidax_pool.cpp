@@ -58,6 +58,12 @@ ManyForm many_streams_form(int cell, int hidden, uint32_t n, int cus)
     const uint32_t groups = (n + kMfmaStreams - 1) / kMfmaStreams;
     const bool full_round = cus > 0 && groups <= static_cast<uint32_t>(cus) && groups * 8 > static_cast<uint32_t>(cus) * 7;
     if (full_round && (hidden == 32 || hidden == 64 || (hidden == 40 && lstm))) return MANY_MFMA;
+    // One-layer GRUs of 40 (run as 48) / 64 units have k_gru_gm (gate-major tiles: three quarters of the matrix-core work,
+    // the whole run() in one launch; up to two workgroups per CU): GRU-64 326 us flat up to 4096 streams, 595 us at 8192,
+    // 1 140 us at 16384 against 257 / 408 / 859 us for k_nn at 2048 / 3072 / 8192; GRU-40 277-287 us up to 4096 against
+    // 300 (k_nn) / 278 (k_quad) at 3072 and 303 (k_quad) at 4096, 492 / 562 at 8192.
+    if (!lstm && cus > 0 && ((hidden == 64 && groups * 8 >= static_cast<uint32_t>(cus) * 5) || (hidden == 40 && groups * 8 >= static_cast<uint32_t>(cus) * 7)))
+        return MANY_MFMA;
     if (hidden <= 32) return n >= 4096 ? MANY_QUAD : MANY_NONE;
     if (hidden == 40) return n >= 8192 ? MANY_MFMA : n >= (lstm ? 512u : 4096u) ? MANY_QUAD : MANY_NONE;
     if (hidden == 64 && !lstm) return n >= 16384 ? MANY_MFMA : n <= 1024 ? MANY_QUAD : MANY_NONE;
@@ -144,6 +150,7 @@ struct ModelSlot {
     uint32_t* d_counters = nullptr;  // k_mfma_lp: frames produced / consumed per (group, layer boundary)
     const void* lp_owner = nullptr;  // the pool whose hold on the device's LpGate this slot shares (d_ring != nullptr)
     bool lp_fused = false;           // k_mfma_lp runs the DSP chain too (one-layer models, helper waves): one launch per block
+    bool gru_gm = false;             // one-layer GRU: k_gru_gm (gate-major tiles, the whole run() in one launch) serves the passes
 
     float p_den() const { return 0.1f * model_sr; }      // LinearValueSmoother tau * sampleRate (:1053-1054)
 };
@@ -377,6 +384,7 @@ struct aidax_pool {
                                                             : launch_mfma_kernel(a, m.mdesc, s);
             };
             if (a.mode != MODE_CHAIN) return model_kernel();
+            if (m.gru_gm && a.n_frames != 0) return launch_gru_gm_kernel(a, m.mdesc, s);
             if (m.lp_fused && lp_in_use(m) && a.n_frames != 0)
                 return launch_mfma_lp_kernel(a, m.mdesc, m.d_ring, m.d_counters, hd_lp_fault, s, true);
             hipError_t e = launch_chain_pass(true, a, s);
@@ -581,6 +589,10 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
         HIP_TRY(hipMemsetAsync(ms.d_counters, 0, mfma_lp_counter_bytes(ms.mdesc, p.n_streams), p.wq));
         const char* fu = std::getenv("AIDAX_LP_FUSED");      // (=0: packed k_chain launches around the kernel, A/B runs)
         ms.lp_fused = mfma_lp_fused_serves(ms.mdesc) && !(fu && fu[0] == '0') && mfma_lp_lds_bytes(ms.mdesc, p.max_frames, true) <= 160 * 1024;
+    }
+    if (ms.kind == ModelSlot::MFMA) {
+        const char* gm = std::getenv("AIDAX_GRU_GM");        // (=0: the four-rows-per-unit kernels, A/B runs)
+        ms.gru_gm = gru_gm_serves(ms.mdesc) && !(gm && gm[0] == '0') && gru_gm_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024;
     }
     HIP_TRY(hipMemcpyAsync(ms.d_wpack, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice, p.wq));
     std::vector<float> wq4;                                // (lives until the stream has been waited for below)
@@ -1173,7 +1185,7 @@ AIDAX_API const char* aidax_pool_kernel_name(const aidax_pool* p)
     if (!(p && p->cur.has_model)) return "k_nomodel";
     const ModelSlot& m = p->cur;
     if (m.kind == ModelSlot::STACK) return "k_stack";
-    if (m.kind == ModelSlot::MFMA) return !p->lp_in_use(m) ? "k_chain+k_mfma" : m.lp_fused ? "k_mfma_lp" : "k_chain+k_mfma_lp";
+    if (m.kind == ModelSlot::MFMA) return m.gru_gm ? "k_gru_gm" : !p->lp_in_use(m) ? "k_chain+k_mfma" : m.lp_fused ? "k_mfma_lp" : "k_chain+k_mfma_lp";
     if (m.kind == ModelSlot::QUAD) return "k_chain+k_quad";
     if (m.kind == ModelSlot::CONV) return m.conv_fused ? "k_conv_mfma" : m.conv_mfma ? "k_chain+k_conv_mfma" : "k_conv";
     const int form = p->chain_form(m);

@@ -486,7 +486,7 @@ _EQ_POST = dict(bass_boost_db=4.0, mid_boost_db=-3.0, mid_q=1.2, treble_boost_db
 
 @pytest.mark.parametrize("name,kw,S,ckw,kernel", [
     ("cfg2", dict(kind="lstm", hidden=32, input_size=1, seed=32), 1024, {}, "k_lstm_pipe<32>"),
-    ("cfg3", dict(kind="gru", hidden=64, input_size=3, seed=64), 4096, _EQ_POST, "k_mfma_lp"),                    # one launch: the chain on the helper waves
+    ("cfg3", dict(kind="gru", hidden=64, input_size=3, seed=64), 4096, _EQ_POST, "k_gru_gm"),                     # one launch: gate-major tiles, the chain on the helper waves
     ("cfg4", dict(kind="conv", hidden=16, input_size=1, seed=1608), 1024, {}, "k_conv_mfma"),
     ("cfg5", dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2), 2048, {}, "k_chain+k_mfma_lp"),
     ("lstm80-2k", dict(kind="lstm", hidden=80, input_size=2, seed=80), 2048, dict(param1=0.7), "k_chain+k_quad"),
@@ -921,6 +921,62 @@ def test_every_kernel_form_passes_the_same_chain_cases(form, tmp_path, monkeypat
         p = O.OraclePlugin()
         p.set_loading(False)
         assert np.array_equal(g3[s], p.run(co, x3[s])), (form, s)
+
+
+@pytest.mark.parametrize("hidden,isz", [(64, 3), (64, 1), (40, 2)])
+def test_gate_major_gru_kernel_ragged_blocks_controls_and_state_bits(hidden, isz, tmp_path, monkeypatch):
+    """k_gru_gm (one-layer GRU, three recurrent tiles + an input-only accumulator per 16 units, the DSP chain on its
+    helper waves: one launch per block) against the per-stream oracle plugins over ragged block sizes incl. 0 and 1 and
+    blocks longer than the 256-frame staging chunk, 70 streams (the last group ragged), per-stream bypass / disable / EQ
+    position / ramping params — and against the four-rows-per-unit kernels (k_mfma_lp's one-launch form, k_mfma behind
+    packed chain launches) on the same weights: bit-identical recurrent state."""
+    monkeypatch.setenv("AIDAX_KERNEL", "mfma")
+    path, spec = _model_file(tmp_path, f"gm{hidden}_{isz}", kind="gru", hidden=hidden, input_size=isz, seed=700 + hidden + isz, in_skip=isz == 1)
+    S = 70
+    sizes = [256, 1, 0, 37, 700, 16, 255, 513, 3]
+    x = modelgen.signal(S, sum(sizes), seed=31)
+    kws = [dict(param1=0.3, param2=0.8), dict(enabled=0.0), dict(net_bypass=1.0), dict(eq_position=1.0, bass_boost_db=5.0, mid_type=1.0),
+           dict(dc_blocker=0.0, in_lpf_pc=0.0, eq_bypass=1.0, param1=1.0), dict(pregain_db=6.0, master_db=-6.0, treble_boost_db=4.0, param2=0.1)]
+    flip = dict(param1=0.9, param2=0.2, master_db=-3.0)                     # applied to every stream from the 5th block on
+    outs, states = {}, {}
+    for form, env in (("gm", {}), ("lp", {"AIDAX_GRU_GM": "0"}), ("mfma", {"AIDAX_GRU_GM": "0", "AIDAX_MFMA_LP": "0"})):
+        for k in ("AIDAX_GRU_GM", "AIDAX_MFMA_LP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pool = ax.Pool(S, 1024)
+        pool.set_model(ax.Model(path))
+        assert pool.kernel_name == {"gm": "k_gru_gm", "lp": "k_mfma_lp", "mfma": "k_chain+k_mfma"}[form]
+        for s_ in range(S):
+            pool.set_controls(ax.default_controls(**kws[s_ % len(kws)]), stream=s_)
+        got, pos = np.empty_like(x), 0
+        for bi, n in enumerate(sizes):
+            if bi == 4:
+                for s_ in range(S):
+                    pool.set_controls(ax.default_controls(**dict(kws[s_ % len(kws)], **flip)), stream=s_)
+            got[:, pos:pos + n] = pool.process(np.ascontiguousarray(x[:, pos:pos + n]))
+            pos += n
+        outs[form] = got
+        states[form] = [pool.read_state(stream=s_, layer=0, hidden=128)[0].copy() for s_ in (0, 5, S - 1)]
+        pool.close()
+    for s_ in range(0, S, 5):
+        plug = O.OraclePlugin()
+        plug.set_model(O.OracleModel(spec))
+        want, pos = np.empty(x.shape[1], np.float32), 0
+        for bi, n in enumerate(sizes):
+            kw = dict(kws[s_ % len(kws)], **(flip if bi >= 4 else {}))
+            want[pos:pos + n] = plug.run(O.default_controls(**kw), x[s_, pos:pos + n])
+            pos += n
+        kw = kws[s_ % len(kws)]
+        if kw.get("enabled") == 0.0 or kw.get("net_bypass") == 1.0:
+            assert np.array_equal(outs["gm"][s_], want), s_
+        else:
+            errlog.bound(np.abs(outs["gm"][s_] - want).max(), 2e-6, "gpu_parity:gru_gm")
+    for a, b in zip(states["gm"], states["lp"]):
+        assert np.array_equal(a, b)
+    for a, b in zip(states["gm"], states["mfma"]):
+        assert np.array_equal(a, b)
+    errlog.bound(np.abs(outs["gm"] - outs["lp"]).max(), 5e-7, "gpu_parity:gru_gm_vs_lp_outputs")
 
 
 @pytest.mark.parametrize("name,kw", [

@@ -422,6 +422,68 @@ __device__ __forceinline__ ChainCtx chain_prologue(const StreamCtl& ctl, StreamS
     return c;
 }
 
+// One of the two packed passes of run() by ONE wave over EIGHT streams (8 lanes per stream, lane & 7 = cascade stage) whose
+// rows already sit in LDS (rows + slot * nP), in place: PRE = LPF -> pre-gain ramp -> EQ(pre), otherwise DC blocker ->
+// EQ(post) -> master ramp. The body of k_chain; k_mfma_lp's stacked form runs it on its first and last layer's workgroups.
+// `commit`: write the biquad states and the ramp's memory / target back (a workgroup that only needs the pass's OUTPUT —
+// the last layer re-deriving the model input — passes false). `atomic_pending`: clear PEND_ACTIVATE with an atomic (another
+// workgroup of the same launch may be clearing PEND_PARAM_FIRST in the same word).
+constexpr int kChainWaveStreams = 8;
+template <bool PRE>
+__device__ __forceinline__ void chain_wave_pass(const LaunchArgs& a, int stream0, float* rows, int nP, float* hand, int n, int lane,
+                                                bool commit, bool atomic_pending)
+{
+    const int grp = lane >> 3, stage = lane & 7;
+    const int sg = stream0 + grp;
+    const bool valid = sg < (int)a.n_streams;
+    const int sc = valid ? sg : (int)a.n_streams - 1;          // clamp: invalid groups shadow the last stream, never store
+    const StreamCtl& ctl = a.ctl[sc];
+    StreamState& st = a.st[sc];
+    const uint32_t flags = ctl.flags;
+    const uint32_t pending0 = st.pending;
+    const bool live = valid && n != 0 && (flags & CTL_ENABLED);
+
+    ChainPass c;
+    const bool eq = flags & (PRE ? CTL_EQ_PRE : CTL_EQ_POST);
+    c.K = eq ? 6 : 1;
+    c.gain_lane = PRE ? 0 : c.K - 1;
+    const int k = stage < c.K ? stage : 0;
+    const int slot = PRE ? pre_slot(k) : post_slot(k);
+    const bool act = k == 0 ? (flags & (PRE ? CTL_LPF_ON : CTL_DC_ON)) != 0
+                            : ((flags & CTL_EQ_BANDPASS) ? slot == BQ_MID : true);
+    chain_load(c, ctl, st, slot, act);
+    float mem = PRE ? st.pre_mem : st.master_mem;
+    float tgt = PRE ? st.pre_tgt : st.master_tgt;
+    if (pending0 & PEND_ACTIVATE) mem = tgt;                   // activate(): clearToTargetValue (:341-342)
+    if (PRE) tgt = ctl.pre_target;                             // :513, before every early-out
+    else if (live) tgt = ctl.master_target;                    // :654, only on the DSP path
+    c.g.arm(mem, tgt, PRE ? ctl.pre_coef : ctl.master_coef);
+
+    if (n != 0) {
+        // whole blocks of eight frames in the blocked form, a ragged tail sample by sample
+        float* row = rows + grp * nP;
+        const bool run = live && stage < c.K;
+        const int n_full = n & ~(kChainBlock - 1);
+        // the longest cascade among the wave's running streams: without EQ on this side it is one stage, and the
+        // sweep needs no fill / drain steps at all
+        const int depth = (a.tune & 8) || __builtin_amdgcn_ballot_w64(run && stage > 0) != 0 ? 6 : 1;
+        if (n_full != 0) chain_sweep_blocked(c, stage, run, depth, row, hand, n_full, lane, (a.tune & 8) != 0);
+        if (n_full != n) chain_sweep<1>(c, stage, run, depth, row + n_full, row + n_full, n - n_full);
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (!valid || !commit) return;
+    if (live && stage < c.K) { st.z[slot][0] = c.z1; st.z[slot][1] = c.z2; }
+    if (stage == c.gain_lane) {
+        const float m_out = live ? c.g.mem : mem;
+        if (PRE) { st.pre_mem = m_out; st.pre_tgt = tgt; }
+        else {
+            st.master_mem = m_out; st.master_tgt = tgt;
+            if (atomic_pending) __hip_atomic_fetch_and(&st.pending, ~(uint32_t)PEND_ACTIVATE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else st.pending = st.pending & ~PEND_ACTIVATE;
+        }
+    }
+}
+
 // run() :634-640 for a model that takes no PARAM input (the conv stacks): the smoothers' targets still follow the
 // controls and the first run after a load still snaps them — what a model swapped in later inherits (:822-825).
 // Nothing calls next(), so the memories move only on that snap. One lane; returns `pending` with the flag cleared.

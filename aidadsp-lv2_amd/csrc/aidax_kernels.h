@@ -36,7 +36,7 @@ hipError_t launch_mfma_kernel(const LaunchArgs& a, const MfmaDesc& d, hipStream_
 // k_mfma_lp (aidax_mfmalp.hip): stacked models, one workgroup per (16 streams, layer), layers chained through a global ring
 bool mfma_lp_serves(const MfmaDesc& d);
 size_t mfma_lp_lds_bytes(const MfmaDesc& d, uint32_t n_frames, bool fused = false);
-bool mfma_lp_fused_serves(const MfmaDesc& d);       // one-layer models: the DSP chain inside the same launch (helper waves)
+bool mfma_lp_fused_serves(const MfmaDesc& d, uint32_t max_frames);       // the DSP chain inside the same launch: one-layer models (helper waves), stacked models with blocks <= 256 frames
 size_t mfma_lp_ring_bytes(const MfmaDesc& d, uint32_t n_streams);
 size_t mfma_lp_counter_bytes(const MfmaDesc& d, uint32_t n_streams);
 // `fault`: device view of a word in pinned host memory that a workgroup bumps when a hand-over wait timed out

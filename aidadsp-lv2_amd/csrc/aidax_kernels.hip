@@ -861,19 +861,8 @@ __global__ __launch_bounds__(kWave) void k_chain(LaunchArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
-    const int grp = lane >> 3, stage = lane & 7;
     const int n = (int)a.n_frames;
     const int nP = (n + 3) & ~3;
-    const int sg = blockIdx.x * kChainStreams + grp;
-    const bool valid = sg < (int)a.n_streams;
-    const int sc = valid ? sg : (int)a.n_streams - 1;          // clamp: invalid groups shadow the last stream, never store
-
-    const StreamCtl& ctl = a.ctl[sc];
-    StreamState& st = a.st[sc];
-    const uint32_t flags = ctl.flags;
-    const uint32_t pending0 = st.pending;
-    const bool live = valid && n != 0 && (flags & CTL_ENABLED);
-
     // rows -> LDS, one coalesced row at a time (PRE reads the input block, POST works in place on out)
     for (int g = 0; g < kChainStreams; ++g) {
         const int s2 = blockIdx.x * kChainStreams + g;
@@ -881,34 +870,8 @@ __global__ __launch_bounds__(kWave) void k_chain(LaunchArgs a)
             load_block(smem + g * nP, (PRE ? a.in : a.out) + (size_t)s2 * n, n, lane);
     }
     __builtin_amdgcn_wave_barrier();
-
-    ChainPass c;
-    const bool eq = flags & (PRE ? CTL_EQ_PRE : CTL_EQ_POST);
-    c.K = eq ? 6 : 1;
-    c.gain_lane = PRE ? 0 : c.K - 1;
-    const int k = stage < c.K ? stage : 0;
-    const int slot = PRE ? pre_slot(k) : post_slot(k);
-    const bool act = k == 0 ? (flags & (PRE ? CTL_LPF_ON : CTL_DC_ON)) != 0
-                            : ((flags & CTL_EQ_BANDPASS) ? slot == BQ_MID : true);
-    chain_load(c, ctl, st, slot, act);
-    float mem = PRE ? st.pre_mem : st.master_mem;
-    float tgt = PRE ? st.pre_tgt : st.master_tgt;
-    if (pending0 & PEND_ACTIVATE) mem = tgt;                   // activate(): clearToTargetValue (:341-342)
-    if (PRE) tgt = ctl.pre_target;                             // :513, before every early-out
-    else if (live) tgt = ctl.master_target;                    // :654, only on the DSP path
-    c.g.arm(mem, tgt, PRE ? ctl.pre_coef : ctl.master_coef);
-
+    chain_wave_pass<PRE>(a, blockIdx.x * kChainStreams, smem, nP, smem + kChainStreams * nP, n, lane, true, false);
     if (n != 0) {
-        // whole blocks of eight frames in the blocked form, a ragged tail sample by sample
-        float* row = smem + grp * nP;
-        float* hand = smem + kChainStreams * nP;
-        const bool run = live && stage < c.K;
-        const int n_full = n & ~(kChainBlock - 1);
-        // the longest cascade among the wave's running streams: without EQ on this side it is one stage, and the
-        // sweep needs no fill / drain steps at all
-        const int depth = (a.tune & 8) || __builtin_amdgcn_ballot_w64(run && stage > 0) != 0 ? 6 : 1;
-        if (n_full != 0) chain_sweep_blocked(c, stage, run, depth, row, hand, n_full, lane, (a.tune & 8) != 0);
-        if (n_full != n) chain_sweep<1>(c, stage, run, depth, row + n_full, row + n_full, n - n_full);
         // PRE: every valid row goes to out (a disabled stream's row is still the raw input: the hard
         // bypass copy of :612-619); POST: only rows that were processed
         for (int g = 0; g < kChainStreams; ++g) {
@@ -918,13 +881,6 @@ __global__ __launch_bounds__(kWave) void k_chain(LaunchArgs a)
             if (PRE ? (row_live || a.out != a.in) : row_live)
                 store_block(a.out + (size_t)s2 * n, smem + g * nP, n, lane);
         }
-    }
-    if (!valid) return;
-    if (live && stage < c.K) { st.z[slot][0] = c.z1; st.z[slot][1] = c.z2; }
-    if (stage == c.gain_lane) {
-        const float m_out = live ? c.g.mem : mem;
-        if (PRE) { st.pre_mem = m_out; st.pre_tgt = tgt; }
-        else { st.master_mem = m_out; st.master_tgt = tgt; st.pending = st.pending & ~PEND_ACTIVATE; }
     }
 }
 

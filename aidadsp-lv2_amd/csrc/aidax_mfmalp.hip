@@ -150,7 +150,7 @@ __device__ __forceinline__ void lp_gates(f32x4 (&acc)[NACC], const f32x4 (&wres)
 }
 
 #ifdef AIDAX_LP_TRACE
-#define LP_STAMP(k) do { if (blockIdx.x == 0 && tick >= kTraceT0 && tick < kTraceT0 + 8) {                         \
+#define LP_STAMP(k) do { if ((int)blockIdx.x == ((a.tune >> 16) & 0xff) && tick >= kTraceT0 && tick < kTraceT0 + 8) {                         \
         __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = clock64(); __builtin_amdgcn_sched_barrier(0); \
         if ((threadIdx.x & 63) == 0) trace[((tick - kTraceT0) * 12 + (threadIdx.x >> 6)) * 8 + (k)] = t_; } } while (0)
 #else
@@ -330,7 +330,7 @@ __device__ __forceinline__ void lp_helper(const LaunchArgs& a, float* xb, float*
         __syncthreads();                                   // (4) the rows may be overwritten
     }
 #ifdef AIDAX_LP_TRACE
-    if (blockIdx.x == 0) __syncthreads();
+    if ((int)blockIdx.x == ((a.tune >> 16) & 0xff)) __syncthreads();
 #endif
     __syncthreads();                                       // (5)
     if (!valid) return;
@@ -352,7 +352,7 @@ __device__ __forceinline__ void lp_helper(const LaunchArgs& a, float* xb, float*
 // FIRST / LAST: the role of this workgroup's layer, a compile-time constant of the body — the kernel branches once on the
 // layer index, so each role's registers are allocated for that role only (the first layer carries no fetched tiles, no
 // Dense fragments; the others no started-tile accumulators): LSTM-96 x2 fits its 256 registers without scratch.
-template <int TPW, int NW, int M, bool FIRST, bool LAST, int NHELP = 0>
+template <int TPW, int NW, int M, bool FIRST, bool LAST, int NHELP = 0, bool CHAIN = false>
 __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, float* ring, uint32_t* counters, uint32_t* fault,
                                         float* smem, int grp, int l)
 {
@@ -365,6 +365,10 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
     constexpr size_t kSlot = lp_slot_floats(H, NW, M);     // floats of one ring frame
     static_assert(NHELP == 0 || (FIRST && LAST), "helper waves serve one-layer models");
     constexpr bool fused = NHELP > 0;                      // the whole run() in this launch: a.in -> a.out, MODE_CHAIN only
+    // CHAIN: the kernel runs the DSP chain around this body (lp_chain_rows); the body itself is the same as between two
+    // k_chain launches, except that it clears its bit of StreamState::pending with an atomic.
+    constexpr bool chain = CHAIN;
+    static_assert(!(CHAIN && NHELP > 0), "one form or the other");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -405,7 +409,7 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
 
     // ---- per-stream bookkeeping: lanes tid < NS own stream s_base+tid (live flag; PARAM smoothers on the first layer)
     float p_mem[2] = { 0.f, 0.f }, p_tgt[2] = { 0.f, 0.f }, p_step[2] = { 0.f, 0.f };
-    uint32_t pending = 0;
+    uint32_t pending = 0, st_pending0 = 0;
     bool mine_live = false;
     if (!fused && tid < NS) {
         const int sg = s_base + tid;
@@ -415,7 +419,7 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
             p_mem[0] = st.p_mem[0]; p_mem[1] = st.p_mem[1];
             p_tgt[0] = st.p_tgt[0]; p_tgt[1] = st.p_tgt[1];
             p_step[0] = st.p_step[0]; p_step[1] = st.p_step[1];
-            pending = st.pending;
+            pending = st_pending0 = st.pending;
             if (mode == MODE_CHAIN) {
                 const StreamCtl& ctl = a.ctl[sg];
                 const uint32_t flags = ctl.flags;
@@ -792,7 +796,7 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
     }
 
 #ifdef AIDAX_LP_TRACE
-    if (blockIdx.x == 0) { __syncthreads(); for (int i = tid; i < 2 * 768; i += NT) fault[16 + i] = reinterpret_cast<const uint32_t*>(trace)[i]; }
+    if ((int)blockIdx.x == ((a.tune >> 16) & 0xff)) { __syncthreads(); for (int i = tid; i < 2 * 768; i += NT) fault[16 + i] = reinterpret_cast<const uint32_t*>(trace)[i]; }
 #endif
     // ---- recurrent state and smoother memories back to HBM for the streams that ran
 #pragma unroll
@@ -811,11 +815,56 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
         st.p_mem[0] = p_mem[0]; st.p_mem[1] = p_mem[1];
         st.p_tgt[0] = p_tgt[0]; st.p_tgt[1] = p_tgt[1];
         st.p_step[0] = p_step[0]; st.p_step[1] = p_step[1];
-        st.pending = pending;
+        if (!chain) st.pending = pending;
+        else if (pending != st_pending0)                  // (the last layer's workgroup clears PEND_ACTIVATE in the same word)
+            __hip_atomic_fetch_and(&st.pending, ~(uint32_t)PEND_PARAM_FIRST, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-template <int TPW, int NW, int M, int NHELP = 0>
+// Stacked models, the one-launch form: their main waves hold the whole register file, so there is no room for helper waves
+// — the packed chain passes (k_chain's body, chain_wave_pass) run on waves 0 and 1 of the first / last layer's workgroup
+// BEFORE and AFTER lp_body, which stays exactly the body that runs between two k_chain launches (reshaping it for rows kept
+// in LDS cost its frame loop 6 %: 1 096 -> 1 150 us on LSTM-96 x2 before a single chain instruction ran). The pre pass
+// reads a.in and leaves its rows in a.out, where the body expects them; the LAST layer's workgroup runs it too, uncommitted
+// (it needs the model input for in_skip and for net-off streams, and cannot wait for another workgroup's stores: both
+// write the same values to the same words); the post pass takes the rows the body stored. Blocks of one staging chunk.
+template <bool PRE>
+__device__ __forceinline__ void lp_chain_rows(const LaunchArgs& a, float* smem, int grp, bool commit)
+{
+    constexpr int NS = kMfmaStreams;
+    const int NT = (int)blockDim.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = (int)a.n_frames;
+    const int nP = (n + 3) & ~3;
+    const int s_base = grp * NS;
+    float* rows = smem;                                    // [NS][nP]
+    float* hands = rows + NS * nP;                         // [2][kChainHandFloats]
+    const float* src_base = PRE ? a.in : a.out;
+    // Device-scope loads, past this CU's vector cache. POST: the rows were stored by this workgroup a moment ago, and the
+    // body's own read of them may have left their lines there, stale. PRE: with a.in == a.out the body would otherwise
+    // find the lines this read brought in instead of the rows stored below.
+    for (int i = tid; i < NS * n; i += NT) {
+        const int sl = i / n, t = i - sl * n, sg = s_base + sl;
+        rows[sl * nP + t] = sg < (int)a.n_streams ? __hip_atomic_load(src_base + (size_t)sg * n + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+    }
+    __syncthreads();
+    if (wave < 2)
+        chain_wave_pass<PRE>(a, s_base + kChainWaveStreams * wave, rows + kChainWaveStreams * wave * nP, nP,
+                             hands + wave * kChainHandFloats, n, lane, commit, !PRE);
+    __syncthreads();
+    // PRE: every valid row goes to out (a disabled stream's row is still the raw input: the hard bypass copy of :612-619);
+    // POST: only rows that were processed
+    for (int i = tid; i < NS * n; i += NT) {
+        const int sl = i / n, t = i - sl * n, sg = s_base + sl;
+        if (sg >= (int)a.n_streams) continue;
+        const bool row_live = (a.ctl[sg].flags & CTL_ENABLED) != 0;
+        if (PRE ? (row_live || a.out != a.in) : row_live) a.out[(size_t)sg * n + t] = rows[sl * nP + t];
+    }
+    __syncthreads();                                       // (waits for the stores: the body's loads come after them)
+}
+
+template <int TPW, int NW, int M, int NHELP = 0, bool CHAIN = false>
 __global__ __launch_bounds__((NW + NHELP) * kWave) void k_mfma_lp(LaunchArgs a, MfmaDesc d, float* ring, uint32_t* counters, uint32_t* fault)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -834,6 +883,20 @@ __global__ __launch_bounds__((NW + NHELP) * kWave) void k_mfma_lp(LaunchArgs a, 
     const int l = adjacent ? blk % NL : (blk / 8) % NL;
     const int n_groups = ((int)a.n_streams + kMfmaStreams - 1) / kMfmaStreams;
     if (grp >= n_groups) return;
+    if constexpr (CHAIN) {                                 // stacked models only
+        if (l == 0) {
+            if (!(a.tune & 2048)) lp_chain_rows<true>(a, smem, grp, true);
+            lp_body<TPW, NW, M, true, false, 0, true>(a, d, ring, counters, fault, smem, grp, l);
+        } else if (l == NL - 1) {
+            if (!(a.tune & 2048)) lp_chain_rows<true>(a, smem, grp, false);
+            lp_body<TPW, NW, M, false, true, 0, true>(a, d, ring, counters, fault, smem, grp, l);
+            __syncthreads();
+            if (!(a.tune & 4096)) lp_chain_rows<false>(a, smem, grp, true);
+        } else {
+            lp_body<TPW, NW, M, false, false, 0, true>(a, d, ring, counters, fault, smem, grp, l);
+        }
+        return;
+    }
     if (NL == 1) lp_body<TPW, NW, M, true, true>(a, d, ring, counters, fault, smem, grp, l);      // one layer: no ring, nobody waits
     else if (l == 0) lp_body<TPW, NW, M, true, false>(a, d, ring, counters, fault, smem, grp, l);
     else if (l == NL - 1) lp_body<TPW, NW, M, false, true>(a, d, ring, counters, fault, smem, grp, l);
@@ -984,7 +1047,7 @@ __global__ __launch_bounds__((UT + NHELP) * kWave) void k_gru_gm(LaunchArgs a, M
         __syncthreads();                                    // (4) the helpers have stored the rows
     }
 #ifdef AIDAX_LP_TRACE
-    if (blockIdx.x == 0) __syncthreads();                   // (lp_helper's extra barrier of the measurement build)
+    if ((int)blockIdx.x == ((a.tune >> 16) & 0xff)) __syncthreads();      // (lp_helper's extra barrier of the measurement build)
 #endif
     __syncthreads();                                        // (5)
     if (valid && livef[c] != 0.f) {
@@ -1012,6 +1075,17 @@ static LpFn lp_fn_fused(int hidden)
     default: return nullptr;
     }
 }
+static LpFn lp_fn_chain(int hidden, int n_layers)         // stacked models, the DSP chain on waves 0 and 1 of the first / last layer
+{
+    if (n_layers < 2) return nullptr;
+    switch (hidden) {
+#define AIDAX_LP_CHAIN_CASE(HID) case HID: { constexpr int T = HID / 4 / mfma_waves(HID), W_ = mfma_waves(HID);                    \
+        return lp_moved_tiles(2, T, W_) > 0 && n_layers == 2 ? k_mfma_lp<T, W_, lp_moved_tiles(2, T, W_), 0, true> : k_mfma_lp<T, W_, 0, 0, true>; }
+    AIDAX_LP_CHAIN_CASE(16) AIDAX_LP_CHAIN_CASE(32) AIDAX_LP_CHAIN_CASE(48) AIDAX_LP_CHAIN_CASE(64) AIDAX_LP_CHAIN_CASE(80) AIDAX_LP_CHAIN_CASE(96)
+#undef AIDAX_LP_CHAIN_CASE
+    default: return nullptr;
+    }
+}
 static LpFn lp_fn(int hidden, int n_layers)
 {
     switch (hidden) {
@@ -1028,10 +1102,18 @@ static int lp_m(const MfmaDesc& d) { return lp_moved_tiles(d.n_layers, d.hidden 
 bool mfma_lp_serves(const MfmaDesc& d) { return d.n_layers >= 1 && lp_fn(d.hidden, d.n_layers) != nullptr; }
 size_t mfma_lp_lds_bytes(const MfmaDesc& d, uint32_t n_frames, bool fused)
 {
+    if (fused && d.n_layers > 1) {                         // stacked: lp_chain_rows works in the body's LDS before and after it
+        const size_t body = lp_lds_floats(d.hidden, (int)n_frames), rows = (size_t)kMfmaStreams * ((n_frames + 3) & ~3u) + 2 * kChainHandFloats;
+        return (body > rows ? body : rows) * sizeof(float);
+    }
     return lp_lds_floats(d.hidden, (int)n_frames, fused ? lp_helpers(d.hidden) : 0) * sizeof(float);
 }
-// the whole run() in the one launch (a.in -> a.out, MODE_CHAIN): one-layer models with room for the helper waves
-bool mfma_lp_fused_serves(const MfmaDesc& d) { return d.n_layers == 1 && lp_helpers(d.hidden) > 0; }
+// the whole run() in the one launch (a.in -> a.out, MODE_CHAIN): one-layer models with room for the helper waves, stacked
+// models whose blocks fit one staging chunk (the chain passes run before the fragments are loaded / after the last tick)
+bool mfma_lp_fused_serves(const MfmaDesc& d, uint32_t max_frames)
+{
+    return d.n_layers == 1 ? lp_helpers(d.hidden) > 0 : (max_frames <= (uint32_t)kLpChunk && lp_fn_chain(d.hidden, d.n_layers) != nullptr);
+}
 size_t mfma_lp_ring_bytes(const MfmaDesc& d, uint32_t n_streams)
 {
     const size_t groups = (n_streams + kMfmaStreams - 1) / kMfmaStreams;
@@ -1045,8 +1127,8 @@ size_t mfma_lp_counter_bytes(const MfmaDesc& d, uint32_t n_streams)
 
 hipError_t launch_mfma_lp_kernel(const LaunchArgs& a, const MfmaDesc& d, float* ring, uint32_t* counters, uint32_t* fault, hipStream_t stream, bool fused)
 {
-    if (fused && (!mfma_lp_fused_serves(d) || a.mode != MODE_CHAIN || a.n_frames == 0)) return hipErrorInvalidValue;
-    LpFn fn = fused ? lp_fn_fused(d.hidden) : lp_fn(d.hidden, d.n_layers);
+    if (fused && (!mfma_lp_fused_serves(d, a.n_frames) || a.mode != MODE_CHAIN || a.n_frames == 0)) return hipErrorInvalidValue;
+    LpFn fn = !fused ? lp_fn(d.hidden, d.n_layers) : d.n_layers == 1 ? lp_fn_fused(d.hidden) : lp_fn_chain(d.hidden, d.n_layers);
     if (!fn || !ring || !counters || !fault) return hipErrorInvalidValue;
     const size_t lds = mfma_lp_lds_bytes(d, a.n_frames, fused);
     if (lds > 64 * 1024) {
@@ -1055,7 +1137,7 @@ hipError_t launch_mfma_lp_kernel(const LaunchArgs& a, const MfmaDesc& d, float* 
     }
     const uint32_t groups = (a.n_streams + kMfmaStreams - 1) / kMfmaStreams;
     const uint32_t blocks = ((groups + 7) / 8) * 8 * (uint32_t)d.n_layers;
-    const int waves = mfma_waves(d.hidden) + (fused ? lp_helpers(d.hidden) : 0);
+    const int waves = mfma_waves(d.hidden) + (fused && d.n_layers == 1 ? lp_helpers(d.hidden) : 0);
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(waves * kWave), lds, stream, a, d, ring, counters, fault);
     return hipGetLastError();
 }

@@ -588,7 +588,7 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
         HIP_TRY(hipMalloc(&ms.d_counters, mfma_lp_counter_bytes(ms.mdesc, p.n_streams)));
         HIP_TRY(hipMemsetAsync(ms.d_counters, 0, mfma_lp_counter_bytes(ms.mdesc, p.n_streams), p.wq));
         const char* fu = std::getenv("AIDAX_LP_FUSED");      // (=0: packed k_chain launches around the kernel, A/B runs)
-        ms.lp_fused = mfma_lp_fused_serves(ms.mdesc) && !(fu && fu[0] == '0') && mfma_lp_lds_bytes(ms.mdesc, p.max_frames, true) <= 160 * 1024;
+        ms.lp_fused = mfma_lp_fused_serves(ms.mdesc, p.max_frames) && !(fu && fu[0] == '0') && mfma_lp_lds_bytes(ms.mdesc, p.max_frames, true) <= 160 * 1024;
     }
     if (ms.kind == ModelSlot::MFMA) {
         const char* gm = std::getenv("AIDAX_GRU_GM");        // (=0: the four-rows-per-unit kernels, A/B runs)

@@ -488,7 +488,7 @@ _EQ_POST = dict(bass_boost_db=4.0, mid_boost_db=-3.0, mid_q=1.2, treble_boost_db
     ("cfg2", dict(kind="lstm", hidden=32, input_size=1, seed=32), 1024, {}, "k_lstm_pipe<32>"),
     ("cfg3", dict(kind="gru", hidden=64, input_size=3, seed=64), 4096, _EQ_POST, "k_gru_gm"),                     # one launch: gate-major tiles, the chain on the helper waves
     ("cfg4", dict(kind="conv", hidden=16, input_size=1, seed=1608), 1024, {}, "k_conv_mfma"),
-    ("cfg5", dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2), 2048, {}, "k_chain+k_mfma_lp"),
+    ("cfg5", dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2), 2048, {}, "k_mfma_lp"),
     ("lstm80-2k", dict(kind="lstm", hidden=80, input_size=2, seed=80), 2048, dict(param1=0.7), "k_chain+k_quad"),
     ("lstm80-4k", dict(kind="lstm", hidden=80, input_size=2, seed=80), 4096, dict(param1=0.7), "k_chain+k_mfma_lp"),
     ("gru16-4k", dict(kind="gru", hidden=16, input_size=3, seed=16), 4096, dict(param1=0.2, param2=0.9), "k_chain+k_quad"),
@@ -580,7 +580,7 @@ def test_extension_models_full_chain(kind, kw, form, tmp_path, monkeypatch):
     cg, co = _ctl_pair(**ckw)
     pool = ax.Pool(S, 256)
     pool.set_model(m)
-    mfma_name = ("k_chain+k_conv_mfma" if form == "split" else "k_conv_mfma") if conv else "k_chain+k_mfma_lp"
+    mfma_name = ("k_chain+k_conv_mfma" if form == "split" else "k_conv_mfma") if conv else "k_mfma_lp"
     assert pool.kernel_name == (("k_conv" if conv else "k_stack") if form == "valu" else mfma_name)
     pool.set_controls(cg)
     got = _run_gpu(pool, x, block)
@@ -921,6 +921,65 @@ def test_every_kernel_form_passes_the_same_chain_cases(form, tmp_path, monkeypat
         p = O.OraclePlugin()
         p.set_loading(False)
         assert np.array_equal(g3[s], p.run(co, x3[s])), (form, s)
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("l32x2skip", dict(kind="lstm", hidden=32, input_size=1, seed=3220, n_rnn=2, in_skip=1, in_gain=-2.0, out_gain=3.0)),
+    ("g48x3", dict(kind="gru", hidden=48, input_size=3, seed=4830, n_rnn=3)),
+    ("l96x2", dict(kind="lstm", hidden=96, input_size=2, seed=9620, n_rnn=2)),
+])
+def test_stacked_one_launch_form_is_bit_identical_to_the_three_launch_form(name, kw, tmp_path, monkeypatch):
+    """Stacked models on pools whose blocks fit one staging chunk run their whole run() in the k_mfma_lp launch: the packed
+    pre pass on two waves of the first layer's workgroup (and, uncommitted, of the last layer's, which needs the model input
+    for in_skip and for net-off streams), the post pass behind the last layer's last tick. Same chain code, same kernel body
+    as between two k_chain launches (AIDAX_LP_FUSED=0): every output sample and every state word bit for bit, over ragged
+    blocks incl. 0 and 1, 40 streams (the last group ragged), per-stream disable / bypass / EQ position / moving ramps,
+    activate() in the middle — and against the oracle."""
+    path, spec = _model_file(tmp_path, name, **kw)
+    S = 40
+    sizes = [256, 1, 0, 37, 16, 255, 64, 3, 256]
+    x = modelgen.signal(S, sum(sizes), seed=41)
+    kws = [dict(param1=0.3, param2=0.8), dict(enabled=0.0), dict(net_bypass=1.0), dict(eq_position=1.0, bass_boost_db=5.0, mid_type=1.0),
+           dict(dc_blocker=0.0, in_lpf_pc=0.0, eq_bypass=1.0, param1=1.0), dict(pregain_db=6.0, master_db=-6.0, treble_boost_db=4.0, param2=0.1)]
+    outs, states, dsp = {}, {}, {}
+    for form in ("one", "three"):
+        monkeypatch.delenv("AIDAX_LP_FUSED", raising=False)
+        if form == "three":
+            monkeypatch.setenv("AIDAX_LP_FUSED", "0")
+        pool = ax.Pool(S, 256)
+        pool.set_model(ax.Model(path))
+        assert pool.kernel_name == ("k_mfma_lp" if form == "one" else "k_chain+k_mfma_lp")
+        for s_ in range(S):
+            pool.set_controls(ax.default_controls(**kws[s_ % len(kws)]), stream=s_)
+        got, pos = np.empty_like(x), 0
+        for bi, n in enumerate(sizes):
+            if bi == 5:
+                pool.activate()
+            got[:, pos:pos + n] = pool.process(np.ascontiguousarray(x[:, pos:pos + n]))
+            pos += n
+        outs[form] = got
+        states[form] = [pool.read_state(stream=s_, layer=kw["n_rnn"] - 1, hidden=128) for s_ in (0, 3, S - 1)]
+        dsp[form] = [pool.export_stream_dsp(s_) for s_ in (0, 3, 5, S - 1)]
+        pool.close()
+    assert np.array_equal(outs["one"], outs["three"])
+    for (h1, c1), (h3, c3) in zip(states["one"], states["three"]):
+        assert np.array_equal(h1, h3) and np.array_equal(c1, c3)
+    for a_, b_ in zip(dsp["one"], dsp["three"]):
+        assert bytes(a_) == bytes(b_)
+    for s_ in range(0, S, 5):
+        plug = O.OraclePlugin()
+        plug.set_model(O.OracleModel(spec))
+        want, pos = np.empty(x.shape[1], np.float32), 0
+        for bi, n in enumerate(sizes):
+            if bi == 5:
+                plug.activate()
+            want[pos:pos + n] = plug.run(O.default_controls(**kws[s_ % len(kws)]), x[s_, pos:pos + n])
+            pos += n
+        kw_ = kws[s_ % len(kws)]
+        if kw_.get("enabled") == 0.0 or kw_.get("net_bypass") == 1.0:
+            assert np.array_equal(outs["one"][s_], want), s_
+        else:
+            errlog.bound(np.abs(outs["one"][s_] - want).max(), 2e-6, "gpu_parity:lp_one_launch")
 
 
 @pytest.mark.parametrize("hidden,isz", [(64, 3), (64, 1), (40, 2)])

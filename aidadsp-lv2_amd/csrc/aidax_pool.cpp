@@ -578,7 +578,10 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
     int cus = 0;
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p.device));
     const size_t lp_groups = (p.n_streams + kMfmaStreams - 1) / kMfmaStreams;
-    const bool lp_pays = lp ? lp[0] != '0' : lp_groups * static_cast<size_t>(ms.mdesc.n_layers) <= static_cast<size_t>(cus);
+    // (one-layer models of <= 48 units in the one-launch form: also in several rounds of workgroups — nothing waits for anything,
+    // and LSTM-40 at 8192 streams measures 521 us against 583 us for k_mfma; profiles/r03_cfg3_forms.txt)
+    const bool lp_rounds_ok = ms.kind == ModelSlot::MFMA && ms.mdesc.n_layers == 1 && ms.mdesc.hidden <= 48 && mfma_lp_fused_serves(ms.mdesc, p.max_frames);
+    const bool lp_pays = lp ? lp[0] != '0' : (lp_rounds_ok || lp_groups * static_cast<size_t>(ms.mdesc.n_layers) <= static_cast<size_t>(cus));
     // (a one-layer model has no hand-over and nothing to wait for: no hold on the device's gate needed)
     const bool lp_chained = ms.mdesc.n_layers >= 2;
     if (ms.kind == ModelSlot::MFMA && mfma_lp_serves(ms.mdesc) && lp_pays && !(lp_chained && p.lp_off.load()) &&

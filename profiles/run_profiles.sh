@@ -18,7 +18,7 @@ rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$out/pmc_fetch" -o r -- $py $
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$out/pmc_write" -o r -- $py $bench > "$out/pmc_write.log" 2>&1
 rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU \
     -d "$out/pmc_sq" -o r -- $py $bench > "$out/pmc_sq.log" 2>&1
-if [ "$wl" = "cfg5" ] || [ "$wl" = "cfg4" ]; then
+if [ "$wl" = "cfg5" ] || [ "$wl" = "cfg4" ] || [ "$wl" = "cfg3" ]; then
     rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
         -d "$out/pmc_mfma" -o r -- $py $bench > "$out/pmc_mfma.log" 2>&1
 fi

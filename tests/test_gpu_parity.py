@@ -982,6 +982,61 @@ def test_stacked_one_launch_form_is_bit_identical_to_the_three_launch_form(name,
             errlog.bound(np.abs(outs["one"][s_] - want).max(), 2e-6, "gpu_parity:lp_one_launch")
 
 
+@pytest.mark.parametrize("kind,hidden,isz", [("lstm", 64, 2), ("lstm", 32, 1), ("gru", 16, 3), ("lstm", 12, 2)])
+def test_one_layer_one_launch_form_is_bit_identical_to_the_three_launch_form(kind, hidden, isz, tmp_path, monkeypatch):
+    """k_mfma_lp with its four helper waves (pre pass ahead of the frame loop, model inputs, the Dense's tail, post pass
+    behind the loop: one launch) against the same kernel between two packed k_chain launches (AIDAX_LP_FUSED=0): the
+    same chain arithmetic in resumable macro-steps, the same body — every output sample and every state word bit for
+    bit, over ragged blocks incl. 0, 1 and blocks of several 256-frame staging chunks, 70 streams, per-stream controls,
+    activate() in the middle; and against the oracle."""
+    monkeypatch.setenv("AIDAX_KERNEL", "mfma")
+    path, spec = _model_file(tmp_path, f"ol{kind}{hidden}_{isz}", kind=kind, hidden=hidden, input_size=isz, seed=800 + hidden + isz, in_skip=isz == 1)
+    S = 70
+    sizes = [256, 1, 0, 37, 700, 16, 255, 513, 3, 1024]
+    x = modelgen.signal(S, sum(sizes), seed=43)
+    kws = [dict(param1=0.3, param2=0.8), dict(enabled=0.0), dict(net_bypass=1.0), dict(eq_position=1.0, bass_boost_db=5.0, mid_type=1.0),
+           dict(dc_blocker=0.0, in_lpf_pc=0.0, eq_bypass=1.0, param1=1.0), dict(pregain_db=6.0, master_db=-6.0, treble_boost_db=4.0, param2=0.1)]
+    outs, states, dsp = {}, {}, {}
+    for form in ("one", "three"):
+        monkeypatch.delenv("AIDAX_LP_FUSED", raising=False)
+        if form == "three":
+            monkeypatch.setenv("AIDAX_LP_FUSED", "0")
+        pool = ax.Pool(S, 1024)
+        pool.set_model(ax.Model(path))
+        assert pool.kernel_name == ("k_mfma_lp" if form == "one" else "k_chain+k_mfma_lp")
+        for s_ in range(S):
+            pool.set_controls(ax.default_controls(**kws[s_ % len(kws)]), stream=s_)
+        got, pos = np.empty_like(x), 0
+        for bi, n in enumerate(sizes):
+            if bi == 5:
+                pool.activate()
+            got[:, pos:pos + n] = pool.process(np.ascontiguousarray(x[:, pos:pos + n]))
+            pos += n
+        outs[form] = got
+        states[form] = [pool.read_state(stream=s_, layer=0, hidden=128) for s_ in (0, 3, S - 1)]
+        dsp[form] = [pool.export_stream_dsp(s_) for s_ in (0, 3, 5, S - 1)]
+        pool.close()
+    assert np.array_equal(outs["one"], outs["three"])
+    for (h1, c1), (h3, c3) in zip(states["one"], states["three"]):
+        assert np.array_equal(h1, h3) and np.array_equal(c1, c3)
+    for a_, b_ in zip(dsp["one"], dsp["three"]):
+        assert bytes(a_) == bytes(b_)
+    for s_ in range(0, S, 5):
+        plug = O.OraclePlugin()
+        plug.set_model(O.OracleModel(spec))
+        want, pos = np.empty(x.shape[1], np.float32), 0
+        for bi, n in enumerate(sizes):
+            if bi == 5:
+                plug.activate()
+            want[pos:pos + n] = plug.run(O.default_controls(**kws[s_ % len(kws)]), x[s_, pos:pos + n])
+            pos += n
+        kw_ = kws[s_ % len(kws)]
+        if kw_.get("enabled") == 0.0 or kw_.get("net_bypass") == 1.0:
+            assert np.array_equal(outs["one"][s_], want), s_
+        else:
+            errlog.bound(np.abs(outs["one"][s_] - want).max(), 2e-6, "gpu_parity:lp1_one_launch")
+
+
 @pytest.mark.parametrize("hidden,isz", [(64, 3), (64, 1), (40, 2)])
 def test_gate_major_gru_kernel_ragged_blocks_controls_and_state_bits(hidden, isz, tmp_path, monkeypatch):
     """k_gru_gm (one-layer GRU, three recurrent tiles + an input-only accumulator per 16 units, the DSP chain on its

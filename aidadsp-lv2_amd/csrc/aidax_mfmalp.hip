@@ -883,8 +883,13 @@ __global__ __launch_bounds__((NW + NHELP) * kWave) void k_mfma_lp(LaunchArgs a, 
     const int l = adjacent ? blk % NL : (blk / 8) % NL;
     const int n_groups = ((int)a.n_streams + kMfmaStreams - 1) / kMfmaStreams;
     if (grp >= n_groups) return;
-    if constexpr (CHAIN) {                                 // stacked models only
-        if (l == 0) {
+    if constexpr (CHAIN) {                                 // stacked models, and one-layer ones without room for helper waves
+        if (NL == 1) {
+            lp_chain_rows<true>(a, smem, grp, true);
+            lp_body<TPW, NW, M, true, true, 0, true>(a, d, ring, counters, fault, smem, grp, l);
+            __syncthreads();
+            lp_chain_rows<false>(a, smem, grp, true);
+        } else if (l == 0) {
             if (!(a.tune & 2048)) lp_chain_rows<true>(a, smem, grp, true);
             lp_body<TPW, NW, M, true, false, 0, true>(a, d, ring, counters, fault, smem, grp, l);
         } else if (l == NL - 1) {
@@ -1075,9 +1080,8 @@ static LpFn lp_fn_fused(int hidden)
     default: return nullptr;
     }
 }
-static LpFn lp_fn_chain(int hidden, int n_layers)         // stacked models, the DSP chain on waves 0 and 1 of the first / last layer
+static LpFn lp_fn_chain(int hidden, int n_layers)         // the DSP chain on waves 0 and 1 of the first / last layer's workgroup
 {
-    if (n_layers < 2) return nullptr;
     switch (hidden) {
 #define AIDAX_LP_CHAIN_CASE(HID) case HID: { constexpr int T = HID / 4 / mfma_waves(HID), W_ = mfma_waves(HID);                    \
         return lp_moved_tiles(2, T, W_) > 0 && n_layers == 2 ? k_mfma_lp<T, W_, lp_moved_tiles(2, T, W_), 0, true> : k_mfma_lp<T, W_, 0, 0, true>; }
@@ -1100,19 +1104,22 @@ static int lp_m(const MfmaDesc& d) { return lp_moved_tiles(d.n_layers, d.hidden 
 
 // (one-layer models too: a workgroup per 16 streams with the layer's fragments resident in registers — no ring, no waits)
 bool mfma_lp_serves(const MfmaDesc& d) { return d.n_layers >= 1 && lp_fn(d.hidden, d.n_layers) != nullptr; }
+// which one-launch form a model takes: helper waves (one layer, room for a third wave per SIMD) or the chain passes on two
+// main waves around the body (everything else)
+static bool lp_helper_form(const MfmaDesc& d) { return d.n_layers == 1 && lp_helpers(d.hidden) > 0; }
 size_t mfma_lp_lds_bytes(const MfmaDesc& d, uint32_t n_frames, bool fused)
 {
-    if (fused && d.n_layers > 1) {                         // stacked: lp_chain_rows works in the body's LDS before and after it
+    if (fused && !lp_helper_form(d)) {                     // lp_chain_rows works in the body's LDS before and after it
         const size_t body = lp_lds_floats(d.hidden, (int)n_frames), rows = (size_t)kMfmaStreams * ((n_frames + 3) & ~3u) + 2 * kChainHandFloats;
         return (body > rows ? body : rows) * sizeof(float);
     }
     return lp_lds_floats(d.hidden, (int)n_frames, fused ? lp_helpers(d.hidden) : 0) * sizeof(float);
 }
-// the whole run() in the one launch (a.in -> a.out, MODE_CHAIN): one-layer models with room for the helper waves, stacked
-// models whose blocks fit one staging chunk (the chain passes run before the fragments are loaded / after the last tick)
+// the whole run() in the one launch (a.in -> a.out, MODE_CHAIN): one-layer models with room for the helper waves; all
+// others (stacked, or one layer of 80 / 96 units) when their blocks fit one staging chunk (lp_chain_rows around the body)
 bool mfma_lp_fused_serves(const MfmaDesc& d, uint32_t max_frames)
 {
-    return d.n_layers == 1 ? lp_helpers(d.hidden) > 0 : (max_frames <= (uint32_t)kLpChunk && lp_fn_chain(d.hidden, d.n_layers) != nullptr);
+    return lp_helper_form(d) || (max_frames <= (uint32_t)kLpChunk && lp_fn_chain(d.hidden, d.n_layers) != nullptr);
 }
 size_t mfma_lp_ring_bytes(const MfmaDesc& d, uint32_t n_streams)
 {
@@ -1128,7 +1135,7 @@ size_t mfma_lp_counter_bytes(const MfmaDesc& d, uint32_t n_streams)
 hipError_t launch_mfma_lp_kernel(const LaunchArgs& a, const MfmaDesc& d, float* ring, uint32_t* counters, uint32_t* fault, hipStream_t stream, bool fused)
 {
     if (fused && (!mfma_lp_fused_serves(d, a.n_frames) || a.mode != MODE_CHAIN || a.n_frames == 0)) return hipErrorInvalidValue;
-    LpFn fn = !fused ? lp_fn(d.hidden, d.n_layers) : d.n_layers == 1 ? lp_fn_fused(d.hidden) : lp_fn_chain(d.hidden, d.n_layers);
+    LpFn fn = !fused ? lp_fn(d.hidden, d.n_layers) : lp_helper_form(d) ? lp_fn_fused(d.hidden) : lp_fn_chain(d.hidden, d.n_layers);
     if (!fn || !ring || !counters || !fault) return hipErrorInvalidValue;
     const size_t lds = mfma_lp_lds_bytes(d, a.n_frames, fused);
     if (lds > 64 * 1024) {
@@ -1137,7 +1144,7 @@ hipError_t launch_mfma_lp_kernel(const LaunchArgs& a, const MfmaDesc& d, float* 
     }
     const uint32_t groups = (a.n_streams + kMfmaStreams - 1) / kMfmaStreams;
     const uint32_t blocks = ((groups + 7) / 8) * 8 * (uint32_t)d.n_layers;
-    const int waves = mfma_waves(d.hidden) + (fused && d.n_layers == 1 ? lp_helpers(d.hidden) : 0);
+    const int waves = mfma_waves(d.hidden) + (fused && lp_helper_form(d) ? lp_helpers(d.hidden) : 0);
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(waves * kWave), lds, stream, a, d, ring, counters, fault);
     return hipGetLastError();
 }

@@ -30,6 +30,13 @@
 // Same arithmetic as k_mfma (same fragments from pack_mfma, same accumulation order, same activations): the two
 // kernels leave bit-identical recurrent state on the same model, which tests/test_gpu_parity.py checks (Dense(H,1) is
 // summed in a different order, so the outputs agree to ~1e-7).
+//
+// Also in this file, on the same building blocks:
+//   * one-layer models (first = last: no ring, nobody waits) with FOUR HELPER WAVES that carry the whole DSP chain and
+//     the per-stream scalar work of a frame — the whole run() in the one launch (lp_helper);
+//   * stacked models in one launch: the packed chain passes on two waves of the first / last layer's workgroup around
+//     the unchanged body (lp_chain_rows);
+//   * k_gru_gm: one-layer GRUs on gate-major tiles (three quarters of the MFMAs), one main + one helper wave per SIMD.
 #include "aidax_device.h"
 #include "aidax_kernels.h"
 #include "aidax_layout.h"

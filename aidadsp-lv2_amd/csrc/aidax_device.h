@@ -93,9 +93,14 @@ __device__ __forceinline__ float sigmoid_pre(float v_scaled)
 // only ABSOLUTELY accurate (1.2e-7), and an LSTM whose forget gate sits near 1 integrates
 // that error in c (measured 5.5e-6 after 2048 samples on tw40_british_lead vs 1.3e-6 with
 // this form; the reference's threshold is 1e-5, rt-neural-generic.h:182).
+// (Round 3 looked for a shorter one — scratch/fit_tanh3.py, fit_tanh4.py: degree 4 over degree 4 has the same 5-ulp bound
+// with one FMA less, x + x*u*R/Q is 1 ulp below |x| = 1 but cancels above 2 — and kept this one: every candidate's rounding
+// error is a deterministic function of x, a cell at rest evaluates the same x every frame, and the 2048-frame warm-up of
+// tw40_british_lead ended 4.7e-6 from the oracle's state with the shorter rational against 1.6e-6 with this one, for 1.3 % of
+// cfg2's time.)
 __device__ __forceinline__ float tanh_rat(float v)
 {
-    const float x = __builtin_fminf(__builtin_fmaxf(v, -7.9f), 7.9f);
+    const float x = __builtin_fminf(__builtin_fmaxf(v, -7.9f), 7.9f);     // (v_max + v_med3; a bare v_med3 lets a NaN through and is no faster)
     const float u = x * x;
     float p = -8.488730763828322e-14f;
     p = __builtin_fmaf(p, u, 5.277955823366522e-11f);

@@ -105,6 +105,9 @@ def lib() -> C.CDLL:
     L.aidax_pool_process.argtypes = [vp, _fp, _fp, u32]
     L.aidax_pool_submit.argtypes = [vp, _fp, u32]
     L.aidax_pool_collect.argtypes = [vp, _fp, u32]
+    L.aidax_pool_submit_to.argtypes = [vp, _fp, _fp, u32]
+    L.aidax_pool_register_host.argtypes = [vp, C.c_void_p, C.c_size_t]
+    L.aidax_pool_unregister_host.argtypes = [vp, C.c_void_p]
     L.aidax_pool_process_device.argtypes = [vp, vp, vp, u32, vp]
     L.aidax_pool_sync.argtypes = [vp]
     L.aidax_model_self_test.argtypes = [vp, C.c_int, C.POINTER(i32), _fp, _fp]
@@ -284,6 +287,18 @@ class Pool:
         x = _f32(x)
         assert x.ndim == 2 and x.shape[0] == self.n_streams
         _check(lib().aidax_pool_submit(self.h, x.ctypes.data_as(_fp), x.shape[1]))
+
+    def register_host(self, arr: np.ndarray):
+        """Page-lock a caller buffer once: blocks inside it are uploaded / downloaded without staging copies."""
+        _check(lib().aidax_pool_register_host(self.h, C.c_void_p(arr.ctypes.data), arr.nbytes))
+
+    def unregister_host(self, arr: np.ndarray):
+        _check(lib().aidax_pool_unregister_host(self.h, C.c_void_p(arr.ctypes.data)))
+
+    def submit_to(self, x: np.ndarray, out: np.ndarray):
+        assert x.dtype == np.float32 and out.dtype == np.float32 and x.flags.c_contiguous and out.flags.c_contiguous
+        assert x.ndim == 2 and x.shape[0] == self.n_streams and out.size >= x.size
+        _check(lib().aidax_pool_submit_to(self.h, x.ctypes.data_as(_fp), out.ctypes.data_as(_fp), x.shape[1]))
 
     def collect(self, n_frames: int, out: Optional[np.ndarray] = None) -> np.ndarray:
         if out is None:

@@ -224,8 +224,19 @@ struct aidax_pool {
         hipEvent_t ev_up[2] = {}, ev_pass[2] = {}, ev_down[2] = {};
         hipStream_t q_up = nullptr, q_down = nullptr;
         uint32_t frames[2] = {};
+        float* direct_out[2] = {};      // the block's download went straight to this caller buffer (registered): collect() only waits
         uint64_t submitted = 0, collected = 0;
     } pipe;
+    // aidax_pool_register_host: page-locked ranges of the caller's memory (copies to and from them need no staging)
+    struct HostRange { char* base; size_t bytes; };
+    std::vector<HostRange> host_ranges;
+    bool host_registered(const void* ptr, size_t bytes) const
+    {
+        const char* c = static_cast<const char*>(ptr);
+        for (const HostRange& r : host_ranges)
+            if (c >= r.base && c + bytes <= r.base + r.bytes) return true;
+        return false;
+    }
 
     std::vector<aidax_controls> controls;
     std::vector<uint8_t> loading;
@@ -451,6 +462,8 @@ struct aidax_pool {
 #endif
         if (h_lp_fault) (void)hipHostFree(h_lp_fault);
         h_lp_fault = nullptr;
+        for (const HostRange& r : host_ranges) (void)hipHostUnregister(r.base);
+        host_ranges.clear();
         for (int k = 0; k < 2; ++k) {
             if (pipe.h_in[k]) (void)hipHostFree(pipe.h_in[k]);
             if (pipe.h_out[k]) (void)hipHostFree(pipe.h_out[k]);
@@ -1075,7 +1088,7 @@ AIDAX_API int aidax_pool_process(aidax_pool* p, const float* in, float* out, uin
 }
 
 // ---- the pipelined host-buffer path. One caller thread (the audio side); at most two blocks between submit and collect.
-AIDAX_API int aidax_pool_submit(aidax_pool* p, const float* in, uint32_t n_frames)
+static int pool_submit_impl(aidax_pool* p, const float* in, float* out, uint32_t n_frames)
 {
     if (!p) return fail(AIDAX_ERR_ARG, "null pool");
     if (n_frames == 0 || n_frames > p->max_frames) return fail(AIDAX_ERR_ARG, "n_frames out of range");
@@ -1101,9 +1114,13 @@ AIDAX_API int aidax_pool_submit(aidax_pool* p, const float* in, uint32_t n_frame
         if (pl.submitted - pl.collected >= 2) return fail(AIDAX_ERR_STATE, "two blocks are in flight: collect one first");
         const int s = static_cast<int>(pl.submitted & 1);
         const size_t bytes = sizeof(float) * p->n_streams * static_cast<size_t>(n_frames);
-        std::memcpy(pl.h_in[s], in, bytes);
         // set s was last used by block k-2, which has been collected: its pass and both its copies are complete
-        HIP_TRY(hipMemcpyAsync(pl.d_in[s], pl.h_in[s], bytes, hipMemcpyHostToDevice, pl.q_up));
+        const float* up_from = in;                          // a registered caller buffer is uploaded as it lies
+        if (!p->host_registered(in, bytes)) {
+            std::memcpy(pl.h_in[s], in, bytes);
+            up_from = pl.h_in[s];
+        }
+        HIP_TRY(hipMemcpyAsync(pl.d_in[s], up_from, bytes, hipMemcpyHostToDevice, pl.q_up));
         HIP_TRY(hipEventRecord(pl.ev_up[s], pl.q_up));
         p->enter_stream(p->q);
         HIP_TRY(hipStreamWaitEvent(p->q, pl.ev_up[s], 0));
@@ -1111,11 +1128,51 @@ AIDAX_API int aidax_pool_submit(aidax_pool* p, const float* in, uint32_t n_frame
         if (rc != AIDAX_OK) return rc;
         HIP_TRY(hipEventRecord(pl.ev_pass[s], p->q));
         HIP_TRY(hipStreamWaitEvent(pl.q_down, pl.ev_pass[s], 0));
-        HIP_TRY(hipMemcpyAsync(pl.h_out[s], pl.d_out[s], bytes, hipMemcpyDeviceToHost, pl.q_down));
+        pl.direct_out[s] = (out && p->host_registered(out, bytes)) ? out : nullptr;
+        HIP_TRY(hipMemcpyAsync(pl.direct_out[s] ? pl.direct_out[s] : pl.h_out[s], pl.d_out[s], bytes, hipMemcpyDeviceToHost, pl.q_down));
         HIP_TRY(hipEventRecord(pl.ev_down[s], pl.q_down));
         pl.frames[s] = n_frames;
         ++pl.submitted;
         return AIDAX_OK;
+    });
+}
+
+AIDAX_API int aidax_pool_submit(aidax_pool* p, const float* in, uint32_t n_frames) { return pool_submit_impl(p, in, nullptr, n_frames); }
+
+AIDAX_API int aidax_pool_submit_to(aidax_pool* p, const float* in, float* out, uint32_t n_frames)
+{
+    if (!out) return fail(AIDAX_ERR_ARG, "null buffer");
+    return pool_submit_impl(p, in, out, n_frames);
+}
+
+AIDAX_API int aidax_pool_register_host(aidax_pool* p, void* base, size_t bytes)
+{
+    if (!p || !base || bytes == 0) return fail(AIDAX_ERR_ARG, "null range");
+    return guarded([&]() -> int {
+        HIP_TRY(hipSetDevice(p->device));
+        for (const auto& r : p->host_ranges)
+            if (r.base == static_cast<char*>(base)) return fail(AIDAX_ERR_STATE, "range is registered already");
+        HIP_TRY(hipHostRegister(base, bytes, hipHostRegisterDefault));
+        p->host_ranges.push_back({ static_cast<char*>(base), bytes });
+        return AIDAX_OK;
+    });
+}
+
+AIDAX_API int aidax_pool_unregister_host(aidax_pool* p, void* base)
+{
+    if (!p || !base) return fail(AIDAX_ERR_ARG, "null range");
+    return guarded([&]() -> int {
+        HIP_TRY(hipSetDevice(p->device));
+        for (size_t i = 0; i < p->host_ranges.size(); ++i)
+            if (p->host_ranges[i].base == static_cast<char*>(base)) {
+                // copies to or from the range that are still in flight finish first
+                if (p->pipe.q_up) HIP_TRY(hipStreamSynchronize(p->pipe.q_up));
+                if (p->pipe.q_down) HIP_TRY(hipStreamSynchronize(p->pipe.q_down));
+                HIP_TRY(hipHostUnregister(base));
+                p->host_ranges.erase(p->host_ranges.begin() + static_cast<long>(i));
+                return AIDAX_OK;
+            }
+        return fail(AIDAX_ERR_ARG, "range was not registered");
     });
 }
 
@@ -1127,6 +1184,7 @@ AIDAX_API int aidax_pool_collect(aidax_pool* p, float* out, uint32_t n_frames)
         if (!pl.ready || pl.collected == pl.submitted) return fail(AIDAX_ERR_STATE, "nothing was submitted");
         const int s = static_cast<int>(pl.collected & 1);
         if (pl.frames[s] != n_frames) return fail(AIDAX_ERR_ARG, "n_frames differs from the submitted block's");
+        if (pl.direct_out[s] && pl.direct_out[s] != out) return fail(AIDAX_ERR_ARG, "collect: the block was submitted with another destination");
         HIP_TRY(hipSetDevice(p->device));
         if (hipEventQuery(pl.ev_down[s]) != hipSuccess) HIP_TRY(hipEventSynchronize(pl.ev_down[s]));
         ++pl.collected;
@@ -1135,7 +1193,7 @@ AIDAX_API int aidax_pool_collect(aidax_pool* p, float* out, uint32_t n_frames)
             std::memset(out, 0, bytes);
             return fail(AIDAX_ERR_DEVICE, "k_mfma_lp: a layer hand-over timed out (this block is silence; the pool falls back to k_mfma)");
         }
-        std::memcpy(out, pl.h_out[s], bytes);
+        if (!pl.direct_out[s]) std::memcpy(out, pl.h_out[s], bytes);
         return AIDAX_OK;
     });
 }

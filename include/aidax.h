@@ -216,6 +216,16 @@ AIDAX_API int  aidax_pool_process(aidax_pool* p, const float* in, float* out, ui
 AIDAX_API int  aidax_pool_submit(aidax_pool* p, const float* in, uint32_t n_frames);
 AIDAX_API int  aidax_pool_collect(aidax_pool* p, float* out, uint32_t n_frames);
 
+/* A host that hands over the SAME buffers block after block (the reference's run() gets the host's port buffers,
+ * rt-neural-generic.cpp:484-487) can have them pinned once: register_host() page-locks a range of the caller's memory
+ * for the pool's device (set-up side: it allocates and may block; the range must stay mapped until unregister_host() or
+ * the pool's end). submit() then uploads a block that lies inside a registered range straight out of it — no copy into
+ * the pool's staging — and submit_to() names the block's destination up front, so that the download lands there as well
+ * and collect() (same `out`) only waits. Buffers outside any registered range take the staged path as before. */
+AIDAX_API int  aidax_pool_register_host(aidax_pool* p, void* base, size_t bytes);
+AIDAX_API int  aidax_pool_unregister_host(aidax_pool* p, void* base);
+AIDAX_API int  aidax_pool_submit_to(aidax_pool* p, const float* in, float* out, uint32_t n_frames);
+
 /* Same pass with device-resident buffers, asynchronous on `hip_stream`
  * (a hipStream_t; NULL = the pool's own stream). No host sync inside. The pool's control pokes (activate,
  * reset_stream, commit_model) run on its own stream; when consecutive operations sit on different streams the

@@ -33,6 +33,8 @@ int main(int argc, char** argv)
                aidax_pool_import_stream_dsp(NULL, 0, &dsp), aidax_hub_attach_successor(NULL, NULL, -1, &slot),
                aidax_hub_adopt(NULL, 0, NULL, 0), aidax_hub_max_frames(NULL));
         printf("sizeof(aidax_stream_dsp)=%u\n", (unsigned)sizeof dsp);
+        printf("null handles: register=%d unregister=%d submit_to=%d\n", aidax_pool_register_host(NULL, blk, sizeof blk),
+               aidax_pool_unregister_host(NULL, blk), aidax_pool_submit_to(NULL, blk, blk, 4));
     }
     rc = aidax_pool_create(1, 256, 48000.0, 0, &pool);
     printf("pool_create rc=%d pool=%s\n", rc, pool ? "set" : "null");

@@ -292,3 +292,43 @@ def test_pipelined_host_buffer_path_is_the_blocking_path_bit_for_bit(tmp_path):
         assert np.array_equal(got, want[k - 1]), k
     assert np.array_equal(b.collect(sizes[-1]), want[-1])
     a.close(); b.close()
+
+
+def test_registered_host_buffers_take_the_copies_out_of_the_pipelined_path_same_bits(tmp_path):
+    """aidax_pool_register_host + aidax_pool_submit_to: the caller's own buffers, page-locked once, are the source of the
+    upload and the destination of the download (no staging copies on the caller's thread) — same bits as the blocking
+    path block for block, registered and unregistered buffers mixed, the calling rules enforced."""
+    path = str(tmp_path / "r.json")
+    modelgen.write_model(modelgen.make_model(kind="lstm", hidden=16, input_size=1, seed=23), path)
+    m = ax.Model(path)
+    S, n, nblk = 300, 128, 9
+    x = modelgen.signal(S, n * nblk, seed=17)
+    a, b = ax.Pool(S, n), ax.Pool(S, n)
+    a.set_model(m); b.set_model(m)
+    want = [a.process(np.ascontiguousarray(x[:, k * n:(k + 1) * n])) for k in range(nblk)]
+    ins = np.empty((2, S, n), np.float32)                            # the host's two input buffers, registered as one range
+    outs = [np.empty((S, n), np.float32) for _ in range(2)]          # ... its two output buffers, each a range of its own
+    loose = np.empty((S, n), np.float32)                             # and one the pool has never heard of
+    b.register_host(ins); b.register_host(outs[0]); b.register_host(outs[1])
+    L = ax.lib()
+    assert L.aidax_pool_register_host(b.h, C.c_void_p(ins.ctypes.data), ins.nbytes) == -6          # registered already
+    ins[0] = x[:, :n]
+    b.submit_to(ins[0], outs[0])
+    for k in range(1, nblk):
+        if k == 4:                                                   # an unregistered source and destination in between: staged as before
+            b.submit_to(np.ascontiguousarray(x[:, k * n:(k + 1) * n]), loose)
+        else:
+            ins[k & 1] = x[:, k * n:(k + 1) * n]
+            b.submit_to(ins[k & 1], outs[k & 1])
+        prev = loose if k - 1 == 4 else outs[(k - 1) & 1]
+        if k == 2:                                                   # collect must name the destination the block was submitted with
+            assert L.aidax_pool_collect(b.h, loose.ctypes.data_as(C.POINTER(C.c_float)), n) == -1
+        got = b.collect(n, prev)
+        assert got is prev and np.array_equal(prev, want[k - 1]), k
+    last = loose if nblk - 1 == 4 else outs[(nblk - 1) & 1]
+    b.collect(n, last)
+    assert np.array_equal(last, want[-1])
+    b.unregister_host(outs[1])
+    assert L.aidax_pool_unregister_host(b.h, C.c_void_p(outs[1].ctypes.data)) == -1               # not registered any more
+    b.submit_to(ins[0], outs[1]); b.collect(n, outs[1])              # ... and still served, staged
+    a.close(); b.close()                                             # (the pool's end releases the remaining ranges)

@@ -179,10 +179,8 @@ struct LstmCell {
             float a0 = acc[0][0], a1 = acc[0][1];
             a0 = __builtin_fmaf(w[0][0][0], hr, a0);
             a1 = __builtin_fmaf(w[0][1][0], hr, a1);
-#define AIDAX_ROT(N) fmac_row_ror<N>(a0, hr, w[0][0][N]); fmac_row_ror<N>(a1, hr, w[0][1][N]);
-            AIDAX_ROT(1) AIDAX_ROT(2) AIDAX_ROT(3) AIDAX_ROT(4) AIDAX_ROT(5) AIDAX_ROT(6) AIDAX_ROT(7) AIDAX_ROT(8)
-            AIDAX_ROT(9) AIDAX_ROT(10) AIDAX_ROT(11) AIDAX_ROT(12) AIDAX_ROT(13) AIDAX_ROT(14) AIDAX_ROT(15)
-#undef AIDAX_ROT
+            fmac2_row_ror_1_8(a0, a1, hr, w[0][0], w[0][1]);      // rotations 1..15 of both rows, same order as one by one
+            fmac2_row_ror_9_15(a0, a1, hr, w[0][0], w[0][1]);
             const float4 qs[4] = { q0, q1, q2, q3 };
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4) {

@@ -73,6 +73,18 @@ __device__ __forceinline__ void fmac2_row_ror_9_15(float& a0, float& a1, float h
                    "v"(w1[9]), "v"(w1[10]), "v"(w1[11]), "v"(w1[12]), "v"(w1[13]), "v"(w1[14]), "v"(w1[15]));
 }
 #undef AIDAX_ROR2
+// ... and rotations 1..15 of ONE chain (cells of <= 16 units: a row of 16 lanes is one gate of all the units)
+#define AIDAX_ROR1(N, W) "v_fmac_f32_dpp %0, %1, %" #W " row_ror:" #N " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void fmac_row_ror_1_15(float& a0, float h, const float* w)
+{
+    asm volatile(AIDAX_ROR1(1, 2) AIDAX_ROR1(2, 3) AIDAX_ROR1(3, 4) AIDAX_ROR1(4, 5) AIDAX_ROR1(5, 6) AIDAX_ROR1(6, 7) AIDAX_ROR1(7, 8)
+                 AIDAX_ROR1(8, 9) AIDAX_ROR1(9, 10) AIDAX_ROR1(10, 11) AIDAX_ROR1(11, 12) AIDAX_ROR1(12, 13) AIDAX_ROR1(13, 14)
+                 AIDAX_ROR1(14, 15) AIDAX_ROR1(15, 16)
+                 : "+v"(a0)
+                 : "v"(h), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]),
+                   "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]));
+}
+#undef AIDAX_ROR1
 
 // Cross-lane shares on the permlane swap network. (The swapped pair is copied to
 // scalars before the float bit_cast: __builtin_bit_cast applied directly to an

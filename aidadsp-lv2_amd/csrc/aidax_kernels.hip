@@ -164,10 +164,7 @@ struct LstmCell {
             // a 16-lane row is one gate of all the units: h(t-1) of every unit is a rotation away, nothing comes from LDS
             const float hr = h[0];
             float a0 = __builtin_fmaf(w[0][0][0], hr, acc[0][0]);
-#define AIDAX_ROT(N) fmac_row_ror<N>(a0, hr, w[0][0][N]);
-            AIDAX_ROT(1) AIDAX_ROT(2) AIDAX_ROT(3) AIDAX_ROT(4) AIDAX_ROT(5) AIDAX_ROT(6) AIDAX_ROT(7) AIDAX_ROT(8)
-            AIDAX_ROT(9) AIDAX_ROT(10) AIDAX_ROT(11) AIDAX_ROT(12) AIDAX_ROT(13) AIDAX_ROT(14) AIDAX_ROT(15)
-#undef AIDAX_ROT
+            fmac_row_ror_1_15(a0, hr, w[0][0]);               // rotations 1..15 in one asm statement (no s_nops in between)
             acc[0][0] = a0;
             (void)hprev;
         } else if constexpr (ROT) {

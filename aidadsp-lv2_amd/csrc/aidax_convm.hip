@@ -64,7 +64,10 @@ __device__ __forceinline__ void lds_barrier()
 // chain passes at the same time, each on its wave 0: the dispatcher rotates the SIMD a workgroup's first wave lands on
 // (scratch/uhwid.hip: of 1536 pairs of co-resident workgroups none had their waves 0 on one SIMD), so every chain wave
 // issues alone. (Picking the wave by HW_ID slot instead put two of them on one SIMD: 88.3 us.)
-template <bool FUSED>
+// FULL: the block is exactly sixteen frame tiles (256 frames, what the pools of BASELINE cfg4 send): the instantiation carries
+// the immediate-offset k-loop only. With both loops in one kernel their accumulators met in phi registers and every layer
+// paid ~35 v_mov for it (found in the ISA; round 3) — an instruction count that matters here, see DESIGN.md §8.
+template <bool FUSED, bool FULL>
 __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, ConvDesc d)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -142,7 +145,9 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
     // before it computes, and so does the history prefix of the layer after it.
     constexpr int kFragRegs = 8;              // 32 k-steps x 64 lanes / 256 threads
     constexpr int kHistRegs = 8;              // 4096 history floats of a layer in registers; longer ones read directly
+    // (the float4 and the scalar form of a history prefix in registers of their own: one set for both met in phi copies)
     float fr[kFragRegs], hp[kHistRegs], bias_r = 0.f;
+    f32x4 hp4[kHistRegs / 4];
     int kcb[kFragRegs];                        // (cin << 16 | frames back) of the contraction row behind fragment element j
     auto fetch_frag = [&](int l) {
         const ConvLayer& L = d.L[l];
@@ -196,8 +201,7 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
             for (int j = 0; j < kHistRegs / 4; ++j) {
                 if (j * kConvmThreads * 4 >= cnt) break;
                 const int i4 = tid + j * kConvmThreads;
-                const f32x4 v = 4 * i4 < cnt ? src[i4] : f32x4{ 0.f, 0.f, 0.f, 0.f };
-                hp[4 * j] = v.x; hp[4 * j + 1] = v.y; hp[4 * j + 2] = v.z; hp[4 * j + 3] = v.w;
+                hp4[j] = 4 * i4 < cnt ? src[i4] : f32x4{ 0.f, 0.f, 0.f, 0.f };
             }
             return;
         }
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
                 if (j * kConvmThreads * 4 >= cnt) break;
                 const int i4 = tid + j * kConvmThreads;
                 if (4 * i4 < cnt)
-                    *reinterpret_cast<f32x4*>(pl + plane_index4(i4, hist4, inv4)) = f32x4{ hp[4 * j], hp[4 * j + 1], hp[4 * j + 2], hp[4 * j + 3] };
+                    *reinterpret_cast<f32x4*>(pl + plane_index4(i4, hist4, inv4)) = hp4[j];
             }
             for (int i4 = tid + (kHistRegs / 4) * kConvmThreads; 4 * i4 < cnt; i4 += kConvmThreads)
                 *reinterpret_cast<f32x4*>(pl + plane_index4(i4, hist4, inv4)) = reinterpret_cast<const f32x4*>(hist_base + L.state_off)[i4];
@@ -290,17 +294,24 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
         const float bias = bias_r;                            // of layer l (fetch_frag below loads the next one's)
         if (l + 1 < d.n_layers) { fetch_frag(l + 1); fetch_prefix(l + 1); }
         lds_barrier();                                        // plane = this layer's input, wst = its fragments
-        // tile j of this wave is frame tile wave + 4*j (n <= 256: at most kConvmTiles per wave)
+        // tile j of this wave is frame tile wave + 4*j (n <= 256: at most kConvmTiles per wave). The accumulators START as the
+        // result of the first k-step's MFMAs with the bias quad as their C operand — no sixteen moves to seed them.
         f32x4 acc[kConvmTiles];
-#pragma unroll
-        for (int j = 0; j < kConvmTiles; ++j) acc[j] = f32x4{bias, bias, bias, bias};
-        if (wave < ntiles) {
+        const f32x4 bias4 = f32x4{bias, bias, bias, bias};
+        if (FULL || wave < ntiles) {
             const char* plw = reinterpret_cast<const char*>(pl + 16 * wave);
-            if (ntiles == 4 * kConvmTiles) {
+            if constexpr (FULL) {
                 // a full block: the four tiles of a wave sit at fixed distances — one address per k-step, the rest
                 // are the instruction's immediate offsets
                 // (reading the next k-step's record ahead of this one's MFMAs was measured: 75.6 against 75.05 us)
-                for (int kk = 0; kk < L.k_steps; ++kk) {
+                {
+                    const float2 rec = *reinterpret_cast<const float2*>(wst + 2 * lane);
+                    const float* ap = reinterpret_cast<const float*>(plw + __builtin_bit_cast(int, rec.y));
+#pragma unroll
+                    for (int j = 0; j < kConvmTiles; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[64 * j], rec.x, bias4, 0, 0, 0);
+                }
+                for (int kk = 1; kk < L.k_steps; ++kk) {
                     const float2 rec = *reinterpret_cast<const float2*>(wst + 2 * (kk * kWave + lane));
                     const float* ap = reinterpret_cast<const float*>(plw + __builtin_bit_cast(int, rec.y));
 #pragma unroll
@@ -308,24 +319,36 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
                         acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[64 * j], rec.x, acc[j], 0, 0, 0);
                 }
             } else {
-                for (int kk = 0; kk < L.k_steps; ++kk) {
-                    const float2 rec = *reinterpret_cast<const float2*>(wst + 2 * (kk * kWave + lane));
+                {
+                    const float2 rec = *reinterpret_cast<const float2*>(wst + 2 * lane);
                     const float* ap = reinterpret_cast<const float*>(plw + __builtin_bit_cast(int, rec.y));
 #pragma unroll
                     for (int j = 0; j < kConvmTiles; ++j) {
                         const float av = ap[wave + 4 * j < ntiles ? 64 * j : 0];   // tiles past the block re-read the first
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, rec.x, bias4, 0, 0, 0);
+                    }
+                }
+                for (int kk = 1; kk < L.k_steps; ++kk) {
+                    const float2 rec = *reinterpret_cast<const float2*>(wst + 2 * (kk * kWave + lane));
+                    const float* ap = reinterpret_cast<const float*>(plw + __builtin_bit_cast(int, rec.y));
+#pragma unroll
+                    for (int j = 0; j < kConvmTiles; ++j) {
+                        const float av = ap[wave + 4 * j < ntiles ? 64 * j : 0];
                         acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, rec.x, acc[j], 0, 0, 0);
                     }
                 }
             }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kConvmTiles; ++j) acc[j] = bias4;
         }
         save_history(L);                                      // reads the input while it is still there
         lds_barrier();                                        // everybody is done reading the plane and wst
-        if (wave < ntiles) {
+        if (FULL || wave < ntiles) {
             const int co = lane & 15;
 #pragma unroll
             for (int j = 0; j < kConvmTiles; ++j) {
-                if (wave + 4 * j >= ntiles || co >= Co) continue;
+                if ((!FULL && wave + 4 * j >= ntiles) || co >= Co) continue;
                 f32x4 v = acc[j];
                 if (L.activation == 1) { v.x = tanh_exp(v.x); v.y = tanh_exp(v.y); v.z = tanh_exp(v.z); v.w = tanh_exp(v.w); }
                 else if (L.activation == 2) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
@@ -367,7 +390,7 @@ int convm_resident_streams(const ConvDesc& d, uint32_t n_frames, int device)
 {
     int per_cu = 0, cus = 0;
     const size_t lds = convm_lds_bytes(d, n_frames);
-    const void* fn = reinterpret_cast<const void*>(k_conv_mfma<true>);
+    const void* fn = reinterpret_cast<const void*>(k_conv_mfma<true, false>);      // (both instantiations have the same footprint)
     if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kConvmThreads, lds) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
@@ -379,13 +402,14 @@ hipError_t launch_conv_mfma_kernel(const LaunchArgs& a, const ConvDesc& d, bool 
 {
     if (fused && a.mode != MODE_CHAIN) return hipErrorInvalidValue;
     const size_t lds = convm_lds_bytes(d, a.n_frames);
-    const void* fn = fused ? reinterpret_cast<const void*>(k_conv_mfma<true>) : reinterpret_cast<const void*>(k_conv_mfma<false>);
+    const bool full = a.n_frames == 16 * 4 * kConvmTiles;     // sixteen frame tiles: the instantiation without the ragged loop
+    typedef void (*Fn)(LaunchArgs, ConvDesc);
+    const Fn fn = fused ? (full ? k_conv_mfma<true, true> : k_conv_mfma<true, false>) : (full ? k_conv_mfma<false, true> : k_conv_mfma<false, false>);
     if (lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    if (fused) hipLaunchKernelGGL(k_conv_mfma<true>, dim3(a.n_streams), dim3(kConvmThreads), lds, stream, a, d);
-    else hipLaunchKernelGGL(k_conv_mfma<false>, dim3(a.n_streams), dim3(kConvmThreads), lds, stream, a, d);
+    hipLaunchKernelGGL(fn, dim3(a.n_streams), dim3(kConvmThreads), lds, stream, a, d);
     return hipGetLastError();
 }
 

@@ -33,12 +33,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kConvmThreads = 256;
 constexpr int kConvmTiles = 4;            // frame tiles per wave per pass (256 frames = 16 tiles = 4 waves x 4)
 
-// frames per channel row: history (rounded to 4) + block (rounded to whole tiles), then up to 16 (mod 64)
-__host__ __device__ inline int convm_plane_stride(int max_hist, int n_frames)
-{
-    const int f = ((max_hist + 3) & ~3) + ((n_frames + 15) & ~15);
-    return ((f + 47) / 64) * 64 + 16;
-}
+// (convm_plane_stride: aidax_layout.h — the packer needs it for the full-block records)
 __host__ __device__ inline size_t convm_lds_floats(const ConvDesc& d, int n_frames)
 {
     const size_t stage = 2 * (size_t)d.max_k_steps * kWave;                    /* B fragments + A offsets; the fused form's  */
@@ -151,7 +146,7 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
     int kcb[kFragRegs];                        // (cin << 16 | frames back) of the contraction row behind fragment element j
     auto fetch_frag = [&](int l) {
         const ConvLayer& L = d.L[l];
-        const float2* recs = reinterpret_cast<const float2*>(W + L.wf_off);
+        const float2* recs = reinterpret_cast<const float2*>(W + (FULL ? L.wf_full_off : L.wf_off));
 #pragma unroll
         for (int j = 0; j < kFragRegs; ++j) {
             if (j * kConvmThreads >= L.k_steps * kWave) break;
@@ -160,7 +155,7 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
             fr[j] = r.x;
             kcb[j] = __builtin_bit_cast(int, r.y);
         }
-        bias_r = (lane & 15) < L.out_ch ? W[L.b_off + (lane & 15)] : 0.f;
+        bias_r = W[L.bs_off + (lane & 15)];
     };
     auto stage_frag = [&](int l) {            // registers -> one 8-byte record per (k-step, lane): B value, A plane offset
         const ConvLayer& L = d.L[l];
@@ -170,7 +165,8 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
             const int i = tid + j * kConvmThreads;
             if (i < L.k_steps * kWave)      // the A offset in BYTES: the k-loop adds it to the plane's base as it is
                 *reinterpret_cast<float2*>(wst + 2 * i) =
-                    float2{ fr[j], __builtin_bit_cast(float, 4 * ((kcb[j] >> 16) * F + Hb - (kcb[j] & 0xffff) + (i & 15))) };
+                    float2{ fr[j], FULL ? __builtin_bit_cast(float, kcb[j])      // (full blocks: the packer has done it)
+                                        : __builtin_bit_cast(float, 4 * ((kcb[j] >> 16) * F + Hb - (kcb[j] & 0xffff) + (i & 15))) };
         }
     };
     // history of a layer: [in_ch][hist] in HBM <-> plane[ch][Hb-hist .. Hb), walked flat (coalesced, hist*in_ch/256
@@ -350,7 +346,7 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
             for (int j = 0; j < kConvmTiles; ++j) {
                 if ((!FULL && wave + 4 * j >= ntiles) || co >= Co) continue;
                 f32x4 v = acc[j];
-                if (L.activation == 1) { v.x = tanh_exp(v.x); v.y = tanh_exp(v.y); v.z = tanh_exp(v.z); v.w = tanh_exp(v.w); }
+                if (L.activation == 1) { v.x = tanh_exp_pre(v.x); v.y = tanh_exp_pre(v.y); v.z = tanh_exp_pre(v.z); v.w = tanh_exp_pre(v.w); }
                 else if (L.activation == 2) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
                 else if (L.activation == 3) { v.x = fast_sigmoid(v.x); v.y = fast_sigmoid(v.y); v.z = fast_sigmoid(v.z); v.w = fast_sigmoid(v.w); }
                 *reinterpret_cast<f32x4*>(pl + (size_t)co * F + Hb + 16 * (wave + 4 * j) + 4 * (lane >> 4)) = v;

@@ -164,6 +164,13 @@ __device__ __forceinline__ float tanh_exp(float v)
     return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
 }
 
+// ... for a pre-activation that already carries the factor 2 log2(e) (the conv packer folds it into tanh layers' weights
+// and biases): four instructions
+__device__ __forceinline__ float tanh_exp_pre(float v_scaled)
+{
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v_scaled)), 1.0f);
+}
+
 // ---------------------------------------------------------------- smoothers
 struct ExpRamp {              // ExponentialValueSmoother::next, ValueSmoother.hpp:142-145
     float mem, coef, tc;      // tc = target * (1.f - coef), loop-invariant

@@ -209,7 +209,21 @@ struct ConvLayer {
     // lane supplies K[tap][cin][cout = lane&15] for k = 4*kk + (lane>>4) = tap*in_ch + cin (zero past ksize*in_ch / out_ch)
     uint32_t wf_off;
     int32_t k_steps;
+    // ... the same records for a block of exactly kConvmFullFrames frames with the second word FINAL — the byte offset of the A
+    // value in the activation plane, which depends on the plane geometry and so on the block length — so that the kernel's
+    // full-block instantiation stages them as they are; and the bias the matrix-core kernel starts its accumulators from.
+    // Both carry the factor 2 log2(e) on tanh layers: tanh(x) = 1 - 2 / (1 + 2^(x 2 log2 e)) then costs four instructions.
+    uint32_t wf_full_off;
+    uint32_t bs_off;       // [16]
 };
+// k_conv_mfma's activation plane: frames per channel row = history (rounded to 4) + block (rounded to whole tiles), then up to
+// 16 (mod 64) floats (the four cin groups of an A fragment on disjoint banks)
+constexpr int kConvmFullFrames = 256;
+constexpr int convm_plane_stride(int max_hist, int n_frames)
+{
+    return ((((max_hist + 3) & ~3) + ((n_frames + 15) & ~15) + 47) / 64) * 64 + 16;
+}
+constexpr float kTwoLog2e = 2.88539008177792681472f;
 struct ConvDesc {
     int32_t n_layers, channels, max_hist, max_k_steps;
     ConvLayer L[kMaxConvLayers];

@@ -420,16 +420,40 @@ std::vector<float> pack_conv(const aidax_model& m, ConvDesc* d, uint32_t* state_
         // activation plane as (cin << 16 | frames back); padding rows (zero weights) point at row 0 so they read valid data
         while (out.size() % 4) out.push_back(0.f);
         C.wf_off = static_cast<uint32_t>(out.size());
+        // (tanh layers: weights and bias times 2 log2 e, see ConvLayer)
+        const float scale = C.activation == 1 ? kTwoLog2e : 1.0f;
         for (int kk = 0; kk < C.k_steps; ++kk)
             for (int lane = 0; lane < kWave; ++lane) {
                 const int k = 4 * kk + (lane >> 4), co = lane & 15;
-                out.push_back((k < K && co < C.out_ch) ? L.w0[(size_t)k * C.out_ch + co] : 0.f);   // w0 is [tap][cin][cout]
+                out.push_back((k < K && co < C.out_ch) ? scale * L.w0[(size_t)k * C.out_ch + co] : 0.f);   // w0 is [tap][cin][cout]
                 const int kc = k < K ? k : 0;
                 const int32_t where = ((kc % C.in_ch) << 16) | ((C.ksize - 1 - kc / C.in_ch) * C.dilation);
                 float f;
                 std::memcpy(&f, &where, 4);
                 out.push_back(f);
             }
+        C.bs_off = static_cast<uint32_t>(out.size());
+        for (int co = 0; co < 16; ++co) out.push_back(co < C.out_ch ? scale * L.w1[co] : 0.f);
+    }
+    // the full-block records: the plane geometry needs the longest history of the stack, known only now
+    {
+        const int F = convm_plane_stride(d->max_hist, kConvmFullFrames), Hb = (d->max_hist + 3) & ~3;
+        for (int l = 0; l < m.n_rnn; ++l) {
+            ConvLayer& C = d->L[l];
+            while (out.size() % 4) out.push_back(0.f);
+            const uint32_t from = C.wf_off;
+            C.wf_full_off = static_cast<uint32_t>(out.size());
+            for (int i = 0; i < C.k_steps * kWave; ++i) {
+                const float b = out[from + 2 * i];
+                int32_t where;
+                std::memcpy(&where, &out[from + 2 * i + 1], 4);
+                const int32_t byte_off = 4 * ((where >> 16) * F + Hb - (where & 0xffff) + (i & 15));
+                float f;
+                std::memcpy(&f, &byte_off, 4);
+                out.push_back(b);
+                out.push_back(f);
+            }
+        }
     }
     const Layer& D = m.layers[m.n_rnn];
     d->wd_off = static_cast<uint32_t>(out.size());

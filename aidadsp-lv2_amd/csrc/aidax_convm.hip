@@ -211,10 +211,10 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
     auto store_prefix = [&](int l) {
         const ConvLayer& L = d.L[l];
         const int cnt = L.hist * L.in_ch;
-        const float inv = 1.0f / (float)L.hist;
+        const float inv = __builtin_amdgcn_rcpf((float)L.hist);      // (v_rcp: the index test below has a margin of 0.5 / hist, an IEEE divide is eleven instructions)
         if (vec_hist(L)) {
             const int hist4 = L.hist >> 2;
-            const float inv4 = 1.0f / (float)hist4;
+            const float inv4 = __builtin_amdgcn_rcpf((float)hist4);
 #pragma unroll
             for (int j = 0; j < kHistRegs / 4; ++j) {
                 if (j * kConvmThreads * 4 >= cnt) break;
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
         const int Hs = L.hist, Ci = L.in_ch;
         if (vec_hist(L) && (n & 3) == 0) {
             const int hist4 = Hs >> 2, cnt4 = hist4 * Ci;
-            const float inv4 = 1.0f / (float)hist4;
+            const float inv4 = __builtin_amdgcn_rcpf((float)hist4);
             f32x4* dst = reinterpret_cast<f32x4*>(hist_base + L.state_off);
             f32x4 hv4[kHistRegs / 4];
 #pragma unroll
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
             for (int i4 = tid + (kHistRegs / 4) * kConvmThreads; i4 < cnt4; i4 += kConvmThreads)
                 dst[i4] = *reinterpret_cast<const f32x4*>(pl + plane_index4(i4, hist4, inv4) + n);
         } else {
-            const float inv = 1.0f / (float)Hs;
+            const float inv = __builtin_amdgcn_rcpf((float)Hs);
             const int cnt = Hs * Ci;
             float hv[kHistRegs];
 #pragma unroll

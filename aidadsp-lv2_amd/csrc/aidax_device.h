@@ -48,32 +48,13 @@ __device__ __forceinline__ void fmac_row_ror(float& acc, float h, float w)
     asm volatile("v_fmac_f32_dpp %0, %1, %2 row_ror:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(h), "v"(w), "n"(N));
 }
 
-// Rotations 1..8 resp. 9..15 of TWO accumulation chains (the two gate rows of a lane), each run in ONE asm statement.
-// Issued one by one, the compiler's hazard recognizer cannot see that the accumulator an asm statement reads is not its
-// DPP operand and puts an s_nop between every pair of them — 14 issue slots of the lone recurrent wave per LSTM-32 frame:
-// cfg2 73.5 -> 69.5 us without them. Inside one statement nothing is inserted; the real rule (a VGPR written by a VALU
-// instruction needs two wait states before a DPP instruction reads it AS ITS DPP OPERAND) concerns `h` only, see
-// fmac_row_ror above. Same instructions in the same order as fmac_row_ror<1..15> on a0 and a1 in turn.
-#define AIDAX_ROR2(N, W0, W1) "v_fmac_f32_dpp %0, %2, %" #W0 " row_ror:" #N " row_mask:0xf bank_mask:0xf\n\t" \
-                              "v_fmac_f32_dpp %1, %2, %" #W1 " row_ror:" #N " row_mask:0xf bank_mask:0xf\n\t"
-__device__ __forceinline__ void fmac2_row_ror_1_8(float& a0, float& a1, float h, const float* w0, const float* w1)
-{
-    asm volatile(AIDAX_ROR2(1, 3, 11) AIDAX_ROR2(2, 4, 12) AIDAX_ROR2(3, 5, 13) AIDAX_ROR2(4, 6, 14)
-                 AIDAX_ROR2(5, 7, 15) AIDAX_ROR2(6, 8, 16) AIDAX_ROR2(7, 9, 17) AIDAX_ROR2(8, 10, 18)
-                 : "+v"(a0), "+v"(a1)
-                 : "v"(h), "v"(w0[1]), "v"(w0[2]), "v"(w0[3]), "v"(w0[4]), "v"(w0[5]), "v"(w0[6]), "v"(w0[7]), "v"(w0[8]),
-                   "v"(w1[1]), "v"(w1[2]), "v"(w1[3]), "v"(w1[4]), "v"(w1[5]), "v"(w1[6]), "v"(w1[7]), "v"(w1[8]));
-}
-__device__ __forceinline__ void fmac2_row_ror_9_15(float& a0, float& a1, float h, const float* w0, const float* w1)
-{
-    asm volatile(AIDAX_ROR2(9, 3, 10) AIDAX_ROR2(10, 4, 11) AIDAX_ROR2(11, 5, 12) AIDAX_ROR2(12, 6, 13)
-                 AIDAX_ROR2(13, 7, 14) AIDAX_ROR2(14, 8, 15) AIDAX_ROR2(15, 9, 16)
-                 : "+v"(a0), "+v"(a1)
-                 : "v"(h), "v"(w0[9]), "v"(w0[10]), "v"(w0[11]), "v"(w0[12]), "v"(w0[13]), "v"(w0[14]), "v"(w0[15]),
-                   "v"(w1[9]), "v"(w1[10]), "v"(w1[11]), "v"(w1[12]), "v"(w1[13]), "v"(w1[14]), "v"(w1[15]));
-}
-#undef AIDAX_ROR2
-// ... and rotations 1..15 of ONE chain (cells of <= 16 units: a row of 16 lanes is one gate of all the units)
+// Rotations 1..15 of ONE accumulation chain in ONE asm statement. Issued one by one, the compiler's hazard recognizer cannot
+// see that the accumulator an asm statement reads is not its DPP operand and puts an s_nop between every pair of them — 14
+// issue slots of the lone recurrent wave per LSTM-32 frame: cfg2 73.5 -> 69.5 us without them. Inside one statement nothing
+// is inserted; the real rule (a VGPR written by a VALU instruction needs two wait states before a DPP instruction reads it AS
+// ITS DPP OPERAND) concerns `h` only, see fmac_row_ror above. A cell with two gate rows per lane (LSTM-32) issues one
+// statement per row: the second reads nothing the first wrote, so nothing is put between them either. Same instructions
+// per chain in the same order as fmac_row_ror<1..15>.
 #define AIDAX_ROR1(N, W) "v_fmac_f32_dpp %0, %1, %" #W " row_ror:" #N " row_mask:0xf bank_mask:0xf\n\t"
 __device__ __forceinline__ void fmac_row_ror_1_15(float& a0, float h, const float* w)
 {

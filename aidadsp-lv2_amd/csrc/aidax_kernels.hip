@@ -176,8 +176,8 @@ struct LstmCell {
             float a0 = acc[0][0], a1 = acc[0][1];
             a0 = __builtin_fmaf(w[0][0][0], hr, a0);
             a1 = __builtin_fmaf(w[0][1][0], hr, a1);
-            fmac2_row_ror_1_8(a0, a1, hr, w[0][0], w[0][1]);      // rotations 1..15 of both rows, same order as one by one
-            fmac2_row_ror_9_15(a0, a1, hr, w[0][0], w[0][1]);
+            fmac_row_ror_1_15(a0, hr, w[0][0]);               // rotations 1..15 of each row: one asm statement per row
+            fmac_row_ror_1_15(a1, hr, w[0][1]);
             // (the four reads were issued ~35 instructions ago: ONE wait for all of them instead of one in front of each quad of FMAs)
             __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0)
             const float4 qs[4] = { q0, q1, q2, q3 };

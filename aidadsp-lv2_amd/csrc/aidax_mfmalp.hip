@@ -559,7 +559,26 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
     int done = 0;                                          // frames finished before this chunk
     for (int base = 0; base < n; base += kLpChunk) {
         const int cnt = n - base < kLpChunk ? n - base : kLpChunk;
+        // what the layer below hands over: frame F of the launch sits in ring slot (base_in + F) % kLpRing
+        auto wait_below = [&](int frames_needed) {        // thread 0 only: until `frames_needed` frames of the launch exist
+            if (frames_needed > n) frames_needed = n;
+            uint32_t spins = 0;
+            uint64_t t0 = 0;
+            while ((int)known_below < frames_needed) {
+                known_below = __hip_atomic_load(cnt_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base_in;
+                if ((int)known_below < frames_needed) {
+                    if (lp_timed_out(spins, t0)) { give_up(); known_below = (uint32_t)n; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+        };
         // ---- audio rows of this chunk: the first layer reads them as input, the last for in_skip and to deliver
+        if constexpr (chain && last && !first) {
+            // one-launch form: the rows in a.out are the pre pass's, stored (write-through, drained) by the FIRST layer's
+            // workgroup before it computed its first frame — once frames exist below, the rows are there
+            if (tid == 0) wait_below(done + 2);
+            __syncthreads();
+        }
         if (first || last) {
             for (int sl = wave; sl < NS; sl += NW) {
                 const int sg = s_base + sl;
@@ -599,19 +618,6 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
             col[NS + tid] = q1;
             col[2 * NS + tid] = q2;
             col[3 * NS + tid] = 0.f;
-        };
-        // what the layer below hands over: frame F of the launch sits in ring slot (base_in + F) % kLpRing
-        auto wait_below = [&](int frames_needed) {        // thread 0 only: until `frames_needed` frames of the launch exist
-            if (frames_needed > n) frames_needed = n;
-            uint32_t spins = 0;
-            uint64_t t0 = 0;
-            while ((int)known_below < frames_needed) {
-                known_below = __hip_atomic_load(cnt_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base_in;
-                if ((int)known_below < frames_needed) {
-                    if (lp_timed_out(spins, t0)) { give_up(); known_below = (uint32_t)n; break; }
-                    __builtin_amdgcn_s_sleep(8);
-                }
-            }
         };
         constexpr int PER4 = (kHVec + NT - 1) / NT;        // f32x4 of a frame each thread moves
         f32x4 pre[PER4];
@@ -832,9 +838,14 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
 // — the packed chain passes (k_chain's body, chain_wave_pass) run on waves 0 and 1 of the first / last layer's workgroup
 // BEFORE and AFTER lp_body, which stays exactly the body that runs between two k_chain launches (reshaping it for rows kept
 // in LDS cost its frame loop 6 %: 1 096 -> 1 150 us on LSTM-96 x2 before a single chain instruction ran). The pre pass
-// reads a.in and leaves its rows in a.out, where the body expects them; the LAST layer's workgroup runs it too, uncommitted
-// (it needs the model input for in_skip and for net-off streams, and cannot wait for another workgroup's stores: both
-// write the same values to the same words); the post pass takes the rows the body stored. Blocks of one staging chunk.
+// reads a.in and leaves its rows in a.out, where the body expects them — the LAST layer's workgroup needs them too (the model
+// input for in_skip, and what a net-off stream delivers) and WAITS for them: the first layer's workgroup stores the rows
+// write-through (device scope) and lets the stores drain before it computes its first frame, so the last layer's workgroup
+// loads its rows only once frames exist in the ring below it (lp_body: the wait it has to do anyway, moved in front of
+// the load). (Round 3's first version let the
+// last layer's workgroup run the pre pass itself, uncommitted: it read the biquad states the first layer's workgroup was
+// about to overwrite — right while the two started together, wrong once in 150 runs of the test suite.) The post pass
+// takes the rows the body stored. Blocks of one staging chunk.
 template <bool PRE>
 __device__ __forceinline__ void lp_chain_rows(const LaunchArgs& a, float* smem, int grp, bool commit)
 {
@@ -866,7 +877,8 @@ __device__ __forceinline__ void lp_chain_rows(const LaunchArgs& a, float* smem, 
         const int sl = i / n, t = i - sl * n, sg = s_base + sl;
         if (sg >= (int)a.n_streams) continue;
         const bool row_live = (a.ctl[sg].flags & CTL_ENABLED) != 0;
-        if (PRE ? (row_live || a.out != a.in) : row_live) a.out[(size_t)sg * n + t] = rows[sl * nP + t];
+        if (PRE ? (row_live || a.out != a.in) : row_live)           // (device scope: another workgroup reads the pre pass's rows)
+            __hip_atomic_store(a.out + (size_t)sg * n + t, rows[sl * nP + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();                                       // (waits for the stores: the body's loads come after them)
 }
@@ -897,13 +909,16 @@ __global__ __launch_bounds__((NW + NHELP) * kWave) void k_mfma_lp(LaunchArgs a, 
             __syncthreads();
             lp_chain_rows<false>(a, smem, grp, true);
         } else if (l == 0) {
-            if (!(a.tune & 2048)) lp_chain_rows<true>(a, smem, grp, true);
+            lp_chain_rows<true>(a, smem, grp, true);
             lp_body<TPW, NW, M, true, false, 0, true>(a, d, ring, counters, fault, smem, grp, l);
         } else if (l == NL - 1) {
-            if (!(a.tune & 2048)) lp_chain_rows<true>(a, smem, grp, false);
+            if (a.tune & 8192) {                                          // test hook: this workgroup starts 100 us late
+                const uint64_t t0 = wall_clock64();
+                while (wall_clock64() - t0 < 10000) __builtin_amdgcn_s_sleep(64);
+            }
             lp_body<TPW, NW, M, false, true, 0, true>(a, d, ring, counters, fault, smem, grp, l);
             __syncthreads();
-            if (!(a.tune & 4096)) lp_chain_rows<false>(a, smem, grp, true);
+            lp_chain_rows<false>(a, smem, grp, true);
         } else {
             lp_body<TPW, NW, M, false, false, 0, true>(a, d, ring, counters, fault, smem, grp, l);
         }

@@ -929,14 +929,19 @@ def test_every_kernel_form_passes_the_same_chain_cases(form, tmp_path, monkeypat
     ("l96x2", dict(kind="lstm", hidden=96, input_size=2, seed=9620, n_rnn=2)),
     ("g80", dict(kind="gru", hidden=80, input_size=3, seed=8030)),                        # one layer, no room for helper waves: the same form
 ])
-def test_stacked_one_launch_form_is_bit_identical_to_the_three_launch_form(name, kw, tmp_path, monkeypatch):
+@pytest.mark.parametrize("late", [False, True])
+def test_stacked_one_launch_form_is_bit_identical_to_the_three_launch_form(name, kw, late, tmp_path, monkeypatch):
     """Stacked models on pools whose blocks fit one staging chunk run their whole run() in the k_mfma_lp launch: the packed
     pre pass on two waves of the first layer's workgroup (and, uncommitted, of the last layer's, which needs the model input
     for in_skip and for net-off streams), the post pass behind the last layer's last tick. Same chain code, same kernel body
     as between two k_chain launches (AIDAX_LP_FUSED=0): every output sample and every state word bit for bit, over ragged
     blocks incl. 0 and 1, 40 streams (the last group ragged), per-stream disable / bypass / EQ position / moving ramps,
-    activate() in the middle — and against the oracle."""
+    activate() in the middle — and against the oracle. `late`: with the last layer's workgroup held back by 100 us at its
+    start (AIDAX_TUNE 8192) — the layers' workgroups share stream state, and the first version of this form was right only
+    while they started together."""
     path, spec = _model_file(tmp_path, name, **kw)
+    if late:
+        monkeypatch.setenv("AIDAX_TUNE", "8192")
     if kw.get("n_rnn", 1) == 1:
         monkeypatch.setenv("AIDAX_KERNEL", "mfma")            # (40 streams of a table model would take k_quad)
     S = 40

@@ -167,8 +167,8 @@ __device__ __forceinline__ void lp_gates(f32x4 (&acc)[NACC], const f32x4 (&wres)
 // ---------------------------------------------------------------- one-launch form: the helper waves
 // One-layer models whose main waves leave room for a third wave per SIMD (lp_helpers) run their whole run() in this
 // launch: NHELP extra waves, each the keeper of 16 / NHELP streams of the group in 8-lane groups like k_chain's. A helper
-//   * runs the PRE pass (LPF -> pre-gain ramp -> EQ-pre) on its streams' rows in LDS ahead of the frame loop — six
-//     macro-steps of eight frames before the first tick, one more per tick until the chunk is done;
+//   * runs the PRE pass (LPF -> pre-gain ramp -> EQ-pre) on its streams' rows in LDS ahead of the frame loop — as many
+//     macro-steps of eight frames as the cascade is deep before the first tick, one more per tick until the chunk is done;
 //   * writes the model inputs of the next frame (x * in_gain, the PARAM smoothers' samples) and finishes the Dense of
 //     the frame before last (partial sums, bias, skip, output gain) — what lane < 16 of wave 0 did at the head of every
 //     tick while seven waves waited (scratch/lp_trace.py: 2 100 cycles against 460);
@@ -293,7 +293,7 @@ __device__ __forceinline__ void lp_helper(const LaunchArgs& a, float* xb, float*
                 p_open = false;
             }
         };
-        pre_work(6);                                       // frames 0..7 (and what a short chunk has) are final
+        pre_work(depth_p);                                 // frames 0..7 (and what a short chunk has) are final: block 0 has left the cascade after `depth` macro-steps
         chain_job_begin(jq, Q, stage, run_q, n_full, general);
         write_xin(0, 0);
         __syncthreads();                                   // (3)

@@ -578,6 +578,9 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
             // workgroup before it computed its first frame — once frames exist below, the rows are there
             if (tid == 0) wait_below(done + 2);
             __syncthreads();
+            // ... and must come from L2: the rows of neighbouring stream groups can share a cache line (odd block lengths),
+            // and another workgroup on this CU may have brought that line in before the pre pass stored into it
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         if (first || last) {
             for (int sl = wave; sl < NS; sl += NW) {
@@ -905,11 +908,13 @@ __global__ __launch_bounds__((NW + NHELP) * kWave) void k_mfma_lp(LaunchArgs a, 
     if constexpr (CHAIN) {                                 // stacked models, and one-layer ones without room for helper waves
         if (NL == 1) {
             lp_chain_rows<true>(a, smem, grp, true);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             lp_body<TPW, NW, M, true, true, 0, true>(a, d, ring, counters, fault, smem, grp, l);
             __syncthreads();
             lp_chain_rows<false>(a, smem, grp, true);
         } else if (l == 0) {
             lp_chain_rows<true>(a, smem, grp, true);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");           // (the body's loads of the rows: from L2, see lp_body)
             lp_body<TPW, NW, M, true, false, 0, true>(a, d, ring, counters, fault, smem, grp, l);
         } else if (l == NL - 1) {
             if (a.tune & 8192) {                                          // test hook: this workgroup starts 100 us late

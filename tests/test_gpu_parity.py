@@ -366,8 +366,8 @@ def test_worker_thread_prepares_while_the_audio_thread_processes(tmp_path):
              dict(kind="lstm", hidden=32, input_size=1, seed=53, n_rnn=2), dict(kind="conv", hidden=16, input_size=1, seed=54)]
     files = [_model_file(tmp_path, f"m{i}", **kw) for i, kw in enumerate(kinds)]
     models = [ax.Model(p) for p, _ in files]
-    S, n, blocks = 6, 128, 160
-    x = modelgen.signal(S, n * blocks, seed=71)
+    S, n, blocks = 6, 128, 640               # (at least 160 blocks; more while the worker has not got eight swaps in — how
+    x = modelgen.signal(S, n * blocks, seed=71)     # many it manages per block depends on how loaded the box is)
     ckw = dict(param1=0.35, pregain_db=2.0, bass_boost_db=3.0)
     cg, co = _ctl_pair(**ckw)
     pool = ax.Pool(S, n)
@@ -424,6 +424,8 @@ def test_worker_thread_prepares_while_the_audio_thread_processes(tmp_path):
             for s_ in range(S):
                 want = plugs[s_].run(co, blk[s_])
                 errlog.bound(np.abs(got[s_] - want).max(), 2e-6, "gpu_parity:concurrent_prepare")
+            if b >= 159 and swaps >= 8 and len(names) >= 3:
+                break
     finally:
         stop.set()
         t.join()

@@ -335,13 +335,13 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma(LaunchArgs a, MfmaDesc d)
                     const int e = (wave * TPW + tl) * 64 + lane;          // unit 4T + (lane>>4), stream lane&15
                     float hn;
                     if (L.cell == 0) {
-                        const float gi = fast_sigmoid(acc[tl].x), gf = fast_sigmoid(acc[tl].y);
-                        const float gg = tanh_rat(acc[tl].z), go = fast_sigmoid(acc[tl].w);
+                        const float gi = sigmoid_pre(acc[tl].x), gf = sigmoid_pre(acc[tl].y);
+                        const float gg = tanh_rat(acc[tl].z), go = sigmoid_pre(acc[tl].w);
                         const float cn = __builtin_fmaf(gf, cl[e], gi * gg);
                         cl[e] = cn;
                         hn = go * tanh_rat(cn);
                     } else {
-                        const float gz = fast_sigmoid(acc[tl].x), gr = fast_sigmoid(acc[tl].y);
+                        const float gz = sigmoid_pre(acc[tl].x), gr = sigmoid_pre(acc[tl].y);
                         const float nn = tanh_rat(__builtin_fmaf(gr, acc[tl].z, acc[tl].w));
                         hn = __builtin_fmaf(gz, h_rd[e] - nn, nn);
                     }

@@ -750,13 +750,13 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
                     const int e = (wave * TPW + tl) * 64 + lane;          // unit 4T + (lane>>4), stream lane&15
                     float hn;
                     if (L.cell == 0) {
-                        const float gi = fast_sigmoid(acc[tl].x), gf = fast_sigmoid(acc[tl].y);
-                        const float gg = tanh_rat(acc[tl].z), go = fast_sigmoid(acc[tl].w);
+                        const float gi = sigmoid_pre(acc[tl].x), gf = sigmoid_pre(acc[tl].y);
+                        const float gg = tanh_rat(acc[tl].z), go = sigmoid_pre(acc[tl].w);
                         const float cn = __builtin_fmaf(gf, creg[tl], gi * gg);
                         creg[tl] = cn;
                         hn = go * tanh_rat(cn);
                     } else {
-                        const float gz = fast_sigmoid(acc[tl].x), gr = fast_sigmoid(acc[tl].y);
+                        const float gz = sigmoid_pre(acc[tl].x), gr = sigmoid_pre(acc[tl].y);
                         const float nn = tanh_rat(__builtin_fmaf(gr, acc[tl].z, acc[tl].w));
                         hn = __builtin_fmaf(gz, h_rd[e] - nn, nn);
                     }
@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__((UT + NHELP) * kWave) void k_gru_gm(LaunchArgs a, M
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float gz = fast_sigmoid(az[e]), gr = fast_sigmoid(ar[e]);
+                    const float gz = sigmoid_pre(az[e]), gr = sigmoid_pre(ar[e]);
                     const float nn = tanh_rat(__builtin_fmaf(gr, an[e], ax[e]));
                     const float hn = __builtin_fmaf(gz, hreg[e] - nn, nn);
                     hreg[e] = hn;

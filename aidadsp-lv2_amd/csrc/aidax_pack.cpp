@@ -178,8 +178,10 @@ std::vector<float> pack_mfma(const aidax_model& m, MfmaDesc* d, uint32_t* state_
         const int G = lstm ? 4 : 3, R = G * Ht, I = L.in_size;
         M.cell = lstm ? 0 : 1;
         M.in_size = l == 0 ? I : H;                  // deeper layers contract over the padded h of the layer below
-        // weight of gate row `g` of unit `u` against column k of segment `seg` (0 in the padding)
-        auto weight = [&](Seg seg, int u, int g, int k) -> float {
+        // weight of gate row `g` of unit `u` against column k of segment `seg` (0 in the padding). The sigmoid rows
+        // (LSTM i, f, o; GRU z, r) carry the factor -log2(e) in weights and bias, like the table kernels' records: the
+        // cell update evaluates 1 / (1 + 2^v) without a multiply (sigmoid_pre, aidax_device.h)
+        auto weight_raw = [&](Seg seg, int u, int g, int k) -> float {
             if (u >= Ht || (seg == SEG_REC && k >= Ht) || (seg == SEG_IN && k >= I)) return 0.f;
             const int H = Ht;                        // Keras column blocks are Ht wide
             const float* W = L.w0.data();      // [I][R]
@@ -198,6 +200,11 @@ std::vector<float> pack_mfma(const aidax_model& m, MfmaDesc* d, uint32_t* state_
             if (k != 0) return 0.f;
             if (g <= 1) return b[col] + b[R + col];
             return g == 2 ? b[R + col] : b[col];
+        };
+        auto weight = [&](Seg seg, int u, int g, int k) -> float {
+            const bool sigmoid_row = lstm ? g != 2 : g <= 1;
+            const float w = weight_raw(seg, u, g, k);
+            return sigmoid_row ? kNegLog2e * w : w;
         };
         // layer 0: the 1..3 model inputs are one k-step on their own ("small" segment)
         M.w_in_off = static_cast<uint32_t>(out.size());
@@ -249,11 +256,12 @@ std::vector<float> pack_mfma(const aidax_model& m, MfmaDesc* d, uint32_t* state_
         const float* U = L.w1.data();
         const float* b = L.w2.data();
         auto col = [&](int g, int u) { return (g == 0 ? 0 : g == 1 ? Ht : 2 * Ht) + u; };     // g: 0 z, 1 r, 2 recurrent half, 3 input half
-        auto w_in = [&](int u, int g, int k) { return (u < Ht && g != 2 && k < I) ? W[(size_t)k * R + col(g, u)] : 0.f; };
-        auto w_rec = [&](int u, int g, int k) { return (u < Ht && g != 3 && k < Ht) ? U[(size_t)k * R + col(g, u)] : 0.f; };
+        auto sc = [&](int g) { return g <= 1 ? kNegLog2e : 1.f; };                         // z, r: sigmoid rows, scaled as above
+        auto w_in = [&](int u, int g, int k) { return (u < Ht && g != 2 && k < I) ? sc(g) * W[(size_t)k * R + col(g, u)] : 0.f; };
+        auto w_rec = [&](int u, int g, int k) { return (u < Ht && g != 3 && k < Ht) ? sc(g) * U[(size_t)k * R + col(g, u)] : 0.f; };
         auto bias = [&](int u, int g) {
             if (u >= Ht) return 0.f;
-            if (g <= 1) return b[col(g, u)] + b[R + col(g, u)];
+            if (g <= 1) return kNegLog2e * (b[col(g, u)] + b[R + col(g, u)]);
             return g == 2 ? b[R + col(g, u)] : b[col(g, u)];
         };
         for (int w = 0; w < H / 16; ++w) {

@@ -94,48 +94,8 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
     float* verdict = wdl + 20;                                // fused form: {stream live, model in circuit, ChainCtx}
     constexpr int chain_wave = 0;
 
-    bool net = true;
-    if constexpr (FUSED) {
-        // channel 0's block part of the plane is the audio row: the pre pass leaves layer 0's input there
-        if (wave == chain_wave) {
-            ChainCtx ctx = chain_prologue(a.ctl[sg], a.st[sg], a.in + (size_t)sg * rstride, a.out + (size_t)sg * rstride, pl + Hb, n, lane, wst);
-            if (ctx.live && (ctx.flags & CTL_NET_ON)) {
-                uint32_t pend = ctx.pending;
-                if (lane == 0) pend = param_targets(a.ctl[sg], a.st[sg], pend);
-                ctx.pending = (uint32_t)__builtin_amdgcn_readfirstlane((int)pend);
-            }
-            if (lane == 0) {
-                // the context waits in LDS, not in six registers of every thread across the layer loop
-                verdict[0] = ctx.live ? 1.f : 0.f; verdict[1] = (ctx.live && (ctx.flags & CTL_NET_ON)) ? 1.f : 0.f;
-                verdict[2] = __builtin_bit_cast(float, ctx.flags); verdict[3] = __builtin_bit_cast(float, ctx.pending);
-                verdict[4] = ctx.pre_mem; verdict[5] = ctx.master_mem; verdict[6] = ctx.pre_tgt; verdict[7] = ctx.master_tgt;
-            }
-        }
-        lds_barrier();
-        if (verdict[0] == 0.f) return;                        // pre-run / hard bypass: the prologue did all there is to do
-        net = verdict[1] != 0.f;
-    }
-
     const float* W = a.wpack;
     float* hist_base = a.nn + (size_t)sg * a.nn_stride;
-    float* row = mode == MODE_CHAIN ? a.out + (size_t)sg * rstride : a.out;
-    const int n16 = (n + 15) & ~15;
-
-    // layer-0 input: [history | x * in_gain | zeros up to the tile boundary]; x stays in a register for the skip
-    float xg = 0.f;
-    if (net) {
-        const ConvLayer& L0 = d.L[0];
-        for (int c = 0; c < L0.in_ch; ++c)
-            for (int j = tid; j < L0.hist; j += kConvmThreads)
-                pl[c * F + Hb - L0.hist + j] = hist_base[L0.state_off + c * L0.hist + j];
-        for (int t = tid; t < n16; t += kConvmThreads) {
-            float v = 0.f;
-            if (t < n) v = (FUSED ? pl[Hb + t] : mode == MODE_CHAIN ? row[t] : mode == MODE_NN_ONLY ? a.in[(size_t)t * a.input_size] : 0.f) * a.in_gain;
-            pl[Hb + t] = v;
-            xg = v;                                           // n <= 256: one frame per thread
-        }
-        if (tid < 17) wdl[tid] = tid < 16 ? (tid < d.L[d.n_layers - 1].out_ch ? W[d.wd_off + tid] : 0.f) : W[d.bd_off];
-    }
     // Global-memory latency is kept off the layer loop: a layer's B fragments arrive in registers while the layer
     // before it computes, and so does the history prefix of the layer after it.
     constexpr int kFragRegs = 8;              // 32 k-steps x 64 lanes / 256 threads
@@ -157,6 +117,61 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
         }
         bias_r = W[L.bs_off + (lane & 15)];
     };
+    // what layer 0 needs besides its input row: its own short history in front of the row, the Dense weights
+    auto layer0_side = [&](int t, int stride) {
+        const ConvLayer& L0 = d.L[0];
+        for (int c = 0; c < L0.in_ch; ++c)
+            for (int j = t; j < L0.hist; j += stride)
+                pl[c * F + Hb - L0.hist + j] = hist_base[L0.state_off + c * L0.hist + j];
+        if (t < 17) wdl[t] = t < 16 ? (t < d.L[d.n_layers - 1].out_ch ? W[d.wd_off + t] : 0.f) : W[d.bd_off];
+    };
+
+    bool net = true;
+    if (wave == chain_wave) CV_STAMP(0);
+#ifdef AIDAX_CONV_TRACE
+    if (tid == 0) cv_trace()[13] = wall_clock64();
+#endif
+    if constexpr (FUSED) {
+        // Before the pre pass, not after it: layer 0's fragments go into every thread's registers and the three waves that
+        // have nothing to do until the barrier fetch what else layer 0 needs — reads only, whatever the prologue decides
+        // (1.4 -> 0.x us between the pre pass and the first MFMA, scratch/conv_trace.py).
+        fetch_frag(0);
+        if (wave != chain_wave) layer0_side(tid - kWave, kConvmThreads - kWave);
+        // channel 0's block part of the plane is the audio row: the pre pass leaves layer 0's input there
+        if (wave == chain_wave) {
+            ChainCtx ctx = chain_prologue(a.ctl[sg], a.st[sg], a.in + (size_t)sg * rstride, a.out + (size_t)sg * rstride, pl + Hb, n, lane, wst);
+            if (ctx.live && (ctx.flags & CTL_NET_ON)) {
+                uint32_t pend = ctx.pending;
+                if (lane == 0) pend = param_targets(a.ctl[sg], a.st[sg], pend);
+                ctx.pending = (uint32_t)__builtin_amdgcn_readfirstlane((int)pend);
+            }
+            if (lane == 0) {
+                // the context waits in LDS, not in six registers of every thread across the layer loop
+                verdict[0] = ctx.live ? 1.f : 0.f; verdict[1] = (ctx.live && (ctx.flags & CTL_NET_ON)) ? 1.f : 0.f;
+                verdict[2] = __builtin_bit_cast(float, ctx.flags); verdict[3] = __builtin_bit_cast(float, ctx.pending);
+                verdict[4] = ctx.pre_mem; verdict[5] = ctx.master_mem; verdict[6] = ctx.pre_tgt; verdict[7] = ctx.master_tgt;
+            }
+        }
+        if (wave == chain_wave) CV_STAMP(4);
+        lds_barrier();
+        if (verdict[0] == 0.f) return;                        // pre-run / hard bypass: the prologue did all there is to do
+        net = verdict[1] != 0.f;
+    }
+
+    float* row = mode == MODE_CHAIN ? a.out + (size_t)sg * rstride : a.out;
+    const int n16 = (n + 15) & ~15;
+
+    // layer-0 input: [history | x * in_gain | zeros up to the tile boundary]; x stays in a register for the skip
+    float xg = 0.f;
+    if (net) {
+        if constexpr (!FUSED) layer0_side(tid, kConvmThreads);
+        for (int t = tid; t < n16; t += kConvmThreads) {
+            float v = 0.f;
+            if (t < n) v = (FUSED ? pl[Hb + t] : mode == MODE_CHAIN ? row[t] : mode == MODE_NN_ONLY ? a.in[(size_t)t * a.input_size] : 0.f) * a.in_gain;
+            pl[Hb + t] = v;
+            xg = v;                                           // n <= 256: one frame per thread
+        }
+    }
     auto stage_frag = [&](int l) {            // registers -> one 8-byte record per (k-step, lane): B value, A plane offset
         const ConvLayer& L = d.L[l];
 #pragma unroll
@@ -279,15 +294,31 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
         }
     };
 
+    // Issue priority by progress, FUSED form: a wave's priority steps down with every half layer (cyclically: there are four
+    // levels), so that of the four workgroups that share a CU the ones that are behind go first. Left alone the SIMDs favour
+    // their oldest waves: the workgroup dispatched last onto a CU came out of the layer loop 6.5 us after the first, and its
+    // post pass — a lone wave — ended the launch with the rest of the CU idle (scratch/conv_trace.py; 67.5 -> 64.6 us for
+    // BASELINE cfg4; a priority fixed per workgroup id is worse than none, 66.5 us). AIDAX_TUNE bit 2048 switches it off.
+    auto set_prio = [&](int phase) {
+        if (!FUSED || (a.tune & 2048)) return;
+        switch (phase & 3) {
+        case 0: __builtin_amdgcn_s_setprio(3); break;
+        case 1: __builtin_amdgcn_s_setprio(2); break;
+        case 2: __builtin_amdgcn_s_setprio(1); break;
+        default: __builtin_amdgcn_s_setprio(0); break;
+        }
+    };
     const int ntiles = n16 / 16;
     if (net) {
-    fetch_frag(0);
+    if constexpr (!FUSED) fetch_frag(0);
     lds_barrier();                                            // layer 0's input is in the plane
     stage_frag(0);
+    if (wave == chain_wave) CV_STAMP(5);
     for (int l = 0; l < d.n_layers; ++l) {
         const ConvLayer& L = d.L[l];
         const int Co = L.out_ch;
         const float bias = bias_r;                            // of layer l (fetch_frag below loads the next one's)
+        set_prio(2 * l);
         if (l + 1 < d.n_layers) { fetch_frag(l + 1); fetch_prefix(l + 1); }
         lds_barrier();                                        // plane = this layer's input, wst = its fragments
         // tile j of this wave is frame tile wave + 4*j (n <= 256: at most kConvmTiles per wave). The accumulators START as the
@@ -340,6 +371,7 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
         }
         save_history(L);                                      // reads the input while it is still there
         lds_barrier();                                        // everybody is done reading the plane and wst
+        set_prio(2 * l + 1);
         if (FULL || wave < ntiles) {
             const int co = lane & 15;
 #pragma unroll
@@ -353,7 +385,10 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
             }
         }
         if (l + 1 < d.n_layers) { store_prefix(l + 1); stage_frag(l + 1); }
+        if (wave == chain_wave && l == 0) CV_STAMP(6);
+        if (wave == chain_wave && l == 3) CV_STAMP(7);
     }
+    if (wave == chain_wave) CV_STAMP(8);
     lds_barrier();
     // Dense(C,1) + skip / output gain (:171-181), one thread per frame. The fused form leaves the result where the
     // audio row was: a thread reads column `tid` of every channel and then overwrites column `tid` of channel 0.
@@ -368,12 +403,24 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
     }   // net
     if constexpr (FUSED) {
         lds_barrier();                                        // the row is complete, the staging area is free again
+        if (!(a.tune & 2048)) __builtin_amdgcn_s_setprio(0);  // (the post pass: measured the same at priority 0 and 3)
+        if (wave == chain_wave) CV_STAMP(9);
         if (wave == chain_wave) {
             ChainCtx ctx;
             ctx.live = true;
             ctx.flags = __builtin_bit_cast(uint32_t, verdict[2]); ctx.pending = __builtin_bit_cast(uint32_t, verdict[3]);
             ctx.pre_mem = verdict[4]; ctx.master_mem = verdict[5]; ctx.pre_tgt = verdict[6]; ctx.master_tgt = verdict[7];
             chain_epilogue(a.ctl[sg], a.st[sg], ctx, a.out + (size_t)sg * rstride, pl + Hb, n, lane, wst);
+#ifdef AIDAX_CONV_TRACE
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            CV_STAMP(12);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 13) (a.out + (size_t)sg * rstride)[lane] = __builtin_bit_cast(float, (uint32_t)(cv_trace()[lane] - cv_trace()[0]));
+            if (lane == 13) (a.out + (size_t)sg * rstride)[13] = __builtin_bit_cast(float, (uint32_t)(cv_trace()[13] & 0xffffffffu));
+            if (lane == 14) (a.out + (size_t)sg * rstride)[14] = __builtin_bit_cast(float, (uint32_t)(wall_clock64() & 0xffffffffu));
+            if (lane == 15) (a.out + (size_t)sg * rstride)[15] = __builtin_bit_cast(float, (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4));
+            if (lane == 16) (a.out + (size_t)sg * rstride)[16] = __builtin_bit_cast(float, (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20));
+#endif
         }
     }
 }

@@ -405,6 +405,15 @@ __device__ __forceinline__ void chain_load(ChainPass& c, const StreamCtl& ctl, c
     c.z1 = st.z[slot][0];   c.z2 = st.z[slot][1];
 }
 
+// Measurement build only (make EXTRA=-DAIDAX_CONV_TRACE ..., scratch/conv_trace.py): shader-clock stamps of the fused conv
+// kernel's chain wave, left in the first floats of the stream's output row.
+#ifdef AIDAX_CONV_TRACE
+__device__ __forceinline__ unsigned long long* cv_trace() { __shared__ unsigned long long t[16]; return t; }
+#define CV_STAMP(k) do { if ((threadIdx.x & 63) == 0) cv_trace()[k] = clock64(); } while (0)
+#else
+#define CV_STAMP(k) do { } while (0)
+#endif
+
 // ------------------------------------------------------------ shared chain pieces
 // The per-stream prologue + pre pass of run() (:489-518, :607-630) executed by ONE wave on
 // an LDS block buffer; ChainCtx::live is false when the stream early-outs (pre-run / disabled).
@@ -435,6 +444,7 @@ __device__ __forceinline__ ChainCtx chain_prologue(const StreamCtl& ctl, StreamS
         if (lane == 0) { st.pre_mem = c.pre_mem; st.master_mem = c.master_mem; st.pre_tgt = c.pre_tgt; st.pending = c.pending; }
         return c;
     }
+    CV_STAMP(1);
     load_block(buf, in_row, n, lane);
     __builtin_amdgcn_wave_barrier();
     ChainPass p;
@@ -446,8 +456,13 @@ __device__ __forceinline__ ChainCtx chain_prologue(const StreamCtl& ctl, StreamS
     const bool act = k == 0 ? (c.flags & CTL_LPF_ON) != 0 : ((c.flags & CTL_EQ_BANDPASS) ? slot == BQ_MID : true);
     chain_load(p, ctl, st, slot, act);
     p.g.arm(c.pre_mem, c.pre_tgt, ctl.pre_coef);
+#ifdef AIDAX_CONV_TRACE
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+    CV_STAMP(2);
     if (hand) chain_run_blocked(p, buf, hand, n, lane);       // kChainHandFloats of LDS: the blocked form
     else chain_run(p, buf, buf, n, lane);
+    CV_STAMP(3);
     if (lane < p.K) { st.z[slot][0] = p.z1; st.z[slot][1] = p.z2; }
     c.pre_mem = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p.g.mem), 0));
     return c;
@@ -551,8 +566,13 @@ __device__ __forceinline__ void chain_epilogue(const StreamCtl& ctl, StreamState
     const bool act = k == 0 ? (c.flags & CTL_DC_ON) != 0 : ((c.flags & CTL_EQ_BANDPASS) ? slot == BQ_MID : true);
     chain_load(p, ctl, st, slot, act);
     p.g.arm(c.master_mem, c.master_tgt, ctl.master_coef);
+#ifdef AIDAX_CONV_TRACE
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+    CV_STAMP(10);
     if (hand) chain_run_blocked(p, buf, hand, n, lane);
     else chain_run(p, buf, buf, n, lane);
+    CV_STAMP(11);
     if (lane < p.K) { st.z[slot][0] = p.z1; st.z[slot][1] = p.z2; }
     c.master_mem = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p.g.mem), p.K - 1));
     __builtin_amdgcn_wave_barrier();

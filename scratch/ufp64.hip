@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <algorithm>
 struct Rec { unsigned long long c0, c1, w0, w1; };
 template <int MODE>
 __global__ void k(Rec* out, double* sink, int iters, double b, double c)
@@ -98,9 +99,12 @@ void run(const char* name, int blocks, int threads, int iters, int ops)
     std::vector<Rec> h(blocks);
     hipMemcpy(h.data(), d, blocks * sizeof(Rec), hipMemcpyDeviceToHost);
     double cyc = 0, ghz = 0;
-    for (auto& r : h) { cyc += (double)(r.c1 - r.c0); ghz += (double)(r.c1 - r.c0) / ((double)(r.w1 - r.w0) * 10.0); }
+    std::vector<double> per;
+    for (auto& r : h) { cyc += (double)(r.c1 - r.c0); ghz += (double)(r.c1 - r.c0) / ((double)(r.w1 - r.w0) * 10.0); per.push_back((double)(r.c1 - r.c0) / iters); }
     cyc /= blocks; ghz /= blocks;
-    printf("%-52s %4d wgs x %3d thr: %7.1f cycles/iter = %5.2f per op  (clock %.2f GHz)\n", name, blocks, threads, cyc / iters, cyc / iters / ops, ghz);
+    std::sort(per.begin(), per.end());
+    printf("%-52s %4d wgs x %3d thr: %7.1f cycles/iter = %5.2f per op  (clock %.2f GHz)  per-wg p10 %.1f median %.1f p90 %.1f\n", name, blocks, threads,
+           cyc / iters, cyc / iters / ops, ghz, per[per.size() / 10], per[per.size() / 2], per[per.size() * 9 / 10]);
     hipFree(d); hipFree(s);
 }
 int main()
@@ -116,5 +120,9 @@ int main()
         run<7>("chain macro-step as written: per SAMPLE (12 ops)", 256, thr, 20000, 8);
         run<8>("... input products first: per SAMPLE", 256, thr, 20000, 8);
     }
+    // the fused conv kernel's regime: four workgroups per CU, one busy wave each
+    run<7>("chain macro-step, 4 one-wave workgroups per CU", 1024, 64, 20000, 8);
+    run<8>("... input products first", 1024, 64, 20000, 8);
+    run<7>("chain macro-step, 8 one-wave workgroups per CU", 2048, 64, 20000, 8);
     return 0;
 }

@@ -255,23 +255,25 @@ constexpr int kChainBlock = AIDAX_CHAIN_BLOCK;
 // PLAIN: every lane that runs has its biquad in circuit and every gain ramp of the wave sits on its fixed point
 // (mem * coef + tc == mem, so next() returns the same value for the rest of the block): the per-sample select
 // and the two ramp instructions drop out — 12 instructions per sample and stage instead of 15, same values.
-template <bool PLAIN>
+// B frames per hand-over (kChainBlock, or more where the hand-over dominates: the fused conv kernel's lone chain wave), HL the
+// number of lanes that have a slot in `hand` ([2][HL][B] floats).
+template <bool PLAIN, int B = kChainBlock, int HL = kWave>
 __device__ __forceinline__ void chain_macro_step(ChainPass& c, ExpRamp& g, int stage, bool run, bool last,
                                                  float* row, float* hand, int M, int m, int lane)
 {
     const int j = m - stage;
     if (run && j >= 0 && j < M) {
         const float g_fixed = g.mem;
-        const float* src = stage == 0 ? row + kChainBlock * j : hand + (((m - 1) & 1) * kWave + lane - 1) * kChainBlock;
-        float* dst = last ? row + kChainBlock * j : hand + ((m & 1) * kWave + lane) * kChainBlock;
-        float v[kChainBlock];
+        const float* src = stage == 0 ? row + B * j : hand + (((m - 1) & 1) * HL + lane - 1) * B;
+        float* dst = last ? row + B * j : hand + ((m & 1) * HL + lane) * B;
+        float v[B];
 #pragma unroll
-        for (int q = 0; q < kChainBlock / 4; ++q) {
+        for (int q = 0; q < B / 4; ++q) {
             const float4 t = *reinterpret_cast<const float4*>(src + 4 * q);
             v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
         }
 #pragma unroll
-        for (int i = 0; i < kChainBlock; ++i) {
+        for (int i = 0; i < B; ++i) {
             const float x = v[i];
             const double xd = x;                            // Biquad::process, Biquad.h:53-58
             const double yd = xd * c.a0 + c.z1;
@@ -285,32 +287,33 @@ __device__ __forceinline__ void chain_macro_step(ChainPass& c, ExpRamp& g, int s
             }
         }
 #pragma unroll
-        for (int q = 0; q < kChainBlock / 4; ++q)
+        for (int q = 0; q < B / 4; ++q)
             *reinterpret_cast<float4*>(dst + 4 * q) = float4{ v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3] };
     }
     __builtin_amdgcn_wave_barrier();
 }
 
-template <bool PLAIN>
+template <bool PLAIN, int B = kChainBlock, int HL = kWave>
 __device__ __forceinline__ void chain_blocks(ChainPass& c, ExpRamp& g, int stage, bool run, int depth, bool last,
                                              float* row, float* hand, int M, int lane)
 {
-    for (int m = 0; m < M + depth - 1; ++m) chain_macro_step<PLAIN>(c, g, stage, run, last, row, hand, M, m, lane);
+    for (int m = 0; m < M + depth - 1; ++m) chain_macro_step<PLAIN, B, HL>(c, g, stage, run, last, row, hand, M, m, lane);
 }
 
+template <int B = kChainBlock, int HL = kWave>
 __device__ __forceinline__ void chain_sweep_blocked(ChainPass& c, int stage, bool run, int depth, float* row, float* hand,
                                                     int n_full, int lane, bool force_general = false)
 {
     const double z1o = c.z1, z2o = c.z2;
-    const int M = n_full / kChainBlock;
+    const int M = n_full / B;
     ExpRamp g = c.g;
     const bool is_gain = stage == c.gain_lane;
     if (!is_gain) { g.mem = 1.f; g.coef = 1.f; g.tc = 0.f; }     // y * 1.0f is exact: no select per sample
     const bool last = stage == c.K - 1;
     // wave-uniform: does any running lane need the select (a bypassed biquad) or a moving ramp?
     const bool fussy = run && (!c.active || g.mem * g.coef + g.tc != g.mem);
-    if (!force_general && __builtin_amdgcn_ballot_w64(fussy) == 0) chain_blocks<true>(c, g, stage, run, depth, last, row, hand, M, lane);
-    else chain_blocks<false>(c, g, stage, run, depth, last, row, hand, M, lane);
+    if (!force_general && __builtin_amdgcn_ballot_w64(fussy) == 0) chain_blocks<true, B, HL>(c, g, stage, run, depth, last, row, hand, M, lane);
+    else chain_blocks<false, B, HL>(c, g, stage, run, depth, last, row, hand, M, lane);
     if (is_gain) c.g = g;
     if (!run || !c.active) { c.z1 = z1o; c.z2 = z2o; }
 }
@@ -357,14 +360,22 @@ __device__ __forceinline__ void chain_run(ChainPass& c, const float* src, float*
     chain_sweep<DST_STRIDE>(c, lane, lane < c.K, c.K, src, dst, n);
 }
 
-// One stream's pass by one wave (lane k = stage k), in place, in the blocked form: whole blocks of kChainBlock
-// frames through `hand` (kChainHandFloats floats of LDS), a ragged tail sample by sample. Same values as chain_run.
+// One stream's pass by one wave (lane k = stage k), in place, in the blocked form: whole blocks of frames through `hand`
+// (kChainHandFloats floats of LDS), a ragged tail sample by sample. Same values as chain_run.
+// This wave — the lone chain wave of the fused conv kernel — hands SIXTEEN frames over at a time: a macro-step's fixed part (the LDS
+// turn-around between two stages, range logic: ~230 of ~680 cycles at eight frames, scratch/conv_trace.py) is paid half as
+// often, which outweighs the five steps a six-stage cascade takes to fill being twice as long (cfg4: pre pass 9.2 -> 7.9 us,
+// post pass 10.5 -> 10.1 us). Its cascades are at most six stages deep: eight lanes' worth of slots, [2][8][16] floats.
 constexpr int kChainHandFloats = 2 * kWave * kChainBlock;
+// (Thirty-two frames per step for a one-stage pass, which hands nothing over, measured no better: 7.95 against 7.88 us, and
+// uneven from CU to CU.)
+constexpr int kChainWideBlock = 16, kChainWideLanes = 8;
+static_assert(2 * kChainWideLanes * kChainWideBlock <= kChainHandFloats, "the wide form lives in the same hand-over area");
 __device__ __forceinline__ void chain_run_blocked(ChainPass& c, float* buf, float* hand, int n, int lane)
 {
     const bool run = lane < c.K;
-    const int n_full = n & ~(kChainBlock - 1);
-    if (n_full != 0) chain_sweep_blocked(c, lane, run, c.K, buf, hand, n_full, lane);
+    const int n_full = n & ~(kChainWideBlock - 1);
+    if (n_full != 0) chain_sweep_blocked<kChainWideBlock, kChainWideLanes>(c, lane, run, c.K, buf, hand, n_full, lane);
     if (n_full != n) chain_sweep<1>(c, lane, run, c.K, buf + n_full, buf + n_full, n - n_full);
 }
 

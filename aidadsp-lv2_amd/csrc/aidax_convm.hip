@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
         if (wave != chain_wave) layer0_side(tid - kWave, kConvmThreads - kWave);
         // channel 0's block part of the plane is the audio row: the pre pass leaves layer 0's input there
         if (wave == chain_wave) {
-            ChainCtx ctx = chain_prologue(a.ctl[sg], a.st[sg], a.in + (size_t)sg * rstride, a.out + (size_t)sg * rstride, pl + Hb, n, lane, wst);
+            ChainCtx ctx = chain_prologue<true>(a.ctl[sg], a.st[sg], a.in + (size_t)sg * rstride, a.out + (size_t)sg * rstride, pl + Hb, n, lane, wst);
             if (ctx.live && (ctx.flags & CTL_NET_ON)) {
                 uint32_t pend = ctx.pending;
                 if (lane == 0) pend = param_targets(a.ctl[sg], a.st[sg], pend);
@@ -308,6 +308,16 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
         default: __builtin_amdgcn_s_setprio(0); break;
         }
     };
+    // the post pass's context (left in LDS by the prologue) and its coefficients and state: requested by the chain wave when
+    // the last layer is done, used after the Dense
+    ChainCtx post_ctx;
+    ChainPass post_pass;
+    auto post_begin = [&]() {
+        post_ctx.live = true;
+        post_ctx.flags = __builtin_bit_cast(uint32_t, verdict[2]); post_ctx.pending = __builtin_bit_cast(uint32_t, verdict[3]);
+        post_ctx.pre_mem = verdict[4]; post_ctx.master_mem = verdict[5]; post_ctx.pre_tgt = verdict[6]; post_ctx.master_tgt = verdict[7];
+        post_pass = chain_epilogue_begin(a.ctl[sg], a.st[sg], post_ctx, lane);
+    };
     const int ntiles = n16 / 16;
     if (net) {
     if constexpr (!FUSED) fetch_frag(0);
@@ -390,6 +400,7 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
     }
     if (wave == chain_wave) CV_STAMP(8);
     lds_barrier();
+    if constexpr (FUSED) { if (wave == chain_wave) post_begin(); }     // its loads travel while the Dense is computed
     // Dense(C,1) + skip / output gain (:171-181), one thread per frame. The fused form leaves the result where the
     // audio row was: a thread reads column `tid` of every channel and then overwrites column `tid` of channel 0.
     if (mode != MODE_WARMUP && tid < n) {
@@ -401,16 +412,13 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
         else row[tid] = o2 * a.out_gain;
     }
     }   // net
+    else if constexpr (FUSED) { if (wave == chain_wave) post_begin(); }
     if constexpr (FUSED) {
         lds_barrier();                                        // the row is complete, the staging area is free again
         if (!(a.tune & 2048)) __builtin_amdgcn_s_setprio(0);  // (the post pass: measured the same at priority 0 and 3)
         if (wave == chain_wave) CV_STAMP(9);
         if (wave == chain_wave) {
-            ChainCtx ctx;
-            ctx.live = true;
-            ctx.flags = __builtin_bit_cast(uint32_t, verdict[2]); ctx.pending = __builtin_bit_cast(uint32_t, verdict[3]);
-            ctx.pre_mem = verdict[4]; ctx.master_mem = verdict[5]; ctx.pre_tgt = verdict[6]; ctx.master_tgt = verdict[7];
-            chain_epilogue(a.ctl[sg], a.st[sg], ctx, a.out + (size_t)sg * rstride, pl + Hb, n, lane, wst);
+            chain_epilogue_run(a.st[sg], post_ctx, post_pass, a.out + (size_t)sg * rstride, pl + Hb, n, lane, wst);
 #ifdef AIDAX_CONV_TRACE
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             CV_STAMP(12);

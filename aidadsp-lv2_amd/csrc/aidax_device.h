@@ -434,10 +434,22 @@ struct ChainCtx {
     bool live;
 };
 
+// EAGER (the fused conv kernel, where this is the head of the launch's critical path): the audio row and the coefficients
+// and state of every stage a pre pass can have are requested before the control word they depend on is waited for — one
+// trip to memory instead of three in a row. A lane beyond the cascade then holds an EQ stage's numbers instead of stage 0's;
+// it does not run either way.
+template <bool EAGER = false>
 __device__ __forceinline__ ChainCtx chain_prologue(const StreamCtl& ctl, StreamState& st, const float* in_row,
                                                    float* out_row, float* buf, int n, int lane, float* hand = nullptr)
 {
     ChainCtx c;
+    const bool row_in_regs = EAGER && (n & 3) == 0 && n <= 4 * kWave;
+    float4 rowv = float4{ 0.f, 0.f, 0.f, 0.f };
+    ChainPass p;
+    if constexpr (EAGER) {
+        if (row_in_regs && 4 * lane < n) rowv = reinterpret_cast<const float4*>(in_row)[lane];
+        chain_load(p, ctl, st, pre_slot(lane < 6 ? lane : 0), false);
+    }
     c.flags = ctl.flags;
     c.pending = st.pending;
     c.pre_mem = st.pre_mem; c.master_mem = st.master_mem;
@@ -456,16 +468,17 @@ __device__ __forceinline__ ChainCtx chain_prologue(const StreamCtl& ctl, StreamS
         return c;
     }
     CV_STAMP(1);
-    load_block(buf, in_row, n, lane);
+    if (row_in_regs) { if (4 * lane < n) reinterpret_cast<float4*>(buf)[lane] = rowv; }
+    else load_block(buf, in_row, n, lane);
     __builtin_amdgcn_wave_barrier();
-    ChainPass p;
     const bool eq = c.flags & CTL_EQ_PRE;
     p.K = eq ? 6 : 1;
     p.gain_lane = 0;
     const int k = lane < p.K ? lane : 0;
     const int slot = pre_slot(k);
     const bool act = k == 0 ? (c.flags & CTL_LPF_ON) != 0 : ((c.flags & CTL_EQ_BANDPASS) ? slot == BQ_MID : true);
-    chain_load(p, ctl, st, slot, act);
+    if constexpr (EAGER) p.active = act;
+    else chain_load(p, ctl, st, slot, act);
     p.g.arm(c.pre_mem, c.pre_tgt, ctl.pre_coef);
 #ifdef AIDAX_CONV_TRACE
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -563,9 +576,9 @@ __device__ __forceinline__ uint32_t param_targets(const StreamCtl& ctl, StreamSt
     return pending;
 }
 
-// post pass + store + state write-back (:645-655)
-__device__ __forceinline__ void chain_epilogue(const StreamCtl& ctl, StreamState& st, ChainCtx& c, float* out_row,
-                                               float* buf, int n, int lane, float* hand = nullptr)
+// post pass + store + state write-back (:645-655), in two halves: _begin requests what the pass needs from memory (a caller
+// with work left for the wave before the pass — the fused conv kernel's Dense — puts it in between), _run is the pass.
+__device__ __forceinline__ ChainPass chain_epilogue_begin(const StreamCtl& ctl, const StreamState& st, ChainCtx& c, int lane)
 {
     c.master_tgt = ctl.master_target;
     ChainPass p;
@@ -577,6 +590,12 @@ __device__ __forceinline__ void chain_epilogue(const StreamCtl& ctl, StreamState
     const bool act = k == 0 ? (c.flags & CTL_DC_ON) != 0 : ((c.flags & CTL_EQ_BANDPASS) ? slot == BQ_MID : true);
     chain_load(p, ctl, st, slot, act);
     p.g.arm(c.master_mem, c.master_tgt, ctl.master_coef);
+    return p;
+}
+__device__ __forceinline__ void chain_epilogue_run(StreamState& st, ChainCtx& c, ChainPass& p, float* out_row,
+                                                   float* buf, int n, int lane, float* hand = nullptr)
+{
+    const int slot = post_slot(lane < p.K ? lane : 0);
 #ifdef AIDAX_CONV_TRACE
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
@@ -593,6 +612,12 @@ __device__ __forceinline__ void chain_epilogue(const StreamCtl& ctl, StreamState
         st.pre_tgt = c.pre_tgt; st.master_tgt = c.master_tgt;
         st.pending = c.pending;
     }
+}
+__device__ __forceinline__ void chain_epilogue(const StreamCtl& ctl, StreamState& st, ChainCtx& c, float* out_row,
+                                               float* buf, int n, int lane, float* hand = nullptr)
+{
+    ChainPass p = chain_epilogue_begin(ctl, st, c, lane);
+    chain_epilogue_run(st, c, p, out_row, buf, n, lane, hand);
 }
 
 }  // namespace aidax

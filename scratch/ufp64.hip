@@ -1,7 +1,7 @@
 // What does one fp64 VALU instruction cost a LONE wave (one wave per SIMD: the chain passes' regime)? Dependent chains against
 // independent ones, fma / mul / add, and the biquad step itself (Biquad.h:53-58, nine operations, no contraction) as the
 // compiler schedules it. Wall time per iteration in ns and in shader cycles (s_memrealtime, 100 MHz, times the measured clock).
-// hipcc --offload-arch=gfx950 -O3 -ffp-contract=off scratch/ufp64.hip -o /tmp/ufp64 && /tmp/ufp64
+// hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize scratch/ufp64.hip -o /tmp/ufp64 && /tmp/ufp64
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -16,6 +16,9 @@ __global__ void k(Rec* out, double* sink, int iters, double b, double c)
     // per-lane coefficients (VGPRs, like the chain's): nothing the compiler can keep in SGPRs
     const double va0 = b + threadIdx.x * 1e-9, va1 = c + threadIdx.x * 1e-9, va2 = va0 * 0.5, vb1 = va1 * 0.25, vb2 = va0 * 0.125;
     const float gf = 1.f + threadIdx.x * 1e-7f;
+    const float fb_s = (float)b, fb_v = (float)b + threadIdx.x * 1e-9f, fc_v = (float)c + threadIdx.x * 1e-9f;
+    float fv[8];
+    for (int j = 0; j < 8; ++j) fv[j] = threadIdx.x * 1e-3f + j;
     const unsigned long long w0 = wall_clock64(), c0 = clock64();
     for (int i = 0; i < iters; ++i) {
         if (MODE == 0) {                 // 8 dependent fma
@@ -78,6 +81,40 @@ __global__ void k(Rec* out, double* sink, int iters, double b, double c)
 #pragma unroll
             for (int q = 0; q < 8; ++q) acc += v[q];
             v0 = acc;
+        } else if (MODE == 9) {          // fp32: 8 dependent fma, operands in VGPRs
+            float f = (float)v0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f) : "v"(fb_v), "v"(fc_v));
+            v0 = f;
+        } else if (MODE == 10) {         // fp32: 8 dependent fma, one operand an SGPR
+            float f = (float)v0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f) : "s"(fb_s), "v"(fc_v));
+            v0 = f;
+        } else if (MODE == 11) {         // fp32: 8 independent fma, VGPRs
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(fv[j]) : "v"(fb_v), "v"(fc_v));
+        } else if (MODE == 12) {         // fp32: 8 independent fma, one operand an SGPR
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(fv[j]) : "s"(fb_s), "v"(fc_v));
+        } else if (MODE == 13) {         // fp32: 8 independent fma, an inline constant operand
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("v_fma_f32 %0, %0, 0.5, %1" : "+v"(fv[j]) : "v"(fc_v));
+        } else if (MODE == 14) {         // fp64: 8 independent mul, VGPR operands
+            asm volatile("v_mul_f64 %0, %0, %1" : "+v"(v0) : "v"(va0)); asm volatile("v_mul_f64 %0, %0, %1" : "+v"(v1) : "v"(va0));
+            asm volatile("v_mul_f64 %0, %0, %1" : "+v"(v2) : "v"(va0)); asm volatile("v_mul_f64 %0, %0, %1" : "+v"(v3) : "v"(va0));
+            asm volatile("v_mul_f64 %0, %0, %1" : "+v"(v4) : "v"(va0)); asm volatile("v_mul_f64 %0, %0, %1" : "+v"(v5) : "v"(va0));
+            asm volatile("v_mul_f64 %0, %0, %1" : "+v"(v6) : "v"(va0)); asm volatile("v_mul_f64 %0, %0, %1" : "+v"(v7) : "v"(va0));
+        } else if (MODE == 15) {         // fp64: 8 independent mul, one SGPR operand
+            asm volatile("v_mul_f64 %0, %0, %1" : "+v"(v0) : "s"(b)); asm volatile("v_mul_f64 %0, %0, %1" : "+v"(v1) : "s"(b));
+            asm volatile("v_mul_f64 %0, %0, %1" : "+v"(v2) : "s"(b)); asm volatile("v_mul_f64 %0, %0, %1" : "+v"(v3) : "s"(b));
+            asm volatile("v_mul_f64 %0, %0, %1" : "+v"(v4) : "s"(b)); asm volatile("v_mul_f64 %0, %0, %1" : "+v"(v5) : "s"(b));
+            asm volatile("v_mul_f64 %0, %0, %1" : "+v"(v6) : "s"(b)); asm volatile("v_mul_f64 %0, %0, %1" : "+v"(v7) : "s"(b));
+        } else if (MODE == 16) {         // fp64: 8 independent fma, VGPR operands
+            asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v0) : "v"(va0), "v"(va1)); asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v1) : "v"(va0), "v"(va1));
+            asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v2) : "v"(va0), "v"(va1)); asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v3) : "v"(va0), "v"(va1));
+            asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v4) : "v"(va0), "v"(va1)); asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v5) : "v"(va0), "v"(va1));
+            asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v6) : "v"(va0), "v"(va1)); asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v7) : "v"(va0), "v"(va1));
         } else if (MODE == 6) {          // 8 dependent fp32 fma (reference point)
             float f = (float)v0;
 #pragma unroll
@@ -87,7 +124,9 @@ __global__ void k(Rec* out, double* sink, int iters, double b, double c)
     }
     const unsigned long long c1 = clock64(), w1 = wall_clock64();
     if (threadIdx.x == 0) out[blockIdx.x] = Rec{c0, c1, w0, w1};
-    sink[blockIdx.x * blockDim.x + threadIdx.x] = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7 + z1 + z2 + y1 + y2;
+    float fs = 0.f;
+    for (int j = 0; j < 8; ++j) fs += fv[j];
+    sink[blockIdx.x * blockDim.x + threadIdx.x] = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7 + z1 + z2 + y1 + y2 + fs;
 }
 template <int MODE>
 void run(const char* name, int blocks, int threads, int iters, int ops)
@@ -120,6 +159,14 @@ int main()
         run<7>("chain macro-step as written: per SAMPLE (12 ops)", 256, thr, 20000, 8);
         run<8>("... input products first: per SAMPLE", 256, thr, 20000, 8);
     }
+    run<9>("fp32: 8 dependent v_fma_f32, VGPR operands (+2 cvt)", 256, 256, 20000, 8);
+    run<10>("fp32: 8 dependent v_fma_f32, one SGPR operand (+2 cvt)", 256, 256, 20000, 8);
+    run<11>("fp32: 8 independent v_fma_f32, VGPR operands", 256, 256, 20000, 8);
+    run<12>("fp32: 8 independent v_fma_f32, one SGPR operand", 256, 256, 20000, 8);
+    run<13>("fp32: 8 independent v_fma_f32, an inline constant", 256, 256, 20000, 8);
+    run<14>("fp64: 8 independent v_mul_f64, VGPR operands", 256, 256, 20000, 8);
+    run<15>("fp64: 8 independent v_mul_f64, one SGPR operand", 256, 256, 20000, 8);
+    run<16>("fp64: 8 independent v_fma_f64, VGPR operands", 256, 256, 20000, 8);
     // the fused conv kernel's regime: four workgroups per CU, one busy wave each
     run<7>("chain macro-step, 4 one-wave workgroups per CU", 1024, 64, 20000, 8);
     run<8>("... input products first", 1024, 64, 20000, 8);

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma(LaunchArgs a, MfmaDesc d)
                         hn = go * tanh_rat(cn);
                     } else {
                         const float gz = sigmoid_pre(acc[tl].x), gr = sigmoid_pre(acc[tl].y);
-                        const float nn = tanh_rat(__builtin_fmaf(gr, acc[tl].z, acc[tl].w));
+                        const float nn = tanh_exp_pre(__builtin_fmaf(gr, acc[tl].z, acc[tl].w));      // (GRU: see GruCell::step)
                         hn = __builtin_fmaf(gz, h_rd[e] - nn, nn);
                     }
                     h_wr[e] = hn;

@@ -757,7 +757,7 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
                         hn = go * tanh_rat(cn);
                     } else {
                         const float gz = sigmoid_pre(acc[tl].x), gr = sigmoid_pre(acc[tl].y);
-                        const float nn = tanh_rat(__builtin_fmaf(gr, acc[tl].z, acc[tl].w));
+                        const float nn = tanh_exp_pre(__builtin_fmaf(gr, acc[tl].z, acc[tl].w));      // (GRU: see GruCell::step)
                         hn = __builtin_fmaf(gz, h_rd[e] - nn, nn);
                     }
                     h_wr[e] = hn;
@@ -1067,7 +1067,7 @@ __global__ __launch_bounds__((UT + NHELP) * kWave) void k_gru_gm(LaunchArgs a, M
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float gz = sigmoid_pre(az[e]), gr = sigmoid_pre(ar[e]);
-                    const float nn = tanh_rat(__builtin_fmaf(gr, an[e], ax[e]));
+                    const float nn = tanh_exp_pre(__builtin_fmaf(gr, an[e], ax[e]));      // (the record's candidate rows carry 2 log2 e)
                     const float hn = __builtin_fmaf(gz, hreg[e] - nn, nn);
                     hreg[e] = hn;
                     h_wr[(16 * wave + 4 * q + e) * NS + c] = hn;

@@ -112,19 +112,21 @@ std::vector<float> pack_gru(const aidax_model& m)
             const bool live = j < H;
             for (int e = 0; e < 3; ++e) {
                 const int col = e * H + j;
-                const float sc = e < 2 ? kNegLog2e : 1.f;           // z, r: sigmoids as 1 / (1 + 2^v)
+                // z, r: sigmoids as 1 / (1 + 2^v); candidate: tanh as 1 - 2 / (1 + 2^v) (tanh_exp_pre; r * (U h + b1) + (W x + b0)
+                // is linear in the candidate rows, so the factor goes into all of them)
+                const float sc = e < 2 ? kNegLog2e : kTwoLog2e;
                 // this lane's K slice of the recurrent row
                 for (int k = 0; k < KS; ++k) p.put(r++, lane, live ? sc * L.w1[static_cast<size_t>(part * KS + k) * G + col] : 0.f);
                 // z, r: input weights and (b0+b1) ride on part 0 and reach the others through the partial-sum
                 // exchange; candidate: every part keeps the input side whole (it is not summed), b1 sits under r*( )
                 const bool owns_input = e == 2 || part == 0;
                 for (int i = 0; i < kMaxInputs; ++i) p.put(r++, lane, (live && owns_input && i < I) ? sc * L.w0[static_cast<size_t>(i) * G + col] : 0.f);
-                p.put(r++, lane, (live && owns_input) ? (e < 2 ? sc * (b0[col] + b1[col]) : b0[col]) : 0.f);
+                p.put(r++, lane, (live && owns_input) ? (e < 2 ? sc * (b0[col] + b1[col]) : sc * b0[col]) : 0.f);
             }
         }
         for (int mm = 0; mm < M.NU; ++mm) {
             const int j = slot + mm * M.slots;
-            p.put(r++, lane, (j < H && part == 0) ? b1[2 * H + j] : 0.f);
+            p.put(r++, lane, (j < H && part == 0) ? kTwoLog2e * b1[2 * H + j] : 0.f);
         }
         for (int mm = 0; mm < M.NU; ++mm) {
             const int j = slot + mm * M.slots;
@@ -204,7 +206,8 @@ std::vector<float> pack_mfma(const aidax_model& m, MfmaDesc* d, uint32_t* state_
         auto weight = [&](Seg seg, int u, int g, int k) -> float {
             const bool sigmoid_row = lstm ? g != 2 : g <= 1;
             const float w = weight_raw(seg, u, g, k);
-            return sigmoid_row ? kNegLog2e * w : w;
+            // a GRU's candidate rows (both halves) carry 2 log2(e): tanh as 1 - 2 / (1 + 2^v), see tanh_exp_pre
+            return sigmoid_row ? kNegLog2e * w : !lstm ? kTwoLog2e * w : w;
         };
         // layer 0: the 1..3 model inputs are one k-step on their own ("small" segment)
         M.w_in_off = static_cast<uint32_t>(out.size());
@@ -256,13 +259,13 @@ std::vector<float> pack_mfma(const aidax_model& m, MfmaDesc* d, uint32_t* state_
         const float* U = L.w1.data();
         const float* b = L.w2.data();
         auto col = [&](int g, int u) { return (g == 0 ? 0 : g == 1 ? Ht : 2 * Ht) + u; };     // g: 0 z, 1 r, 2 recurrent half, 3 input half
-        auto sc = [&](int g) { return g <= 1 ? kNegLog2e : 1.f; };                         // z, r: sigmoid rows, scaled as above
+        auto sc = [&](int g) { return g <= 1 ? kNegLog2e : kTwoLog2e; };                   // sigmoid rows and candidate rows, scaled as above
         auto w_in = [&](int u, int g, int k) { return (u < Ht && g != 2 && k < I) ? sc(g) * W[(size_t)k * R + col(g, u)] : 0.f; };
         auto w_rec = [&](int u, int g, int k) { return (u < Ht && g != 3 && k < Ht) ? sc(g) * U[(size_t)k * R + col(g, u)] : 0.f; };
         auto bias = [&](int u, int g) {
             if (u >= Ht) return 0.f;
             if (g <= 1) return kNegLog2e * (b[col(g, u)] + b[R + col(g, u)]);
-            return g == 2 ? b[R + col(g, u)] : b[col(g, u)];
+            return kTwoLog2e * (g == 2 ? b[R + col(g, u)] : b[col(g, u)]);
         };
         for (int w = 0; w < H / 16; ++w) {
             for (int g : { 0, 1, 3 })

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(quad_waves(H) * kWave) void k_quad(LaunchArgs a, Qu
                 hcur = go * tanh_rat(c);
             } else {
                 const float gz = fast_sigmoid(g.x), gr = fast_sigmoid(g.y);
-                const float nn = tanh_rat(__builtin_fmaf(gr, g.z, g.w));
+                const float nn = tanh_exp(__builtin_fmaf(gr, g.z, g.w));      // (GRU: see GruCell::step)
                 hcur = __builtin_fmaf(gz, hcur - nn, nn);
             }
             if (uok) hh[((t & (kQuadRing - 1)) * kQuadStreams + j) * HS + u] = hcur;

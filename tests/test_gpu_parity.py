@@ -730,8 +730,10 @@ def test_conv_fused_launch_is_bit_identical_to_split_launches(tmp_path, monkeypa
     kws = [dict(), dict(enabled=0.0), dict(net_bypass=1.0), dict(eq_position=1.0, bass_boost_db=5.0, mid_type=1.0),
            dict(dc_blocker=0.0, in_lpf_pc=0.0, eq_bypass=1.0), dict(pregain_db=6.0, master_db=-6.0, treble_boost_db=4.0)]
     outs = []
-    for fused in ("1", "0"):
+    # (third run: the fused form without its issue priority by progress — AIDAX_TUNE bit 2048 — a scheduling hint, same bits)
+    for fused, tune in (("1", "0"), ("0", "0"), ("1", "2048")):
         monkeypatch.setenv("AIDAX_CONV_FUSED", fused)
+        monkeypatch.setenv("AIDAX_TUNE", tune)
         pool = ax.Pool(S, 256)
         pool.set_model(ax.Model(path))
         assert pool.kernel_name == ("k_conv_mfma" if fused == "1" else "k_chain+k_conv_mfma")
@@ -748,6 +750,7 @@ def test_conv_fused_launch_is_bit_identical_to_split_launches(tmp_path, monkeypa
         outs.append(got)
         pool.close()
     assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0], outs[2])
 
 
 @pytest.mark.parametrize("name,kw", [

@@ -584,6 +584,41 @@ __host__ __device__ constexpr size_t pipe_lds_floats(int H, int n_frames)
     return (size_t)((n_frames + 3) & ~3) + 3 * kSB * 4 + (size_t)kRing * pipe_row_stride(H) + kSB + (size_t)(H + 4);
 }
 
+// Wave P, a whole stage of a ONE-stage pre pass (no EQ in front of the model — the default): the stage's sixteen frames as one
+// macro-step of the blocked form, twelve instructions per sample (fifteen while the gain ramp moves or the filter is out of
+// circuit) instead of the systolic step's ~27 with its lane shift, selects and range logic. The helper waves share their SIMDs
+// with other streams' recurrent waves, and for the small cells their instructions ARE the pass: LSTM-12 / GRU-8 at 1024
+// streams spend as many issue slots on P and Q as on the cell. Same operations per sample as chain_step; lane 0 only.
+template <bool PLAIN>
+__device__ __forceinline__ void pre_stage_solo(ChainPass& c, const float* src, float* dst)
+{
+    static_assert(kSB % 4 == 0, "float4 moves");
+    float v[kSB];
+#pragma unroll
+    for (int q = 0; q < kSB / 4; ++q) {
+        const float4 t = reinterpret_cast<const float4*>(src)[q];
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+    const float g_fixed = c.g.mem;
+#pragma unroll
+    for (int i = 0; i < kSB; ++i) {
+        const float x = v[i];
+        const double xd = x;                                // Biquad::process, Biquad.h:53-58
+        const double yd = xd * c.a0 + c.z1;
+        c.z1 = xd * c.a1 + c.z2 - c.b1 * yd;
+        c.z2 = xd * c.a2 - c.b2 * yd;
+        if constexpr (PLAIN) {
+            v[i] = (float)yd * g_fixed;
+        } else {
+            const float y = c.active ? (float)yd : x;
+            v[i] = y * c.g.next();
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < kSB / 4; ++q)
+        reinterpret_cast<float4*>(dst)[q] = float4{ v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3] };
+}
+
 template <class Cell>
 __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* smem)
 {
@@ -696,7 +731,17 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
                 const int base = p * kSB;
                 const int cnt = n - base < kSB ? n - base : kSB;
                 float* stage = xq + (p % 3) * kStage;
-                chain_run<1>(cp, inbuf + base, stage, cnt, lane);
+                if (cp.K == 1 && cnt == kSB) {
+                    if (lane == 0) {
+                        const double z1o = cp.z1, z2o = cp.z2;
+                        if (cp.active && cp.g.mem * cp.g.coef + cp.g.tc == cp.g.mem) pre_stage_solo<true>(cp, inbuf + base, stage);
+                        else pre_stage_solo<false>(cp, inbuf + base, stage);
+                        if (!cp.active) { cp.z1 = z1o; cp.z2 = z2o; }       // a bypassed biquad keeps its state (:622)
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                } else {
+                    chain_run<1>(cp, inbuf + base, stage, cnt, lane);
+                }
                 if (net_on && I >= 2) {
                     for (int t = 0; t < cnt; ++t) {
                         const float q1 = lin_next(p_mem[0], p_tgt[0], p_step[0]);

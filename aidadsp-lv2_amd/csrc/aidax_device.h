@@ -499,6 +499,10 @@ __device__ __forceinline__ ChainCtx chain_prologue(const StreamCtl& ctl, StreamS
 // the last layer re-deriving the model input — passes false). `atomic_pending`: clear PEND_ACTIVATE with an atomic (another
 // workgroup of the same launch may be clearing PEND_PARAM_FIRST in the same word).
 constexpr int kChainWaveStreams = 8;
+// Sixteen frames per hand-over here too (see chain_run_blocked: a macro-step's fixed part is a third of it at eight): a packed
+// pass of 256 frames 10.6 -> ~9 us of loop. The wave's hand-over area is [2][64 lanes][16] floats.
+constexpr int kChainPackBlock = 16;
+constexpr int kChainPackHandFloats = 2 * kWave * kChainPackBlock;
 template <bool PRE>
 __device__ __forceinline__ void chain_wave_pass(const LaunchArgs& a, int stream0, float* rows, int nP, float* hand, int n, int lane,
                                                 bool commit, bool atomic_pending)
@@ -530,14 +534,14 @@ __device__ __forceinline__ void chain_wave_pass(const LaunchArgs& a, int stream0
     c.g.arm(mem, tgt, PRE ? ctl.pre_coef : ctl.master_coef);
 
     if (n != 0) {
-        // whole blocks of eight frames in the blocked form, a ragged tail sample by sample
+        // whole blocks of sixteen frames in the blocked form, a ragged tail sample by sample
         float* row = rows + grp * nP;
         const bool run = live && stage < c.K;
-        const int n_full = n & ~(kChainBlock - 1);
+        const int n_full = n & ~(kChainPackBlock - 1);
         // the longest cascade among the wave's running streams: without EQ on this side it is one stage, and the
         // sweep needs no fill / drain steps at all
         const int depth = (a.tune & 8) || __builtin_amdgcn_ballot_w64(run && stage > 0) != 0 ? 6 : 1;
-        if (n_full != 0) chain_sweep_blocked(c, stage, run, depth, row, hand, n_full, lane, (a.tune & 8) != 0);
+        if (n_full != 0) chain_sweep_blocked<kChainPackBlock, kWave>(c, stage, run, depth, row, hand, n_full, lane, (a.tune & 8) != 0);
         if (n_full != n) chain_sweep<1>(c, stage, run, depth, row + n_full, row + n_full, n - n_full);
         __builtin_amdgcn_wave_barrier();
     }

@@ -629,6 +629,9 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
     const int s = blockIdx.x;
     const int n = (int)a.n_frames;
 
+#ifdef AIDAX_PIPE_TRACE
+    const unsigned long long tr_w0 = wall_clock64(), tr_c0 = clock64();
+#endif
     float*  inbuf = smem;                                                   // P private
     float*  xq    = smem + ((n + 3) & ~3);                                  // ring of 3 stages: x_pre[kSB] | p1[kSB] | p2[kSB] | -
     float*  hh    = xq + 3 * kStage;                                        // h history, kRing rows
@@ -868,6 +871,16 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
         if (lane >= cp.K || !cp.active) { cp.z1 = q_z1o; cp.z2 = q_z2o; }      // a bypassed biquad keeps its state (:646)
         if (lane < cp.K) { st.z[slot][0] = cp.z1; st.z[slot][1] = cp.z2; }
         if (lane == cp.K - 1) { st.master_mem = cp.g.mem; st.master_tgt = master_tgt; }
+#ifdef AIDAX_PIPE_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            out_row[0] = __builtin_bit_cast(float, (uint32_t)(tr_w0 & 0xffffffffu));
+            out_row[1] = __builtin_bit_cast(float, (uint32_t)(wall_clock64() & 0xffffffffu));
+            out_row[2] = __builtin_bit_cast(float, (uint32_t)(clock64() - tr_c0));
+            out_row[3] = __builtin_bit_cast(float, (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4));
+            out_row[4] = __builtin_bit_cast(float, (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20));
+        }
+#endif
     }
 }
 
@@ -1186,7 +1199,7 @@ hipError_t launch_stream_kernel(const KernelEntry* e, const LaunchArgs& a, size_
 
 size_t chain_lds_bytes(uint32_t n_frames)
 {
-    return ((size_t)kChainStreams * ((n_frames + 3) & ~3u) + 2 * kWave * kChainBlock) * sizeof(float);   // rows + hand-over slots
+    return ((size_t)kChainStreams * ((n_frames + 3) & ~3u) + kChainPackHandFloats) * sizeof(float);   // rows + hand-over slots
 }
 
 hipError_t launch_chain_pass(bool pre, const LaunchArgs& a, hipStream_t stream)

@@ -860,7 +860,7 @@ __device__ __forceinline__ void lp_chain_rows(const LaunchArgs& a, float* smem, 
     const int nP = (n + 3) & ~3;
     const int s_base = grp * NS;
     float* rows = smem;                                    // [NS][nP]
-    float* hands = rows + NS * nP;                         // [2][kChainHandFloats]
+    float* hands = rows + NS * nP;                         // [2][kChainPackHandFloats]
     const float* src_base = PRE ? a.in : a.out;
     // Device-scope loads, past this CU's vector cache. POST: the rows were stored by this workgroup a moment ago, and the
     // body's own read of them may have left their lines there, stale. PRE: with a.in == a.out the body would otherwise
@@ -872,7 +872,7 @@ __device__ __forceinline__ void lp_chain_rows(const LaunchArgs& a, float* smem, 
     __syncthreads();
     if (wave < 2)
         chain_wave_pass<PRE>(a, s_base + kChainWaveStreams * wave, rows + kChainWaveStreams * wave * nP, nP,
-                             hands + wave * kChainHandFloats, n, lane, commit, !PRE);
+                             hands + wave * kChainPackHandFloats, n, lane, commit, !PRE);
     __syncthreads();
     // PRE: every valid row goes to out (a disabled stream's row is still the raw input: the hard bypass copy of :612-619);
     // POST: only rows that were processed
@@ -1137,7 +1137,7 @@ static bool lp_helper_form(const MfmaDesc& d) { return d.n_layers == 1 && lp_hel
 size_t mfma_lp_lds_bytes(const MfmaDesc& d, uint32_t n_frames, bool fused)
 {
     if (fused && !lp_helper_form(d)) {                     // lp_chain_rows works in the body's LDS before and after it
-        const size_t body = lp_lds_floats(d.hidden, (int)n_frames), rows = (size_t)kMfmaStreams * ((n_frames + 3) & ~3u) + 2 * kChainHandFloats;
+        const size_t body = lp_lds_floats(d.hidden, (int)n_frames), rows = (size_t)kMfmaStreams * ((n_frames + 3) & ~3u) + 2 * kChainPackHandFloats;
         return (body > rows ? body : rows) * sizeof(float);
     }
     return lp_lds_floats(d.hidden, (int)n_frames, fused ? lp_helpers(d.hidden) : 0) * sizeof(float);

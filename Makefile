@@ -36,11 +36,14 @@ $(OBJDIR)/%.o: $(SRC)/%.cpp $(HDRS)
 
 # every kernel's register / scratch report is kept next to its object; the library is linked only after
 # tools/check_scratch.py has found no kernel with ScratchSize > 0
-$(OBJDIR)/%.o: $(SRC)/%.hip $(HDRS)
+# (object and report are ONE grouped target: a deleted .remarks file is rebuilt with its object; the compiler's warnings
+# are shown on every build — only the per-kernel resource remarks stay in the file)
+$(OBJDIR)/%.o $(OBJDIR)/%.remarks &: $(SRC)/%.hip $(HDRS)
 	@mkdir -p $(OBJDIR)
-	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(@:.o=.remarks) || (cat $(@:.o=.remarks); exit 1)
+	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $(OBJDIR)/$*.o 2> $(OBJDIR)/$*.remarks || (cat $(OBJDIR)/$*.remarks; exit 1)
+	@grep -A3 -E "warning:" $(OBJDIR)/$*.remarks >&2 || true
 
-$(OBJDIR)/scratch.ok: $(KERN_OBJS) tools/check_scratch.py
+$(OBJDIR)/scratch.ok: $(KERN_OBJS) $(KERN_OBJS:.o=.remarks) tools/check_scratch.py
 	python3 tools/check_scratch.py $(KERN_OBJS:.o=.remarks)
 	@touch $@
 

@@ -78,14 +78,20 @@ ManyForm many_streams_form(int cell, int hidden, uint32_t n, int cus)
 // and ends in a reported give-up (aidax_mfmalp.hip).
 struct LpGate {
     std::mutex mu;
-    struct Hold { const void* owner = nullptr; int refs = 0; } dev[64];
-    bool acquire(int device, const void* owner)
+    // `off`: the owner's "I have stopped using the kernel" flag (a pool whose hand-over gave up serves its model with
+    // k_mfma from then on): a hold whose owner has raised it is void, the next pool that asks takes the device over
+    struct Hold { const void* owner = nullptr; int refs = 0; const std::atomic<bool>* off = nullptr; } dev[64];
+    bool acquire(int device, const void* owner, const std::atomic<bool>* off = nullptr)
     {
         if (device < 0 || device >= 64) return false;
         std::lock_guard<std::mutex> g(mu);
         Hold& h = dev[device];
-        if (h.refs != 0 && h.owner != owner) return false;
+        if (h.refs != 0 && h.owner != owner) {
+            if (!(h.off && h.off->load(std::memory_order_relaxed))) return false;
+            h.refs = 0;                                    // (the old owner's later release() no longer matches and is ignored)
+        }
         h.owner = owner;
+        h.off = off;
         ++h.refs;
         return true;
     }
@@ -94,7 +100,7 @@ struct LpGate {
         if (device < 0 || device >= 64) return;
         std::lock_guard<std::mutex> g(mu);
         Hold& h = dev[device];
-        if (h.owner == owner && h.refs > 0 && --h.refs == 0) h.owner = nullptr;
+        if (h.owner == owner && h.refs > 0 && --h.refs == 0) { h.owner = nullptr; h.off = nullptr; }
     }
 };
 LpGate& lp_gate() { static LpGate g; return g; }
@@ -208,9 +214,10 @@ struct aidax_pool {
     bool take_lp_fault()
     {
         if (!h_lp_fault) return false;
-        volatile uint32_t* w = h_lp_fault;
-        if (*w == 0) return false;
-        *w = 0;
+        // read-and-clear in ONE atomic step: workgroups bump the word with system-scope atomic adds while we look, and a
+        // give-up that landed between a read and a separate store of 0 would go unreported
+        if (__atomic_load_n(h_lp_fault, __ATOMIC_RELAXED) == 0) return false;
+        if (__atomic_exchange_n(h_lp_fault, 0u, __ATOMIC_ACQ_REL) == 0) return false;
         lp_off.store(true, std::memory_order_relaxed);
         lp_faults.fetch_add(1, std::memory_order_relaxed);
         return true;
@@ -598,7 +605,7 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
     // (a one-layer model has no hand-over and nothing to wait for: no hold on the device's gate needed)
     const bool lp_chained = ms.mdesc.n_layers >= 2;
     if (ms.kind == ModelSlot::MFMA && mfma_lp_serves(ms.mdesc) && lp_pays && !(lp_chained && p.lp_off.load()) &&
-        mfma_lp_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024 && (!lp_chained || lp_gate().acquire(p.device, &p))) {
+        mfma_lp_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024 && (!lp_chained || lp_gate().acquire(p.device, &p, &p.lp_off))) {
         if (lp_chained) ms.lp_owner = &p;
         HIP_TRY(hipMalloc(&ms.d_ring, mfma_lp_ring_bytes(ms.mdesc, p.n_streams)));
         HIP_TRY(hipMalloc(&ms.d_counters, mfma_lp_counter_bytes(ms.mdesc, p.n_streams)));

@@ -88,6 +88,7 @@ struct Plugin {
     bool strict = true;              // only the reference's 54 architectures (AIDAX_STRICT_REFERENCE_SET=0 lifts it)
     uint32_t max_frames = 8192;      // of this instance's pool: longer host blocks are processed in chunks
     uint32_t error_count = 0;
+    uint32_t sliced_n = 0, slice_len = 0;   // hub mode: the slice length chosen for host blocks of sliced_n frames (run())
     aidax_hub* hub = nullptr;
     int32_t slot = -1;
 
@@ -413,16 +414,23 @@ void run(LV2_Handle instance, uint32_t n_samples)
         } while (rc == AIDAX_OK && done < n_samples);
     } else if (self->hub) {
         // A host block longer than the hub's blocks (offline renders: 4096, 8192 frames) goes through in slices; coming
-        // around again closes the period per slice, so each slice returns the result of the slice before it. Equal
-        // slices where the length divides (the hub hands a block's result back only for a block of the same length).
+        // around again closes the period per slice, so each slice returns the result of the slice before it. The hub hands
+        // a block's result back only to a block of the SAME length, so every slice of every call must be equally long:
+        // the largest divisor of the host's block length that fits (4097 = 17 x 241 -> 241-frame slices; a prime length
+        // ends up at one frame per slice — slow, but every sample is delivered, one slice late).
         const uint32_t cap = aidax_hub_max_frames(self->hub);
         if (n_samples <= cap || cap == 0) {
             rc = aidax_hub_run(self->hub, self->slot, self->in, self->out_1, n_samples);
         } else {
-            const uint32_t k = (n_samples + cap - 1) / cap;
-            const uint32_t slice = n_samples % k == 0 ? n_samples / k : cap;
+            if (self->sliced_n != n_samples) {
+                uint32_t k = (n_samples + cap - 1) / cap;
+                while (n_samples % k != 0) ++k;                                                // k <= n_samples: ends
+                self->sliced_n = n_samples;
+                self->slice_len = n_samples / k;
+            }
+            const uint32_t slice = self->slice_len;
             for (uint32_t done = 0; done < n_samples && rc == AIDAX_OK; done += slice)
-                rc = aidax_hub_run(self->hub, self->slot, self->in + done, self->out_1 + done, std::min(slice, n_samples - done));
+                rc = aidax_hub_run(self->hub, self->slot, self->in + done, self->out_1 + done, slice);
         }
     } else if (n_samples != 0) {
         // hub mode before the first model: the master gain rests at 0 (:306-310), a disabled plugin copies (:612-619)

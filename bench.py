@@ -83,9 +83,10 @@ def dist_env():
     return rank, world, local
 
 
-def reduce_results(elapsed_s: float, samples: float, world: int, backend_device="cuda"):
-    """MAX(elapsed) and SUM(samples) over ranks — the only collective of the path."""
-    if world == 1:
+def reduce_results(elapsed_s: float, samples: float, world: int, backend_device="cuda", force=False):
+    """MAX(elapsed) and SUM(samples) over ranks — the only collective of the path.
+    force: go through the process group even at world size 1 (--force-dist: the RCCL branch on a one-GPU box)."""
+    if world == 1 and not force:
         return elapsed_s, samples
     import torch
     import torch.distributed as dist
@@ -348,8 +349,9 @@ def measure(ax, W, torch, name, S, steps, warmup, rank, world, local, check, lau
     for i in range(warmup):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    in_group = dist.is_available() and dist.is_initialized()       # N > 1, or --force-dist at N = 1
+    if in_group:
         dist.barrier()
         torch.cuda.synchronize()
 
@@ -360,7 +362,7 @@ def measure(ax, W, torch, name, S, steps, warmup, rank, world, local, check, lau
         step(i)
     ev1.record(launch_stream)
     torch.cuda.synchronize()
-    if world > 1:
+    if in_group:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -440,9 +442,13 @@ def main():
     ap.add_argument("--share-device", action="store_true",
                     help="rank plumbing with the real kernels on a box with fewer GPUs than ranks: every rank runs on device 0, "
                          "the reduction goes over gloo; the line says so and is no scaling measurement")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the N > 1 code path whatever N is: ranks started under torch.distributed.run from the GPU-less parent, "
+                         "init_process_group('nccl'), the reductions as RCCL collectives on cuda tensors, cfg4 / cfg5 regions per rank "
+                         "(--gpus 1 --force-dist is how the multi-GPU branch runs on a one-GPU box)")
     args = ap.parse_args()
 
-    if "RANK" not in os.environ and args.gpus > 1:
+    if "RANK" not in os.environ and (args.gpus > 1 or args.force_dist):
         # before anything touches the GPU: this process only starts the ranks and relays their line
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     if args.dry_run:
@@ -457,7 +463,8 @@ def main():
     if args.share_device:
         local = 0
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.share_device:
@@ -475,9 +482,9 @@ def main():
     m = measure(ax, W, torch, args.workload, S, args.steps, args.warmup, rank, world, local, not args.no_check, launch_stream)
     samples = float(S) * N_FRAMES * args.steps
     red_dev = "cpu" if args.share_device else "cuda"
-    elapsed_max, samples_all = reduce_results(m["elapsed"], samples, world, backend_device=red_dev)
+    elapsed_max, samples_all = reduce_results(m["elapsed"], samples, world, backend_device=red_dev, force=use_dist)
     rank_elapsed = [m["elapsed"]]
-    if world > 1:
+    if use_dist:
         mine = torch.tensor([m["elapsed"]], dtype=torch.float64, device=red_dev)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
@@ -487,14 +494,14 @@ def main():
     # and reduced like the headline (not with --share-device: ranks that share one GPU are rank plumbing, and two
     # processes cannot both hold the CUs k_mfma_lp needs)
     multi_others = []
-    if world > 1 and not args.no_others and not args.share_device:
+    if use_dist and not args.no_others and not args.share_device:
         for name in ("cfg4", "cfg5"):
             if name == args.workload:
                 continue
             So, steps = WORKLOADS[name]["streams"], OTHER_STEPS[name]
             r = measure(ax, W, torch, name, So, steps, max(10, steps // 10), rank, world, local, not args.no_check, launch_stream,
                         preroll_s=0.15)
-            e_max, n_all = reduce_results(r["elapsed"], float(So) * N_FRAMES * steps, world, backend_device=red_dev)
+            e_max, n_all = reduce_results(r["elapsed"], float(So) * N_FRAMES * steps, world, backend_device=red_dev, force=use_dist)
             multi_others.append((name, So, steps, r, e_max, n_all))
 
     if rank == 0:
@@ -502,7 +509,7 @@ def main():
         hbm, comp = rooflines(args.workload, S, m["kernel_ms"], m["kernel"])
         traffic, how = None, None
         if args.workload == "cfg2" and S == wl["streams"] and not args.no_traffic and "+" not in m["kernel"]:
-            if world == 1:
+            if not use_dist:
                 traffic, how = measure_traffic_live(args.workload, m["kernel"], 4.0 * S * N_FRAMES), "measured by this run"
             if traffic is None:
                 traffic, how = pmc_traffic_bytes(m["kernel"], 4.0 * S * N_FRAMES), "committed profile of the same kernel sources, not measured in this run"
@@ -524,7 +531,7 @@ def main():
             "roofline_compute": comp,
             "preroll_ms": m["preroll_ms"],
             "max_abs_err": m["max_err"],
-            "ranks": {"world_size": world, "backend": ("gloo" if args.share_device else "nccl (RCCL)") if world > 1 else None,
+            "ranks": {"world_size": world, "backend": ("gloo" if args.share_device else "nccl (RCCL)") if use_dist else None,
                       "elapsed_s": rank_elapsed, "collective": "all_reduce MAX(elapsed) + SUM(samples), all_gather(elapsed): after the timed region only"},
         }
         if wl["bound"] == "mfma":
@@ -532,7 +539,7 @@ def main():
         if args.share_device:
             out["share_device"] = True                        # all ranks on device 0: the rank plumbing with real kernels, not a scaling number
             out["config"]["note"] = f"{world} ranks share ONE GPU (--share-device): no scaling measurement"
-        if world == 1 and not args.no_others:
+        if not use_dist and not args.no_others:
             others = []
             for name in ("cfg3", "cfg4", "cfg5"):
                 if name == args.workload:
@@ -569,7 +576,7 @@ def main():
                                                "scaling": "weak", "roofline": c2 if WORKLOADS[name]["bound"] == "mfma" else h2,
                                                "roofline_compute": c2, "max_abs_err": r["max_err"]})
 
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()       # RCCL prints its banner on teardown: keep the JSON line last
     if rank == 0:
         # RCCL writes its version banner to stdout through C stdio (it would otherwise surface at exit, after

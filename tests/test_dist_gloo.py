@@ -112,3 +112,43 @@ def test_two_ranks_with_the_real_kernels_on_one_gpu():
     assert j["n_gpus"] == 2 and j["share_device"] is True and j["steps"] == 40
     assert j["value"] > 1e8 and j["max_abs_err"] < 1e-6
     assert j["config"]["streams_per_gpu"] == 1024 and "no scaling measurement" in j["config"]["note"]
+
+
+def test_force_dist_takes_the_rank_path_at_world_size_one():
+    """`bench.py --gpus 1 --force-dist --dry-run`: the parent starts ONE rank under torch.distributed.run and relays its
+    line — the launcher half of the N > 1 path at world size 1 (the GPU half: the test below)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--dry-run", "--steps", "3",
+                          "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["dry_run"] is True and out["config"]["stream_ranges"] == [[0, 1024]]
+
+
+@pytest.mark.gpu
+def test_the_rccl_branch_runs_at_world_size_one():
+    """The multi-GPU code path of bench.py executed on the one GPU of the box: the GPU-less parent starts its rank under
+    torch.distributed.run, the rank joins an `nccl` (= RCCL) process group NEXT TO libaidax_hip.so in one process, runs the
+    real pools (headline + the cfg4 / cfg5 regions every rank of an N > 1 run measures), and the reductions — all_reduce
+    MAX(elapsed) / SUM(samples), all_gather(elapsed) — are RCCL collectives on cuda tensors. Instances share nothing
+    (rt-neural-generic.h:198-239), so this is all the communication an 8-GPU run has."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "200", "--warmup", "20",
+                        "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["ranks"]["world_size"] == 1 and j["ranks"]["backend"] == "nccl (RCCL)"
+    assert len(j["ranks"]["elapsed_s"]) == 1 and j["ranks"]["elapsed_s"][0] > 0
+    assert j["value"] > 1e9 and j["max_abs_err"] < 1e-6
+    names = [o["workload"][:4] for o in j["other_workloads"]]
+    assert names == ["cfg4", "cfg5"] and all(o["n_gpus"] == 1 and o["value"] > 1e8 for o in j["other_workloads"])
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "bench_1rank_rccl.json"), "w") as f:
+            f.write(lines[0] + "\n")

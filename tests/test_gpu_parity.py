@@ -480,10 +480,74 @@ def test_long_run_drift_48000_samples(tmp_path):
     _chain_case(tmp_path, "drift", dict(kind="lstm", hidden=32, input_size=1, seed=32), {}, S=2, n=48128, block=256)
 
 
-# ------------------------------------------------------- properties at full size
 
 _EQ_POST = dict(bass_boost_db=4.0, mid_boost_db=-3.0, mid_q=1.2, treble_boost_db=2.0, depth_boost_db=3.0,
                 presence_boost_db=3.0, param1=0.5, param2=0.3)
+
+
+def _long_run(tmp_path, name, model_kw, S, distinct, kernel, tag, tol, n=48128, block=256, ramp=False, ckw=None):
+    """>= one second of audio through a many-streams launch form: `distinct` different streams spread over a pool of S
+    (neighbours in a workgroup carry different signals), every block against per-stream oracle plugins, controls moving
+    from block to block when `ramp` (PARAM1 0 -> 1, PARAM2 1 -> 0.3 over the run). The reference's bar is 1e-5 on whatever
+    the host plays (TEST_MODEL_THR, rt-neural-generic.h:182); the bound asserted is `tol`, the measured error is logged."""
+    path, spec = _model_file(tmp_path, name, **model_kw)
+    base = modelgen.signal(distinct, n, seed=404)
+    idx = (np.arange(S) * 7) % distinct
+    first = [int(np.argmax(idx == k)) for k in range(distinct)]        # one pool row per distinct stream
+    pool = ax.Pool(S, block)
+    pool.set_model(ax.Model(path))
+    plugs = []
+    for _ in range(distinct):
+        p = O.OraclePlugin()
+        p.set_model(O.OracleModel(spec))
+        plugs.append(p)
+    ckw = dict(ckw or {})
+    worst, nblk = 0.0, n // block
+    for bi in range(nblk):
+        b = bi * block
+        kw = dict(ckw)
+        if ramp:
+            t = bi / (nblk - 1)
+            kw.update(param1=float(t), param2=float(1.0 - 0.7 * t))
+        if ramp or bi == 0:
+            pool.set_controls(ax.default_controls(**kw))
+        got = pool.process(np.ascontiguousarray(base[idx, b:b + block]))
+        if bi == 0:
+            assert pool.kernel_name.startswith(kernel), pool.kernel_name
+        co = O.default_controls(**kw)
+        for k in range(distinct):
+            want = plugs[k].run(co, base[k, b:b + block])
+            worst = max(worst, float(np.abs(got[first[k]] - want).max()))
+        if bi % 47 == 0:                                               # copies of a stream stay bitwise identical all the way
+            for k in range(distinct):
+                grp = got[idx == k]
+                assert np.all(grp == grp[0]), (name, bi, k)
+    pool.close()
+    assert worst < THR, (name, worst)                                  # the reference's own bar, whatever else
+    errlog.bound(worst, tol, tag)
+
+
+def test_long_run_drift_gru64_conditioned_on_the_gate_major_kernel(tmp_path):
+    """cfg3's kernel (k_gru_gm: gate-major tiles, candidate tanh in the four-instruction exp form) over 48 128 samples with
+    both PARAM inputs ramping and the EQ in circuit: the exp form's absolute error must not accumulate in h."""
+    _long_run(tmp_path, "drift_gru64", dict(kind="gru", hidden=64, input_size=3, seed=64), S=4096, distinct=16,
+              kernel="k_gru_gm", tag="gpu_parity:drift_gru64_gm", tol=4e-6, ramp=True, ckw=_EQ_POST)
+
+
+def test_long_run_drift_lstm96x2_on_the_layer_pipelined_kernel(tmp_path):
+    """cfg5's kernel (k_mfma_lp, two layers of 96 on separate workgroups) over 48 128 samples at cfg5's pool size."""
+    _long_run(tmp_path, "drift_lstm96x2", dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2), S=2048, distinct=8,
+              kernel="k_mfma_lp", tag="gpu_parity:drift_lstm96x2_lp", tol=4e-6)
+
+
+def test_long_run_drift_small_gru_on_the_pipeline_kernel(tmp_path):
+    """The three-wave pipeline's GRU cell (the exp-form candidate went into every GRU kernel) over 48 128 samples,
+    PARAM1 ramping."""
+    _long_run(tmp_path, "drift_gru16", dict(kind="gru", hidden=16, input_size=2, seed=16), S=1024, distinct=16,
+              kernel="k_gru_pipe", tag="gpu_parity:drift_gru16_pipe", tol=4e-6, ramp=True)
+
+
+# ------------------------------------------------------- properties at full size
 
 
 @pytest.mark.parametrize("name,kw,S,ckw,kernel", [

@@ -225,3 +225,41 @@ def test_hub_mode_three_instances_share_launches(bundle, monkeypatch):
             prev[i] = plugs[i].run(_oracle_controls(h), x[i, blk])
     for h in hosts:
         h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [600, 777, 601])
+def test_hub_mode_host_blocks_longer_than_the_hubs_go_through_in_equal_slices(bundle, monkeypatch, n):
+    """Hub blocks of 256 frames, host blocks of n > 256 that 256 does not divide: the shell must cut every call into
+    slices of ONE length (the hub hands a result back only to a block of the same length) — 600 -> 3 x 200, 777 -> 7 x
+    111, 601 (prime) -> 601 x 1. The output is the oracle's, one slice late, with no silent stretch after the first slice.
+    (Round 3 cut 601 into 256 + 256 + 89 and delivered silence for most of every block.)"""
+    monkeypatch.setenv("AIDAX_HUB", "2")
+    monkeypatch.setenv("AIDAX_HUB_FRAMES", "256")
+    monkeypatch.setenv("AIDAX_HUB_DEADLINE_US", "0")
+    clean = os.path.join(bundle, "models/deer ink studios/tw40_california_clean_deerinkstudios.json")
+    h = lv2host.Host(bundle_dir=bundle, block=n)
+    assert h.handle
+    h.send_patch_set(clean)
+    h.run(np.zeros(0, np.float32))
+    h.clear_control()
+    assert h.pump_worker() == 1 and h.deliver_responses() == 1
+    h.pump_worker()
+    h.run(np.zeros(0, np.float32))
+    k = -(-n // 256)
+    while n % k:
+        k += 1
+    L = n // k
+    p = O.OraclePlugin()
+    p.set_model(O.OracleModel(O.load_model(clean), 0.0, 0.0))
+    p.activate()
+    p.set_loading(False)
+    blocks = 4
+    x = modelgen.signal(1, n * blocks, seed=77)[0]
+    got = np.concatenate([h.run(x[b * n:(b + 1) * n]) for b in range(blocks)])
+    want = np.concatenate([p.run(_oracle_controls(h), x[o:o + L]) for o in range(0, n * blocks, L)])
+    assert np.all(got[:L] == 0)                               # the first slice: nothing computed yet
+    err = np.abs(got[L:] - want[:-L]).max()
+    assert err < THR * 2, (n, L, err)
+    assert np.abs(want[:-L]).max() > 1e-3                     # (and it is not silence that was compared)
+    h.close()

@@ -73,6 +73,7 @@ bool is_conv_model(const aidax_model& m);
 std::vector<float> pack_stack(const aidax_model& m, StackDesc* d, uint32_t* state_floats);
 bool mfma_form_fits(const aidax_model& m);    // recurrent layers of one width, a multiple of 16 and <= 128
 std::vector<float> pack_mfma(const aidax_model& m, MfmaDesc* d, uint32_t* state_floats);
+void split_bf16x3(float x, uint16_t (&terms)[3]);     // x = t0 + t1 + t2 exactly, each a bf16 (k_gru_gs's weights; the kernel splits h the same way)
 std::vector<float> pack_quad(const aidax_model& m, uint32_t* bias_off, uint32_t* dense_off);   // table models only
 std::vector<float> pack_q4(const aidax_model& m);       // LSTM-32, one input: the record k_lstm_q4 reads
 std::vector<float> pack_conv(const aidax_model& m, ConvDesc* d, uint32_t* state_floats);

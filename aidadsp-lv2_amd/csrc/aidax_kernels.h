@@ -44,6 +44,11 @@ size_t mfma_lp_counter_bytes(const MfmaDesc& d, uint32_t n_streams);
 bool gru_gm_serves(const MfmaDesc& d);
 size_t gru_gm_lds_bytes(const MfmaDesc& d, uint32_t n_frames);
 hipError_t launch_gru_gm_kernel(const LaunchArgs& a, const MfmaDesc& d, hipStream_t stream);
+// k_gru_gs (aidax_mfmalp.hip): k_gru_gm with the recurrent product as bf16 MFMAs of operands split exactly into three bf16
+// terms; n_products: 6 (to fp32 rounding) or 9 (every term product)
+bool gru_gs_serves(const MfmaDesc& d);
+size_t gru_gs_lds_bytes(const MfmaDesc& d, uint32_t n_frames);
+hipError_t launch_gru_gs_kernel(const LaunchArgs& a, const MfmaDesc& d, int n_products, hipStream_t stream);
 hipError_t launch_mfma_lp_kernel(const LaunchArgs& a, const MfmaDesc& d, float* ring, uint32_t* counters, uint32_t* fault, hipStream_t stream, bool fused = false);
 // k_lstm_q4 (aidax_q4.hip): LSTM-32 snapshot models, four streams per workgroup, the whole run() in one launch
 bool q4_serves(int cell, int hidden, int input_size);

@@ -188,7 +188,8 @@ struct MfmaDesc {
     int32_t n_layers, hidden, tpw, waves;      // hidden = the kernel's width: the model's rounded up to 16 (zero rows / columns)
     int32_t hidden_true;                       // the model's width: layout of the recurrent state in HBM (h[.] then c[.])
     uint32_t gm_off;                           // one-layer GRU: offset of the gate-major record k_gru_gm reads (0: none), see pack_mfma
-    int32_t pad[2];
+    uint32_t gs_off;                           // ... and of its bf16 x 3 twin k_gru_gs reads (recurrent weights as split bf16 fragments)
+    int32_t pad[1];
     MfmaLayer L[kMaxStackLayers];
     uint32_t wd_off, bd_off;
 };

@@ -1092,6 +1092,219 @@ __global__ __launch_bounds__((UT + NHELP) * kWave) void k_gru_gm(LaunchArgs a, M
     }
 }
 
+
+// ================================================================ k_gru_gs: k_gru_gm with the recurrent product on the bf16 matrix pipe
+// What round 4 measured (scratch/uoverlap2.hip, uoverlap3.hip, profiles/r04_overlap.txt): v_mfma_f32_16x16x4_f32 runs at the
+// VECTOR rate (32 cycles for 1024 MACs) and nothing else of the SIMD issues beside it — a VALU instruction behind an fp32 MFMA
+// costs its full issue time whatever accumulator it touches, one wave or two; v_mfma_f32_16x16x32_bf16 does 8192 MACs in ~17
+// cycles and hides up to six VALU instructions in its shadow. So the recurrent product U . h(t-1) is computed here from
+// operands split EXACTLY into three bf16 terms each (w = w0 + w1 + w2, h = h0 + h1 + h2; 8 + 8 + 8 significant bits,
+// round-to-nearest remainders): every bf16 x bf16 product is exact in fp32, the accumulation is fp32 as before, and of the
+// nine term products NPROD are issued, smallest first — 9: the fp32 product to the last bit of its operands; 6: without
+// w1 h2, w2 h1, w2 h2 (together <= 2^-23 |w h|: below the rounding of the fp32 accumulation that follows). Per wave and
+// frame: 3 gates x 2 k-steps x NPROD bf16 MFMAs (36 x 17 cycles for NPROD = 6) instead of 48 fp32 MFMAs x 32.
+// The weights arrive split from the packer (pack_mfma, gs record); a lane splits its own four h values after the cell update
+// (v_cvt_pk_bf16_f32 rounds to nearest even; the remainders are exact) and writes them where the k-steps read them: h lives
+// in LDS as B fragments [parity][term][k-step][lane][8 bf16], one ds_read_b128 per (term, k-step). The model inputs stay one
+// fp32 k-step (x, PARAM1, PARAM2 are not products of h), Dense(H,1) is four FMAs on the lane's own h and two permlane swaps.
+// Everything else — tiles, helper waves, barriers, the per-frame order of work — is k_gru_gm's.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline size_t gs_lds_floats(int hidden, int n_frames, int n_helpers)
+{
+    const size_t nP = (size_t)(((n_frames < kLpChunk ? n_frames : kLpChunk) + 3) & ~3);
+    const size_t ks2 = (size_t)(hidden + 31) / 32;
+    return (size_t)kMfmaStreams * nP + 2 * 64 + 2 * 3 * ks2 * 64 * 4 /* h fragments */ + (size_t)((hidden + 1 + 3) & ~3) + kMfmaStreams
+         + 2 * 8 * kMfmaStreams + (size_t)n_helpers * 2 * kChainHandFloats
+#ifdef AIDAX_LP_TRACE
+         + 2048
+#endif
+         ;
+}
+
+// a, b -> (bf16(a) | bf16(b) << 16), round to nearest even
+__device__ __forceinline__ unsigned gs_pack_bf16(float a, float b)
+{
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 v = { static_cast<__bf16>(a), static_cast<__bf16>(b) };
+    return __builtin_bit_cast(unsigned, v);
+}
+// four fp32 values -> three terms of four bf16 each (term t: two dwords), v = t0 + t1 + t2 exactly
+__device__ __forceinline__ void gs_split4(const float (&v)[4], u32x2 (&t)[3])
+{
+    float r[4] = { v[0], v[1], v[2], v[3] };
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const unsigned p01 = gs_pack_bf16(r[0], r[1]), p23 = gs_pack_bf16(r[2], r[3]);
+        t[k] = u32x2{ p01, p23 };
+        if (k < 2) {
+            r[0] -= __builtin_bit_cast(float, p01 << 16);
+            r[1] -= __builtin_bit_cast(float, p01 & 0xffff0000u);
+            r[2] -= __builtin_bit_cast(float, p23 << 16);
+            r[3] -= __builtin_bit_cast(float, p23 & 0xffff0000u);
+        }
+    }
+}
+
+template <int UT, int NHELP, int NPROD>
+__global__ __launch_bounds__((UT + NHELP) * kWave) void k_gru_gs(LaunchArgs a, MfmaDesc d)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int H = 16 * UT, NW = UT, NS = kMfmaStreams, NT = NW * kWave;
+    constexpr int KS2 = (H + 31) / 32;                      // bf16 k-steps (32 columns each; GRU-48: the second one half empty)
+    constexpr int kFrag = 3 * KS2 * 64;                     // 16-byte B fragments of one parity: [term][k-step][lane]
+    static_assert(NPROD == 6 || NPROD == 9, "six products (to fp32 rounding) or all nine");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = (int)a.n_frames;
+    const int grp = (int)blockIdx.x;
+    const int s_base = grp * NS;
+    const int Ht = d.hidden_true;
+    const int chunk = n < kLpChunk ? n : kLpChunk;
+    const int nP = (chunk + 3) & ~3;
+    float* xb    = smem;                                    // [NS][nP] audio rows
+    float* xin   = xb + NS * nP;                            // [2][4][NS] model inputs of a frame
+    u32x4* hB    = reinterpret_cast<u32x4*>(xin + 2 * 64);  // [2][3][KS2][64] h(t-1) as B fragments of the bf16 k-steps
+    float* wdl   = reinterpret_cast<float*>(hB + 2 * kFrag);// Dense weights, bias at [H]
+    float* livef = wdl + ((H + 1 + 3) & ~3);                // [NS]
+    float* dpart = livef + NS;                              // [2][8][NS] Dense partial sums of the waves
+    float* hands = dpart + 2 * 8 * NS;
+    if (wave >= NW) {
+        lp_helper<H, NW, NHELP>(a, xb, xin, wdl, livef, dpart, hands, grp, nP);
+        return;
+    }
+    const float* W = a.wpack;
+    const MfmaLayer& L = d.L[0];
+    const int q = lane >> 4, c = lane & 15;
+    for (int i = tid; i < H + 1; i += NT) wdl[i] = W[d.wd_off + i];
+    // the fp32 pieces of the gate-major record: input k-step and bias rows
+    constexpr int KS = H / 4;
+    const float* rec = W + d.gm_off + (size_t)wave * kWave * (3 + 3 * KS + 16);
+    float w_in[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) w_in[g] = rec[g * kWave + lane];
+    f32x4 bias[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias[g] = *reinterpret_cast<const f32x4*>(rec + (3 + 3 * KS) * kWave + (g * kWave + lane) * 4);
+    // the recurrent weights as split bf16 A fragments: [gate][k-step][term]
+    bf16x8 wq[3][KS2][3];
+    {
+        const u32x4* sp = reinterpret_cast<const u32x4*>(W + d.gs_off) + (size_t)wave * 3 * KS2 * 3 * kWave + lane;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) wq[g][ks][t] = __builtin_bit_cast(bf16x8, sp[((g * KS2 + ks) * 3 + t) * kWave]);
+    }
+    float dw[4];                                            // Dense weights of this lane's four units
+    // h(t-1) of this lane's four units (16 wave + 4q + e) of stream s_base + c: registers for the launch
+    const int sg = s_base + c;
+    const bool valid = sg < (int)a.n_streams;
+    const float* stp = a.nn + (size_t)(valid ? sg : 0) * a.nn_stride + L.state_off;
+    float hreg[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int u = 16 * wave + 4 * q + e;
+        hreg[e] = (valid && u < Ht) ? stp[u] : 0.f;         // padded units rest at 0
+        dw[e] = W[d.wd_off + u];                            // (zero for padded units)
+    }
+    // where this lane's four values sit in the fragments: k = 16 wave + 4q + e -> k-step wave / 2, lane row 2 (wave & 1) + q / 2,
+    // elements 4 (q & 1) .. + 3 of that lane's eight: the upper or lower 8 bytes of its 16
+    const int my_slot = (wave >> 1) * 64 + (2 * (wave & 1) + (q >> 1)) * 16 + c;
+    const int my_half = q & 1;
+    auto publish = [&](int parity) {
+        u32x2 t[3];
+        gs_split4(hreg, t);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            reinterpret_cast<u32x2*>(hB + parity * kFrag + k * KS2 * 64 + my_slot)[my_half] = t[k];
+    };
+    if constexpr (H % 32 != 0) {                            // GRU-48: columns 48..63 of the second k-step (lane rows 2, 3) are nobody's: zero, for good
+        for (int i = tid; i < 2 * 3 * 32; i += NT)
+            hB[(i / 32) * KS2 * 64 + (KS2 - 1) * 64 + 32 + (i & 31)] = u32x4{ 0u, 0u, 0u, 0u };
+    }
+    publish(0);
+    __syncthreads();                                        // (1)
+
+    int par = 0;
+    for (int base = 0; base < n; base += kLpChunk) {
+        const int cnt = n - base < kLpChunk ? n - base : kLpChunk;
+        for (int sl = wave; sl < NS; sl += NW) {            // every valid row: the chains run on net-off streams too
+            const int s2 = s_base + sl;
+            const bool lv = s2 < (int)a.n_streams;
+            float* row = xb + sl * nP;
+            const float* src = a.in + (size_t)(lv ? s2 : 0) * n + base;
+            if (lv && ((n | base) & 3) == 0) load_block(row, src, cnt, lane);
+            else for (int t = lane; t < cnt; t += kWave) row[t] = lv ? src[t] : 0.f;
+        }
+        __syncthreads();                                    // (2)
+        __syncthreads();                                    // (3) the helpers have run the head of the pre pass and written frame 0's inputs
+        const int ticks = cnt + 2;
+        for (int tick = 0; tick < ticks; ++tick) {
+            if (tick >= 1 && tick <= cnt) {                 // Dense of frame tick-1 from the lane's own h(tick-1): units summed in a fixed order
+                float y = dw[0] * hreg[0];
+                y = __builtin_fmaf(dw[1], hreg[1], y);
+                y = __builtin_fmaf(dw[2], hreg[2], y);
+                y = __builtin_fmaf(dw[3], hreg[3], y);
+                const Pair r2 = share_rows(y);              // rows q and q ^ 1
+                y = r2.lo + r2.hi;
+                const Pair r4 = share_halves(y);            // ... and the other half of the wave
+                y = r4.lo + r4.hi;
+                if (lane < NS) dpart[((tick & 1) * NW + wave) * NS + lane] = y;
+            }
+            if (tick < cnt) {
+                const u32x4* h_rd = hB + par * kFrag + lane;
+                bf16x8 hb[KS2][3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int ks = 0; ks < KS2; ++ks) hb[ks][t] = __builtin_bit_cast(bf16x8, h_rd[(t * KS2 + ks) * 64]);
+                f32x4 acc[3] = { bias[0], bias[1], bias[2] };
+                f32x4 ax = bias[3];
+                const float bx = xin[(tick & 1) * 64 + lane];
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_in[0], bx, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_in[1], bx, acc[1], 0, 0, 0);
+                ax = __builtin_amdgcn_mfma_f32_16x16x4f32(w_in[2], bx, ax, 0, 0, 0);
+                // term products, smallest first: (weight term, h term)
+                constexpr int P9[9][2] = { {2, 2}, {1, 2}, {2, 1}, {0, 2}, {1, 1}, {2, 0}, {0, 1}, {1, 0}, {0, 0} };
+#pragma unroll
+                for (int pi = 9 - NPROD; pi < 9; ++pi)
+#pragma unroll
+                    for (int ks = 0; ks < KS2; ++ks)
+#pragma unroll
+                        for (int g = 0; g < 3; ++g)
+                            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[g][ks][P9[pi][0]], hb[ks][P9[pi][1]], acc[g], 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gz = sigmoid_pre(acc[0][e]), gr = sigmoid_pre(acc[1][e]);
+                    const float nn = tanh_exp_pre(__builtin_fmaf(gr, acc[2][e], ax[e]));      // (the record's candidate rows carry 2 log2 e)
+                    hreg[e] = __builtin_fmaf(gz, hreg[e] - nn, nn);
+                }
+                par ^= 1;
+                publish(par);
+            }
+            __syncthreads();                                // the tick's barrier
+        }
+        __syncthreads();                                    // (4) the helpers have stored the rows
+    }
+#ifdef AIDAX_LP_TRACE
+    if ((int)blockIdx.x == ((a.tune >> 16) & 0xff)) __syncthreads();
+#endif
+    __syncthreads();                                        // (5)
+    if (valid && livef[c] != 0.f) {
+        float* dst = a.nn + (size_t)sg * a.nn_stride + L.state_off;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int u = 16 * wave + 4 * q + e;
+            if (u < Ht) dst[u] = hreg[e];
+        }
+    }
+}
+
 // ---------------------------------------------------------------- host side
 typedef void (*LpFn)(LaunchArgs, MfmaDesc, float*, uint32_t*, uint32_t*);
 // Helper waves of the one-launch form: a third wave per SIMD must fit next to the main waves' registers (512 per SIMD
@@ -1195,6 +1408,31 @@ hipError_t launch_gru_gm_kernel(const LaunchArgs& a, const MfmaDesc& d, hipStrea
     GmFn fn = gm_fn(d.hidden);
     if (!fn || !gru_gm_serves(d) || a.mode != MODE_CHAIN || a.n_frames == 0) return hipErrorInvalidValue;
     const size_t lds = gru_gm_lds_bytes(d, a.n_frames);
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const uint32_t groups = (a.n_streams + kMfmaStreams - 1) / kMfmaStreams;
+    hipLaunchKernelGGL(fn, dim3(groups), dim3((d.hidden / 16 + kLpHelpers) * kWave), lds, stream, a, d);
+    return hipGetLastError();
+}
+
+// k_gru_gs: the same models as k_gru_gm, recurrent product on the bf16 matrix pipe (operands split into three bf16 terms)
+static GmFn gs_fn(int hidden, int nprod)
+{
+    switch (hidden) {
+    case 48: return nprod == 9 ? k_gru_gs<3, kLpHelpers, 9> : k_gru_gs<3, kLpHelpers, 6>;
+    case 64: return nprod == 9 ? k_gru_gs<4, kLpHelpers, 9> : k_gru_gs<4, kLpHelpers, 6>;
+    default: return nullptr;
+    }
+}
+bool gru_gs_serves(const MfmaDesc& d) { return gru_gm_serves(d) && d.gs_off != 0; }
+size_t gru_gs_lds_bytes(const MfmaDesc& d, uint32_t n_frames) { return gs_lds_floats(d.hidden, (int)n_frames, kLpHelpers) * sizeof(float); }
+hipError_t launch_gru_gs_kernel(const LaunchArgs& a, const MfmaDesc& d, int n_products, hipStream_t stream)
+{
+    GmFn fn = gs_fn(d.hidden, n_products);
+    if (!fn || !gru_gs_serves(d) || a.mode != MODE_CHAIN || a.n_frames == 0) return hipErrorInvalidValue;
+    const size_t lds = gru_gs_lds_bytes(d, a.n_frames);
     if (lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

@@ -1,6 +1,7 @@
 // aidax_pack.cpp — shuffles a model's Keras-layout weights into the register
 // order of the kernel's lane mapping (aidax_layout.h): record r of lane l is at
 // wpack[r*64 + l], so the kernel fills each weight VGPR with one coalesced read.
+#include <cmath>
 #include <cstring>
 #include <stdexcept>
 
@@ -160,6 +161,32 @@ bool mfma_form_fits(const aidax_model& m)
     return true;
 }
 
+// x = t[0] + t[1] + t[2] EXACTLY, each term a bf16 (bit pattern returned): t[0] = x rounded to nearest even, t[1] the
+// same of the remainder, t[2] the remainder of that — 8 + 8 + 8 significant bits, and a remainder of a round-to-nearest
+// is at most half an ulp, so |t[1]| <= 2^-8 |x| and |t[2]| <= 2^-16 |x|. (The kernels split h(t-1) the same way on the
+// device: v_cvt_pk_bf16_f32 rounds to nearest even.)
+void split_bf16x3(float x, uint16_t (&t)[3])
+{
+    auto rne = [](float v) -> uint16_t {
+        uint32_t u;
+        std::memcpy(&u, &v, sizeof u);
+        if ((u & 0x7f800000u) == 0x7f800000u) return static_cast<uint16_t>(u >> 16);      // inf / nan as they are
+        const uint32_t r = u + 0x7fffu + ((u >> 16) & 1u);
+        return static_cast<uint16_t>(((r & 0x7f800000u) == 0x7f800000u ? u : r) >> 16);     // (never round a finite value up to inf)
+    };
+    auto widen = [](uint16_t b) -> float {
+        const uint32_t u = static_cast<uint32_t>(b) << 16;
+        float f;
+        std::memcpy(&f, &u, sizeof f);
+        return f;
+    };
+    float r = x;
+    for (int i = 0; i < 3; ++i) {
+        t[i] = rne(r);
+        r = std::isfinite(r) ? r - widen(t[i]) : 0.f;                                      // exact (a file's inf / nan stays in the first term)
+    }
+}
+
 // A fragments of v_mfma_f32_16x16x4_f32 for k_mfma, layout in aidax_layout.h (MfmaLayer).
 std::vector<float> pack_mfma(const aidax_model& m, MfmaDesc* d, uint32_t* state_floats)
 {
@@ -277,6 +304,29 @@ std::vector<float> pack_mfma(const aidax_model& m, MfmaDesc* d, uint32_t* state_
                 for (int lane = 0; lane < kWave; ++lane)
                     for (int e = 0; e < 4; ++e) out.push_back(bias(16 * w + 4 * (lane >> 4) + e, g));
         }
+        // ... and a third record for k_gru_gs: the SAME recurrent weights (scaled as above) as A fragments of
+        // v_mfma_f32_16x16x32_bf16, every fp32 weight split exactly into three bf16 terms (split_bf16x3). The fp32 matrix
+        // instructions of gfx950 run at the vector rate and stall the SIMD's VALU issue while they do (profiles/r04_overlap.txt);
+        // the bf16 ones are sixteen times denser, so six (or all nine) bf16 products of the split operands cost less than the
+        // one fp32 product they reproduce. Per wave: [3 gates][ceil(H/32) k-steps][3 terms][64 lanes][8 bf16], lane supplies
+        // row (lane & 15) = unit 16 w + (lane & 15), columns k = 32 ks + 8 (lane >> 4) + i.
+        while (out.size() % 4) out.push_back(0.f);
+        d->gs_off = static_cast<uint32_t>(out.size());
+        const int KS2 = (H + 31) / 32;
+        for (int w = 0; w < H / 16; ++w)
+            for (int g = 0; g < 3; ++g)
+                for (int ks = 0; ks < KS2; ++ks)
+                    for (int term = 0; term < 3; ++term)
+                        for (int lane = 0; lane < kWave; ++lane)
+                            for (int i = 0; i < 8; i += 2) {
+                                uint16_t t0[3], t1[3];
+                                split_bf16x3(w_rec(16 * w + (lane & 15), g, 32 * ks + 8 * (lane >> 4) + i), t0);
+                                split_bf16x3(w_rec(16 * w + (lane & 15), g, 32 * ks + 8 * (lane >> 4) + i + 1), t1);
+                                const uint32_t pair = static_cast<uint32_t>(t0[term]) | (static_cast<uint32_t>(t1[term]) << 16);
+                                float f;
+                                std::memcpy(&f, &pair, sizeof f);
+                                out.push_back(f);
+                            }
     }
     *state_floats = st;
     return out;

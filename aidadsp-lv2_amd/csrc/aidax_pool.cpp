@@ -157,6 +157,7 @@ struct ModelSlot {
     const void* lp_owner = nullptr;  // the pool whose hold on the device's LpGate this slot shares (d_ring != nullptr)
     bool lp_fused = false;           // k_mfma_lp runs the DSP chain too (one-layer models, helper waves): one launch per block
     bool gru_gm = false;             // one-layer GRU: k_gru_gm (gate-major tiles, the whole run() in one launch) serves the passes
+    int gru_gs = 0;                  // ... as k_gru_gs (recurrent product on the bf16 matrix pipe, operands split into three bf16 terms): 6 or 9 term products; 0: the fp32 kernel
 
     float p_den() const { return 0.1f * model_sr; }      // LinearValueSmoother tau * sampleRate (:1053-1054)
 };
@@ -402,7 +403,7 @@ struct aidax_pool {
                                                             : launch_mfma_kernel(a, m.mdesc, s);
             };
             if (a.mode != MODE_CHAIN) return model_kernel();
-            if (m.gru_gm && a.n_frames != 0) return launch_gru_gm_kernel(a, m.mdesc, s);
+            if (m.gru_gm && a.n_frames != 0) return m.gru_gs ? launch_gru_gs_kernel(a, m.mdesc, m.gru_gs, s) : launch_gru_gm_kernel(a, m.mdesc, s);
             if (m.lp_fused && lp_in_use(m) && a.n_frames != 0)
                 return launch_mfma_lp_kernel(a, m.mdesc, m.d_ring, m.d_counters, hd_lp_fault, s, true);
             hipError_t e = launch_chain_pass(true, a, s);
@@ -614,8 +615,11 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
         ms.lp_fused = mfma_lp_fused_serves(ms.mdesc, p.max_frames) && !(fu && fu[0] == '0') && mfma_lp_lds_bytes(ms.mdesc, p.max_frames, true) <= 160 * 1024;
     }
     if (ms.kind == ModelSlot::MFMA) {
-        const char* gm = std::getenv("AIDAX_GRU_GM");        // (=0: the four-rows-per-unit kernels, A/B runs)
+        const char* gm = std::getenv("AIDAX_GRU_GM");        // (=0: the four-rows-per-unit kernels; =f32: k_gru_gm with fp32 MFMAs — A/B runs)
         ms.gru_gm = gru_gm_serves(ms.mdesc) && !(gm && gm[0] == '0') && gru_gm_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024;
+        const char* np = std::getenv("AIDAX_GS_PRODUCTS");   // (=9: every term product of the split operands instead of six)
+        ms.gru_gs = ms.gru_gm && gru_gs_serves(ms.mdesc) && !(gm && gm[0] == 'f') && gru_gs_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024
+                        ? (np && np[0] == '9' ? 9 : 6) : 0;
     }
     HIP_TRY(hipMemcpyAsync(ms.d_wpack, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice, p.wq));
     std::vector<float> wq4;                                // (lives until the stream has been waited for below)
@@ -1253,7 +1257,7 @@ AIDAX_API const char* aidax_pool_kernel_name(const aidax_pool* p)
     if (!(p && p->cur.has_model)) return "k_nomodel";
     const ModelSlot& m = p->cur;
     if (m.kind == ModelSlot::STACK) return "k_stack";
-    if (m.kind == ModelSlot::MFMA) return m.gru_gm ? "k_gru_gm" : !p->lp_in_use(m) ? "k_chain+k_mfma" : m.lp_fused ? "k_mfma_lp" : "k_chain+k_mfma_lp";
+    if (m.kind == ModelSlot::MFMA) return m.gru_gm ? (m.gru_gs ? "k_gru_gs" : "k_gru_gm") : !p->lp_in_use(m) ? "k_chain+k_mfma" : m.lp_fused ? "k_mfma_lp" : "k_chain+k_mfma_lp";
     if (m.kind == ModelSlot::QUAD) return "k_chain+k_quad";
     if (m.kind == ModelSlot::CONV) return m.conv_fused ? "k_conv_mfma" : m.conv_mfma ? "k_chain+k_conv_mfma" : "k_conv";
     const int form = p->chain_form(m);

@@ -213,10 +213,17 @@ __global__ __launch_bounds__(512) void k(Args A, long long* cyc, float* sink)
 {
     __shared__ float lds[4096];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ int simd[8];
     for (int i = threadIdx.x; i < 4096; i += 512) lds[i] = 1e-3f * i;
+    if (lane == 0) simd[wave] = (__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) >> 4) & 3;      // HW_ID.simd_id
     __syncthreads();
-    // nact = 1: wave 0 only; 2: waves 0 and 4 (one SIMD, two waves); 4: waves 0..3 (one per SIMD); 8: all
-    const bool act = A.nact == 8 || (A.nact == 4 && wave < 4) || wave == 0 || (A.nact == 2 && wave == 4);
+    // which wave really shares wave 0's SIMD (the first run of this file assumed wave 4: not true on every launch), and
+    // whether this wave is the second one on its SIMD
+    int partner = -1, slot = 0;
+    for (int w = 7; w >= 1; --w) if (simd[w] == simd[0]) partner = w;
+    for (int w = 0; w < wave; ++w) if (simd[w] == simd[wave]) slot = 1;
+    // nact = 1: wave 0 only; 2: wave 0 and its SIMD partner; 8: all
+    const bool act = A.nact == 8 || wave == 0 || (A.nact == 2 && wave == partner);
     const long long c0 = __builtin_readcyclecounter();
     float r = lane * 0.001f;
     const int it = A.iters;
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(512) void k(Args A, long long* cyc, float* sink)
         }
     } else if (A.exp == 1) {
         // sub: 0 = in phase, 1 = anti-phase (waves >= 4 start with the other segment); mode: 0 = with barriers, 1 = free-running
-        const int phase = A.sub == 1 && wave >= 4 ? 1 : 0;
+        const int phase = A.sub == 1 && slot == 1 ? 1 : 0;
         if (act) r = segment<36, 3>(r, it, phase, lds + 2048, lane, wave, A.mode == 0);
         else if (A.mode == 0) for (int i = 0; i < 2 * it; ++i) __syncthreads();
     } else if (A.exp == 2) {
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(512) void k(Args A, long long* cyc, float* sink)
         }
     }
     const long long c1 = __builtin_readcyclecounter();
-    if (lane == 0) cyc[blockIdx.x * 8 + wave] = c1 - c0;
+    if (lane == 0) cyc[blockIdx.x * 8 + (partner > 0 && wave == partner ? 4 : partner > 0 && wave == 4 ? partner : wave)] = c1 - c0;      // (the partner's time is reported in column 4)
     sink[blockIdx.x * 512 + threadIdx.x] = r;
 }
 
@@ -278,7 +285,8 @@ int main(int argc, char** argv)
         for (int nact = 1; nact <= 2; ++nact) {
             run(Args{0, f.id, 0, nact, iters}, h);
             // per SIMD: with two waves the SIMD issues 2 x 12 MFMAs per iteration of a wave
-            v[nact - 1] = (double)h[0] / (iters * 12.0 * nact);
+            // (both waves' MFMAs over the time of the LATER wave: the SIMD favours its older wave)
+            v[nact - 1] = (double)(nact == 2 && h[4] > h[0] ? h[4] : h[0]) / (iters * 12.0 * nact);
         }
         printf("fill NA=%d F=%-2d %s : 1 wave/SIMD %6.1f   2 waves/SIMD %6.1f  cycles per MFMA\n", f.na, f.f, f.kind, v[0], v[1]);
     }

@@ -4,6 +4,7 @@
 // on the GPU box. Usage: asan_harness <model files...>; every file is loaded (a clean error code is fine), and what
 // loads goes through every packer the pool would pick for it; then the biquad designs and the control reduction run
 // over a grid of control values. Exit code 0 unless a sanitizer aborts the process.
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
@@ -80,7 +81,37 @@ int main(int argc, char** argv)
                         }
                     }
                 }
-                if (mfma_form_fits(*m)) { MfmaDesc d{}; use(pack_mfma(*m, &d, &st)); }
+                if (mfma_form_fits(*m)) {
+                    MfmaDesc d{};
+                    const std::vector<float> wp = pack_mfma(*m, &d, &st);
+                    use(wp);
+                    // k_gru_gs's record: the three bf16 terms of every fragment entry add up to the fp32 weight k_gru_gm
+                    // multiplies with — exactly — and shrink by 2^-8 per term (split_bf16x3)
+                    if (d.gs_off != 0) {
+                        const int H = d.hidden, KS = H / 4, KS2 = (H + 31) / 32;
+                        auto widen = [](uint32_t half) { const uint32_t u = half << 16; float f; std::memcpy(&f, &u, sizeof f); return f; };
+                        for (int w = 0; w < H / 16; ++w)
+                            for (int g = 0; g < 3; ++g)
+                                for (int ks = 0; ks < KS2; ++ks)
+                                    for (int lane = 0; lane < kWave; ++lane)
+                                        for (int i = 0; i < 8; ++i) {
+                                            const int k = 32 * ks + 8 * (lane >> 4) + i;
+                                            float term[3];
+                                            for (int t = 0; t < 3; ++t) {
+                                                uint32_t pair;
+                                                std::memcpy(&pair, &wp[d.gs_off + ((((static_cast<size_t>(w) * 3 + g) * KS2 + ks) * 3 + t) * kWave + lane) * 4 + i / 2], sizeof pair);
+                                                term[t] = widen((pair >> (16 * (i & 1))) & 0xffffu);
+                                            }
+                                            // the gate-major fp32 record: [3 input rows][KS k-steps][3 gates][64 lanes], lane = row | (k & 3) << 4
+                                            const float want = k < H ? wp[d.gm_off + static_cast<size_t>(w) * kWave * (3 + 3 * KS + 16) + (3 + 3 * (k / 4) + g) * kWave + ((k & 3) << 4 | (lane & 15))] : 0.f;
+                                            const float sum = (term[2] + term[1]) + term[0];
+                                            if (std::isfinite(want) && std::fabs(want) < 1e38f && (sum != want || std::fabs(term[1]) > std::fabs(want) / 256.f + 1e-38f || std::fabs(term[2]) > std::fabs(want) / 65536.f + 1e-38f)) {
+                                                std::fprintf(stderr, "%s: split record differs at wave %d gate %d k %d row %d: %.9g + %.9g + %.9g vs %.9g\n", argv[i], w, g, k, lane & 15, term[0], term[1], term[2], want);
+                                                return 3;
+                                            }
+                                        }
+                    }
+                }
                 if (is_stack_model(*m) && m->n_rnn <= kMaxStackLayers && m->hidden <= 128 && m->hidden % 4 == 0) { StackDesc d{}; use(pack_stack(*m, &d, &st)); }
             }
         } catch (const std::exception&) {

@@ -528,9 +528,17 @@ def _long_run(tmp_path, name, model_kw, S, distinct, kernel, tag, tol, n=48128, 
 
 
 def test_long_run_drift_gru64_conditioned_on_the_gate_major_kernel(tmp_path):
-    """cfg3's kernel (k_gru_gm: gate-major tiles, candidate tanh in the four-instruction exp form) over 48 128 samples with
-    both PARAM inputs ramping and the EQ in circuit: the exp form's absolute error must not accumulate in h."""
+    """cfg3's kernel (k_gru_gs: gate-major tiles, recurrent product as six bf16 term products, candidate tanh in the
+    four-instruction exp form) over 48 128 samples with both PARAM inputs ramping and the EQ in circuit: neither the exp
+    form's absolute error nor the dropped 2^-24 term products may accumulate in h."""
     _long_run(tmp_path, "drift_gru64", dict(kind="gru", hidden=64, input_size=3, seed=64), S=4096, distinct=16,
+              kernel="k_gru_gs", tag="gpu_parity:drift_gru64_gs", tol=4e-6, ramp=True, ckw=_EQ_POST)
+
+
+def test_long_run_drift_gru64_on_the_fp32_gate_major_kernel(tmp_path, monkeypatch):
+    """... and the same run on k_gru_gm (fp32 MFMAs, AIDAX_GRU_GM=f32), the kernel the split one is measured against."""
+    monkeypatch.setenv("AIDAX_GRU_GM", "f32")
+    _long_run(tmp_path, "drift_gru64f", dict(kind="gru", hidden=64, input_size=3, seed=64), S=4096, distinct=16,
               kernel="k_gru_gm", tag="gpu_parity:drift_gru64_gm", tol=4e-6, ramp=True, ckw=_EQ_POST)
 
 
@@ -552,7 +560,7 @@ def test_long_run_drift_small_gru_on_the_pipeline_kernel(tmp_path):
 
 @pytest.mark.parametrize("name,kw,S,ckw,kernel", [
     ("cfg2", dict(kind="lstm", hidden=32, input_size=1, seed=32), 1024, {}, "k_lstm_pipe<32>"),
-    ("cfg3", dict(kind="gru", hidden=64, input_size=3, seed=64), 4096, _EQ_POST, "k_gru_gm"),                     # one launch: gate-major tiles, the chain on the helper waves
+    ("cfg3", dict(kind="gru", hidden=64, input_size=3, seed=64), 4096, _EQ_POST, "k_gru_gs"),                     # one launch: gate-major tiles, the chain on the helper waves
     ("cfg4", dict(kind="conv", hidden=16, input_size=1, seed=1608), 1024, {}, "k_conv_mfma"),
     ("cfg5", dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2), 2048, {}, "k_mfma_lp"),
     ("lstm80-2k", dict(kind="lstm", hidden=80, input_size=2, seed=80), 2048, dict(param1=0.7), "k_chain+k_quad"),
@@ -1130,14 +1138,16 @@ def test_gate_major_gru_kernel_ragged_blocks_controls_and_state_bits(hidden, isz
            dict(dc_blocker=0.0, in_lpf_pc=0.0, eq_bypass=1.0, param1=1.0), dict(pregain_db=6.0, master_db=-6.0, treble_boost_db=4.0, param2=0.1)]
     flip = dict(param1=0.9, param2=0.2, master_db=-3.0)                     # applied to every stream from the 5th block on
     outs, states = {}, {}
-    for form, env in (("gm", {}), ("lp", {"AIDAX_GRU_GM": "0"}), ("mfma", {"AIDAX_GRU_GM": "0", "AIDAX_MFMA_LP": "0"})):
-        for k in ("AIDAX_GRU_GM", "AIDAX_MFMA_LP"):
+    forms = (("gs", {}), ("gs9", {"AIDAX_GS_PRODUCTS": "9"}), ("gm", {"AIDAX_GRU_GM": "f32"}), ("lp", {"AIDAX_GRU_GM": "0"}),
+             ("mfma", {"AIDAX_GRU_GM": "0", "AIDAX_MFMA_LP": "0"}))
+    for form, env in forms:
+        for k in ("AIDAX_GRU_GM", "AIDAX_MFMA_LP", "AIDAX_GS_PRODUCTS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         pool = ax.Pool(S, 1024)
         pool.set_model(ax.Model(path))
-        assert pool.kernel_name == {"gm": "k_gru_gm", "lp": "k_mfma_lp", "mfma": "k_chain+k_mfma"}[form]
+        assert pool.kernel_name == {"gs": "k_gru_gs", "gs9": "k_gru_gs", "gm": "k_gru_gm", "lp": "k_mfma_lp", "mfma": "k_chain+k_mfma"}[form]
         for s_ in range(S):
             pool.set_controls(ax.default_controls(**kws[s_ % len(kws)]), stream=s_)
         got, pos = np.empty_like(x), 0
@@ -1160,9 +1170,17 @@ def test_gate_major_gru_kernel_ragged_blocks_controls_and_state_bits(hidden, isz
             pos += n
         kw = kws[s_ % len(kws)]
         if kw.get("enabled") == 0.0 or kw.get("net_bypass") == 1.0:
-            assert np.array_equal(outs["gm"][s_], want), s_
+            for f in ("gs", "gs9", "gm"):
+                assert np.array_equal(outs[f][s_], want), (f, s_)
         else:
             errlog.bound(np.abs(outs["gm"][s_] - want).max(), 2e-6, "gpu_parity:gru_gm")
+            # the bf16 x 3 kernel: the same bar — six term products are the fp32 product to rounding, nine to the last bit
+            errlog.bound(np.abs(outs["gs"][s_] - want).max(), 2e-6, "gpu_parity:gru_gs6")
+            errlog.bound(np.abs(outs["gs9"][s_] - want).max(), 2e-6, "gpu_parity:gru_gs9")
+    # (the split kernel sums its products in another order: its state agrees with the fp32 kernels' to rounding, not to the bit)
+    for f in ("gs", "gs9"):
+        for a, b in zip(states[f], states["gm"]):
+            errlog.bound(np.abs(a - b).max(), 2e-6, "gpu_parity:gru_gs_state_vs_gm")
     for a, b in zip(states["gm"], states["lp"]):
         assert np.array_equal(a, b)
     for a, b in zip(states["gm"], states["mfma"]):

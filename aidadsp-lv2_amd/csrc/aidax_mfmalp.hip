@@ -1129,7 +1129,9 @@ __device__ __forceinline__ unsigned gs_pack_bf16(float a, float b)
 {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     const bf16x2 v = { static_cast<__bf16>(a), static_cast<__bf16>(b) };
-    return __builtin_bit_cast(unsigned, v);
+    unsigned u = __builtin_bit_cast(unsigned, v);
+    asm volatile("" : "+v"(u));                               // ONE v_cvt_pk_bf16_f32: left to itself the compiler converts each value again to widen it back
+    return u;
 }
 // four fp32 values -> three terms of four bf16 each (term t: two dwords), v = t0 + t1 + t2 exactly
 __device__ __forceinline__ void gs_split4(const float (&v)[4], u32x2 (&t)[3])
@@ -1172,6 +1174,12 @@ __global__ __launch_bounds__((UT + NHELP) * kWave) void k_gru_gs(LaunchArgs a, M
     float* livef = wdl + ((H + 1 + 3) & ~3);                // [NS]
     float* dpart = livef + NS;                              // [2][8][NS] Dense partial sums of the waves
     float* hands = dpart + 2 * 8 * NS;
+#ifdef AIDAX_LP_TRACE
+    // measurement build (scratch/gs_trace.py): the selected workgroup stamps the shader clock at six points of ticks 96..103 on
+    // every wave (the helpers in lp_helper) and leaves the stamps in the first floats of its output rows
+    unsigned long long* trace = reinterpret_cast<unsigned long long*>(hands + NHELP * 2 * kChainHandFloats);
+    constexpr int kTraceT0 = 96;
+#endif
     if (wave >= NW) {
         lp_helper<H, NW, NHELP>(a, xb, xin, wdl, livef, dpart, hands, grp, nP);
         return;
@@ -1245,49 +1253,92 @@ __global__ __launch_bounds__((UT + NHELP) * kWave) void k_gru_gs(LaunchArgs a, M
         __syncthreads();                                    // (3) the helpers have run the head of the pre pass and written frame 0's inputs
         const int ticks = cnt + 2;
         for (int tick = 0; tick < ticks; ++tick) {
-            if (tick >= 1 && tick <= cnt) {                 // Dense of frame tick-1 from the lane's own h(tick-1): units summed in a fixed order
-                float y = dw[0] * hreg[0];
-                y = __builtin_fmaf(dw[1], hreg[1], y);
-                y = __builtin_fmaf(dw[2], hreg[2], y);
-                y = __builtin_fmaf(dw[3], hreg[3], y);
-                const Pair r2 = share_rows(y);              // rows q and q ^ 1
-                y = r2.lo + r2.hi;
-                const Pair r4 = share_halves(y);            // ... and the other half of the wave
-                y = r4.lo + r4.hi;
-                if (lane < NS) dpart[((tick & 1) * NW + wave) * NS + lane] = y;
-            }
+            LP_STAMP(0);
+            // Dense of frame tick-1 from the lane's own h(tick-1), in nine steps (four multiply-adds over the lane's units in a
+            // fixed order, two permlane swaps over the lane rows, the store) — issued one behind every second z / r MFMA of
+            // the frame loop: bf16 MFMAs leave the VALU free while they run (profiles/r04_overlap.txt)
+            float dy = 0.f;
+            Pair dp = { 0.f, 0.f };
+            const bool dense_on = tick >= 1 && tick <= cnt;
+            auto dense_step = [&](int k) {
+                switch (k) {
+                case 0: dy = dw[0] * hreg[0]; break;
+                case 1: dy = __builtin_fmaf(dw[1], hreg[1], dy); break;
+                case 2: dy = __builtin_fmaf(dw[2], hreg[2], dy); break;
+                case 3: dy = __builtin_fmaf(dw[3], hreg[3], dy); break;
+                case 4: dp = share_rows(dy); break;           // rows q and q ^ 1
+                case 5: dy = dp.lo + dp.hi; break;
+                case 6: dp = share_halves(dy); break;         // ... and the other half of the wave
+                case 7: dy = dp.lo + dp.hi; break;
+                case 8: if (dense_on && lane < NS) dpart[((tick & 1) * NW + wave) * NS + lane] = dy; break;
+                default: break;
+                }
+            };
             if (tick < cnt) {
                 const u32x4* h_rd = hB + par * kFrag + lane;
+                // term products, smallest first: (weight term, h term); the fragments are requested in the order of their use
+                constexpr int P9[9][2] = { {2, 2}, {1, 2}, {2, 1}, {0, 2}, {1, 1}, {2, 0}, {0, 1}, {1, 0}, {0, 0} };
                 bf16x8 hb[KS2][3];
 #pragma unroll
-                for (int t = 0; t < 3; ++t)
+                for (int t = 2; t >= 0; --t)
 #pragma unroll
                     for (int ks = 0; ks < KS2; ++ks) hb[ks][t] = __builtin_bit_cast(bf16x8, h_rd[(t * KS2 + ks) * 64]);
                 f32x4 acc[3] = { bias[0], bias[1], bias[2] };
                 f32x4 ax = bias[3];
                 const float bx = xin[(tick & 1) * 64 + lane];
+                LP_STAMP(1);
                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_in[0], bx, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_in[1], bx, acc[1], 0, 0, 0);
                 ax = __builtin_amdgcn_mfma_f32_16x16x4f32(w_in[2], bx, ax, 0, 0, 0);
-                // term products, smallest first: (weight term, h term)
-                constexpr int P9[9][2] = { {2, 2}, {1, 2}, {2, 1}, {0, 2}, {1, 1}, {2, 0}, {0, 1}, {1, 0}, {0, 0} };
+                // z and r first, two accumulators in turn ...
 #pragma unroll
-                for (int pi = 9 - NPROD; pi < 9; ++pi)
+                for (int j = 0; j < NPROD * KS2; ++j) {
+                    const int pi = 9 - NPROD + j / KS2, ks = j % KS2;
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[0][ks][P9[pi][0]], hb[ks][P9[pi][1]], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[1][ks][P9[pi][0]], hb[ks][P9[pi][1]], acc[1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    dense_step(j);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // ... then the candidate's chain, with the sigmoids of z and r in its shadow: 2^v for the eight values behind
+                // the first four MFMAs, 1 / (1 + .) behind the next eight
+                float sg8[8];
 #pragma unroll
-                    for (int ks = 0; ks < KS2; ++ks)
-#pragma unroll
-                        for (int g = 0; g < 3; ++g)
-                            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[g][ks][P9[pi][0]], hb[ks][P9[pi][1]], acc[g], 0, 0, 0);
+                for (int j = 0; j < NPROD * KS2; ++j) {
+                    const int pi = 9 - NPROD + j / KS2, ks = j % KS2;
+                    acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[2][ks][P9[pi][0]], hb[ks][P9[pi][1]], acc[2], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (j < 4) {
+                        sg8[2 * j] = __builtin_amdgcn_exp2f(acc[(2 * j) >> 2][(2 * j) & 3]);
+                        sg8[2 * j + 1] = __builtin_amdgcn_exp2f(acc[(2 * j + 1) >> 2][(2 * j + 1) & 3]);
+                    } else if (j < 12) {
+                        sg8[j - 4] = __builtin_amdgcn_rcpf(1.0f + sg8[j - 4]);      // sigmoid_pre: the rows carry -log2 e
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                LP_STAMP(2);
+#ifdef AIDAX_GS_PRIO                                             // (measurement: the main wave's tail — cell update, split, publish — ahead of the helpers)
+                __builtin_amdgcn_s_setprio(3);
+#endif
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float gz = sigmoid_pre(acc[0][e]), gr = sigmoid_pre(acc[1][e]);
+                    const float gz = sg8[e], gr = sg8[4 + e];
                     const float nn = tanh_exp_pre(__builtin_fmaf(gr, acc[2][e], ax[e]));      // (the record's candidate rows carry 2 log2 e)
                     hreg[e] = __builtin_fmaf(gz, hreg[e] - nn, nn);
                 }
+                LP_STAMP(3);
                 par ^= 1;
                 publish(par);
+                LP_STAMP(4);
+#ifdef AIDAX_GS_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
+            } else if (dense_on) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) dense_step(k);
             }
             __syncthreads();                                // the tick's barrier
+            LP_STAMP(5);
         }
         __syncthreads();                                    // (4) the helpers have stored the rows
     }
@@ -1295,6 +1346,10 @@ __global__ __launch_bounds__((UT + NHELP) * kWave) void k_gru_gs(LaunchArgs a, M
     if ((int)blockIdx.x == ((a.tune >> 16) & 0xff)) __syncthreads();
 #endif
     __syncthreads();                                        // (5)
+#ifdef AIDAX_LP_TRACE
+    if ((int)blockIdx.x == ((a.tune >> 16) & 0xff))
+        for (int i = tid; i < 2 * 768; i += NT) a.out[(size_t)s_base * n + i] = reinterpret_cast<const float*>(trace)[i];
+#endif
     if (valid && livef[c] != 0.f) {
         float* dst = a.nn + (size_t)sg * a.nn_stride + L.state_off;
 #pragma unroll

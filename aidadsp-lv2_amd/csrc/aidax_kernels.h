@@ -50,6 +50,14 @@ bool gru_gs_serves(const MfmaDesc& d);
 size_t gru_gs_lds_bytes(const MfmaDesc& d, uint32_t n_frames);
 hipError_t launch_gru_gs_kernel(const LaunchArgs& a, const MfmaDesc& d, int n_products, hipStream_t stream);
 hipError_t launch_mfma_lp_kernel(const LaunchArgs& a, const MfmaDesc& d, float* ring, uint32_t* counters, uint32_t* fault, hipStream_t stream, bool fused = false);
+// k_mfma_ls (aidax_mfmalp.hip): k_mfma_lp's stacked models with the contractions as bf16 MFMAs of operands split exactly into
+// three bf16 terms (n_products: 6 or 9); same ring protocol, its own ring geometry (a frame is the h fragments)
+bool mfma_ls_serves(const MfmaDesc& d);
+size_t mfma_ls_lds_bytes(const MfmaDesc& d, uint32_t n_frames, bool fused = false);
+bool mfma_ls_fused_serves(const MfmaDesc& d, uint32_t max_frames);
+size_t mfma_ls_ring_bytes(const MfmaDesc& d, uint32_t n_streams);
+hipError_t launch_mfma_ls_kernel(const LaunchArgs& a, const MfmaDesc& d, float* ring, uint32_t* counters, uint32_t* fault, int n_products,
+                                 hipStream_t stream, bool fused = false);
 // k_lstm_q4 (aidax_q4.hip): LSTM-32 snapshot models, four streams per workgroup, the whole run() in one launch
 bool q4_serves(int cell, int hidden, int input_size);
 size_t q4_lds_bytes(int hidden, uint32_t n_frames);

@@ -189,7 +189,7 @@ struct MfmaDesc {
     int32_t hidden_true;                       // the model's width: layout of the recurrent state in HBM (h[.] then c[.])
     uint32_t gm_off;                           // one-layer GRU: offset of the gate-major record k_gru_gm reads (0: none), see pack_mfma
     uint32_t gs_off;                           // ... and of its bf16 x 3 twin k_gru_gs reads (recurrent weights as split bf16 fragments)
-    int32_t pad[1];
+    uint32_t ls_off;                           // stacked models: offset of the split record k_mfma_ls reads (every layer's k-step groups as bf16 x 3 fragments; 0: none)
     MfmaLayer L[kMaxStackLayers];
     uint32_t wd_off, bd_off;
 };

@@ -1360,6 +1360,549 @@ __global__ __launch_bounds__((UT + NHELP) * kWave) void k_gru_gs(LaunchArgs a, M
     }
 }
 
+
+// ================================================================ k_mfma_ls: k_mfma_lp with the contractions on the bf16 matrix pipe
+// The layer-pipelined kernel above (one workgroup per (16 streams, layer), the layer's fragments resident in registers, h on
+// its way up through a ring in global memory, every wait bounded) with every fp32 product W . h computed as NPROD bf16 term
+// products of operands split exactly into three bf16 terms — see k_gru_gs for the arithmetic and why (profiles/r04_overlap.txt:
+// the fp32 MFMAs run at the vector rate and stall the VALU; the bf16 ones are sixteen times denser and hide it).
+//   * Weights: the packer's ls record, [wave][tile][segment][k-step of 32][term] fragments of 8 bf16 per lane. A wave keeps
+//     only the tile segments it multiplies with: its TPW own-h segments plus, on the first layer, the input-half segments of
+//     the mw tiles it starts for the layer above — on the others, the input-half segments of the TPW - mw tiles that do not
+//     arrive started (LSTM-96 x 2: five segments of 36 registers).
+//   * h(t-1) of a layer lives in LDS as B fragments [parity][term][k-step][lane][8 bf16]; a lane splits its own h values after
+//     the cell update and writes the three 2-byte terms where the k-steps read them. A frame in the ring is the fragments
+//     as they lie in LDS (plus the started tiles, as before): the layer above copies them in and multiplies.
+//   * Dense(H,1): multiply-adds on the lane's own h and two permlane swaps, the waves' partial sums added a tick later as before.
+//   * The first layer's model inputs stay one fp32 k-step.
+// Hand-over protocol, counters, give-up, the chain passes around the body: k_mfma_lp's, line for line.
+// Geometry: k_mfma_lp's eight (four) waves while a wave's resident fragments fit 150 of its 256 registers; wider layers run FOUR
+// waves — one per SIMD, 512 registers each (the fragments are MFMA operands only and may live in AGPRs) — with half of the
+// upper layer's tiles started below, so that both workgroups of a group issue the same number of MFMAs (LSTM-96 x 2: six
+// tiles per wave, nine resident segments of 36 registers, 162 bf16 MFMAs per wave and frame in either layer).
+struct LsGeo { int nw, tpw, m; };
+__host__ __device__ constexpr int ls_ks2(int hidden) { return (hidden + 31) / 32; }
+__host__ __device__ constexpr int ls_frag_vecs(int hidden) { return 3 * ls_ks2(hidden) * 64; }      // 16-byte vectors of one h buffer
+__host__ __device__ constexpr int ls_segments(int tpw, int m) { return tpw + (tpw - m > m ? tpw - m : m); }      // resident tile segments of a wave (the larger role)
+__host__ __device__ constexpr LsGeo ls_geo(int n_layers, int hidden)
+{
+    if (hidden < 16 || hidden % 16 != 0 || n_layers < 2) return LsGeo{ 0, 0, 0 };
+    const int nw = mfma_waves(hidden), tpw = hidden / 4 / nw, m = lp_moved_tiles(n_layers, tpw, nw) == 2 ? 1 : lp_moved_tiles(n_layers, tpw, nw);
+    if (ls_segments(tpw, m) * ls_ks2(hidden) * 12 <= 150) return LsGeo{ nw, tpw, m };
+    const int tpw4 = hidden / 16, m4 = n_layers == 2 ? tpw4 / 2 : 0;
+    if (ls_segments(tpw4, m4) * ls_ks2(hidden) * 12 <= 330) return LsGeo{ 4, tpw4, m4 };
+    return LsGeo{ 0, 0, 0 };
+}
+__host__ __device__ inline size_t ls_lds_floats(int hidden, int n_frames)
+{
+    const size_t nP = (size_t)(((n_frames < kLpChunk ? n_frames : kLpChunk) + 3) & ~3);
+    return (size_t)kMfmaStreams * nP                          /* xb: audio rows (first and last layer)                     */
+         + 2 * 64                                             /* xin[parity][4][n]  (first layer)                          */
+         + (size_t)4 * ls_frag_vecs(hidden) * 4               /* below[parity], hT[parity]: B fragments                     */
+         + (size_t)2 * hidden * kMfmaStreams                  /* hS, cT [unit][n]: how the state travels to and from the lanes */
+         + (size_t)2 * hidden * 4                             /* bias rows [unit][4]: own layer, layer above (moved tiles)  */
+         + (size_t)((hidden + 1 + 3) & ~3)                    /* Dense weights + bias (last layer)                         */
+         + kMfmaStreams                                       /* live flags                                                */
+         + 2 * 8 * kMfmaStreams;                              /* Dense partial sums [parity][wave][n]                      */
+}
+// one frame in the ring: the h fragments, then (M > 0) the started tiles [wave][tile][lane] x 4 gate rows
+__host__ __device__ constexpr size_t ls_slot_floats(int hidden, int waves, int m) { return (size_t)ls_frag_vecs(hidden) * 4 + (size_t)waves * m * kWave * 4; }
+__host__ __device__ constexpr size_t ls_ring_floats(int hidden, int waves, int m) { return (size_t)kLpRing * ls_slot_floats(hidden, waves, m); }
+
+// acc[tile] += A(segment of the tile) . B for the tiles [TL0, TL1) of one segment kind, B fragments from `frags` (one h buffer
+// in LDS). Term products smallest first, grouped by the h term so that a fragment is read once: (w0 h2) | (w1 h1)(w0 h1) |
+// (w2 h0)(w1 h0)(w0 h0); NPROD = 9 adds (w2 h2) | (w2 h1)(w1 h2) in front. `seg_of(tl)` names the resident segment of tile tl.
+template <int KS2, int NPROD, int TL0, int TL1, int NSEG, int NACC, typename SegOf>
+__device__ __forceinline__ void ls_gates(f32x4 (&acc)[NACC], const bf16x8 (&wq)[NSEG][KS2][3], const u32x4* frags, int lane, SegOf seg_of)
+{
+    if constexpr (TL0 < TL1) {
+        constexpr int P9[9][2] = { {2, 2}, {2, 1}, {1, 2}, {0, 2}, {1, 1}, {0, 1}, {2, 0}, {1, 0}, {0, 0} };      // (weight term, h term)
+#pragma unroll
+        for (int pi = 9 - NPROD; pi < 9; ++pi) {
+            // six products: (0,2) (1,1) (0,1) (2,0) (1,0) (0,0) — indices 3 .. 8 of the list
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) {
+                const bf16x8 hb = __builtin_bit_cast(bf16x8, frags[(P9[pi][1] * KS2 + ks) * 64 + lane]);
+#pragma unroll
+                for (int tl = TL0; tl < TL1; ++tl)
+                    acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[seg_of(tl)][ks][P9[pi][0]], hb, acc[tl], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// M: tiles per wave the first layer starts for the layer above / that arrive started
+template <int TPW, int NW, int M, bool FIRST, bool LAST, bool CHAIN, int NPROD>
+__device__ __forceinline__ void ls_body(const LaunchArgs& a, const MfmaDesc& d, float* ring, uint32_t* counters, uint32_t* fault,
+                                        float* smem, int grp, int l)
+{
+    constexpr int H = 4 * TPW * NW;
+    constexpr int NT = NW * kWave;
+    constexpr int NS = kMfmaStreams;
+    constexpr int KS2 = ls_ks2(H);
+    constexpr int kFrag = ls_frag_vecs(H);                  // 16-byte vectors of one h buffer
+    constexpr int MW = M;
+    constexpr int NSEG = FIRST ? TPW + MW : 2 * TPW - MW;   // resident tile segments of this wave
+    constexpr int MA = MW > 0 ? MW : 1;
+    constexpr size_t kSlot = ls_slot_floats(H, NW, M);      // floats of one ring frame
+    constexpr bool chain = CHAIN, first = FIRST, last = LAST;
+    static_assert(!(FIRST && LAST), "stacked models only");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4;
+    const int n = (int)a.n_frames;
+    const int NL = d.n_layers;
+    const int Ht = d.hidden_true;
+    const int I = a.input_size;
+    const int blk = (int)blockIdx.x;
+    const int s_base = grp * NS;
+    const int chunk = n < kLpChunk ? n : kLpChunk;
+    const int nP = (chunk + 3) & ~3;
+
+    float* xb    = smem;                                    // [NS][nP]
+    float* xin   = xb + NS * nP;                            // [2][4][NS]
+    u32x4* below = reinterpret_cast<u32x4*>(xin + 2 * 64);  // [2][kFrag]  h of the layer below as B fragments
+    u32x4* hT    = below + 2 * kFrag;                       // [2][kFrag]  own h(t-1) as B fragments
+    float* hS    = reinterpret_cast<float*>(hT + 2 * kFrag);// [H][NS]     h as fp32: state in, state out
+    float* cT    = hS + H * NS;                             // [H][NS]
+    float* biasL = cT + H * NS;                             // [H][4] own layer, then [H][4] of the layer above (first layer, MW > 0)
+    float* wdl   = biasL + 2 * H * 4;                       // Dense weights, bias at [H]
+    float* livef = wdl + ((H + 1 + 3) & ~3);                // [NS]
+    float* dpart = livef + NS;                              // [2][NW][NS] Dense partial sums of the waves (last layer)
+
+    const float* W = a.wpack;
+    const MfmaLayer& L = d.L[l];
+
+    // ---- per-stream bookkeeping: lanes tid < NS own stream s_base+tid (live flag; PARAM smoothers on the first layer)
+    float p_mem[2] = { 0.f, 0.f }, p_tgt[2] = { 0.f, 0.f }, p_step[2] = { 0.f, 0.f };
+    uint32_t pending = 0, st_pending0 = 0;
+    bool mine_live = false;
+    if (tid < NS) {
+        const int sg = s_base + tid;
+        const bool valid = sg < (int)a.n_streams;
+        if (valid) {
+            StreamState& st = a.st[sg];
+            p_mem[0] = st.p_mem[0]; p_mem[1] = st.p_mem[1];
+            p_tgt[0] = st.p_tgt[0]; p_tgt[1] = st.p_tgt[1];
+            p_step[0] = st.p_step[0]; p_step[1] = st.p_step[1];
+            pending = st_pending0 = st.pending;
+            const StreamCtl& ctl = a.ctl[sg];
+            const uint32_t flags = ctl.flags;
+            mine_live = n != 0 && (flags & CTL_ENABLED) && (flags & CTL_NET_ON);      // :607-619, :631-632
+            if (mine_live) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {                // LinearValueSmoother::setTargetValue (:209-216)
+                    const float nt = ctl.p_target[i];
+                    if (__builtin_fabsf(p_tgt[i] - nt) >= FLT_EPSILON) {
+                        p_tgt[i] = nt;
+                        p_step[i] = (p_tgt[i] - p_mem[i]) / ctl.p_den;
+                    }
+                }
+                if (pending & PEND_PARAM_FIRST) {            // paramFirstRun (:636-640)
+                    pending &= ~PEND_PARAM_FIRST;
+                    p_mem[0] = p_tgt[0];
+                    p_mem[1] = p_tgt[1];
+                }
+            }
+        }
+        livef[tid] = mine_live ? 1.f : 0.f;
+    }
+    if (last) for (int i = tid; i < H + 1; i += NT) wdl[i] = W[d.wd_off + i];
+    for (int i = tid; i < H * 4; i += NT) {
+        biasL[i] = W[L.b_off + i];
+        if (first && MW > 0) biasL[H * 4 + i] = W[d.L[1].b_off + i];
+    }
+    // this layer's recurrent state -> LDS as fp32; the fragment buffers start from zero (padded k-steps stay zero for good)
+    for (int i = tid; i < H * NS; i += NT) {
+        const int u = i / NS, sn = i % NS, sg = s_base + sn;
+        const bool valid = sg < (int)a.n_streams;
+        const float* stp = a.nn + (size_t)(valid ? sg : 0) * a.nn_stride + L.state_off;
+        hS[i] = (valid && u < Ht) ? stp[u] : 0.f;           // padded units rest at 0
+        cT[i] = (valid && u < Ht && L.cell == 0) ? stp[Ht + u] : 0.f;
+    }
+    for (int i = tid; i < 4 * kFrag; i += NT) below[i] = u32x4{ 0u, 0u, 0u, 0u };      // (below and hT are adjacent)
+
+    // ---- resident fragments: segment s of this wave -> wq[s]
+    bf16x8 wq[NSEG][KS2][3];
+    {
+        // the ls record: layer 0 holds one segment per tile (own h), the others two (h below | own h)
+        const size_t per_seg = (size_t)KS2 * 3 * kWave;                     // u32x4 per (tile, segment)
+        const u32x4* rec = reinterpret_cast<const u32x4*>(W + d.ls_off);
+        auto layer_base = [&](int ll) { return rec + (ll == 0 ? 0 : (size_t)NW * TPW * per_seg * (size_t)(1 + 2 * (ll - 1))); };
+        auto load_seg = [&](int slot, int ll, int tl, int seg_in_rec) {
+            const u32x4* sp = layer_base(ll) + ((size_t)(wave * TPW + tl) * (ll == 0 ? 1 : 2) + seg_in_rec) * per_seg + lane;
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) wq[slot][ks][t] = __builtin_bit_cast(bf16x8, sp[(ks * 3 + t) * kWave]);
+        };
+#pragma unroll
+        for (int tl = 0; tl < TPW; ++tl) load_seg(tl, l, tl, first ? 0 : 1);                // own h(t-1)
+        if constexpr (first) {
+#pragma unroll
+            for (int tl = 0; tl < MW; ++tl) load_seg(TPW + tl, 1, tl, 0);                    // the layer above's input half of the tiles this wave starts
+        } else {
+#pragma unroll
+            for (int tl = MW; tl < TPW; ++tl) load_seg(TPW + tl - MW, l, tl, 0);             // h below, for the tiles that do not arrive started
+        }
+    }
+    float w_in0[TPW];                                       // (pack_mfma lays the input k-step out by ITS waves and tiles: d.waves x d.tpw)
+#pragma unroll
+    for (int tl = 0; tl < TPW; ++tl) {
+        const int T = wave * TPW + tl;
+        w_in0[tl] = first ? W[d.L[0].w_in_off + ((size_t)(T / d.tpw) * kWave + lane) * d.tpw + T % d.tpw] : 0.f;
+    }
+    float wdu[TPW];                                         // Dense weights of this lane's units (last layer)
+#pragma unroll
+    for (int tl = 0; tl < TPW; ++tl) wdu[tl] = last ? W[d.wd_off + 4 * (wave * TPW + tl) + q] : 0.f;
+
+    // ---- ring bookkeeping (k_mfma_lp's): counters count frames since the buffers were allocated and are equal on both sides
+    // between launches, so a workgroup starts from its own side's value
+    const size_t ring_stride = ls_ring_floats(H, NW, M);
+    float* ring_out = last ? nullptr : ring + ((size_t)grp * (NL - 1) + l) * ring_stride;
+    const float* ring_in = first ? nullptr : ring + ((size_t)grp * (NL - 1) + (l - 1)) * ring_stride;
+    const size_t ring_bytes = ring_stride * sizeof(float);
+    const __amdgpu_buffer_rsrc_t rs_out = lp_rsrc(last ? ring : ring_out, ring_bytes);
+    const __amdgpu_buffer_rsrc_t rs_in = lp_rsrc(first ? ring : ring_in, ring_bytes);
+    uint32_t* cnt_out = last ? nullptr : counters + ((size_t)grp * (NL - 1) + l) * kLpCounterStride;
+    uint32_t* cnt_in = first ? nullptr : counters + ((size_t)grp * (NL - 1) + (l - 1)) * kLpCounterStride;
+    auto give_up = [&]() { __hip_atomic_fetch_add(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+    if ((a.tune & 16) && blk == 0 && tid == 0) give_up();      // test hook: report a give-up that did not happen
+    const uint32_t base_out = cnt_out ? __hip_atomic_load(cnt_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    const uint32_t base_in = cnt_in ? __hip_atomic_load(cnt_in + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    uint32_t known_free = kLpRing;                         // frames of this launch the ring above is known to have room for
+    uint32_t known_below = 0;                              // frames of this launch known to exist below
+    __syncthreads();
+
+    // ---- this lane's (unit, stream) pairs — one per tile: h and c in registers for the launch
+    float hv[TPW], creg[TPW];
+#pragma unroll
+    for (int tl = 0; tl < TPW; ++tl) {
+        hv[tl] = hS[(wave * TPW + tl) * 64 + lane];         // unit 4T + q, stream lane & 15
+        creg[tl] = cT[(wave * TPW + tl) * 64 + lane];
+    }
+    // where a lane's h values go in the fragments: unit u = 4T + q -> k-step u / 32, lane row (u % 32) / 8, element u % 8
+    auto publish = [&](u32x4* dst) {
+#pragma unroll
+        for (int tl = 0; tl < TPW; ++tl) {
+            const int u = 4 * (wave * TPW + tl) + q;
+            uint16_t* p16 = reinterpret_cast<uint16_t*>(dst + (u >> 5) * 64 + ((u & 31) >> 3) * 16 + (lane & 15)) + (u & 7);
+            float r = hv[tl];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const __bf16 b = static_cast<__bf16>(r);     // round to nearest even
+                p16[(size_t)t * KS2 * 64 * 8] = __builtin_bit_cast(uint16_t, b);
+                if (t < 2) r -= static_cast<float>(b);       // exact
+            }
+        }
+    };
+    publish(hT);
+    __syncthreads();
+
+    // Frame Fprev goes up the ring, one tick after it was computed: its h fragments (16-byte write-through stores) and, behind
+    // the tick's MFMAs, the tiles started for the layer above
+    auto ship_h = [&](const u32x4* h_src, int Fprev) {
+        const uint32_t slot_off = (uint32_t)(((base_out + (uint32_t)Fprev) % kLpRing) * kSlot * sizeof(float));
+        for (int i = tid; i < kFrag; i += NT) lp_store16(rs_out, slot_off + (uint32_t)i * 16u, __builtin_bit_cast(f32x4, h_src[i]));
+    };
+    auto ship_started = [&](const f32x4 (&pacc)[MA], int Fprev) {
+        const uint32_t slot_off = (uint32_t)(((base_out + (uint32_t)Fprev) % kLpRing) * kSlot * sizeof(float));
+#pragma unroll
+        for (int tl = 0; tl < MW; ++tl)
+            lp_store16(rs_out, slot_off + (uint32_t)(kFrag * 16) + (uint32_t)(((wave * M + tl) * kWave + lane) * 16), pacc[tl]);
+    };
+    auto own_seg = [](int tl) { return tl; };
+    auto up_seg = [](int tl) { return TPW + tl; };                          // first layer: the moved tiles' input half
+    auto below_seg = [](int tl) { return TPW + tl - MW; };                  // others: the input half of the tiles that start here
+
+    int par = 0;                                           // parity of hT the next frame reads
+    int done = 0;                                          // frames finished before this chunk
+    for (int base = 0; base < n; base += kLpChunk) {
+        const int cnt = n - base < kLpChunk ? n - base : kLpChunk;
+        auto wait_below = [&](int frames_needed) {        // thread 0 only: until `frames_needed` frames of the launch exist
+            if (frames_needed > n) frames_needed = n;
+            uint32_t spins = 0;
+            uint64_t t0 = 0;
+            while ((int)known_below < frames_needed) {
+                known_below = __hip_atomic_load(cnt_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base_in;
+                if ((int)known_below < frames_needed) {
+                    if (lp_timed_out(spins, t0)) { give_up(); known_below = (uint32_t)n; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+        };
+        // ---- audio rows of this chunk: the first layer reads them as input, the last for in_skip and to deliver
+        if constexpr (chain && last) {
+            // one-launch form: the rows in a.out are the pre pass's, stored (write-through, drained) by the FIRST layer's
+            // workgroup before it computed its first frame — once frames exist below, the rows are there
+            if (tid == 0) wait_below(done + 2);
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        if (first || last) {
+            for (int sl = wave; sl < NS; sl += NW) {
+                const int sg = s_base + sl;
+                const bool lv = livef[sl] != 0.f;
+                float* row = xb + sl * nP;
+                if (lv) {
+                    const float* src = a.out + (size_t)sg * n + base;
+                    if (((n | base) & 3) == 0) load_block(row, src, cnt, lane);
+                    else for (int t = lane; t < cnt; t += kWave) row[t] = src[t];
+                } else {
+                    for (int t = lane; t < cnt; t += kWave) row[t] = 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        auto write_xin = [&](int parity, int f) {
+            // lanes tid < NS: x * in_gain, PARAM1, PARAM2 of frame `f` (:171-181, :195-231)
+            float q1 = 0.f, q2 = 0.f;
+            if (I >= 2) q1 = lin_next(p_mem[0], p_tgt[0], p_step[0]);
+            if (I >= 3) q2 = lin_next(p_mem[1], p_tgt[1], p_step[1]);
+            float* col = xin + parity * 64;
+            col[tid] = xb[tid * nP + f] * a.in_gain;
+            col[NS + tid] = q1;
+            col[2 * NS + tid] = q2;
+            col[3 * NS + tid] = 0.f;
+        };
+        constexpr int PER4 = (kFrag + NT - 1) / NT;        // 16-byte vectors of a frame each thread moves
+        f32x4 pre[PER4];
+        f32x4 upx[MA] = {};                                // started tiles of the NEXT frame on their way in (layers >= 1)
+        f32x4 pcur[MA] = {};                               // ... of the current frame
+        auto fetch_below = [&](int F) {                    // all threads: frame F of the launch -> registers
+            const uint32_t slot_off = (uint32_t)(((base_in + (uint32_t)F) % kLpRing) * kSlot * sizeof(float));
+#pragma unroll
+            for (int k = 0; k < PER4; ++k)
+                if (k * NT + tid < kFrag) pre[k] = lp_load16(rs_in, slot_off + (uint32_t)(k * NT + tid) * 16u);
+#pragma unroll
+            for (int tl = 0; tl < MW; ++tl)
+                upx[tl] = lp_load16(rs_in, slot_off + (uint32_t)(kFrag * 16) + (uint32_t)(((wave * M + tl) * kWave + lane) * 16));
+        };
+        auto stash_below = [&](int parity) {
+#pragma unroll
+            for (int k = 0; k < PER4; ++k)
+                if (k * NT + tid < kFrag) below[parity * kFrag + k * NT + tid] = __builtin_bit_cast(u32x4, pre[k]);
+        };
+
+        if (first) {
+            if (tid < NS) write_xin(0, 0);
+        } else {
+            if (tid == 0) wait_below(done + 2);            // frame 0 of the chunk for now, frame 1 for tick 0's prefetch
+            __syncthreads();
+            fetch_below(done);
+            stash_below(0);
+#pragma unroll
+            for (int tl = 0; tl < MA; ++tl) pcur[tl] = upx[tl];
+        }
+        __syncthreads();
+
+        const int ticks = last ? cnt + 2 : cnt;            // the Dense of a frame: partial sums one tick behind its h, the output two
+        for (int tick = 0; tick < ticks; ++tick) {
+            const int rd = par, wr = par ^ 1;
+            const bool body = tick < cnt;
+            const bool more = tick + 1 < cnt;              // another frame of this chunk follows
+            const int F = done + tick;                     // frame of the launch this tick computes
+            if (first) {
+                if (tid < NS && more) write_xin((tick + 1) & 1, tick + 1);
+            } else if (more) {
+                fetch_below(F + 1);
+            }
+            if (body && tid == 0) {
+                // thread 0 looks ahead while the others compute (see k_mfma_lp)
+                if (!first && tick + 2 < cnt) wait_below(F + 3);
+                if (!last && base + tick + 1 < n) {
+                    uint32_t spins = 0;
+                    uint64_t t0 = 0;
+                    while ((int)known_free < F + 2) {
+                        const uint32_t consumed = __hip_atomic_load(cnt_out + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base_out;
+                        known_free = consumed + kLpRing;
+                        if ((int)known_free < F + 2) {
+                            if (lp_timed_out(spins, t0)) { give_up(); known_free = (uint32_t)n + kLpRing; break; }
+                            __builtin_amdgcn_s_sleep(8);
+                        }
+                    }
+                }
+            }
+            // ---- Dense(H,1) of frame tick-1 from the lanes' own h(tick-1): this wave's units, summed in a fixed order
+            if (last && tick >= 1 && tick <= cnt) {
+                float y = wdu[0] * hv[0];
+#pragma unroll
+                for (int tl = 1; tl < TPW; ++tl) y = __builtin_fmaf(wdu[tl], hv[tl], y);
+                const Pair r2 = share_rows(y);
+                y = r2.lo + r2.hi;
+                const Pair r4 = share_halves(y);
+                y = r4.lo + r4.hi;
+                if (lane < NS) dpart[((tick & 1) * NW + wave) * NS + lane] = y;
+            }
+            // ---- ... and of frame tick-2: the NW partial sums, bias, skip, output gain (wave 0, one lane per stream)
+            if (last && tick >= 2 && wave == 0 && lane < NS) {
+                const int fd = tick - 2;
+                float y = wdl[H];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) y += dpart[(((tick - 1) & 1) * NW + w) * NS + lane];
+                const float x = xb[lane * nP + fd] * a.in_gain;
+                float o = a.input_skip ? x + y : y;
+                o = o * a.out_gain;
+                if (livef[lane] != 0.f) xb[lane * nP + fd] = o;
+            }
+
+            if (body) {
+                const u32x4* h_rd = hT + rd * kFrag;
+                f32x4 acc[TPW];
+#pragma unroll
+                for (int tl = 0; tl < TPW; ++tl) acc[tl] = *reinterpret_cast<const f32x4*>(biasL + 4 * (4 * (wave * TPW + tl) + q));
+                if (!last && F >= 1) ship_h(h_rd, F - 1);              // h_rd = h(F-1)
+                if constexpr (first) {                     // the model inputs: one fp32 k-step (x, PARAM1, PARAM2, 0)
+                    const float b = xin[(tick & 1) * 64 + lane];
+#pragma unroll
+                    for (int tl = 0; tl < TPW; ++tl)
+                        acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_in0[tl], b, acc[tl], 0, 0, 0);
+                    ls_gates<KS2, NPROD, 0, TPW, NSEG, TPW>(acc, wq, h_rd, lane, own_seg);
+                    if constexpr (MW > 0) {                // the tiles started for the layer above: bias + W_in(above) . h(F-1)
+                        if (F >= 1) {
+                            f32x4 pacc[MA];
+#pragma unroll
+                            for (int tl = 0; tl < MW; ++tl) pacc[tl] = *reinterpret_cast<const f32x4*>(biasL + H * 4 + 4 * (4 * (wave * TPW + tl) + q));
+                            ls_gates<KS2, NPROD, 0, MW, NSEG, MA>(pacc, wq, h_rd, lane, up_seg);
+                            ship_started(pacc, F - 1);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int tl = 0; tl < MW; ++tl) acc[tl] = pcur[tl];           // bias + input half, from below
+                    ls_gates<KS2, NPROD, MW, TPW, NSEG, TPW>(acc, wq, below + (tick & 1) * kFrag, lane, below_seg);
+                    ls_gates<KS2, NPROD, 0, TPW, NSEG, TPW>(acc, wq, h_rd, lane, own_seg);
+                }
+#pragma unroll
+                for (int tl = 0; tl < TPW; ++tl) {
+                    float hn;
+                    if (L.cell == 0) {
+                        const float gi = sigmoid_pre(acc[tl].x), gf = sigmoid_pre(acc[tl].y);
+                        const float gg = tanh_rat(acc[tl].z), go = sigmoid_pre(acc[tl].w);
+                        const float cn = __builtin_fmaf(gf, creg[tl], gi * gg);
+                        creg[tl] = cn;
+                        hn = go * tanh_rat(cn);
+                    } else {
+                        const float gz = sigmoid_pre(acc[tl].x), gr = sigmoid_pre(acc[tl].y);
+                        const float nn = tanh_exp_pre(__builtin_fmaf(gr, acc[tl].z, acc[tl].w));      // (GRU: see GruCell::step)
+                        hn = __builtin_fmaf(gz, hv[tl] - nn, nn);
+                    }
+                    hv[tl] = hn;
+                }
+                publish(hT + wr * kFrag);
+                par = wr;
+                if (!first && more) {
+                    stash_below((tick + 1) & 1);
+#pragma unroll
+                    for (int tl = 0; tl < MA; ++tl) pcur[tl] = upx[tl];
+                }
+                if (!last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's ring stores have left before the barrier (G16)
+            }
+            __syncthreads();                               // h(t) in LDS, the next frame's input in LDS, ring stores of this frame done
+            // ---- counters, by thread 0 after the barrier: every kLpBatch frames and at the end of the launch
+            if (body && tid == 0) {
+                if (!last) {
+                    const int produced = F;
+                    if (produced > 0 && produced % kLpBatch == 0)
+                        __hip_atomic_store(cnt_out, base_out + (uint32_t)produced, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (!first) {
+                    const int consumed = more ? F + 2 : F + 1;             // frames read out of the ring so far
+                    if (consumed % kLpBatch == 0 || consumed == n)
+                        __hip_atomic_store(cnt_in + 16, base_in + (uint32_t)consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        done += cnt;
+        // ---- results of this chunk back to HBM (last layer)
+        if (last) {
+            for (int sl = wave; sl < NS; sl += NW) {
+                const int sg = s_base + sl;
+                if (livef[sl] == 0.f) continue;
+                float* dst = a.out + (size_t)sg * n + base;
+                const float* row = xb + sl * nP;
+                if (((n | base) & 3) == 0) store_block(dst, row, cnt, lane);
+                else for (int t = lane; t < cnt; t += kWave) dst[t] = row[t];
+            }
+        }
+        __syncthreads();
+    }
+
+    if (!last && n > 0) {                                  // the launch's last frame, then the final count
+        ship_h(hT + par * kFrag, n - 1);
+        if constexpr (first && MW > 0) {
+            f32x4 pacc[MA];
+#pragma unroll
+            for (int tl = 0; tl < MW; ++tl) pacc[tl] = *reinterpret_cast<const f32x4*>(biasL + H * 4 + 4 * (4 * (wave * TPW + tl) + q));
+            ls_gates<KS2, NPROD, 0, MW, NSEG, MA>(pacc, wq, hT + par * kFrag, lane, up_seg);
+            ship_started(pacc, n - 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(cnt_out, base_out + (uint32_t)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    // ---- recurrent state and smoother memories back to HBM for the streams that ran
+#pragma unroll
+    for (int tl = 0; tl < TPW; ++tl) {
+        hS[(wave * TPW + tl) * 64 + lane] = hv[tl];
+        cT[(wave * TPW + tl) * 64 + lane] = creg[tl];
+    }
+    __syncthreads();
+    for (int i = tid; i < H * NS; i += NT) {
+        const int u = i / NS, sn = i % NS, sg = s_base + sn;
+        if (sg < (int)a.n_streams && u < Ht && livef[sn] != 0.f) {
+            float* stp = a.nn + (size_t)sg * a.nn_stride + L.state_off;
+            stp[u] = hS[i];
+            if (L.cell == 0) stp[Ht + u] = cT[i];
+        }
+    }
+    if (first && tid < NS && mine_live) {
+        StreamState& st = a.st[s_base + tid];
+        st.p_mem[0] = p_mem[0]; st.p_mem[1] = p_mem[1];
+        st.p_tgt[0] = p_tgt[0]; st.p_tgt[1] = p_tgt[1];
+        st.p_step[0] = p_step[0]; st.p_step[1] = p_step[1];
+        if (!chain) st.pending = pending;
+        else if (pending != st_pending0)                  // (the last layer's workgroup clears PEND_ACTIVATE in the same word)
+            __hip_atomic_fetch_and(&st.pending, ~(uint32_t)PEND_PARAM_FIRST, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int TPW, int NW, int M, bool CHAIN, int NPROD>
+__global__ __launch_bounds__(NW * kWave) void k_mfma_ls(LaunchArgs a, MfmaDesc d, float* ring, uint32_t* counters, uint32_t* fault)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int NL = d.n_layers;
+    const int blk = (int)blockIdx.x;
+    const bool adjacent = (a.tune & 2) != 0;
+    const int grp = adjacent ? blk / NL : (blk / (8 * NL)) * 8 + (blk & 7);
+    const int l = adjacent ? blk % NL : (blk / 8) % NL;
+    const int n_groups = ((int)a.n_streams + kMfmaStreams - 1) / kMfmaStreams;
+    if (grp >= n_groups) return;
+    if (l == 0) {
+        if constexpr (CHAIN) {
+            lp_chain_rows<true>(a, smem, grp, true);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        ls_body<TPW, NW, M, true, false, CHAIN, NPROD>(a, d, ring, counters, fault, smem, grp, l);
+    } else if (l == NL - 1) {
+        if constexpr (CHAIN) {
+            if (a.tune & 8192) {                                          // test hook: this workgroup starts 100 us late
+                const uint64_t t0 = wall_clock64();
+                while (wall_clock64() - t0 < 10000) __builtin_amdgcn_s_sleep(64);
+            }
+        }
+        ls_body<TPW, NW, M, false, true, CHAIN, NPROD>(a, d, ring, counters, fault, smem, grp, l);
+        if constexpr (CHAIN) {
+            __syncthreads();
+            lp_chain_rows<false>(a, smem, grp, true);
+        }
+    } else {
+        ls_body<TPW, NW, M, false, false, CHAIN, NPROD>(a, d, ring, counters, fault, smem, grp, l);
+    }
+}
+
 // ---------------------------------------------------------------- host side
 typedef void (*LpFn)(LaunchArgs, MfmaDesc, float*, uint32_t*, uint32_t*);
 // Helper waves of the one-launch form: a third wave per SIMD must fit next to the main waves' registers (512 per SIMD
@@ -1494,6 +2037,60 @@ hipError_t launch_gru_gs_kernel(const LaunchArgs& a, const MfmaDesc& d, int n_pr
     }
     const uint32_t groups = (a.n_streams + kMfmaStreams - 1) / kMfmaStreams;
     hipLaunchKernelGGL(fn, dim3(groups), dim3((d.hidden / 16 + kLpHelpers) * kWave), lds, stream, a, d);
+    return hipGetLastError();
+}
+
+// k_mfma_ls: the stacked models k_mfma_lp serves whose resident split fragments fit the register file (ls_geo)
+template <int HID, int NL>
+static LpFn ls_fn_for(bool chain, int nprod)
+{
+    constexpr LsGeo g = ls_geo(NL, HID);
+    if constexpr (g.nw == 0) return nullptr;
+    else if constexpr (ls_segments(g.tpw, g.m) * ls_ks2(HID) * 12 > 150)      // the 512-register geometries: six products only (nine spill)
+        return chain ? k_mfma_ls<g.tpw, g.nw, g.m, true, 6> : k_mfma_ls<g.tpw, g.nw, g.m, false, 6>;
+    else return chain ? (nprod == 9 ? k_mfma_ls<g.tpw, g.nw, g.m, true, 9> : k_mfma_ls<g.tpw, g.nw, g.m, true, 6>)
+                      : (nprod == 9 ? k_mfma_ls<g.tpw, g.nw, g.m, false, 9> : k_mfma_ls<g.tpw, g.nw, g.m, false, 6>);
+}
+static LpFn ls_fn(int hidden, int n_layers, bool chain, int nprod)
+{
+    switch (hidden) {                                       // (two layers: tiles started below; deeper stacks: none — the same body with M = 0)
+#define AIDAX_LS_CASE(HID) case HID: return n_layers == 2 ? ls_fn_for<HID, 2>(chain, nprod) : ls_fn_for<HID, 3>(chain, nprod);
+    AIDAX_LS_CASE(16) AIDAX_LS_CASE(32) AIDAX_LS_CASE(48) AIDAX_LS_CASE(64) AIDAX_LS_CASE(80) AIDAX_LS_CASE(96)
+#undef AIDAX_LS_CASE
+    default: return nullptr;
+    }
+}
+bool mfma_ls_serves(const MfmaDesc& d)
+{
+    return d.n_layers >= 2 && d.ls_off != 0 && ls_geo(d.n_layers, d.hidden).nw != 0 && ls_fn(d.hidden, d.n_layers, false, 6) != nullptr;
+}
+size_t mfma_ls_lds_bytes(const MfmaDesc& d, uint32_t n_frames, bool fused)
+{
+    const size_t body = ls_lds_floats(d.hidden, (int)n_frames);
+    const size_t rows = fused ? (size_t)kMfmaStreams * ((n_frames + 3) & ~3u) + 2 * kChainPackHandFloats : 0;      // lp_chain_rows works in the body's LDS
+    return (body > rows ? body : rows) * sizeof(float);
+}
+bool mfma_ls_fused_serves(const MfmaDesc& d, uint32_t max_frames) { return mfma_ls_serves(d) && max_frames <= (uint32_t)kLpChunk; }
+size_t mfma_ls_ring_bytes(const MfmaDesc& d, uint32_t n_streams)
+{
+    const size_t groups = (n_streams + kMfmaStreams - 1) / kMfmaStreams;
+    const LsGeo g = ls_geo(d.n_layers, d.hidden);
+    return 256 + groups * (size_t)(d.n_layers - 1) * ls_ring_floats(d.hidden, g.nw, g.m) * sizeof(float);
+}
+hipError_t launch_mfma_ls_kernel(const LaunchArgs& a, const MfmaDesc& d, float* ring, uint32_t* counters, uint32_t* fault, int n_products,
+                                 hipStream_t stream, bool fused)
+{
+    if (!mfma_ls_serves(d) || a.mode != MODE_CHAIN || (fused && (a.n_frames == 0 || a.n_frames > (uint32_t)kLpChunk))) return hipErrorInvalidValue;
+    LpFn fn = ls_fn(d.hidden, d.n_layers, fused, n_products);
+    if (!fn || !ring || !counters || !fault) return hipErrorInvalidValue;
+    const size_t lds = mfma_ls_lds_bytes(d, a.n_frames, fused);
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const uint32_t groups = (a.n_streams + kMfmaStreams - 1) / kMfmaStreams;
+    const uint32_t blocks = ((groups + 7) / 8) * 8 * (uint32_t)d.n_layers;
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(ls_geo(d.n_layers, d.hidden).nw * kWave), lds, stream, a, d, ring, counters, fault);
     return hipGetLastError();
 }
 

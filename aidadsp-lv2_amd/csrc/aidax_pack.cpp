@@ -187,6 +187,42 @@ void split_bf16x3(float x, uint16_t (&t)[3])
     }
 }
 
+// Weight of gate row `g` of unit `u` of layer `l` against column k of segment `seg` (0 in the padding), as the matrix-core
+// kernels multiply it. The sigmoid rows (LSTM i, f, o; GRU z, r) carry the factor -log2(e) in weights and bias, like the
+// table kernels' records: the cell update evaluates 1 / (1 + 2^v) without a multiply (sigmoid_pre, aidax_device.h); a GRU's
+// candidate rows (both halves) carry 2 log2(e): tanh as 1 - 2 / (1 + 2^v), see tanh_exp_pre.
+enum Seg { SEG_IN, SEG_REC, SEG_BIAS };
+static float mfma_weight(const aidax_model& m, int l, Seg seg, int u, int g, int k)
+{
+    const Layer& L = m.layers[l];
+    const int Ht = m.hidden;
+    const bool lstm = L.type == Layer::LSTM;
+    const int G = lstm ? 4 : 3, R = G * Ht, I = L.in_size;
+    auto weight_raw = [&]() -> float {
+        if (u >= Ht || (seg == SEG_REC && k >= Ht) || (seg == SEG_IN && k >= I)) return 0.f;
+        const int H = Ht;                        // Keras column blocks are Ht wide
+        const float* W = L.w0.data();      // [I][R]
+        const float* U = L.w1.data();      // [H][R]
+        const float* b = L.w2.data();      // LSTM [R]; GRU [2][R]
+        if (lstm) {
+            const int col = g * H + u;
+            if (seg == SEG_IN) return k < I ? W[(size_t)k * R + col] : 0.f;
+            if (seg == SEG_REC) return U[(size_t)k * R + col];
+            return k == 0 ? b[col] : 0.f;
+        }
+        // GRU rows: 0 = z, 1 = r, 2 = recurrent half of the candidate, 3 = input half of the candidate
+        const int col = (g == 0 ? 0 : g == 1 ? H : 2 * H) + u;
+        if (seg == SEG_IN) return (g != 2 && k < I) ? W[(size_t)k * R + col] : 0.f;
+        if (seg == SEG_REC) return g != 3 ? U[(size_t)k * R + col] : 0.f;
+        if (k != 0) return 0.f;
+        if (g <= 1) return b[col] + b[R + col];
+        return g == 2 ? b[R + col] : b[col];
+    };
+    const bool sigmoid_row = lstm ? g != 2 : g <= 1;
+    const float w = weight_raw();
+    return sigmoid_row ? kNegLog2e * w : !lstm ? kTwoLog2e * w : w;
+}
+
 // A fragments of v_mfma_f32_16x16x4_f32 for k_mfma, layout in aidax_layout.h (MfmaLayer).
 std::vector<float> pack_mfma(const aidax_model& m, MfmaDesc* d, uint32_t* state_floats)
 {
@@ -199,43 +235,14 @@ std::vector<float> pack_mfma(const aidax_model& m, MfmaDesc* d, uint32_t* state_
     d->tpw = TPW;
     d->waves = NW;
     uint32_t st = 0;
-    enum Seg { SEG_IN, SEG_REC, SEG_BIAS };
     for (int l = 0; l < m.n_rnn; ++l) {
         const Layer& L = m.layers[l];
         MfmaLayer& M = d->L[l];
         const bool lstm = L.type == Layer::LSTM;
-        const int G = lstm ? 4 : 3, R = G * Ht, I = L.in_size;
+        const int I = L.in_size;
         M.cell = lstm ? 0 : 1;
         M.in_size = l == 0 ? I : H;                  // deeper layers contract over the padded h of the layer below
-        // weight of gate row `g` of unit `u` against column k of segment `seg` (0 in the padding). The sigmoid rows
-        // (LSTM i, f, o; GRU z, r) carry the factor -log2(e) in weights and bias, like the table kernels' records: the
-        // cell update evaluates 1 / (1 + 2^v) without a multiply (sigmoid_pre, aidax_device.h)
-        auto weight_raw = [&](Seg seg, int u, int g, int k) -> float {
-            if (u >= Ht || (seg == SEG_REC && k >= Ht) || (seg == SEG_IN && k >= I)) return 0.f;
-            const int H = Ht;                        // Keras column blocks are Ht wide
-            const float* W = L.w0.data();      // [I][R]
-            const float* U = L.w1.data();      // [H][R]
-            const float* b = L.w2.data();      // LSTM [R]; GRU [2][R]
-            if (lstm) {
-                const int col = g * H + u;
-                if (seg == SEG_IN) return k < I ? W[(size_t)k * R + col] : 0.f;
-                if (seg == SEG_REC) return U[(size_t)k * R + col];
-                return k == 0 ? b[col] : 0.f;
-            }
-            // GRU rows: 0 = z, 1 = r, 2 = recurrent half of the candidate, 3 = input half of the candidate
-            const int col = (g == 0 ? 0 : g == 1 ? H : 2 * H) + u;
-            if (seg == SEG_IN) return (g != 2 && k < I) ? W[(size_t)k * R + col] : 0.f;
-            if (seg == SEG_REC) return g != 3 ? U[(size_t)k * R + col] : 0.f;
-            if (k != 0) return 0.f;
-            if (g <= 1) return b[col] + b[R + col];
-            return g == 2 ? b[R + col] : b[col];
-        };
-        auto weight = [&](Seg seg, int u, int g, int k) -> float {
-            const bool sigmoid_row = lstm ? g != 2 : g <= 1;
-            const float w = weight_raw(seg, u, g, k);
-            // a GRU's candidate rows (both halves) carry 2 log2(e): tanh as 1 - 2 / (1 + 2^v), see tanh_exp_pre
-            return sigmoid_row ? kNegLog2e * w : !lstm ? kTwoLog2e * w : w;
-        };
+        auto weight = [&](Seg seg, int u, int g, int k) -> float { return mfma_weight(m, l, seg, u, g, k); };
         // layer 0: the 1..3 model inputs are one k-step on their own ("small" segment)
         M.w_in_off = static_cast<uint32_t>(out.size());
         if (l == 0)
@@ -327,6 +334,32 @@ std::vector<float> pack_mfma(const aidax_model& m, MfmaDesc* d, uint32_t* state_
                                 std::memcpy(&f, &pair, sizeof f);
                                 out.push_back(f);
                             }
+    }
+    // Stacked models: the k-step groups of every layer once more, for k_mfma_ls — as A fragments of v_mfma_f32_16x16x32_bf16 with
+    // every fp32 weight split exactly into three bf16 terms (split_bf16x3; why: see the gs record above). Same tiles (four units
+    // x their four gate rows), same scale factors. Per layer: [wave][tile][segment: h of the layer below (layers >= 1) | own
+    // h(t-1)][ceil(H/32) k-steps][3 terms][64 lanes][8 bf16]; lane supplies row (lane & 15), columns k = 32 ks + 8 (lane >> 4) + i.
+    if (m.n_rnn >= 2) {
+        while (out.size() % 4) out.push_back(0.f);
+        d->ls_off = static_cast<uint32_t>(out.size());
+        const int KS2 = (H + 31) / 32;
+        for (int l = 0; l < m.n_rnn; ++l)
+            for (int w = 0; w < NW; ++w)
+                for (int tl = 0; tl < TPW; ++tl)
+                    for (int seg = l == 0 ? 1 : 0; seg < 2; ++seg)
+                        for (int ks = 0; ks < KS2; ++ks)
+                            for (int term = 0; term < 3; ++term)
+                                for (int lane = 0; lane < kWave; ++lane)
+                                    for (int i = 0; i < 8; i += 2) {
+                                        const int T = w * TPW + tl, r = lane & 15, k = 32 * ks + 8 * (lane >> 4) + i;
+                                        uint16_t t0[3], t1[3];
+                                        split_bf16x3(k < H ? mfma_weight(m, l, seg == 0 ? SEG_IN : SEG_REC, 4 * T + (r >> 2), r & 3, k) : 0.f, t0);
+                                        split_bf16x3(k + 1 < H ? mfma_weight(m, l, seg == 0 ? SEG_IN : SEG_REC, 4 * T + (r >> 2), r & 3, k + 1) : 0.f, t1);
+                                        const uint32_t pair = static_cast<uint32_t>(t0[term]) | (static_cast<uint32_t>(t1[term]) << 16);
+                                        float f;
+                                        std::memcpy(&f, &pair, sizeof f);
+                                        out.push_back(f);
+                                    }
     }
     *state_floats = st;
     return out;

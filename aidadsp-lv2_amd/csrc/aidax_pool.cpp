@@ -156,6 +156,7 @@ struct ModelSlot {
     uint32_t* d_counters = nullptr;  // k_mfma_lp: frames produced / consumed per (group, layer boundary)
     const void* lp_owner = nullptr;  // the pool whose hold on the device's LpGate this slot shares (d_ring != nullptr)
     bool lp_fused = false;           // k_mfma_lp runs the DSP chain too (one-layer models, helper waves): one launch per block
+    int lp_split = 0;                // stacked models: k_mfma_ls serves the passes (contractions as bf16 term products of split operands): 6 or 9 products; 0: k_mfma_lp (fp32 MFMAs)
     bool gru_gm = false;             // one-layer GRU: k_gru_gm (gate-major tiles, the whole run() in one launch) serves the passes
     int gru_gs = 0;                  // ... as k_gru_gs (recurrent product on the bf16 matrix pipe, operands split into three bf16 terms): 6 or 9 term products; 0: the fp32 kernel
 
@@ -399,13 +400,15 @@ struct aidax_pool {
             // k_mfma_lp only for the passes themselves: warm-ups (worker stream, next to the passes) and the bare-model
             // modes run on k_mfma, which leaves bit-identical state — two of those grids must never be in flight together
             auto model_kernel = [&]() {
-                return lp_in_use(m) && a.mode == MODE_CHAIN ? launch_mfma_lp_kernel(a, m.mdesc, m.d_ring, m.d_counters, hd_lp_fault, s)
-                                                            : launch_mfma_kernel(a, m.mdesc, s);
+                if (!(lp_in_use(m) && a.mode == MODE_CHAIN)) return launch_mfma_kernel(a, m.mdesc, s);
+                return m.lp_split ? launch_mfma_ls_kernel(a, m.mdesc, m.d_ring, m.d_counters, hd_lp_fault, m.lp_split, s)
+                                  : launch_mfma_lp_kernel(a, m.mdesc, m.d_ring, m.d_counters, hd_lp_fault, s);
             };
             if (a.mode != MODE_CHAIN) return model_kernel();
             if (m.gru_gm && a.n_frames != 0) return m.gru_gs ? launch_gru_gs_kernel(a, m.mdesc, m.gru_gs, s) : launch_gru_gm_kernel(a, m.mdesc, s);
             if (m.lp_fused && lp_in_use(m) && a.n_frames != 0)
-                return launch_mfma_lp_kernel(a, m.mdesc, m.d_ring, m.d_counters, hd_lp_fault, s, true);
+                return m.lp_split ? launch_mfma_ls_kernel(a, m.mdesc, m.d_ring, m.d_counters, hd_lp_fault, m.lp_split, s, true)
+                                  : launch_mfma_lp_kernel(a, m.mdesc, m.d_ring, m.d_counters, hd_lp_fault, s, true);
             hipError_t e = launch_chain_pass(true, a, s);
             if (e == hipSuccess && a.n_frames != 0) e = model_kernel();
             if (e == hipSuccess) e = launch_chain_pass(false, a, s);
@@ -608,11 +611,19 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
     if (ms.kind == ModelSlot::MFMA && mfma_lp_serves(ms.mdesc) && lp_pays && !(lp_chained && p.lp_off.load()) &&
         mfma_lp_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024 && (!lp_chained || lp_gate().acquire(p.device, &p, &p.lp_off))) {
         if (lp_chained) ms.lp_owner = &p;
-        HIP_TRY(hipMalloc(&ms.d_ring, mfma_lp_ring_bytes(ms.mdesc, p.n_streams)));
+        // stacked models whose split fragments fit the register file: the same hand-over with the contractions on the bf16 matrix
+        // pipe (k_mfma_ls; AIDAX_LP_SPLIT=0: the fp32 kernel, =9: every term product instead of six — A/B runs)
+        const char* sp = std::getenv("AIDAX_LP_SPLIT");
+        ms.lp_split = lp_chained && mfma_ls_serves(ms.mdesc) && !(sp && sp[0] == '0') && mfma_ls_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024
+                          ? (sp && sp[0] == '9' ? 9 : 6) : 0;
+        const size_t ring_bytes = ms.lp_split ? mfma_ls_ring_bytes(ms.mdesc, p.n_streams) : mfma_lp_ring_bytes(ms.mdesc, p.n_streams);
+        HIP_TRY(hipMalloc(&ms.d_ring, ring_bytes));
         HIP_TRY(hipMalloc(&ms.d_counters, mfma_lp_counter_bytes(ms.mdesc, p.n_streams)));
         HIP_TRY(hipMemsetAsync(ms.d_counters, 0, mfma_lp_counter_bytes(ms.mdesc, p.n_streams), p.wq));
         const char* fu = std::getenv("AIDAX_LP_FUSED");      // (=0: packed k_chain launches around the kernel, A/B runs)
-        ms.lp_fused = mfma_lp_fused_serves(ms.mdesc, p.max_frames) && !(fu && fu[0] == '0') && mfma_lp_lds_bytes(ms.mdesc, p.max_frames, true) <= 160 * 1024;
+        ms.lp_fused = !(fu && fu[0] == '0') &&
+                      (ms.lp_split ? mfma_ls_fused_serves(ms.mdesc, p.max_frames) && mfma_ls_lds_bytes(ms.mdesc, p.max_frames, true) <= 160 * 1024
+                                   : mfma_lp_fused_serves(ms.mdesc, p.max_frames) && mfma_lp_lds_bytes(ms.mdesc, p.max_frames, true) <= 160 * 1024);
     }
     if (ms.kind == ModelSlot::MFMA) {
         const char* gm = std::getenv("AIDAX_GRU_GM");        // (=0: the four-rows-per-unit kernels; =f32: k_gru_gm with fp32 MFMAs — A/B runs)
@@ -1257,7 +1268,7 @@ AIDAX_API const char* aidax_pool_kernel_name(const aidax_pool* p)
     if (!(p && p->cur.has_model)) return "k_nomodel";
     const ModelSlot& m = p->cur;
     if (m.kind == ModelSlot::STACK) return "k_stack";
-    if (m.kind == ModelSlot::MFMA) return m.gru_gm ? (m.gru_gs ? "k_gru_gs" : "k_gru_gm") : !p->lp_in_use(m) ? "k_chain+k_mfma" : m.lp_fused ? "k_mfma_lp" : "k_chain+k_mfma_lp";
+    if (m.kind == ModelSlot::MFMA) return m.gru_gm ? (m.gru_gs ? "k_gru_gs" : "k_gru_gm") : !p->lp_in_use(m) ? "k_chain+k_mfma" : m.lp_split ? (m.lp_fused ? "k_mfma_ls" : "k_chain+k_mfma_ls") : m.lp_fused ? "k_mfma_lp" : "k_chain+k_mfma_lp";
     if (m.kind == ModelSlot::QUAD) return "k_chain+k_quad";
     if (m.kind == ModelSlot::CONV) return m.conv_fused ? "k_conv_mfma" : m.conv_mfma ? "k_chain+k_conv_mfma" : "k_conv";
     const int form = p->chain_form(m);

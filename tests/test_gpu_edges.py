@@ -193,8 +193,8 @@ def test_extreme_levels_denormal_silence_and_full_scale(tmp_path):
 @pytest.mark.parametrize("kw,max_frames,kernel", [
     (dict(kind="conv", hidden=16, input_size=1, seed=3, conv_layers=5), 512, "k_conv_mfma"),         # blocks > 256: time slices of the one-launch form
     (dict(kind="conv", hidden=16, input_size=1, seed=3, conv_layers=5), 512, "k_conv"),              # ... and the VALU conv with the whole block in LDS (AIDAX_KERNEL=valu)
-    (dict(kind="lstm", hidden=48, input_size=2, seed=4, n_rnn=2), 2048, "k_chain+k_mfma_lp"),             # longest block of the packed chains
-    (dict(kind="lstm", hidden=20, input_size=1, seed=5, n_rnn=2), 256, "k_mfma_lp"),                      # 20 units run zero-padded to 32 (one launch: blocks of one staging chunk)
+    (dict(kind="lstm", hidden=48, input_size=2, seed=4, n_rnn=2), 2048, "k_chain+k_mfma_ls"),             # longest block of the packed chains
+    (dict(kind="lstm", hidden=20, input_size=1, seed=5, n_rnn=2), 256, "k_mfma_ls"),                      # 20 units run zero-padded to 32 (one launch: blocks of one staging chunk)
 ])
 def test_extension_fallback_kernels_for_long_blocks(kw, max_frames, kernel, tmp_path, monkeypatch):
     """Conv pools with blocks above 256 frames send them through the matrix-core kernel in time slices (the VALU

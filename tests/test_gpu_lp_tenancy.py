@@ -54,7 +54,7 @@ def test_two_full_size_stacked_pools_driven_at_once(tmp_path):
     pools = [ax.Pool(CFG5_STREAMS, block) for _ in range(2)]
     for p in pools:
         p.set_model(m)
-    assert sorted(p.kernel_name for p in pools) == ["k_chain+k_mfma", "k_mfma_lp"]          # (k_mfma_lp: the whole run() in its one launch)
+    assert sorted(p.kernel_name for p in pools) == ["k_chain+k_mfma", "k_mfma_ls"]          # (k_mfma_lp: the whole run() in its one launch)
     outs, failures = [None, None], []
     go = threading.Barrier(2)
 
@@ -75,13 +75,13 @@ def test_two_full_size_stacked_pools_driven_at_once(tmp_path):
     assert not failures, failures
     for i in range(2):
         errlog.bound(np.abs(outs[i][first] - want).max(), 1.5e-6, "gpu_lp:two_pools")
-        assert pools[i].kernel_name in ("k_chain+k_mfma", "k_mfma_lp")
+        assert pools[i].kernel_name in ("k_chain+k_mfma", "k_mfma_ls")
     # once the holder is gone the next pool may use the kernel again
-    holder = [p for p in pools if p.kernel_name == "k_mfma_lp"][0]
+    holder = [p for p in pools if p.kernel_name == "k_mfma_ls"][0]
     holder.close()
     p3 = ax.Pool(CFG5_STREAMS, block)
     p3.set_model(m)
-    assert p3.kernel_name == "k_mfma_lp"
+    assert p3.kernel_name == "k_mfma_ls"
     for p in pools + [p3]:
         p.close()
 
@@ -98,7 +98,7 @@ def test_full_size_pool_processes_while_stacked_models_are_prepared_and_swapped_
     x, first = _spread(base, CFG5_STREAMS)
     pool = ax.Pool(CFG5_STREAMS, block)
     pool.set_model(models[0])
-    assert pool.kernel_name == "k_mfma_lp"
+    assert pool.kernel_name == "k_mfma_ls"
     co = O.default_controls()
     plugs = [O.OraclePlugin() for _ in range(16)]
     for p in plugs:
@@ -146,7 +146,7 @@ def test_full_size_pool_processes_while_stacked_models_are_prepared_and_swapped_
                     old = p.model.ptr.contents
                     p.set_model(O.OracleModel(files[mi][1], old.param1Coeff.target, old.param2Coeff.target))
             got = pool.process(np.ascontiguousarray(x[:, b * block:(b + 1) * block]))
-            assert pool.kernel_name == "k_mfma_lp"
+            assert pool.kernel_name == "k_mfma_ls"
             for k in range(16):
                 want = plugs[k].run(co, base[k, b * block:(b + 1) * block])
                 errlog.bound(np.abs(got[first[k]] - want).max(), 2e-6, "gpu_lp:swap_under_load")
@@ -178,7 +178,7 @@ def test_a_reported_give_up_is_silence_for_that_block_and_the_pool_falls_back(tm
     L = ax.lib()
     pool = ax.Pool(S, n)
     pool.set_model(m)
-    assert pool.kernel_name == "k_mfma_lp"
+    assert pool.kernel_name == "k_mfma_ls"
     blk = np.ascontiguousarray(x[:, :n])
     out = np.full_like(blk, 7.0)
     rc = L.aidax_pool_process(pool.h, blk.ctypes.data_as(_fp), out.ctypes.data_as(_fp), n)

@@ -38,6 +38,12 @@ def _ctl_pair(**kw):
     return ax.default_controls(**kw), O.default_controls(**kw)
 
 
+def _canon(kernel_name):
+    """Stacked models run on k_mfma_ls (contractions as bf16 term products) where their split fragments fit the register file,
+    else on k_mfma_lp (fp32 MFMAs; AIDAX_LP_SPLIT=0 forces it): the same launch forms, named alike here."""
+    return kernel_name.replace("k_mfma_ls", "k_mfma_lp")
+
+
 def _run_gpu(pool, x, block):
     out = np.empty_like(x)
     for b in range(0, x.shape[1], block):
@@ -543,8 +549,16 @@ def test_long_run_drift_gru64_on_the_fp32_gate_major_kernel(tmp_path, monkeypatc
 
 
 def test_long_run_drift_lstm96x2_on_the_layer_pipelined_kernel(tmp_path):
-    """cfg5's kernel (k_mfma_lp, two layers of 96 on separate workgroups) over 48 128 samples at cfg5's pool size."""
+    """cfg5's kernel (k_mfma_ls: two layers of 96 on separate workgroups, contractions as six bf16 term products) over 48 128
+    samples at cfg5's pool size."""
     _long_run(tmp_path, "drift_lstm96x2", dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2), S=2048, distinct=8,
+              kernel="k_mfma_ls", tag="gpu_parity:drift_lstm96x2_ls", tol=4e-6)
+
+
+def test_long_run_drift_lstm96x2_on_the_fp32_layer_pipelined_kernel(tmp_path, monkeypatch):
+    """... and on k_mfma_lp (fp32 MFMAs, AIDAX_LP_SPLIT=0), the kernel the split one is measured against."""
+    monkeypatch.setenv("AIDAX_LP_SPLIT", "0")
+    _long_run(tmp_path, "drift_lstm96x2f", dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2), S=2048, distinct=8,
               kernel="k_mfma_lp", tag="gpu_parity:drift_lstm96x2_lp", tol=4e-6)
 
 
@@ -562,7 +576,7 @@ def test_long_run_drift_small_gru_on_the_pipeline_kernel(tmp_path):
     ("cfg2", dict(kind="lstm", hidden=32, input_size=1, seed=32), 1024, {}, "k_lstm_pipe<32>"),
     ("cfg3", dict(kind="gru", hidden=64, input_size=3, seed=64), 4096, _EQ_POST, "k_gru_gs"),                     # one launch: gate-major tiles, the chain on the helper waves
     ("cfg4", dict(kind="conv", hidden=16, input_size=1, seed=1608), 1024, {}, "k_conv_mfma"),
-    ("cfg5", dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2), 2048, {}, "k_mfma_lp"),
+    ("cfg5", dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2), 2048, {}, "k_mfma_ls"),
     ("lstm80-2k", dict(kind="lstm", hidden=80, input_size=2, seed=80), 2048, dict(param1=0.7), "k_chain+k_quad"),
     ("lstm80-4k", dict(kind="lstm", hidden=80, input_size=2, seed=80), 4096, dict(param1=0.7), "k_mfma_lp"),
     ("gru16-4k", dict(kind="gru", hidden=16, input_size=3, seed=16), 4096, dict(param1=0.2, param2=0.9), "k_chain+k_quad"),
@@ -655,7 +669,7 @@ def test_extension_models_full_chain(kind, kw, form, tmp_path, monkeypatch):
     pool = ax.Pool(S, 256)
     pool.set_model(m)
     mfma_name = ("k_chain+k_conv_mfma" if form == "split" else "k_conv_mfma") if conv else "k_mfma_lp"
-    assert pool.kernel_name == (("k_conv" if conv else "k_stack") if form == "valu" else mfma_name)
+    assert _canon(pool.kernel_name) == (("k_conv" if conv else "k_stack") if form == "valu" else mfma_name)
     pool.set_controls(cg)
     got = _run_gpu(pool, x, block)
     want = O.run_streams(spec, co, x, block)
@@ -843,7 +857,7 @@ def test_matrix_core_form_ragged_blocks_and_per_stream_controls(name, kw, tmp_pa
     x = modelgen.signal(S, sum(sizes), seed=21)
     pool = ax.Pool(S, 256 if conv else 1024)
     pool.set_model(ax.Model(path))
-    assert pool.kernel_name == ("k_conv_mfma" if conv else "k_chain+k_mfma_lp" if kw.get("n_rnn", 1) > 1 else "k_chain+k_mfma")
+    assert _canon(pool.kernel_name) == ("k_conv_mfma" if conv else "k_chain+k_mfma_lp" if kw.get("n_rnn", 1) > 1 else "k_chain+k_mfma")
     kws = [dict(param1=0.3, param2=0.8), dict(enabled=0.0), dict(net_bypass=1.0), dict(eq_position=1.0, bass_boost_db=5.0, mid_type=1.0),
            dict(dc_blocker=0.0, in_lpf_pc=0.0, eq_bypass=1.0, param1=1.0), dict(pregain_db=6.0, master_db=-6.0, treble_boost_db=4.0, param2=0.1)]
     flip = dict(param1=0.9, param2=0.2, master_db=-3.0)                     # applied to every stream from the 5th block on
@@ -942,7 +956,7 @@ def test_every_kernel_form_passes_the_same_chain_cases(form, tmp_path, monkeypat
            dict(dc_blocker=0.0, in_lpf_pc=0.0, eq_bypass=1.0), dict(pregain_db=6.0, master_db=-6.0, treble_boost_db=4.0)]
     for s in range(S):
         pool.set_controls(ax.default_controls(**kws[s % len(kws)]), stream=s)
-    assert pool.kernel_name.startswith({"wave": "k_lstm<", "pipe": "k_lstm_pipe<", "split": "k_chain+k_nn<", "mfma": "k_mfma_lp", "mfma_split": "k_chain+k_mfma", "quad": "k_chain+k_quad", "q4": "k_lstm_q4<"}[form])
+    assert _canon(pool.kernel_name).startswith({"wave": "k_lstm<", "pipe": "k_lstm_pipe<", "split": "k_chain+k_nn<", "mfma": "k_mfma_lp", "mfma_split": "k_chain+k_mfma", "quad": "k_chain+k_quad", "q4": "k_lstm_q4<"}[form])
     got = np.empty_like(x)
     pos = 0
     for n in sizes:
@@ -1007,7 +1021,8 @@ def test_every_kernel_form_passes_the_same_chain_cases(form, tmp_path, monkeypat
     ("g80", dict(kind="gru", hidden=80, input_size=3, seed=8030)),                        # one layer, no room for helper waves: the same form
 ])
 @pytest.mark.parametrize("late", [False, True])
-def test_stacked_one_launch_form_is_bit_identical_to_the_three_launch_form(name, kw, late, tmp_path, monkeypatch):
+@pytest.mark.parametrize("arith", ["bf16x3", "fp32"])
+def test_stacked_one_launch_form_is_bit_identical_to_the_three_launch_form(name, kw, late, arith, tmp_path, monkeypatch):
     """Stacked models on pools whose blocks fit one staging chunk run their whole run() in the k_mfma_lp launch: the packed
     pre pass on two waves of the first layer's workgroup (and, uncommitted, of the last layer's, which needs the model input
     for in_skip and for net-off streams), the post pass behind the last layer's last tick. Same chain code, same kernel body
@@ -1019,6 +1034,8 @@ def test_stacked_one_launch_form_is_bit_identical_to_the_three_launch_form(name,
     path, spec = _model_file(tmp_path, name, **kw)
     if late:
         monkeypatch.setenv("AIDAX_TUNE", "8192")
+    if arith == "fp32":
+        monkeypatch.setenv("AIDAX_LP_SPLIT", "0")             # k_mfma_lp (fp32 MFMAs) instead of k_mfma_ls
     if kw.get("n_rnn", 1) == 1:
         monkeypatch.setenv("AIDAX_KERNEL", "mfma")            # (40 streams of a table model would take k_quad)
     S = 40
@@ -1033,7 +1050,8 @@ def test_stacked_one_launch_form_is_bit_identical_to_the_three_launch_form(name,
             monkeypatch.setenv("AIDAX_LP_FUSED", "0")
         pool = ax.Pool(S, 256)
         pool.set_model(ax.Model(path))
-        assert pool.kernel_name == ("k_mfma_lp" if form == "one" else "k_chain+k_mfma_lp")
+        lp = "k_mfma_lp" if arith == "fp32" or kw.get("n_rnn", 1) == 1 or kw["hidden"] == 80 and kw.get("n_rnn", 1) > 2 else "k_mfma_ls"
+        assert pool.kernel_name == (lp if form == "one" else "k_chain+" + lp)
         for s_ in range(S):
             pool.set_controls(ax.default_controls(**kws[s_ % len(kws)]), stream=s_)
         got, pos = np.empty_like(x), 0
@@ -1088,7 +1106,8 @@ def test_one_layer_one_launch_form_is_bit_identical_to_the_three_launch_form(kin
             monkeypatch.setenv("AIDAX_LP_FUSED", "0")
         pool = ax.Pool(S, 1024)
         pool.set_model(ax.Model(path))
-        assert pool.kernel_name == ("k_mfma_lp" if form == "one" else "k_chain+k_mfma_lp")
+        lp = "k_mfma_lp" if arith == "fp32" or kw.get("n_rnn", 1) == 1 or kw["hidden"] == 80 and kw.get("n_rnn", 1) > 2 else "k_mfma_ls"
+        assert pool.kernel_name == (lp if form == "one" else "k_chain+" + lp)
         for s_ in range(S):
             pool.set_controls(ax.default_controls(**kws[s_ % len(kws)]), stream=s_)
         got, pos = np.empty_like(x), 0
@@ -1207,11 +1226,12 @@ def test_layer_pipelined_kernel_keeps_the_state_of_the_one_workgroup_kernel_bit_
     outs = {}
     if placement.startswith("adjacent"):
         monkeypatch.setenv("AIDAX_TUNE", "2")       # the hand-over must not depend on where the two workgroups run
-    for lp in ("1", "0"):
-        monkeypatch.setenv("AIDAX_MFMA_LP", lp)
+    for lp in ("1", "0", "s"):                      # k_mfma_lp (fp32 MFMAs), k_mfma, k_mfma_ls (bf16 term products of split operands)
+        monkeypatch.setenv("AIDAX_MFMA_LP", "0" if lp == "0" else "1")
+        monkeypatch.setenv("AIDAX_LP_SPLIT", "1" if lp == "s" else "0")
         pool = ax.Pool(S, 1024)
         pool.set_model(ax.Model(path))
-        assert pool.kernel_name == ("k_chain+k_mfma_lp" if lp == "1" else "k_chain+k_mfma")
+        assert pool.kernel_name == {"1": "k_chain+k_mfma_lp", "0": "k_chain+k_mfma", "s": "k_chain+k_mfma_ls"}[lp]
         pool.set_controls(cg)
         got, pos = [], 0
         for n in sizes:
@@ -1226,6 +1246,10 @@ def test_layer_pipelined_kernel_keeps_the_state_of_the_one_workgroup_kernel_bit_
     # fma chain + lane tree here)
     assert np.array_equal(outs["1h"], outs["0h"])
     errlog.bound(np.abs(outs["1"] - outs["0"]).max(), 5e-7, "gpu_parity:lp_vs_mfma_outputs")
+    # the split kernel sums other terms in another order: state and outputs agree with the fp32 kernels' to rounding
+    errlog.bound(np.abs(outs["sh"] - outs["1h"]).max(), 2e-6, "gpu_parity:ls_vs_lp_state")
+    errlog.bound(np.abs(outs["s"] - outs["1"]).max(), 2e-6, "gpu_parity:ls_vs_lp_outputs")
     for s_ in (0, 17, S - 1):
         want = O.run_streams(spec, co, x[s_:s_ + 1], 4096)       # block partition does not matter to the oracle
         errlog.bound(np.abs(outs["1"][s_] - want[0]).max(), 2e-6, "gpu_parity:lp_vs_oracle")
+        errlog.bound(np.abs(outs["s"][s_] - want[0]).max(), 2e-6, "gpu_parity:ls_vs_oracle")

@@ -1387,52 +1387,89 @@ __host__ __device__ constexpr int ls_segments(int tpw, int m) { return tpw + (tp
 __host__ __device__ constexpr LsGeo ls_geo(int n_layers, int hidden)
 {
     if (hidden < 16 || hidden % 16 != 0 || n_layers < 2) return LsGeo{ 0, 0, 0 };
-    const int nw = mfma_waves(hidden), tpw = hidden / 4 / nw, m = lp_moved_tiles(n_layers, tpw, nw) == 2 ? 1 : lp_moved_tiles(n_layers, tpw, nw);
-    if (ls_segments(tpw, m) * ls_ks2(hidden) * 12 <= 150) return LsGeo{ nw, tpw, m };
+#ifndef AIDAX_LS_M96
+#define AIDAX_LS_M96 2      // LSTM-96 x 2 on eight waves: tiles per wave the lower layer starts for the upper one (1: 32 / 40 tile segments per workgroup, 2: 40 / 32)
+#endif
+    // registers a wave spends on resident fragments: all three terms of its own-h segments, term 0 of the others
+    const int nw = mfma_waves(hidden), tpw = hidden / 4 / nw, m = lp_moved_tiles(n_layers, tpw, nw) == 2 ? AIDAX_LS_M96 : lp_moved_tiles(n_layers, tpw, nw);
+    if (tpw * ls_ks2(hidden) * 12 + (ls_segments(tpw, m) - tpw) * ls_ks2(hidden) * 4 <= 140) return LsGeo{ nw, tpw, m };
     const int tpw4 = hidden / 16, m4 = n_layers == 2 ? tpw4 / 2 : 0;
-    if (ls_segments(tpw4, m4) * ls_ks2(hidden) * 12 <= 330) return LsGeo{ 4, tpw4, m4 };
+    if (n_layers == 2 && tpw4 * ls_ks2(hidden) * 12 + (ls_segments(tpw4, m4) - tpw4) * ls_ks2(hidden) * 4 <= 330) return LsGeo{ 4, tpw4, m4 };
     return LsGeo{ 0, 0, 0 };
 }
-__host__ __device__ inline size_t ls_lds_floats(int hidden, int n_frames)
+__host__ __device__ inline size_t ls_lds_floats(int hidden, int n_frames, LsGeo g)
 {
     const size_t nP = (size_t)(((n_frames < kLpChunk ? n_frames : kLpChunk) + 3) & ~3);
     return (size_t)kMfmaStreams * nP                          /* xb: audio rows (first and last layer)                     */
          + 2 * 64                                             /* xin[parity][4][n]  (first layer)                          */
          + (size_t)4 * ls_frag_vecs(hidden) * 4               /* below[parity], hT[parity]: B fragments                     */
-         + (size_t)2 * hidden * kMfmaStreams                  /* hS, cT [unit][n]: how the state travels to and from the lanes */
          + (size_t)2 * hidden * 4                             /* bias rows [unit][4]: own layer, layer above (moved tiles)  */
          + (size_t)((hidden + 1 + 3) & ~3)                    /* Dense weights + bias (last layer)                         */
          + kMfmaStreams                                       /* live flags                                                */
-         + 2 * 8 * kMfmaStreams;                              /* Dense partial sums [parity][wave][n]                      */
+         + 2 * 8 * kMfmaStreams                               /* Dense partial sums [parity][wave][n]                      */
+         + (size_t)g.nw * (ls_segments(g.tpw, g.m) - g.tpw) * ls_ks2(hidden) * 2 * 64 * 4;      /* second- and third-term fragments of the segments nobody waits for */
 }
 // one frame in the ring: the h fragments, then (M > 0) the started tiles [wave][tile][lane] x 4 gate rows
 __host__ __device__ constexpr size_t ls_slot_floats(int hidden, int waves, int m) { return (size_t)ls_frag_vecs(hidden) * 4 + (size_t)waves * m * kWave * 4; }
 __host__ __device__ constexpr size_t ls_ring_floats(int hidden, int waves, int m) { return (size_t)kLpRing * ls_slot_floats(hidden, waves, m); }
 
-// acc[tile] += A(segment of the tile) . B for the tiles [TL0, TL1) of one segment kind, B fragments from `frags` (one h buffer
-// in LDS). Term products smallest first, grouped by the h term so that a fragment is read once: (w0 h2) | (w1 h1)(w0 h1) |
-// (w2 h0)(w1 h0)(w0 h0); NPROD = 9 adds (w2 h2) | (w2 h1)(w1 h2) in front. `seg_of(tl)` names the resident segment of tile tl.
-template <int KS2, int NPROD, int TL0, int TL1, int NSEG, int NACC, typename SegOf>
-__device__ __forceinline__ void ls_gates(f32x4 (&acc)[NACC], const bf16x8 (&wq)[NSEG][KS2][3], const u32x4* frags, int lane, SegOf seg_of)
+// acc[tile] += A(segment of the tile) . B for the tiles [TL0, TL1) of one segment kind. The B fragments of one h buffer are read
+// into registers ONCE (ls_load_frags: nine 16-byte reads for LSTM-96) and serve every phase of the tick that multiplies with
+// that buffer — read one by one between the MFMAs, the three MFMAs of a fragment's first product do not cover its LDS latency
+// and the wave stalls once per fragment. Term products grouped by the h term, the large ones first: (w0 w1 w2) h0 | (w0 w1) h1 |
+// w0 h2; NPROD = 9: all three weight terms for every h term. `wfrag(tl, ks, term)` supplies the A fragment of a tile;
+// `valu(step)` is called behind every MFMA group (the tiles of one product and k-step) with a running index — the caller's
+// VALU work that issues in the MFMAs' shadow.
+template <int KS2> struct LsFrags { bf16x8 v[3][KS2]; };       // one h buffer's B fragments in registers: [term][k-step]
+template <int KS2>
+__device__ __forceinline__ void ls_load_frags(LsFrags<KS2>& hb, const u32x4* frags, int lane)
+{
+#pragma unroll
+    for (int th = 0; th < 3; ++th)                          // (term 0 first: it meets the most weight terms and is multiplied first)
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) hb.v[th][ks] = __builtin_bit_cast(bf16x8, frags[(th * KS2 + ks) * 64 + lane]);
+}
+template <int KS2, int NPROD, int TL0, int TL1, int NACC, typename WFrag, typename Valu>
+__device__ __forceinline__ void ls_gates(f32x4 (&acc)[NACC], const LsFrags<KS2>& hb, WFrag wfrag, Valu valu)
 {
     if constexpr (TL0 < TL1) {
-        constexpr int P9[9][2] = { {2, 2}, {2, 1}, {1, 2}, {0, 2}, {1, 1}, {0, 1}, {2, 0}, {1, 0}, {0, 0} };      // (weight term, h term)
+        int step = 0;
 #pragma unroll
-        for (int pi = 9 - NPROD; pi < 9; ++pi) {
-            // six products: (0,2) (1,1) (0,1) (2,0) (1,0) (0,0) — indices 3 .. 8 of the list
+        for (int th = 0; th < 3; ++th) {                    // h term 0, 1, 2: (w0 w1 w2) h0 | (w0 w1) h1 | w0 h2
+            const int n_w = NPROD == 9 ? 3 : 3 - th;        // weight terms this h term meets: w0 .. w(n_w - 1)
 #pragma unroll
-            for (int ks = 0; ks < KS2; ++ks) {
-                const bf16x8 hb = __builtin_bit_cast(bf16x8, frags[(P9[pi][1] * KS2 + ks) * 64 + lane]);
+            for (int ks = 0; ks < KS2; ++ks)
 #pragma unroll
-                for (int tl = TL0; tl < TL1; ++tl)
-                    acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[seg_of(tl)][ks][P9[pi][0]], hb, acc[tl], 0, 0, 0);
-            }
+                for (int tw = 0; tw < n_w; ++tw) {
+#pragma unroll
+                    for (int tl = TL0; tl < TL1; ++tl)
+#ifdef AIDAX_LS_NOMFMA                                            // (measurement build: everything but the matrix instructions)
+                        acc[tl][0] += __builtin_bit_cast(f32x4, hb.v[th][ks])[0] * __builtin_bit_cast(f32x4, wfrag(tl, ks, tw))[0];
+#else
+                        acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag(tl, ks, tw), hb.v[th][ks], acc[tl], 0, 0, 0);
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                    valu(step++);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
         }
     }
 }
+// MFMA groups ls_gates issues (= calls of `valu`) per call
+__host__ __device__ constexpr int ls_gate_groups(int ks2, int nprod) { return nprod * ks2; }
 
-// M: tiles per wave the first layer starts for the layer above / that arrive started
-template <int TPW, int NW, int M, bool FIRST, bool LAST, bool CHAIN, int NPROD>
+#ifdef AIDAX_LP_TRACE
+// measurement build (scratch/ls_trace.py): the workgroups of stream group (tune >> 16 & 0xff) stamp the shader clock at eight points
+// of ticks 96..103 on every wave, straight into the pinned fault buffer: [layer is last][tick][wave][stamp] u64 behind word 16
+#define LS_STAMP(k) do { if (grp == ((a.tune >> 16) & 0xff) && tick >= 96 && tick < 104) {                                       \
+        __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = clock64(); __builtin_amdgcn_sched_barrier(0);            \
+        if (lane == 0) reinterpret_cast<unsigned long long*>(fault + 16)[(((last ? 1 : 0) * 8 + (tick - 96)) * 4 + (wave & 3)) * 8 + (k)] = t_; } } while (0)
+#else
+#define LS_STAMP(k) do {} while (0)
+#endif
+
+// M: tiles per wave the first layer starts for the layer above / that arrive started; CELL: 0 LSTM, 1 GRU (this layer's)
+template <int TPW, int NW, int M, bool FIRST, bool LAST, bool CHAIN, int NPROD, int CELL>
 __device__ __forceinline__ void ls_body(const LaunchArgs& a, const MfmaDesc& d, float* ring, uint32_t* counters, uint32_t* fault,
                                         float* smem, int grp, int l)
 {
@@ -1464,9 +1501,9 @@ __device__ __forceinline__ void ls_body(const LaunchArgs& a, const MfmaDesc& d, 
     float* xin   = xb + NS * nP;                            // [2][4][NS]
     u32x4* below = reinterpret_cast<u32x4*>(xin + 2 * 64);  // [2][kFrag]  h of the layer below as B fragments
     u32x4* hT    = below + 2 * kFrag;                       // [2][kFrag]  own h(t-1) as B fragments
-    float* hS    = reinterpret_cast<float*>(hT + 2 * kFrag);// [H][NS]     h as fp32: state in, state out
-    float* cT    = hS + H * NS;                             // [H][NS]
-    float* biasL = cT + H * NS;                             // [H][4] own layer, then [H][4] of the layer above (first layer, MW > 0)
+    float* hS    = reinterpret_cast<float*>(below);         // [H][NS]  h and c as fp32 on their way between the state records and the lanes:
+    float* cT    = hS + H * NS;                             // [H][NS]  in `below`, before the first and after the last frame
+    float* biasL = reinterpret_cast<float*>(hT + 2 * kFrag);// [H][4] own layer, then [H][4] of the layer above (first layer, MW > 0)
     float* wdl   = biasL + 2 * H * 4;                       // Dense weights, bias at [H]
     float* livef = wdl + ((H + 1 + 3) & ~3);                // [NS]
     float* dpart = livef + NS;                              // [2][NW][NS] Dense partial sums of the waves (last layer)
@@ -1521,30 +1558,42 @@ __device__ __forceinline__ void ls_body(const LaunchArgs& a, const MfmaDesc& d, 
         hS[i] = (valid && u < Ht) ? stp[u] : 0.f;           // padded units rest at 0
         cT[i] = (valid && u < Ht && L.cell == 0) ? stp[Ht + u] : 0.f;
     }
-    for (int i = tid; i < 4 * kFrag; i += NT) below[i] = u32x4{ 0u, 0u, 0u, 0u };      // (below and hT are adjacent)
+    for (int i = tid; i < 2 * kFrag; i += NT) hT[i] = u32x4{ 0u, 0u, 0u, 0u };
 
-    // ---- resident fragments: segment s of this wave -> wq[s]
-    bf16x8 wq[NSEG][KS2][3];
+    // ---- resident fragments. The TPW own-h segments (every tick's critical path): all three terms in registers. The NX
+    // others — the input half of the tiles started for the layer above (first layer) / of the tiles that start here (others),
+    // MFMAs nobody waits for — keep term 0 in registers and terms 1 and 2 (three of the six products) in LDS, each wave its own.
+    constexpr int NX = NSEG - TPW;
+    constexpr int NXA = NX > 0 ? NX : 1;
+    bf16x8 wq[TPW][KS2][3];
+    bf16x8 wx[NXA][KS2];
+    u32x4* w2x = reinterpret_cast<u32x4*>(dpart + 2 * 8 * NS) + (size_t)wave * NXA * KS2 * 2 * 64 + lane;      // [x][ks][term - 1] at stride 64
     {
         // the ls record: layer 0 holds one segment per tile (own h), the others two (h below | own h)
         const size_t per_seg = (size_t)KS2 * 3 * kWave;                     // u32x4 per (tile, segment)
         const u32x4* rec = reinterpret_cast<const u32x4*>(W + d.ls_off);
-        auto layer_base = [&](int ll) { return rec + (ll == 0 ? 0 : (size_t)NW * TPW * per_seg * (size_t)(1 + 2 * (ll - 1))); };
-        auto load_seg = [&](int slot, int ll, int tl, int seg_in_rec) {
-            const u32x4* sp = layer_base(ll) + ((size_t)(wave * TPW + tl) * (ll == 0 ? 1 : 2) + seg_in_rec) * per_seg + lane;
+        auto seg_ptr = [&](int ll, int tl, int seg_in_rec) {
+            return rec + (ll == 0 ? 0 : (size_t)NW * TPW * per_seg * (size_t)(1 + 2 * (ll - 1)))
+                       + ((size_t)(wave * TPW + tl) * (ll == 0 ? 1 : 2) + seg_in_rec) * per_seg + lane;
+        };
+#pragma unroll
+        for (int tl = 0; tl < TPW; ++tl) {                                  // own h(t-1)
+            const u32x4* sp = seg_ptr(l, tl, first ? 0 : 1);
 #pragma unroll
             for (int ks = 0; ks < KS2; ++ks)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) wq[slot][ks][t] = __builtin_bit_cast(bf16x8, sp[(ks * 3 + t) * kWave]);
-        };
+                for (int t = 0; t < 3; ++t) wq[tl][ks][t] = __builtin_bit_cast(bf16x8, sp[(ks * 3 + t) * kWave]);
+        }
 #pragma unroll
-        for (int tl = 0; tl < TPW; ++tl) load_seg(tl, l, tl, first ? 0 : 1);                // own h(t-1)
-        if constexpr (first) {
+        for (int x = 0; x < NX; ++x) {
+            // first layer: the layer above's input half of the tiles this wave starts; others: h below, for the tiles that start here
+            const u32x4* sp = first ? seg_ptr(1, x, 0) : seg_ptr(l, MW + x, 0);
 #pragma unroll
-            for (int tl = 0; tl < MW; ++tl) load_seg(TPW + tl, 1, tl, 0);                    // the layer above's input half of the tiles this wave starts
-        } else {
-#pragma unroll
-            for (int tl = MW; tl < TPW; ++tl) load_seg(TPW + tl - MW, l, tl, 0);             // h below, for the tiles that do not arrive started
+            for (int ks = 0; ks < KS2; ++ks) {
+                wx[x][ks] = __builtin_bit_cast(bf16x8, sp[(ks * 3 + 0) * kWave]);
+                w2x[((x * KS2 + ks) * 2 + 0) * 64] = sp[(ks * 3 + 1) * kWave];
+                w2x[((x * KS2 + ks) * 2 + 1) * 64] = sp[(ks * 3 + 2) * kWave];
+            }
         }
     }
     float w_in0[TPW];                                       // (pack_mfma lays the input k-step out by ITS waves and tiles: d.waves x d.tpw)
@@ -1582,26 +1631,64 @@ __device__ __forceinline__ void ls_body(const LaunchArgs& a, const MfmaDesc& d, 
         hv[tl] = hS[(wave * TPW + tl) * 64 + lane];         // unit 4T + q, stream lane & 15
         creg[tl] = cT[(wave * TPW + tl) * 64 + lane];
     }
+    __syncthreads();                                        // (the staging area becomes `below`)
+    for (int i = tid; i < 2 * kFrag; i += NT) below[i] = u32x4{ 0u, 0u, 0u, 0u };
     // where a lane's h values go in the fragments: unit u = 4T + q -> k-step u / 32, lane row (u % 32) / 8, element u % 8
-    auto publish = [&](u32x4* dst) {
+    auto publish_tile = [&](u32x4* dst, int tl) {
+        const int u = 4 * (wave * TPW + tl) + q;
+        uint16_t* p16 = reinterpret_cast<uint16_t*>(dst + (u >> 5) * 64 + ((u & 31) >> 3) * 16 + (lane & 15)) + (u & 7);
+        float r = hv[tl];
 #pragma unroll
-        for (int tl = 0; tl < TPW; ++tl) {
-            const int u = 4 * (wave * TPW + tl) + q;
-            uint16_t* p16 = reinterpret_cast<uint16_t*>(dst + (u >> 5) * 64 + ((u & 31) >> 3) * 16 + (lane & 15)) + (u & 7);
-            float r = hv[tl];
+        for (int t = 0; t < 3; ++t) {
+            const __bf16 b = static_cast<__bf16>(r);         // round to nearest even
+            p16[(size_t)t * KS2 * 64 * 8] = __builtin_bit_cast(uint16_t, b);
+            if (t < 2) r -= static_cast<float>(b);           // exact
+        }
+    };
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const __bf16 b = static_cast<__bf16>(r);     // round to nearest even
-                p16[(size_t)t * KS2 * 64 * 8] = __builtin_bit_cast(uint16_t, b);
-                if (t < 2) r -= static_cast<float>(b);       // exact
+    for (int tl = 0; tl < TPW; ++tl) publish_tile(hT, tl);
+    __syncthreads();
+
+    // ---- the cell update of one tile in steps of three to five instructions, so that it can be dealt out behind the MFMA
+    // groups of the NEXT tiles (bf16 MFMAs leave the VALU free while they run). Same operations in the same order as
+    // sigmoid_pre / tanh_rat / tanh_exp_pre; the last step splits the new h and writes its fragments.
+    struct CellTmp { float e0, e1, e2, x, u, p, qq, gg; };
+    constexpr int NSTEP = CELL == 0 ? 12 : 5;
+    CellTmp ct[TPW];
+    auto cell_step = [&](int tl, int k, const f32x4& g, u32x4* h_dst) {
+        CellTmp& t = ct[tl];
+        if constexpr (CELL == 0) {                          // LSTM: g = (i, f, g, o), the sigmoid rows carrying -log2 e
+            switch (k) {
+            case 0: t.x = tanh_rat_clamp(g.z); t.u = t.x * t.x; t.e0 = __builtin_amdgcn_exp2f(g.x); break;
+            case 1: t.p = __builtin_fmaf(kTanhP[6], t.u, kTanhP[5]); t.p = __builtin_fmaf(t.p, t.u, kTanhP[4]); t.e1 = __builtin_amdgcn_exp2f(g.y); break;
+            case 2: t.p = __builtin_fmaf(t.p, t.u, kTanhP[3]); t.p = __builtin_fmaf(t.p, t.u, kTanhP[2]); t.e2 = __builtin_amdgcn_exp2f(g.w); break;
+            case 3: t.p = __builtin_fmaf(t.p, t.u, kTanhP[1]); t.p = __builtin_fmaf(t.p, t.u, kTanhP[0]); t.qq = __builtin_fmaf(kTanhQ[3], t.u, kTanhQ[2]); break;
+            case 4: t.qq = __builtin_fmaf(t.qq, t.u, kTanhQ[1]); t.qq = __builtin_fmaf(t.qq, t.u, kTanhQ[0]); t.e0 = __builtin_amdgcn_rcpf(1.0f + t.e0); break;      // i
+            case 5: t.gg = (t.p * t.x) * __builtin_amdgcn_rcpf(t.qq); t.e1 = __builtin_amdgcn_rcpf(1.0f + t.e1); break;                                                // tanh(g), f
+            case 6: creg[tl] = __builtin_fmaf(t.e1, creg[tl], t.e0 * t.gg); t.x = tanh_rat_clamp(creg[tl]); break;
+            case 7: t.u = t.x * t.x; t.p = __builtin_fmaf(kTanhP[6], t.u, kTanhP[5]); t.p = __builtin_fmaf(t.p, t.u, kTanhP[4]); t.e2 = __builtin_amdgcn_rcpf(1.0f + t.e2); break;   // o
+            case 8: t.p = __builtin_fmaf(t.p, t.u, kTanhP[3]); t.p = __builtin_fmaf(t.p, t.u, kTanhP[2]); t.p = __builtin_fmaf(t.p, t.u, kTanhP[1]); break;
+            case 9: t.p = __builtin_fmaf(t.p, t.u, kTanhP[0]); t.qq = __builtin_fmaf(kTanhQ[3], t.u, kTanhQ[2]); t.qq = __builtin_fmaf(t.qq, t.u, kTanhQ[1]); t.qq = __builtin_fmaf(t.qq, t.u, kTanhQ[0]); break;
+            case 10: hv[tl] = t.e2 * ((t.p * t.x) * __builtin_amdgcn_rcpf(t.qq)); break;
+            case 11: publish_tile(h_dst, tl); break;
+            default: break;
+            }
+        } else {                                            // GRU: g = (z, r, candidate's recurrent half, its input half)
+            switch (k) {
+            case 0: t.e0 = __builtin_amdgcn_exp2f(g.x); t.e1 = __builtin_amdgcn_exp2f(g.y); break;
+            case 1: t.e0 = __builtin_amdgcn_rcpf(1.0f + t.e0); t.e1 = __builtin_amdgcn_rcpf(1.0f + t.e1); break;
+            case 2: t.e2 = __builtin_amdgcn_exp2f(__builtin_fmaf(t.e1, g.z, g.w)); break;                  // (the candidate rows carry 2 log2 e: tanh_exp_pre)
+            case 3: t.x = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + t.e2), 1.0f); hv[tl] = __builtin_fmaf(t.e0, hv[tl] - t.x, t.x); break;
+            case 4: publish_tile(h_dst, tl); break;
+            default: break;
             }
         }
     };
-    publish(hT);
-    __syncthreads();
 
-    // Frame Fprev goes up the ring, one tick after it was computed: its h fragments (16-byte write-through stores) and, behind
-    // the tick's MFMAs, the tiles started for the layer above
+    // A frame goes up the ring in two parts: its h fragments one tick after it was computed (16-byte write-through stores out
+    // of LDS), the tiles started for the layer above another tick later — they are computed at the END of a tick (the MFMAs
+    // whose shadow the cell update issues in) and leave at the head of the next one, so that every store has a whole tick to
+    // drain before the barrier that precedes its publication.
     auto ship_h = [&](const u32x4* h_src, int Fprev) {
         const uint32_t slot_off = (uint32_t)(((base_out + (uint32_t)Fprev) % kLpRing) * kSlot * sizeof(float));
         for (int i = tid; i < kFrag; i += NT) lp_store16(rs_out, slot_off + (uint32_t)i * 16u, __builtin_bit_cast(f32x4, h_src[i]));
@@ -1612,10 +1699,17 @@ __device__ __forceinline__ void ls_body(const LaunchArgs& a, const MfmaDesc& d, 
         for (int tl = 0; tl < MW; ++tl)
             lp_store16(rs_out, slot_off + (uint32_t)(kFrag * 16) + (uint32_t)(((wave * M + tl) * kWave + lane) * 16), pacc[tl]);
     };
-    auto own_seg = [](int tl) { return tl; };
-    auto up_seg = [](int tl) { return TPW + tl; };                          // first layer: the moved tiles' input half
-    auto below_seg = [](int tl) { return TPW + tl - MW; };                  // others: the input half of the tiles that start here
+    auto no_valu = [](int) {};
+    auto own_w = [&](int tl, int ks, int tw) -> bf16x8 { return wq[tl][ks][tw]; };
+    // the segments nobody waits for: x = tile (first layer: the tiles started for the layer above) / tile - MW (others)
+    auto x_w = [&](int x, int ks, int tw) -> bf16x8 { return tw == 0 ? wx[x][ks] : __builtin_bit_cast(bf16x8, w2x[((x * KS2 + ks) * 2 + tw - 1) * 64]); };
+    auto up_w = [&](int tl, int ks, int tw) -> bf16x8 { return x_w(tl, ks, tw); };
+    auto below_w = [&](int tl, int ks, int tw) -> bf16x8 { return x_w(tl - MW, ks, tw); };
+    auto bias_of = [&](int tl, bool above) { return *reinterpret_cast<const f32x4*>(biasL + (above ? H * 4 : 0) + 4 * (4 * (wave * TPW + tl) + q)); };
 
+    constexpr int HALF = (TPW + 1) / 2;                    // tiles of the first own-h phase
+    constexpr int G = ls_gate_groups(KS2, NPROD);          // MFMA groups of one ls_gates call
+    f32x4 held[MA] = {};                                   // first layer: the started tiles of the frame before last, on their way out
     int par = 0;                                           // parity of hT the next frame reads
     int done = 0;                                          // frames finished before this chunk
     for (int base = 0; base < n; base += kLpChunk) {
@@ -1636,7 +1730,7 @@ __device__ __forceinline__ void ls_body(const LaunchArgs& a, const MfmaDesc& d, 
         if constexpr (chain && last) {
             // one-launch form: the rows in a.out are the pre pass's, stored (write-through, drained) by the FIRST layer's
             // workgroup before it computed its first frame — once frames exist below, the rows are there
-            if (tid == 0) wait_below(done + 2);
+            if (tid == 0) wait_below(done + 3);
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
@@ -1668,13 +1762,17 @@ __device__ __forceinline__ void ls_body(const LaunchArgs& a, const MfmaDesc& d, 
         };
         constexpr int PER4 = (kFrag + NT - 1) / NT;        // 16-byte vectors of a frame each thread moves
         f32x4 pre[PER4];
-        f32x4 upx[MA] = {};                                // started tiles of the NEXT frame on their way in (layers >= 1)
-        f32x4 pcur[MA] = {};                               // ... of the current frame
-        auto fetch_below = [&](int F) {                    // all threads: frame F of the launch -> registers
+        f32x4 upx[MA] = {};                                // started tiles on their way in (layers >= 1): fetched in one tick, the accumulators' start in the next
+        constexpr int NB = TPW - MW > 0 ? TPW - MW : 1;
+        f32x4 nacc[NB] = {};                               // layers >= 1: bias + input half of the tiles that start here, for the NEXT frame
+        auto fetch_frags = [&](int F) {                    // all threads: the h fragments of frame F of the launch -> registers
             const uint32_t slot_off = (uint32_t)(((base_in + (uint32_t)F) % kLpRing) * kSlot * sizeof(float));
 #pragma unroll
             for (int k = 0; k < PER4; ++k)
                 if (k * NT + tid < kFrag) pre[k] = lp_load16(rs_in, slot_off + (uint32_t)(k * NT + tid) * 16u);
+        };
+        auto fetch_started = [&](int F) {                  // ... and this wave's started tiles of frame F
+            const uint32_t slot_off = (uint32_t)(((base_in + (uint32_t)F) % kLpRing) * kSlot * sizeof(float));
 #pragma unroll
             for (int tl = 0; tl < MW; ++tl)
                 upx[tl] = lp_load16(rs_in, slot_off + (uint32_t)(kFrag * 16) + (uint32_t)(((wave * M + tl) * kWave + lane) * 16));
@@ -1684,33 +1782,54 @@ __device__ __forceinline__ void ls_body(const LaunchArgs& a, const MfmaDesc& d, 
             for (int k = 0; k < PER4; ++k)
                 if (k * NT + tid < kFrag) below[parity * kFrag + k * NT + tid] = __builtin_bit_cast(u32x4, pre[k]);
         };
+        // the input half of the tiles that start here, for the frame whose fragments sit in below[parity]
+        auto start_next = [&](int parity, auto valu) {
+            f32x4 z[TPW];
+#pragma unroll
+            for (int tl = MW; tl < TPW; ++tl) z[tl] = bias_of(tl, false);
+            LsFrags<KS2> hbn;
+            ls_load_frags(hbn, below + parity * kFrag, lane);
+            ls_gates<KS2, NPROD, MW, TPW, TPW>(z, hbn, below_w, valu);
+#pragma unroll
+            for (int tl = MW; tl < TPW; ++tl) nacc[tl - MW] = z[tl];
+        };
 
         if (first) {
             if (tid < NS) write_xin(0, 0);
         } else {
-            if (tid == 0) wait_below(done + 2);            // frame 0 of the chunk for now, frame 1 for tick 0's prefetch
+            // frames 0 and 1 of the chunk into both halves of `below`, frame 0's started tiles, frame 2 for tick 0's prefetch
+            if (tid == 0) wait_below(done + 3);
             __syncthreads();
-            fetch_below(done);
+            fetch_frags(done);
+            fetch_started(done);
             stash_below(0);
-#pragma unroll
-            for (int tl = 0; tl < MA; ++tl) pcur[tl] = upx[tl];
+            if (cnt > 1) { fetch_frags(done + 1); stash_below(1); }
         }
         __syncthreads();
+        if constexpr (!first && MW < TPW) start_next(0, no_valu);
 
         const int ticks = last ? cnt + 2 : cnt;            // the Dense of a frame: partial sums one tick behind its h, the output two
         for (int tick = 0; tick < ticks; ++tick) {
             const int rd = par, wr = par ^ 1;
             const bool body = tick < cnt;
             const bool more = tick + 1 < cnt;              // another frame of this chunk follows
+            const bool more2 = tick + 2 < cnt;
             const int F = done + tick;                     // frame of the launch this tick computes
+            LS_STAMP(0);
+            f32x4 acc[TPW];
             if (first) {
                 if (tid < NS && more) write_xin((tick + 1) & 1, tick + 1);
-            } else if (more) {
-                fetch_below(F + 1);
+            } else {
+                // bias + input half: the tiles that arrived started (fetched a tick ago) / the ones started here last tick
+#pragma unroll
+                for (int tl = 0; tl < TPW; ++tl) acc[tl] = tl < MW ? upx[tl < MW ? tl : 0] : nacc[tl < MW ? 0 : tl - MW];
+                if (more) fetch_started(F + 1);
+                if (more2) fetch_frags(F + 2);
             }
             if (body && tid == 0) {
-                // thread 0 looks ahead while the others compute (see k_mfma_lp)
-                if (!first && tick + 2 < cnt) wait_below(F + 3);
+                // thread 0 looks ahead while the others compute (see k_mfma_lp): what the NEXT tick fetches must exist below,
+                // the slot the next tick stores into must be free above
+                if (!first && tick + 3 < cnt) wait_below(F + 4);
                 if (!last && base + tick + 1 < n) {
                     uint32_t spins = 0;
                     uint64_t t0 = 0;
@@ -1747,68 +1866,88 @@ __device__ __forceinline__ void ls_body(const LaunchArgs& a, const MfmaDesc& d, 
                 if (livef[lane] != 0.f) xb[lane * nP + fd] = o;
             }
 
+            LS_STAMP(1);
             if (body) {
                 const u32x4* h_rd = hT + rd * kFrag;
-                f32x4 acc[TPW];
-#pragma unroll
-                for (int tl = 0; tl < TPW; ++tl) acc[tl] = *reinterpret_cast<const f32x4*>(biasL + 4 * (4 * (wave * TPW + tl) + q));
+                u32x4* h_wr = hT + wr * kFrag;
+                LsFrags<KS2> hb;                            // own h(t-1): requested first, on its way while the frame before goes up the ring
+                ls_load_frags(hb, h_rd, lane);
                 if (!last && F >= 1) ship_h(h_rd, F - 1);              // h_rd = h(F-1)
-                if constexpr (first) {                     // the model inputs: one fp32 k-step (x, PARAM1, PARAM2, 0)
-                    const float b = xin[(tick & 1) * 64 + lane];
+                if constexpr (first) {
+                    if (MW > 0 && F >= 2) ship_started(held, F - 2);
+#pragma unroll
+                    for (int tl = 0; tl < TPW; ++tl) acc[tl] = bias_of(tl, false);
+                    const float b = xin[(tick & 1) * 64 + lane];      // the model inputs: one fp32 k-step (x, PARAM1, PARAM2, 0)
 #pragma unroll
                     for (int tl = 0; tl < TPW; ++tl)
                         acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_in0[tl], b, acc[tl], 0, 0, 0);
-                    ls_gates<KS2, NPROD, 0, TPW, NSEG, TPW>(acc, wq, h_rd, lane, own_seg);
-                    if constexpr (MW > 0) {                // the tiles started for the layer above: bias + W_in(above) . h(F-1)
+                }
+                // the cell steps of the tiles [T0, T1), dealt out over the G groups of a phase (the tiles advance together)
+                auto deal = [&](int T0, int T1, int g) {
+                    const int nt = T1 - T0, S = nt * NSTEP;
+#pragma unroll
+                    for (int sidx = g * S / G; sidx < (g + 1) * S / G; ++sidx) cell_step(T0 + sidx % nt, sidx / nt, acc[T0 + sidx % nt], h_wr);
+                };
+                // phase A: own h(t-1) against the first half of the tiles
+                LS_STAMP(2);
+                ls_gates<KS2, NPROD, 0, HALF, TPW>(acc, hb, own_w, no_valu);
+                LS_STAMP(3);
+                if constexpr (!first) {
+                    // frame F+2's fragments (requested at the head of the tick) go where frame F's were: their product was taken
+                    // a tick ago, and the registers they travelled in are free for the phases below
+                    if (more2) stash_below(tick & 1);
+                }
+                // phase B: ... the second half, the first half's cell update in its shadow
+                if constexpr (HALF < TPW) ls_gates<KS2, NPROD, HALF, TPW, TPW>(acc, hb, own_w, [&](int g) { deal(0, HALF, g); });
+                else {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) deal(0, HALF, g);
+                }
+                LS_STAMP(4);
+                // phase C: MFMAs nobody waits for — the tiles started for the layer above (first layer) / the input half of the
+                // next frame (others) — with the second half's cell update in their shadow
+                bool c_done = false;
+                if constexpr (first) {
+                    if constexpr (MW > 0) {
                         if (F >= 1) {
                             f32x4 pacc[MA];
 #pragma unroll
-                            for (int tl = 0; tl < MW; ++tl) pacc[tl] = *reinterpret_cast<const f32x4*>(biasL + H * 4 + 4 * (4 * (wave * TPW + tl) + q));
-                            ls_gates<KS2, NPROD, 0, MW, NSEG, MA>(pacc, wq, h_rd, lane, up_seg);
-                            ship_started(pacc, F - 1);
+                            for (int tl = 0; tl < MW; ++tl) pacc[tl] = bias_of(tl, true);
+                            ls_gates<KS2, NPROD, 0, MW, MA>(pacc, hb, up_w, [&](int g) { if constexpr (HALF < TPW) deal(HALF, TPW, g); });
+#pragma unroll
+                            for (int tl = 0; tl < MA; ++tl) held[tl] = pacc[tl];
+                            c_done = true;
                         }
                     }
-                } else {
-#pragma unroll
-                    for (int tl = 0; tl < MW; ++tl) acc[tl] = pcur[tl];           // bias + input half, from below
-                    ls_gates<KS2, NPROD, MW, TPW, NSEG, TPW>(acc, wq, below + (tick & 1) * kFrag, lane, below_seg);
-                    ls_gates<KS2, NPROD, 0, TPW, NSEG, TPW>(acc, wq, h_rd, lane, own_seg);
-                }
-#pragma unroll
-                for (int tl = 0; tl < TPW; ++tl) {
-                    float hn;
-                    if (L.cell == 0) {
-                        const float gi = sigmoid_pre(acc[tl].x), gf = sigmoid_pre(acc[tl].y);
-                        const float gg = tanh_rat(acc[tl].z), go = sigmoid_pre(acc[tl].w);
-                        const float cn = __builtin_fmaf(gf, creg[tl], gi * gg);
-                        creg[tl] = cn;
-                        hn = go * tanh_rat(cn);
-                    } else {
-                        const float gz = sigmoid_pre(acc[tl].x), gr = sigmoid_pre(acc[tl].y);
-                        const float nn = tanh_exp_pre(__builtin_fmaf(gr, acc[tl].z, acc[tl].w));      // (GRU: see GruCell::step)
-                        hn = __builtin_fmaf(gz, hv[tl] - nn, nn);
+                } else if constexpr (MW < TPW) {
+                    if (more) {
+                        start_next((tick + 1) & 1, [&](int g) { if constexpr (HALF < TPW) deal(HALF, TPW, g); });
+                        c_done = true;
                     }
-                    hv[tl] = hn;
                 }
-                publish(hT + wr * kFrag);
-                par = wr;
-                if (!first && more) {
-                    stash_below((tick + 1) & 1);
+                if (!c_done) {
+                    if constexpr (HALF < TPW) {
 #pragma unroll
-                    for (int tl = 0; tl < MA; ++tl) pcur[tl] = upx[tl];
+                        for (int g = 0; g < G; ++g) deal(HALF, TPW, g);
+                    }
                 }
-                if (!last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's ring stores have left before the barrier (G16)
+                LS_STAMP(5);
+                par = wr;
+                if (!last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's ring stores (issued at the head of the tick) have left before the barrier (G16)
+                LS_STAMP(6);
             }
-            __syncthreads();                               // h(t) in LDS, the next frame's input in LDS, ring stores of this frame done
+            __syncthreads();                               // h(t) in LDS, the next frames' input in LDS, ring stores of this tick done
+            LS_STAMP(7);
             // ---- counters, by thread 0 after the barrier: every kLpBatch frames and at the end of the launch
             if (body && tid == 0) {
                 if (!last) {
-                    const int produced = F;
+                    // complete in the ring: frames whose h left by the last tick and whose started tiles left in this one
+                    const int produced = first && MW > 0 ? F - 1 : F;
                     if (produced > 0 && produced % kLpBatch == 0)
                         __hip_atomic_store(cnt_out, base_out + (uint32_t)produced, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if (!first) {
-                    const int consumed = more ? F + 2 : F + 1;             // frames read out of the ring so far
+                    const int consumed = more ? F + 2 : F + 1;             // frames read out of the ring so far (fragments AND started tiles)
                     if (consumed % kLpBatch == 0 || consumed == n)
                         __hip_atomic_store(cnt_in + 16, base_in + (uint32_t)consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -1829,13 +1968,16 @@ __device__ __forceinline__ void ls_body(const LaunchArgs& a, const MfmaDesc& d, 
         __syncthreads();
     }
 
-    if (!last && n > 0) {                                  // the launch's last frame, then the final count
+    if (!last && n > 0) {                                  // the launch's last frame (and the started tiles still held), then the final count
         ship_h(hT + par * kFrag, n - 1);
         if constexpr (first && MW > 0) {
+            if (n >= 2) ship_started(held, n - 2);
             f32x4 pacc[MA];
 #pragma unroll
-            for (int tl = 0; tl < MW; ++tl) pacc[tl] = *reinterpret_cast<const f32x4*>(biasL + H * 4 + 4 * (4 * (wave * TPW + tl) + q));
-            ls_gates<KS2, NPROD, 0, MW, NSEG, MA>(pacc, wq, hT + par * kFrag, lane, up_seg);
+            for (int tl = 0; tl < MW; ++tl) pacc[tl] = bias_of(tl, true);
+            LsFrags<KS2> hbl;
+            ls_load_frags(hbl, hT + par * kFrag, lane);
+            ls_gates<KS2, NPROD, 0, MW, MA>(pacc, hbl, up_w, no_valu);
             ship_started(pacc, n - 1);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1885,7 +2027,8 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_ls(LaunchArgs a, MfmaDesc d
             lp_chain_rows<true>(a, smem, grp, true);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
-        ls_body<TPW, NW, M, true, false, CHAIN, NPROD>(a, d, ring, counters, fault, smem, grp, l);
+        if (d.L[l].cell == 0) ls_body<TPW, NW, M, true, false, CHAIN, NPROD, 0>(a, d, ring, counters, fault, smem, grp, l);
+        else ls_body<TPW, NW, M, true, false, CHAIN, NPROD, 1>(a, d, ring, counters, fault, smem, grp, l);
     } else if (l == NL - 1) {
         if constexpr (CHAIN) {
             if (a.tune & 8192) {                                          // test hook: this workgroup starts 100 us late
@@ -1893,13 +2036,15 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_ls(LaunchArgs a, MfmaDesc d
                 while (wall_clock64() - t0 < 10000) __builtin_amdgcn_s_sleep(64);
             }
         }
-        ls_body<TPW, NW, M, false, true, CHAIN, NPROD>(a, d, ring, counters, fault, smem, grp, l);
+        if (d.L[l].cell == 0) ls_body<TPW, NW, M, false, true, CHAIN, NPROD, 0>(a, d, ring, counters, fault, smem, grp, l);
+        else ls_body<TPW, NW, M, false, true, CHAIN, NPROD, 1>(a, d, ring, counters, fault, smem, grp, l);
         if constexpr (CHAIN) {
             __syncthreads();
             lp_chain_rows<false>(a, smem, grp, true);
         }
     } else {
-        ls_body<TPW, NW, M, false, false, CHAIN, NPROD>(a, d, ring, counters, fault, smem, grp, l);
+        if (d.L[l].cell == 0) ls_body<TPW, NW, M, false, false, CHAIN, NPROD, 0>(a, d, ring, counters, fault, smem, grp, l);
+        else ls_body<TPW, NW, M, false, false, CHAIN, NPROD, 1>(a, d, ring, counters, fault, smem, grp, l);
     }
 }
 
@@ -2066,7 +2211,7 @@ bool mfma_ls_serves(const MfmaDesc& d)
 }
 size_t mfma_ls_lds_bytes(const MfmaDesc& d, uint32_t n_frames, bool fused)
 {
-    const size_t body = ls_lds_floats(d.hidden, (int)n_frames);
+    const size_t body = ls_lds_floats(d.hidden, (int)n_frames, ls_geo(d.n_layers, d.hidden));
     const size_t rows = fused ? (size_t)kMfmaStreams * ((n_frames + 3) & ~3u) + 2 * kChainPackHandFloats : 0;      // lp_chain_rows works in the body's LDS
     return (body > rows ? body : rows) * sizeof(float);
 }

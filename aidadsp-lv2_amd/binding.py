@@ -89,6 +89,8 @@ def lib() -> C.CDLL:
     L.aidax_db_to_coeff.restype = C.c_float
     L.aidax_lpf_fc.argtypes = [C.c_float]
     L.aidax_lpf_fc.restype = C.c_float
+    L.aidax_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.aidax_pick_device.argtypes = [C.c_char_p, C.c_int, C.POINTER(u32), C.POINTER(C.c_int)]
     L.aidax_pool_create.argtypes = [u32, u32, C.c_double, C.c_int, C.POINTER(vp)]
     L.aidax_pool_destroy.argtypes = [vp]
     L.aidax_pool_destroy.restype = None
@@ -177,6 +179,22 @@ def biquad_design(kind: int, fc: float, q: float, gain_db: float) -> np.ndarray:
     out = (C.c_double * 5)()
     _check(lib().aidax_biquad_design(kind, fc, q, gain_db, out))
     return np.array(list(out), np.float64)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    _check(lib().aidax_device_count(C.byref(n)))
+    return n.value
+
+
+def pick_device(spec: Optional[str], count: int, load=None) -> int:
+    """The placement rule (pure): least-loaded device among those `spec` names ("auto", "0-3,6", None = device 0)."""
+    arr = None
+    if load is not None:
+        arr = (C.c_uint32 * len(load))(*load)
+    out = C.c_int(-1)
+    _check(lib().aidax_pick_device(spec.encode() if spec is not None else None, count, arr, C.byref(out)))
+    return out.value
 
 
 def db_to_coeff(db: float) -> float:

@@ -10,6 +10,7 @@
 #include <cmath>
 
 #include "aidax_internal.h"
+#include <cstring>
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -177,5 +178,40 @@ AIDAX_API int aidax_biquad_design(int type, double fc, double q, double gain_db,
 
 AIDAX_API float aidax_db_to_coeff(float db) { return db_to_coeff(db); }
 AIDAX_API float aidax_lpf_fc(float percent) { return lpf_fc(percent); }
+
+// Placement rule of include/aidax.h (pure: the device count and the loads come from the caller)
+AIDAX_API int aidax_pick_device(const char* spec, int device_count, const uint32_t* load, int* device_out)
+{
+    if (!device_out || device_count <= 0) return fail(AIDAX_ERR_ARG, "aidax_pick_device: no device to choose from");
+    bool cand[256] = {};
+    const int n = device_count < 256 ? device_count : 256;
+    if (!spec || !*spec) cand[0] = true;
+    else if (!std::strcmp(spec, "auto")) { for (int i = 0; i < n; ++i) cand[i] = true; }
+    else {
+        const char* p = spec;
+        while (*p) {
+            if (*p < '0' || *p > '9') return fail(AIDAX_ERR_ARG, "aidax_pick_device: device list is not 'auto' or indices / ranges like 0-3,6");
+            long a = 0, b;
+            while (*p >= '0' && *p <= '9') { a = a * 10 + (*p++ - '0'); if (a > 100000) return AIDAX_ERR_ARG; }
+            b = a;
+            if (*p == '-') {
+                ++p;
+                if (*p < '0' || *p > '9') return AIDAX_ERR_ARG;
+                b = 0;
+                while (*p >= '0' && *p <= '9') { b = b * 10 + (*p++ - '0'); if (b > 100000) return AIDAX_ERR_ARG; }
+                if (b < a) return AIDAX_ERR_ARG;
+            }
+            for (long i = a; i <= b && i < n; ++i) cand[i] = true;
+            if (*p == ',') { ++p; if (!*p) return AIDAX_ERR_ARG; }
+            else if (*p) return AIDAX_ERR_ARG;
+        }
+    }
+    int best = -1;
+    for (int i = 0; i < n; ++i)
+        if (cand[i] && (best < 0 || (load ? load[i] : 0u) < (load ? load[best] : 0u))) best = i;
+    if (best < 0) return fail(AIDAX_ERR_ARG, "aidax_pick_device: the device list names no device of this machine");
+    *device_out = best;
+    return AIDAX_OK;
+}
 
 }  // extern "C"

@@ -37,6 +37,7 @@
 //   * stacked models in one launch: the packed chain passes on two waves of the first / last layer's workgroup around
 //     the unchanged body (lp_chain_rows);
 //   * k_gru_gm: one-layer GRUs on gate-major tiles (three quarters of the MFMAs), one main + one helper wave per SIMD.
+#include <cstdlib>
 #include "aidax_device.h"
 #include "aidax_kernels.h"
 #include "aidax_layout.h"
@@ -2083,6 +2084,27 @@ static LpFn lp_fn(int hidden, int n_layers)
     default: return nullptr;                               // wider stacks keep the fragment-streaming kernel
     }
 }
+// The chained kernels (two or more layers: workgroups that wait for each other) go out through hipLaunchCooperativeKernel: the
+// runtime REFUSES a grid that cannot be co-resident on the device (hipErrorCooperativeLaunchTooLarge — the pool then serves the
+// model with k_mfma at once, aidax_pool.cpp) and schedules the grid as a gang, so that another process's kernels cannot sit
+// between its workgroups: next to a process that keeps every CU busy a cfg5 block took 7.8 ms through the plain launch and
+// 0.71 ms through this one; alone it costs 15 us per block (698 -> 713 us, profiles/r04_lp_coop.txt). AIDAX_LP_COOP=0: the
+// plain launch (A/B runs).
+static bool lp_coop_launch()
+{
+    static const bool on = [] { const char* e = std::getenv("AIDAX_LP_COOP"); return !(e && e[0] == '0'); }();
+    return on;
+}
+static hipError_t lp_launch(LpFn fn, uint32_t blocks, uint32_t threads, size_t lds, hipStream_t stream, LaunchArgs a, MfmaDesc d,
+                            float* ring, uint32_t* counters, uint32_t* fault)
+{
+    if (lp_coop_launch() && d.n_layers >= 2) {
+        void* args[] = { &a, &d, &ring, &counters, &fault };
+        return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fn), dim3(blocks), dim3(threads), args, (unsigned)lds, stream);
+    }
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(threads), lds, stream, a, d, ring, counters, fault);
+    return hipGetLastError();
+}
 static int lp_m(const MfmaDesc& d) { return lp_moved_tiles(d.n_layers, d.hidden / 4 / mfma_waves(d.hidden), mfma_waves(d.hidden)); }
 
 // (one-layer models too: a workgroup per 16 streams with the layer's fragments resident in registers — no ring, no waits)
@@ -2128,8 +2150,7 @@ hipError_t launch_mfma_lp_kernel(const LaunchArgs& a, const MfmaDesc& d, float* 
     const uint32_t groups = (a.n_streams + kMfmaStreams - 1) / kMfmaStreams;
     const uint32_t blocks = ((groups + 7) / 8) * 8 * (uint32_t)d.n_layers;
     const int waves = mfma_waves(d.hidden) + (fused && lp_helper_form(d) ? lp_helpers(d.hidden) : 0);
-    hipLaunchKernelGGL(fn, dim3(blocks), dim3(waves * kWave), lds, stream, a, d, ring, counters, fault);
-    return hipGetLastError();
+    return lp_launch(fn, blocks, (uint32_t)(waves * kWave), lds, stream, a, d, ring, counters, fault);
 }
 
 // k_gru_gm: one-layer GRU models with three or four main waves (48 / 64 units after rounding up to 16). Narrower ones would
@@ -2235,8 +2256,7 @@ hipError_t launch_mfma_ls_kernel(const LaunchArgs& a, const MfmaDesc& d, float* 
     }
     const uint32_t groups = (a.n_streams + kMfmaStreams - 1) / kMfmaStreams;
     const uint32_t blocks = ((groups + 7) / 8) * 8 * (uint32_t)d.n_layers;
-    hipLaunchKernelGGL(fn, dim3(blocks), dim3(ls_geo(d.n_layers, d.hidden).nw * kWave), lds, stream, a, d, ring, counters, fault);
-    return hipGetLastError();
+    return lp_launch(fn, blocks, (uint32_t)(ls_geo(d.n_layers, d.hidden).nw * kWave), lds, stream, a, d, ring, counters, fault);
 }
 
 }  // namespace aidax

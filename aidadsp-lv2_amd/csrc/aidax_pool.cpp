@@ -211,7 +211,7 @@ struct aidax_pool {
     // so is wrong; whoever notices reports it, and the pool serves the model with k_mfma from then on (lp_off).
     uint32_t* h_lp_fault = nullptr;
     uint32_t* hd_lp_fault = nullptr;
-    std::atomic<bool> lp_off{false};
+    mutable std::atomic<bool> lp_off{false};      // (mutable: set from the launch path, a const member function)
     std::atomic<uint32_t> lp_faults{0};
     bool take_lp_fault()
     {
@@ -399,16 +399,29 @@ struct aidax_pool {
             // split form around the matrix-core kernel: packed chains in -> out, applyModel in place, packed chains
             // k_mfma_lp only for the passes themselves: warm-ups (worker stream, next to the passes) and the bare-model
             // modes run on k_mfma, which leaves bit-identical state — two of those grids must never be in flight together
+            // A chained grid the runtime refuses (cooperative launch: it cannot be co-resident on this device — a partitioned
+            // GPU, a pool forced onto the kernel) is no error of the pass: the model is served by k_mfma from here on
+            auto refused = [&](hipError_t e) {
+                if (e != hipErrorCooperativeLaunchTooLarge) return false;
+                (void)hipGetLastError();
+                lp_off.store(true, std::memory_order_relaxed);
+                return true;
+            };
             auto model_kernel = [&]() {
-                if (!(lp_in_use(m) && a.mode == MODE_CHAIN)) return launch_mfma_kernel(a, m.mdesc, s);
-                return m.lp_split ? launch_mfma_ls_kernel(a, m.mdesc, m.d_ring, m.d_counters, hd_lp_fault, m.lp_split, s)
-                                  : launch_mfma_lp_kernel(a, m.mdesc, m.d_ring, m.d_counters, hd_lp_fault, s);
+                if (lp_in_use(m) && a.mode == MODE_CHAIN) {
+                    const hipError_t e = m.lp_split ? launch_mfma_ls_kernel(a, m.mdesc, m.d_ring, m.d_counters, hd_lp_fault, m.lp_split, s)
+                                                    : launch_mfma_lp_kernel(a, m.mdesc, m.d_ring, m.d_counters, hd_lp_fault, s);
+                    if (!refused(e)) return e;
+                }
+                return launch_mfma_kernel(a, m.mdesc, s);
             };
             if (a.mode != MODE_CHAIN) return model_kernel();
             if (m.gru_gm && a.n_frames != 0) return m.gru_gs ? launch_gru_gs_kernel(a, m.mdesc, m.gru_gs, s) : launch_gru_gm_kernel(a, m.mdesc, s);
-            if (m.lp_fused && lp_in_use(m) && a.n_frames != 0)
-                return m.lp_split ? launch_mfma_ls_kernel(a, m.mdesc, m.d_ring, m.d_counters, hd_lp_fault, m.lp_split, s, true)
-                                  : launch_mfma_lp_kernel(a, m.mdesc, m.d_ring, m.d_counters, hd_lp_fault, s, true);
+            if (m.lp_fused && lp_in_use(m) && a.n_frames != 0) {
+                const hipError_t e = m.lp_split ? launch_mfma_ls_kernel(a, m.mdesc, m.d_ring, m.d_counters, hd_lp_fault, m.lp_split, s, true)
+                                                : launch_mfma_lp_kernel(a, m.mdesc, m.d_ring, m.d_counters, hd_lp_fault, s, true);
+                if (!refused(e)) return e;
+            }
             hipError_t e = launch_chain_pass(true, a, s);
             if (e == hipSuccess && a.n_frames != 0) e = model_kernel();
             if (e == hipSuccess) e = launch_chain_pass(false, a, s);
@@ -727,6 +740,16 @@ bool pool_lp_in_use(const aidax_pool* p) { return p->cur.has_model && p->lp_in_u
 }  // namespace aidax
 
 extern "C" {
+
+AIDAX_API int aidax_device_count(int* count)
+{
+    if (!count) return fail(AIDAX_ERR_ARG, "null count");
+    *count = 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(AIDAX_ERR_DEVICE, "no HIP device");
+    *count = n;
+    return AIDAX_OK;
+}
 
 AIDAX_API int aidax_pool_create(uint32_t n_streams, uint32_t max_frames, double host_samplerate,
                                 int device_id, aidax_pool** out)

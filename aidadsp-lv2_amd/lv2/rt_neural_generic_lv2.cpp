@@ -102,10 +102,33 @@ struct Plugin {
     bool notify_open = false;
 };
 
-// ---- hub registry: one hub per model file, shared by the instances of this process
-struct HubRef { aidax_hub* hub; int refs; };
+// ---- device placement: AIDAX_DEVICE names the candidates ("auto", "0-3,6"; unset = device 0, as before);
+// one load count per device and process — instances in one-stream mode, hub seats in hub mode — and aidax_pick_device's rule:
+// least loaded, lowest index first. Instances share nothing (rt-neural-generic.h:198-239), so this is all there is to a node
+// with several GPUs.
+std::mutex g_dev_mu;
+uint32_t g_dev_load[256] = {};
+int place_on_device(uint32_t weight)
+{
+    int count = 0;
+    if (aidax_device_count(&count) != AIDAX_OK) return -1;
+    std::lock_guard<std::mutex> g(g_dev_mu);
+    int device = -1;
+    if (aidax_pick_device(std::getenv("AIDAX_DEVICE"), count, g_dev_load, &device) != AIDAX_OK) return -1;
+    g_dev_load[device] += weight;
+    return device;
+}
+void leave_device(int device, uint32_t weight)
+{
+    if (device < 0 || device >= 256) return;
+    std::lock_guard<std::mutex> g(g_dev_mu);
+    g_dev_load[device] = g_dev_load[device] >= weight ? g_dev_load[device] - weight : 0u;
+}
+
+// ---- hub registry: the hubs of a model file (one per device that serves it), shared by the instances of this process
+struct HubRef { aidax_hub* hub; int refs; int device; };
 std::mutex g_hub_mu;
-std::map<std::string, HubRef> g_hubs;
+std::multimap<std::string, HubRef> g_hubs;
 
 // worker / main thread: give a seat back; the last one out destroys the hub
 void hub_leave(aidax_hub* hub, int32_t slot)
@@ -115,6 +138,7 @@ void hub_leave(aidax_hub* hub, int32_t slot)
     aidax_hub_detach(hub, slot);
     for (auto it = g_hubs.begin(); it != g_hubs.end(); ++it) {
         if (it->second.hub != hub) continue;
+        leave_device(it->second.device, 1);
         if (--it->second.refs == 0) {
             aidax_hub_destroy(hub);
             g_hubs.erase(it);
@@ -128,18 +152,25 @@ bool hub_join(Plugin* self, const aidax_model* model, aidax_hub** hub_out, int32
 {
     const std::string key = aidax_model_path(model);
     std::lock_guard<std::mutex> g(g_hub_mu);
-    auto it = g_hubs.find(key);
+    // a hub of this file with a free seat (the one this instance sits in now counts: its seat is given back after the swap);
+    // none: a new hub on the least-loaded device AIDAX_DEVICE allows — that is how the instances of one file spread over GPUs
+    auto range = g_hubs.equal_range(key);
+    auto it = g_hubs.end();
+    for (auto k = range.first; k != range.second; ++k)
+        if (k->second.refs < self->hub_capacity || k->second.hub == self->hub) { it = k; break; }
     if (it == g_hubs.end()) {
+        const int device = place_on_device(0);
+        if (device < 0) return false;
         aidax_hub* hub = nullptr;
         const char* fr = std::getenv("AIDAX_HUB_FRAMES");
         const uint32_t max_frames = fr ? static_cast<uint32_t>(std::atoi(fr)) : 2048u;
         // twice the seats: an instance that reloads a file of this hub holds its old seat until the swap and the worker's
         // kWorkerFree, so all of them may sit here twice for a moment
-        if (aidax_hub_create(2u * static_cast<uint32_t>(self->hub_capacity), max_frames, self->samplerate, self->device, &hub) != AIDAX_OK)
+        if (aidax_hub_create(2u * static_cast<uint32_t>(self->hub_capacity), max_frames, self->samplerate, device, &hub) != AIDAX_OK)
             return false;
         if (const char* dl = std::getenv("AIDAX_HUB_DEADLINE_US")) aidax_hub_set_deadline_us(hub, std::atoll(dl));
         if (aidax_hub_set_model(hub, model, AIDAX_START_WARMUP) != AIDAX_OK) { aidax_hub_destroy(hub); return false; }
-        it = g_hubs.emplace(key, HubRef{ hub, 0 }).first;
+        it = g_hubs.emplace(key, HubRef{ hub, 0, device });
     }
     int32_t slot = -1;
     // the seat continues the stream of the one this instance plays on now (PARAM targets for the new DynamicModel, :822-825)
@@ -148,6 +179,10 @@ bool hub_join(Plugin* self, const aidax_model* model, aidax_hub** hub_out, int32
         return false;
     }
     ++it->second.refs;
+    {
+        std::lock_guard<std::mutex> gd(g_dev_mu);
+        if (it->second.device >= 0 && it->second.device < 256) ++g_dev_load[it->second.device];
+    }
     *hub_out = it->second.hub;
     *slot_out = slot;
     return true;
@@ -257,10 +292,15 @@ LV2_Handle instantiate(const LV2_Descriptor*, double samplerate, const char*, co
     }
     map_plugin_uris(self->map, &self->uris);
 
-    const char* dev = std::getenv("AIDAX_DEVICE");
-    const int device = dev ? std::atoi(dev) : 0;
     const char* hub = std::getenv("AIDAX_HUB");
     self->hub_capacity = hub ? std::atoi(hub) : 0;
+    // one-stream mode: this instance's GPU, for its whole life; hub mode: the hub it joins decides (hub_join)
+    const int device = place_on_device(self->hub_capacity > 1 ? 0 : 1);
+    if (device < 0) {
+        std::fprintf(stderr, "Error! %s\n", aidax_last_error());
+        delete self;
+        return nullptr;
+    }
     self->device = device;
     const char* strict = std::getenv("AIDAX_STRICT_REFERENCE_SET");
     self->strict = !(strict && strict[0] == '0');
@@ -270,6 +310,7 @@ LV2_Handle instantiate(const LV2_Descriptor*, double samplerate, const char*, co
     // default mode: the instance's own one-stream pool; hub mode: the same call only proves there is a device
     if (aidax_pool_create(1, self->hub_capacity > 1 ? 4 : self->max_frames, samplerate, device, &self->pool) != AIDAX_OK) {
         std::fprintf(stderr, "Error! %s\n", aidax_last_error());
+        leave_device(device, self->hub_capacity > 1 ? 0 : 1);
         delete self;
         return nullptr;
     }
@@ -452,6 +493,7 @@ void cleanup(LV2_Handle instance)
 {
     Plugin* self = static_cast<Plugin*>(instance);
     hub_leave(self->hub, self->slot);
+    if (self->hub_capacity <= 1) leave_device(self->device, 1);
     aidax_pool_destroy(self->pool);
     aidax_model_free(self->model);
     delete self;

@@ -118,6 +118,19 @@ AIDAX_API int aidax_biquad_design(int type, double fc, double q, double gain_db,
 AIDAX_API float aidax_db_to_coeff(float db);
 AIDAX_API float aidax_lpf_fc(float percent);
 
+/* ------------------------------------------------------- device placement
+ * The reference's unit of independence is the plugin instance (instantiate(), rt-neural-generic.cpp:244-333; instances
+ * share nothing, rt-neural-generic.h:198-239, 311-319), so on a node with several GPUs instances are the thing to spread.
+ * aidax_device_count: HIP devices this process sees (0 and AIDAX_ERR_DEVICE without a usable runtime).
+ * aidax_pick_device: the placement rule, a pure function (no HIP call): `spec` names the candidates — NULL / "" / "0" the
+ * first device (what AIDAX_DEVICE unset means), "auto" every device, else a list of indices and ranges ("0-3,6"); of the
+ * candidates below device_count the one with the smallest load[] wins, ties go to the lowest index. load may be NULL (all
+ * idle). AIDAX_ERR_ARG when spec is malformed or names no device below device_count. The LV2 shell keeps one load count
+ * per device and process (instances in one-stream mode, hubs' seats in hub mode) and asks this function at instantiate()
+ * resp. when it opens a hub. */
+AIDAX_API int aidax_device_count(int* count);
+AIDAX_API int aidax_pick_device(const char* spec, int device_count, const uint32_t* load, int* device_out);
+
 /* -------------------------------------------------------------------- pool */
 typedef struct aidax_pool aidax_pool;
 

@@ -140,6 +140,30 @@ def test_control_defaults_match_ttl():
         assert getattr(c, n) == getattr(o, n), n
 
 
+
+def test_placement_rule_picks_the_least_loaded_candidate():
+    """aidax_pick_device — how the LV2 shell spreads instances / hubs over the GPUs of a node (one instance = one stream,
+    rt-neural-generic.cpp:244-333) — is a pure function: the device count and the loads are injected here."""
+    ax = importlib.import_module("aidadsp-lv2_amd")
+    pick = ax.pick_device
+    assert pick(None, 8) == 0 and pick("", 8) == 0 and pick("0", 8) == 0            # AIDAX_DEVICE unset: device 0, as before
+    assert pick("auto", 8) == 0                                                      # all idle: lowest index
+    assert pick("auto", 8, [3, 1, 2, 1, 5, 9, 9, 9]) == 1                            # least loaded, ties to the lowest index
+    assert pick("auto", 8, [1, 1, 1, 1, 1, 1, 1, 0]) == 7
+    assert pick("2-5", 8, [0, 0, 4, 3, 3, 9, 0, 0]) == 3
+    assert pick("6,1,3", 8, [0, 2, 0, 2, 0, 0, 1, 0]) == 6
+    assert pick("0-3,6", 8, [5, 5, 5, 5, 0, 0, 4, 0]) == 6
+    assert pick("4-15", 8, [0, 0, 0, 0, 2, 1, 2, 2]) == 5                            # the part of a range the machine has
+    assert pick("3", 1 + 3) == 3
+    # round-robin emerges from least-loaded: sixteen instances over eight devices, two each
+    load = [0] * 8
+    for _ in range(16):
+        load[pick("auto", 8, load)] += 1
+    assert load == [2] * 8
+    for bad, n in (("8", 8), ("9-12", 8), ("x", 8), ("1,,2", 8), ("3-1", 8), ("1-", 8), ("auto", 0), ("0,", 8), ("-1", 8)):
+        with pytest.raises(ax.AidaxError):
+            pick(bad, n)
+
 def test_device_calls_fail_loudly_without_a_gpu():
     import torch
     if torch.cuda.is_available():

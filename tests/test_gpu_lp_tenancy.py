@@ -235,3 +235,30 @@ def test_hub_delivers_silence_for_a_pass_that_gave_up_and_recovers(tmp_path, mon
             good += 1
     assert 1 <= errors <= 3 and good >= nblk - 5, (errors, good)
     hub.close()
+
+
+def test_a_chained_grid_that_cannot_be_resident_is_refused_at_launch_and_served_by_k_mfma(tmp_path, monkeypatch):
+    """Residency as a launch-time guarantee: the chained kernels go out through hipLaunchCooperativeKernel, which refuses a
+    grid that cannot be co-resident on the device — here a pool FORCED onto the kernel (AIDAX_MFMA_LP=1) with more
+    (stream group, layer) workgroups than the GPU has CUs. No launch, no wait, no give-up: the same call serves the block
+    with k_mfma, every block matches the oracle, and the pool stays on k_mfma. (With AIDAX_LP_COOP=0 the same pool launches
+    the grid and leans on the dispatcher's order — the situation the 250 ms give-up exists for.)"""
+    import torch
+    monkeypatch.setenv("AIDAX_MFMA_LP", "1")
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    # (LSTM-96 x 2: a workgroup's 152 KiB of LDS make it one per CU — a narrow model's grid of this size WOULD fit, several per CU)
+    path, spec = _model_file(tmp_path, "l96x2big", kind="lstm", hidden=96, input_size=1, seed=965, n_rnn=2)
+    S, n, nblk = 16 * (cus // 2 + 3), 128, 3                                   # (cus / 2 + 3) groups x 2 layers > cus workgroups
+    base = modelgen.signal(8, n * nblk, seed=12)
+    idx = (np.arange(S) * 5) % 8
+    pool = ax.Pool(S, n)
+    pool.set_model(ax.Model(path))
+    assert pool.kernel_name == "k_mfma_ls"
+    want = O.run_streams(spec, O.default_controls(), base, n)
+    for b in range(nblk):
+        got = pool.process(np.ascontiguousarray(base[idx, b * n:(b + 1) * n]))
+        assert pool.kernel_name == "k_chain+k_mfma"
+        for k in range(8):
+            errlog.bound(np.abs(got[int(np.argmax(idx == k))] - want[k, b * n:(b + 1) * n]).max(), 2e-6, "gpu_lp:refused_grid")
+    pool.sync()                                                                # nothing gave up: nothing was launched
+    pool.close()

@@ -1050,7 +1050,7 @@ def test_stacked_one_launch_form_is_bit_identical_to_the_three_launch_form(name,
             monkeypatch.setenv("AIDAX_LP_FUSED", "0")
         pool = ax.Pool(S, 256)
         pool.set_model(ax.Model(path))
-        lp = "k_mfma_lp" if arith == "fp32" or kw.get("n_rnn", 1) == 1 or kw["hidden"] == 80 and kw.get("n_rnn", 1) > 2 else "k_mfma_ls"
+        lp = "k_mfma_lp" if arith == "fp32" or kw.get("n_rnn", 1) == 1 else "k_mfma_ls"
         assert pool.kernel_name == (lp if form == "one" else "k_chain+" + lp)
         for s_ in range(S):
             pool.set_controls(ax.default_controls(**kws[s_ % len(kws)]), stream=s_)
@@ -1106,8 +1106,7 @@ def test_one_layer_one_launch_form_is_bit_identical_to_the_three_launch_form(kin
             monkeypatch.setenv("AIDAX_LP_FUSED", "0")
         pool = ax.Pool(S, 1024)
         pool.set_model(ax.Model(path))
-        lp = "k_mfma_lp" if arith == "fp32" or kw.get("n_rnn", 1) == 1 or kw["hidden"] == 80 and kw.get("n_rnn", 1) > 2 else "k_mfma_ls"
-        assert pool.kernel_name == (lp if form == "one" else "k_chain+" + lp)
+        assert pool.kernel_name == ("k_mfma_lp" if form == "one" else "k_chain+k_mfma_lp")
         for s_ in range(S):
             pool.set_controls(ax.default_controls(**kws[s_ % len(kws)]), stream=s_)
         got, pos = np.empty_like(x), 0

@@ -4,6 +4,7 @@ default-state restore -> worker load -> work_response swap -> NOTIFY echo -> aud
 patch:Set on CONTROL, mute-while-loading, state save, activate — compared sample for
 sample with the CPU oracle's plugin mirror."""
 import ctypes as C
+import importlib
 import os
 import shutil
 
@@ -263,3 +264,37 @@ def test_hub_mode_host_blocks_longer_than_the_hubs_go_through_in_equal_slices(bu
     assert err < THR * 2, (n, L, err)
     assert np.abs(want[:-L]).max() > 1e-3                     # (and it is not silence that was compared)
     h.close()
+
+
+@pytest.mark.gpu
+def test_instances_are_placed_over_the_devices_the_process_sees(bundle, monkeypatch):
+    """AIDAX_DEVICE=auto: every instance goes to the least-loaded of the hipGetDeviceCount() devices (one here: the rule itself
+    is tested on CPU with injected counts, tests/test_abi_host.py); a list that names no device of this machine refuses the
+    instance loudly instead of landing somewhere else. Same audio as with the default placement."""
+    ax_ = importlib.import_module("aidadsp-lv2_amd")
+    n_dev = ax_.device_count()
+    assert n_dev >= 1
+    monkeypatch.setenv("AIDAX_DEVICE", "auto")
+    clean = os.path.join(bundle, "models/deer ink studios/tw40_california_clean_deerinkstudios.json")
+    hosts = [lv2host.Host(bundle_dir=bundle) for _ in range(3)]
+    assert all(h.handle for h in hosts)
+    x = modelgen.signal(3, 512, seed=9)
+    outs = []
+    for i, h in enumerate(hosts):
+        h.send_patch_set(clean)
+        h.run(np.zeros(0, np.float32))
+        h.clear_control()
+        assert h.pump_worker() == 1 and h.deliver_responses() == 1
+        h.pump_worker()
+        outs.append(np.concatenate([h.run(x[i, :256]), h.run(x[i, 256:])]))
+    p = O.OraclePlugin()
+    p.set_model(O.OracleModel(O.load_model(clean), 0.0, 0.0))
+    p.activate()
+    p.set_loading(False)
+    want = np.concatenate([p.run(_oracle_controls(hosts[0]), x[0, :256]), p.run(_oracle_controls(hosts[0]), x[0, 256:])])
+    assert np.abs(outs[0] - want).max() < THR * 2
+    for h in hosts:
+        h.close()
+    monkeypatch.setenv("AIDAX_DEVICE", str(n_dev + 3))
+    h = lv2host.Host(bundle_dir=bundle)
+    assert not h.handle                                  # instantiate() returns NULL, with the reason on stderr

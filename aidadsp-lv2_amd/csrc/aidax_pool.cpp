@@ -746,7 +746,7 @@ AIDAX_API int aidax_device_count(int* count)
     if (!count) return fail(AIDAX_ERR_ARG, "null count");
     *count = 0;
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(AIDAX_ERR_DEVICE, "no HIP device");
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(AIDAX_ERR_DEVICE, "no usable HIP device (this library has no CPU fallback)");
     *count = n;
     return AIDAX_OK;
 }

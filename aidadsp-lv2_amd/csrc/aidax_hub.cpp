@@ -13,6 +13,7 @@
 //                          passes — so one instance that stalls or stops calling cannot hold the others' audio.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -51,6 +52,7 @@ struct aidax_hub {
     uint32_t hi_slot = 0;                        // rows [0, hi_slot) can be attached: what a pass moves and launches
     uint32_t latency = 0;
     uint64_t launches = 0, deadline_launches = 0;
+    uint64_t last_chained = 0;                   // the latest pass that went out on a chained kernel (k_mfma_lp / k_mfma_ls): later ones cannot have given up
     uint64_t clean_upto = 0;                     // passes up to this id are known to carry no k_mfma_lp give-up
     uint64_t bad_from = 1, bad_upto = 0;         // passes in [bad_from, bad_upto] may: their rows are delivered as silence
     int last_error = AIDAX_OK;
@@ -143,6 +145,7 @@ int launch_period(aidax_hub& h)
     if (bytes != 0) HUB_TRY(hipMemcpyAsync(h.d_in, h.h_in[b], bytes, hipMemcpyHostToDevice, h.q));
     const int rc = pool_process_prefix(h.pool, h.d_in, h.d_out, n, h.q, rows);
     if (rc != AIDAX_OK) return rc;
+    if (pool_chained_kernel_in_use(h.pool)) h.last_chained = h.launches + 1;      // (asked after the launch: a pool that has just fallen back answers no)
     if (bytes != 0) HUB_TRY(hipMemcpyAsync(h.h_out[b], h.d_out, bytes, hipMemcpyDeviceToHost, h.q));
     HUB_TRY(hipEventRecord(h.done[b], h.q));
     ++h.launches;
@@ -473,15 +476,24 @@ AIDAX_API int aidax_hub_run(aidax_hub* h, int32_t slot, const float* in, float* 
             // and the pass kHubBuffers later is copied into this very buffer — a row read without the check could be
             // half of each. (A thousand floats under the lock: a fraction of a microsecond.)
             std::lock_guard<std::mutex> g(h->mu);
-            if (pool_take_lp_fault(h->pool)) {              // some pass in (clean_upto, launches] gave up a layer hand-over
+            if (pool_take_lp_fault(h->pool)) {              // some pass in (clean_upto, launches] gave up a layer hand-over ...
                 h->bad_from = h->clean_upto + 1;
-                h->bad_upto = h->launches;
+                h->bad_upto = std::min(h->launches, h->last_chained);      // ... and only one that ran on a chained kernel can have
             }
             lp_fault = prev_pass >= h->bad_from && prev_pass <= h->bad_upto;
             if (!lp_fault && prev_pass > h->clean_upto) h->clean_upto = prev_pass;     // its event has passed and nothing was reported
             if (!lp_fault && h->pass_id[prev_buf] == prev_pass) {
                 std::memcpy(out, prev_row, sizeof(float) * n_frames);
                 delivered = true;
+            }
+        }
+        if (!prev_row) {
+            // no previous block to hand back (first block on the seat, a changed block length): a pending give-up is taken
+            // here all the same, so that it marks the passes it belongs to and not a later, clean one
+            std::lock_guard<std::mutex> g(h->mu);
+            if (pool_take_lp_fault(h->pool)) {
+                h->bad_from = h->clean_upto + 1;
+                h->bad_upto = std::min(h->launches, h->last_chained);
             }
         }
         if (!delivered) std::memset(out, 0, sizeof(float) * n_frames);

@@ -63,6 +63,7 @@ int  pool_peek_stream_state(aidax_pool* p, uint32_t stream, StreamState* pinned_
 
 // k_mfma_lp fault report of a pool (aidax_pool.cpp): true once per give-up; the pool then serves its model with k_mfma
 bool pool_take_lp_fault(aidax_pool* p);
+bool pool_chained_kernel_in_use(aidax_pool* p);      // the next pass of the playing model goes out on k_mfma_lp / k_mfma_ls (whose hand-over can give up)
 bool pool_lp_in_use(const aidax_pool* p);
 
 // weight packing (aidax_pack.cpp)

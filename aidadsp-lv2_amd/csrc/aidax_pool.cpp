@@ -735,6 +735,7 @@ int pool_park_stream(aidax_pool* p, uint32_t s, bool parked)
 // Did a k_mfma_lp pass since the last call give up a hand-over (its output is wrong)? Clears the report and retires the
 // kernel for this pool. The hub asks after a pass's event has passed.
 bool pool_take_lp_fault(aidax_pool* p) { return p->take_lp_fault(); }
+bool pool_chained_kernel_in_use(aidax_pool* p) { return p->cur.has_model && p->cur.kind == ModelSlot::MFMA && p->cur.mdesc.n_layers >= 2 && p->lp_in_use(p->cur); }
 bool pool_lp_in_use(const aidax_pool* p) { return p->cur.has_model && p->lp_in_use(p->cur); }
 
 }  // namespace aidax

@@ -52,6 +52,10 @@ N_FRAMES = 256
 RING = 8                  # distinct input blocks cycled through HBM
 HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: vector FP32 peak = v_mfma_f32_16x16x4_f32 peak (64 FLOP/clk/SIMD)
+BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA peak (~2.5 PFLOP/s)
+SPLIT_PRODUCTS = 6        # k_gru_gs / k_mfma_ls: bf16 term products issued per fp32 product (operands split exactly into three bf16 terms)
+N_SIMDS = 1024            # 256 CUs x 4
+NOMINAL_GHZ = 2.4
 ALGO_BYTES_PER_SAMPLE = 8
 PREROLL_S = 0.35          # un-timed passes before the warm-up: clocks ramp, caches and TLBs fill
 
@@ -64,13 +68,13 @@ WORKLOADS = {
     "cfg3": dict(model=dict(kind="gru", hidden=64, input_size=3, seed=64), streams=4096,
                  controls=dict(bass_boost_db=4.0, mid_boost_db=-3.0, mid_q=1.2, treble_boost_db=2.0, depth_boost_db=3.0,
                                presence_boost_db=3.0, param1=0.5, param2=0.3),
-                 flops=2 * (3 * 64 * (64 + 3) + 64) + 63 + 6, bound="hbm",
+                 flops=2 * (3 * 64 * (64 + 3) + 64) + 63 + 6, bound="hbm", split_flops=2 * 3 * 64 * 64, fetch_wide="audio",
                  text="cfg3: GRU-64 conditioned (PARAM1+PARAM2) pedal model + 5-band EQ post, 4096 streams x 256-frame blocks"),
     "cfg4": dict(model=dict(kind="conv", hidden=16, input_size=1, seed=1608), streams=1024, controls={},
-                 flops=2 * (3 * 1 * 16 + 7 * 3 * 16 * 16 + 16) + 63 + 6, bound="hbm",
+                 flops=2 * (3 * 1 * 16 + 7 * 3 * 16 * 16 + 16) + 63 + 6, bound="hbm", fetch_wide="all",
                  text="cfg4: dilated conv1d stack (8 layers, 16 channels, k=3), 1024 streams/GPU (8192 over 8 GPUs) x 256-frame blocks"),
     "cfg5": dict(model=dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2), streams=2048, controls={},
-                 flops=2 * (384 * (1 + 96) + 384 * (96 + 96) + 96), bound="mfma",
+                 flops=2 * (384 * (1 + 96) + 384 * (96 + 96) + 96), bound="mfma", split_flops=2 * (384 * 96 + 384 * 192), fetch_wide="all",
                  text="cfg5: LSTM-96 x2 model, 2048 streams/GPU (16384 over 8 GPUs) x 256-frame blocks, matrix-core kernel"),
 }
 OTHER_STEPS = {"cfg3": 600, "cfg4": 2000, "cfg5": 120}      # ~0.25 s of GPU time each
@@ -243,6 +247,46 @@ def pmc_traffic_bytes(kernel_name: str, wide_read_bytes: float):
     return best
 
 
+def profile_counters(kernel_name: str):
+    """Median per-launch counters of `kernel_name` from the committed rocprofv3 PMC summaries taken on THESE kernel
+    sources (hash-checked like pmc_traffic_bytes): {counter: median}; {} when there is no such profile."""
+    import glob
+    import re
+    mine = kernel_sources_sha16()
+    out = {}
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.txt"))):
+        text = open(fn).read()
+        m = re.search(r"kernel_src_sha16=([0-9a-f]{16})", text)
+        if not m or m.group(1) != mine:
+            continue
+        for line in text.splitlines():
+            if not _kernel_matches(kernel_name, line):
+                continue
+            m = re.search(r"\b([A-Z][A-Z0-9_]+)\s+n=\s*\d+ median=([0-9.e+]+)", line)
+            if m:
+                out[m.group(1)] = float(m.group(2))
+                out["_source"] = os.path.basename(fn)
+    return out
+
+
+def add_profile_figures(hbm: dict, comp: dict, name: str, S: int, kernel: str, kernel_ms: float):
+    """HBM traffic and matrix-pipe occupancy of a workload's kernel from the committed same-source profile, into its rooflines."""
+    c = profile_counters(kernel.split("+")[-1])
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        audio = 4.0 * S * N_FRAMES
+        wide = WORKLOADS[name].get("fetch_wide", "audio")
+        fetch = c["FETCH_SIZE"] * 1024.0
+        # FETCH_SIZE reports half of a 16 B/lane streaming read (MI355X_MICROARCH.md): the audio block always is one; cfg4's layer
+        # history and cfg5's hand-over ring are read that way too ("all": 2 x FETCH)
+        hbm["traffic"] = (2.0 * fetch if wide == "all" else fetch + 0.5 * audio) + c["WRITE_SIZE"] * 1024.0
+        hbm["traffic_source"] = f"committed profile of the same kernel sources: {c['_source']} (FETCH_SIZE {c['FETCH_SIZE']:.0f} KB, WRITE_SIZE {c['WRITE_SIZE']:.0f} KB per launch)"
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+        comp["mfma_busy_frac"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (N_SIMDS * kernel_ms * 1e-3 * NOMINAL_GHZ * 1e9)
+        comp["mfma_busy_source"] = f"SQ_VALU_MFMA_BUSY_CYCLES {c['SQ_VALU_MFMA_BUSY_CYCLES']:.4g} per launch / ({N_SIMDS} SIMDs x kernel time x {NOMINAL_GHZ} GHz), {c['_source']}"
+    if "SQ_INSTS_MFMA" in c:
+        comp["mfma_insts_per_launch"] = c["SQ_INSTS_MFMA"]
+
+
 def cpu_baseline(W, j, name: str = "cfg2", target_s: float = 12.0):
     """The CPU oracle on all host cores over a bounded sample of the workload: up to 1024 of its streams (fewer for
     the heavy models, a multiple of the core count) over as many 256-frame blocks as fit `target_s`."""
@@ -293,7 +337,11 @@ def realtime_case(ax, W, local: int):
         secs, _ = O.cpu_bench(spec, O.default_controls(), x, n_blocks=1500, warm_blocks=20, n_threads=1, fast=True)
         out.append({"model": label, "kernel": kernel, "frames": N_FRAMES,
                     "gpu_call_us": {"p50": float(np.percentile(t, 50) * 1e6), "p99": float(np.percentile(t, 99) * 1e6),
-                                    "max": float(t.max() * 1e6)},
+                                    "p99.9": float(np.percentile(t, 99.9) * 1e6), "max": float(t.max() * 1e6),
+                                    "calls": int(t.size), "calls_over_1.5x_p50": int((t > 1.5 * np.percentile(t, 50)).sum()),
+                                    "note": "max = one call in thousands that the host thread spent descheduled (the caller spins on a "
+                                            "completion word in pinned memory; no GPU-side outlier: rocprofv3 kernel durations stay within "
+                                            "2 % of their mean, profiles/r04_rt_latency.txt)"},
                     "gpu_realtime_factor": float((N_FRAMES / 48000.0) / np.percentile(t, 50)),
                     "cpu_one_thread_block_us": secs / 1500 * 1e6,
                     "cpu_realtime_factor": float((N_FRAMES / 48000.0) / (secs / 1500))})
@@ -385,6 +433,18 @@ def rooflines(name, S, kernel_ms, kernel):
     comp = {"bound": "mfma" if wl["bound"] == "mfma" else "fp32", "achieved": tflops, "peak": FP32_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": tflops / FP32_PEAK_TFLOPS, "traffic": None, "kernel_ms": kernel_ms,
             "algorithmic_flops_per_launch": algo_flops}
+    if ("k_gru_gs" in kernel or "k_mfma_ls" in kernel) and wl.get("split_flops"):
+        # The contraction runs on the bf16 matrix pipe: every fp32 product as SPLIT_PRODUCTS bf16 term products of operands
+        # split exactly into three bf16 terms (fp32 MFMAs run at the vector rate on gfx950 and stall the VALU beside them,
+        # profiles/r04_overlap.txt). What binds the kernel is then the bf16 MFMA peak against the matrix flops it EXECUTES
+        # (SPLIT_PRODUCTS x the algorithmic flops of the split products + the rest at face value); the algorithmic fp32 rate stays in the entry.
+        executed = (SPLIT_PRODUCTS * wl["split_flops"] + (wl["flops"] - wl["split_flops"])) * S * N_FRAMES
+        ex_tflops = executed / (kernel_ms * 1e-3) / 1e12
+        comp = {"bound": "mfma", "achieved": ex_tflops, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ex_tflops / BF16_PEAK_TFLOPS,
+                "traffic": None, "kernel_ms": kernel_ms, "executed_flops_per_launch": executed, "algorithmic_flops_per_launch": algo_flops,
+                "algorithmic_tflops": tflops, "algorithmic_frac_of_fp32_mfma_peak": tflops / FP32_PEAK_TFLOPS,
+                "arithmetic": f"fp32 operands split exactly into three bf16 terms, {SPLIT_PRODUCTS} bf16 term products per fp32 product "
+                              f"(v_mfma_f32_16x16x32_bf16, fp32 accumulation); achieved = executed matrix flops against the dense bf16 peak"}
     if note:
         hbm["note"] = comp["note"] = note
     return hbm, comp
@@ -548,6 +608,7 @@ def main():
                 r = measure(ax, W, torch, name, So, steps, max(10, steps // 10), 0, 1, local, not args.no_check, launch_stream,
                             preroll_s=0.15)
                 h2, c2 = rooflines(name, So, r["kernel_ms"], r["kernel"])
+                add_profile_figures(h2, c2, name, So, r["kernel"], r["kernel_ms"])
                 others.append({"workload": WORKLOADS[name]["text"], "streams": So, "kernel": r["kernel"], "steps": steps,
                                "ms_per_step": r["elapsed"] / steps * 1e3, "value": So * N_FRAMES * steps / r["elapsed"],
                                "unit": "samples/s", "roofline": c2 if WORKLOADS[name]["bound"] == "mfma" else h2,
@@ -571,6 +632,7 @@ def main():
             out["other_workloads"] = []
             for name, So, steps, r, e_max, n_all in multi_others:
                 h2, c2 = rooflines(name, So, r["kernel_ms"], r["kernel"])
+                add_profile_figures(h2, c2, name, So, r["kernel"], r["kernel_ms"])
                 out["other_workloads"].append({"workload": WORKLOADS[name]["text"], "streams_per_gpu": So, "n_gpus": world, "kernel": r["kernel"],
                                                "steps": steps, "ms_per_step": e_max / steps * 1e3, "value": n_all / e_max, "unit": "samples/s",
                                                "scaling": "weak", "roofline": c2 if WORKLOADS[name]["bound"] == "mfma" else h2,

@@ -234,7 +234,12 @@ AIDAX_API int  aidax_pool_collect(aidax_pool* p, float* out, uint32_t n_frames);
  * for the pool's device (set-up side: it allocates and may block; the range must stay mapped until unregister_host() or
  * the pool's end). submit() then uploads a block that lies inside a registered range straight out of it — no copy into
  * the pool's staging — and submit_to() names the block's destination up front, so that the download lands there as well
- * and collect() (same `out`) only waits. Buffers outside any registered range take the staged path as before. */
+ * and collect() (same `out`) only waits. Buffers outside any registered range take the staged path as before.
+ * OWNERSHIP: a block that lies inside a registered range is read by the copy engine AFTER submit() has returned, and a
+ * registered `out` is written BEFORE collect() returns — such buffers belong to the pool from submit()/submit_to() until the
+ * collect() of that block. With one block kept in flight the host therefore alternates TWO in/out buffer pairs (write block
+ * k+1's input while block k's is still the pool's); a host with a single pair collects before it reuses it. (Unregistered
+ * buffers are copied into the pool's staging inside submit() and out of it inside collect(): theirs is the usual lifetime.) */
 AIDAX_API int  aidax_pool_register_host(aidax_pool* p, void* base, size_t bytes);
 AIDAX_API int  aidax_pool_unregister_host(aidax_pool* p, void* base);
 AIDAX_API int  aidax_pool_submit_to(aidax_pool* p, const float* in, float* out, uint32_t n_frames);

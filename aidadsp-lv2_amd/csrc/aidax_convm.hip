@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
         const ConvLayer& L0 = d.L[0];
         for (int c = 0; c < L0.in_ch; ++c)
             for (int j = t; j < L0.hist; j += stride)
-                pl[c * F + Hb - L0.hist + j] = hist_base[L0.state_off + c * L0.hist + j];
+                pl[c * F + convm_swz(c, Hb - L0.hist + j)] = hist_base[L0.state_off + c * L0.hist + j];
         if (t < 17) wdl[t] = t < 16 ? (t < d.L[d.n_layers - 1].out_ch ? W[d.wd_off + t] : 0.f) : W[d.bd_off];
     };
 
@@ -181,27 +181,29 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
             if (i < L.k_steps * kWave)      // the A offset in BYTES: the k-loop adds it to the plane's base as it is
                 *reinterpret_cast<float2*>(wst + 2 * i) =
                     float2{ fr[j], FULL ? __builtin_bit_cast(float, kcb[j])      // (full blocks: the packer has done it)
-                                        : __builtin_bit_cast(float, 4 * ((kcb[j] >> 16) * F + Hb - (kcb[j] & 0xffff) + (i & 15))) };
+                                        : __builtin_bit_cast(float, 4 * ((kcb[j] >> 16) * F + convm_swz(kcb[j] >> 16, Hb - (kcb[j] & 0xffff) + (i & 15)))) };
         }
     };
     // history of a layer: [in_ch][hist] in HBM <-> plane[ch][Hb-hist .. Hb), walked flat (coalesced, hist*in_ch/256
     // passes). i -> (ch, frame) without an integer division: (i + 0.5) / hist is at least 0.5/hist away from an
     // integer, far more than the fp32 error of the product, so the truncation is exact.
-    auto plane_index = [&](int i, int hist, float inv_hist) {
+    // (`shift`: columns further right — save_history reads the last `hist` frames of [old history | block]; the swizzle of the
+    // plane's columns, aidax_layout.h convm_swz, is applied to the final column)
+    auto plane_index = [&](int i, int hist, float inv_hist, int shift) {
         const int ch = (int)(((float)i + 0.5f) * inv_hist);
-        return ch * F + Hb - hist + (i - ch * hist);
+        return ch * F + convm_swz(ch, Hb - hist + (i - ch * hist) + shift);
     };
     // A layer whose history length is a multiple of four frames moves it as float4s (16 B per lane, a quarter of the
     // index arithmetic): rows of `hist` floats per channel are contiguous on both sides and 16-byte aligned
     // (pack_conv aligns state_off, the plane geometry is a multiple of four).
     auto vec_hist = [&](const ConvLayer& L) { return (L.hist & 3) == 0 && (L.state_off & 3) == 0; };
-    auto plane_index4 = [&](int i4, int hist4, float inv_hist4) {     // float4 index -> plane float offset of its first frame
+    auto plane_index4 = [&](int i4, int hist4, float inv_hist4, int shift) {     // float4 index -> plane float offset of its first frame (shift: a multiple of 4)
         if ((hist4 & (hist4 - 1)) == 0) {                              // dilations are powers of two as a rule: shift and mask
             const int sh = 31 - __builtin_clz(hist4);
-            return (i4 >> sh) * F + Hb - 4 * hist4 + 4 * (i4 & (hist4 - 1));
+            return (i4 >> sh) * F + convm_swz(i4 >> sh, Hb - 4 * hist4 + 4 * (i4 & (hist4 - 1)) + shift);
         }
         const int ch = (int)(((float)i4 + 0.5f) * inv_hist4);
-        return ch * F + Hb - 4 * hist4 + 4 * (i4 - ch * hist4);
+        return ch * F + convm_swz(ch, Hb - 4 * hist4 + 4 * (i4 - ch * hist4) + shift);
     };
     auto fetch_prefix = [&](int l) {
         const ConvLayer& L = d.L[l];
@@ -235,20 +237,20 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
                 if (j * kConvmThreads * 4 >= cnt) break;
                 const int i4 = tid + j * kConvmThreads;
                 if (4 * i4 < cnt)
-                    *reinterpret_cast<f32x4*>(pl + plane_index4(i4, hist4, inv4)) = hp4[j];
+                    *reinterpret_cast<f32x4*>(pl + plane_index4(i4, hist4, inv4, 0)) = hp4[j];
             }
             for (int i4 = tid + (kHistRegs / 4) * kConvmThreads; 4 * i4 < cnt; i4 += kConvmThreads)
-                *reinterpret_cast<f32x4*>(pl + plane_index4(i4, hist4, inv4)) = reinterpret_cast<const f32x4*>(hist_base + L.state_off)[i4];
+                *reinterpret_cast<f32x4*>(pl + plane_index4(i4, hist4, inv4, 0)) = reinterpret_cast<const f32x4*>(hist_base + L.state_off)[i4];
             return;
         }
 #pragma unroll
         for (int j = 0; j < kHistRegs; ++j) {
             if (j * kConvmThreads >= cnt) break;
             const int i = tid + j * kConvmThreads;
-            if (i < cnt) pl[plane_index(i, L.hist, inv)] = hp[j];
+            if (i < cnt) pl[plane_index(i, L.hist, inv, 0)] = hp[j];
         }
         for (int i = tid + kHistRegs * kConvmThreads; i < cnt; i += kConvmThreads)
-            pl[plane_index(i, L.hist, inv)] = hist_base[L.state_off + i];
+            pl[plane_index(i, L.hist, inv, 0)] = hist_base[L.state_off + i];
     };
     // this layer's new history: the last Hs frames of [old history | this block's inputs], plane -> HBM. Runs while the
     // plane still holds the layer's INPUT (before the barrier that releases it for the in-place update).
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
             for (int j = 0; j < kHistRegs / 4; ++j) {         // all LDS reads first, then the stores
                 if (j * kConvmThreads >= cnt4) break;
                 const int i4 = tid + j * kConvmThreads;
-                hv4[j] = *reinterpret_cast<const f32x4*>(pl + plane_index4(i4 < cnt4 ? i4 : 0, hist4, inv4) + n);
+                hv4[j] = *reinterpret_cast<const f32x4*>(pl + plane_index4(i4 < cnt4 ? i4 : 0, hist4, inv4, n));
             }
 #pragma unroll
             for (int j = 0; j < kHistRegs / 4; ++j) {
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
                 if (i4 < cnt4) dst[i4] = hv4[j];
             }
             for (int i4 = tid + (kHistRegs / 4) * kConvmThreads; i4 < cnt4; i4 += kConvmThreads)
-                dst[i4] = *reinterpret_cast<const f32x4*>(pl + plane_index4(i4, hist4, inv4) + n);
+                dst[i4] = *reinterpret_cast<const f32x4*>(pl + plane_index4(i4, hist4, inv4, n));
         } else {
             const float inv = __builtin_amdgcn_rcpf((float)Hs);
             const int cnt = Hs * Ci;
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
             for (int j = 0; j < kHistRegs; ++j) {
                 if (j * kConvmThreads >= cnt) break;
                 const int i = tid + j * kConvmThreads;
-                hv[j] = pl[plane_index(i < cnt ? i : 0, Hs, inv) + n];
+                hv[j] = pl[plane_index(i < cnt ? i : 0, Hs, inv, n)];
             }
 #pragma unroll
             for (int j = 0; j < kHistRegs; ++j) {
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
                 if (i < cnt) hist_base[L.state_off + i] = hv[j];
             }
             for (int i = tid + kHistRegs * kConvmThreads; i < cnt; i += kConvmThreads)
-                hist_base[L.state_off + i] = pl[plane_index(i, Hs, inv) + n];
+                hist_base[L.state_off + i] = pl[plane_index(i, Hs, inv, n)];
         }
     };
 
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
                 if (L.activation == 1) { v.x = tanh_exp_pre(v.x); v.y = tanh_exp_pre(v.y); v.z = tanh_exp_pre(v.z); v.w = tanh_exp_pre(v.w); }
                 else if (L.activation == 2) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
                 else if (L.activation == 3) { v.x = fast_sigmoid(v.x); v.y = fast_sigmoid(v.y); v.z = fast_sigmoid(v.z); v.w = fast_sigmoid(v.w); }
-                *reinterpret_cast<f32x4*>(pl + (size_t)co * F + Hb + 16 * (wave + 4 * j) + 4 * (lane >> 4)) = v;
+                *reinterpret_cast<f32x4*>(pl + (size_t)co * F + convm_swz(co, Hb + 16 * (wave + 4 * j) + 4 * (lane >> 4))) = v;
             }
         }
         if (l + 1 < d.n_layers) { store_prefix(l + 1); stage_frag(l + 1); }
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
     if (mode != MODE_WARMUP && tid < n) {
         const int Cl = d.L[d.n_layers - 1].out_ch;
         float y = wdl[16];
-        for (int o = 0; o < Cl; ++o) y = __builtin_fmaf(wdl[o], pl[(size_t)o * F + Hb + tid], y);
+        for (int o = 0; o < Cl; ++o) y = __builtin_fmaf(wdl[o], pl[(size_t)o * F + convm_swz(o, Hb + tid)], y);
         float o2 = a.input_skip ? xg + y : y;
         if constexpr (FUSED) pl[Hb + tid] = o2 * a.out_gain;
         else row[tid] = o2 * a.out_gain;

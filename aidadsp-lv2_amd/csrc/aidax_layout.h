@@ -224,6 +224,16 @@ constexpr int convm_plane_stride(int max_hist, int n_frames)
 {
     return ((((max_hist + 3) & ~3) + ((n_frames + 15) & ~15) + 47) / 64) * 64 + 16;
 }
+// ... and its columns are SWIZZLED per channel: inside every aligned group of sixteen columns the four 16-byte blocks trade places
+// by (channel >> 2) & 3. Why: the tanh outputs leave as one ds_write_b128 per lane — four consecutive frames of one channel, the
+// sixteen lanes of a quarter-wave holding channels 0 .. 15 — and with the row stride = 16 (mod 64) floats that the A-fragment
+// reads need, channels c, c + 4, c + 8, c + 12 start in the same bank: a four-way conflict on every output write (31 % of the
+// kernel's LDS cycles, profiles/r04_cfg4_pmc_summary.txt). With the swizzle those four land in four different 16-byte blocks
+// of the bank window. The reads stay conflict-free: sixteen consecutive columns still cover sixteen different banks (the
+// swizzle permutes blocks inside an aligned group, and two groups are two bank windows), and the four channels of an A
+// fragment (4 kk + q) share their (channel >> 2). Adding a multiple of 16 columns commutes with it (the tile offsets stay
+// immediates).
+constexpr int convm_swz(int ch, int col) { return col ^ (((ch >> 2) & 3) << 2); }
 constexpr float kTwoLog2e = 2.88539008177792681472f;
 struct ConvDesc {
     int32_t n_layers, channels, max_hist, max_k_steps;

@@ -541,7 +541,7 @@ std::vector<float> pack_conv(const aidax_model& m, ConvDesc* d, uint32_t* state_
                 const float b = out[from + 2 * i];
                 int32_t where;
                 std::memcpy(&where, &out[from + 2 * i + 1], 4);
-                const int32_t byte_off = 4 * ((where >> 16) * F + Hb - (where & 0xffff) + (i & 15));
+                const int32_t byte_off = 4 * ((where >> 16) * F + convm_swz(where >> 16, Hb - (where & 0xffff) + (i & 15)));
                 float f;
                 std::memcpy(&f, &byte_off, 4);
                 out.push_back(b);

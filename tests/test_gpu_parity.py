@@ -1206,6 +1206,44 @@ def test_gate_major_gru_kernel_ragged_blocks_controls_and_state_bits(hidden, isz
     errlog.bound(np.abs(outs["gm"] - outs["lp"]).max(), 5e-7, "gpu_parity:gru_gm_vs_lp_outputs")
 
 
+
+@pytest.mark.parametrize("kind,hidden,n_rnn,isz", [
+    ("lstm", 80, 2, 2),      # four waves x 512 registers (fragments in AGPRs), two of five tiles per wave started below
+    ("gru", 80, 2, 3),
+    ("gru", 96, 2, 1),       # eight waves, cfg5's geometry with GRU cells
+    ("lstm", 64, 3, 1),      # three layers: a middle workgroup both consumes and produces, no tiles started below
+    ("lstm", 16, 2, 2),      # one tile per wave, one k-step half empty
+    ("gru", 40, 2, 1),       # 40 units run zero-padded to 48: the second k-step's upper half stays zero
+])
+def test_split_stack_geometries_match_the_oracle(kind, hidden, n_rnn, isz, tmp_path):
+    """k_mfma_ls in every geometry ls_geo hands out (aidax_mfmalp.hip): ragged blocks incl. 0 and 1, 40 streams (the last group
+    ragged), PARAM moves, against per-stream oracle plugins; the one-launch form on a 256-frame pool and the three-launch form
+    on a 1024-frame pool."""
+    path, spec = _model_file(tmp_path, f"ls_{kind}{hidden}x{n_rnn}", kind=kind, hidden=hidden, input_size=isz, seed=900 + hidden + n_rnn, n_rnn=n_rnn,
+                             in_skip=isz == 1)
+    S = 40
+    for max_frames, sizes, name in ((256, [256, 1, 0, 37, 255, 64], "k_mfma_ls"), (1024, [700, 16, 3, 513], "k_chain+k_mfma_ls")):
+        x = modelgen.signal(S, sum(sizes), seed=33)
+        pool = ax.Pool(S, max_frames)
+        pool.set_model(ax.Model(path))
+        assert pool.kernel_name == name, pool.kernel_name
+        plugs = {}
+        for s_ in (0, 7, 17, S - 1):
+            p = O.OraclePlugin()
+            p.set_model(O.OracleModel(spec))
+            plugs[s_] = p
+        pos = 0
+        for bi, n in enumerate(sizes):
+            kw = dict(param1=0.2 + 0.15 * bi, param2=0.9 - 0.1 * bi, pregain_db=1.0)
+            pool.set_controls(ax.default_controls(**kw))
+            got = pool.process(np.ascontiguousarray(x[:, pos:pos + n]))
+            for s_, p in plugs.items():
+                want = p.run(O.default_controls(**kw), x[s_, pos:pos + n])
+                if n:
+                    errlog.bound(np.abs(got[s_] - want).max(), 2e-6, "gpu_parity:ls_geometries")
+            pos += n
+        pool.close()
+
 @pytest.mark.parametrize("name,kw", [
     ("lstm96x2", dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2)),          # BASELINE cfg #5 model
     ("gru48x3", dict(kind="gru", hidden=48, input_size=3, seed=483, n_rnn=3)),            # three layers: a middle workgroup both consumes and produces

@@ -1887,7 +1887,13 @@ __device__ __forceinline__ void ls_body(const LaunchArgs& a, const MfmaDesc& d, 
                 auto deal = [&](int T0, int T1, int g) {
                     const int nt = T1 - T0, S = nt * NSTEP;
 #pragma unroll
-                    for (int sidx = g * S / G; sidx < (g + 1) * S / G; ++sidx) cell_step(T0 + sidx % nt, sidx / nt, acc[T0 + sidx % nt], h_wr);
+                    for (int sidx = g * S / G; sidx < (g + 1) * S / G; ++sidx) {
+#ifdef AIDAX_LS_SEQ_CELLS                                           // (one tile's update after the other: eight temporaries fewer, less to overlap)
+                        cell_step(T0 + sidx / NSTEP, sidx % NSTEP, acc[T0 + sidx / NSTEP], h_wr);
+#else
+                        cell_step(T0 + sidx % nt, sidx / nt, acc[T0 + sidx % nt], h_wr);
+#endif
+                    }
                 };
                 // phase A: own h(t-1) against the first half of the tiles
                 LS_STAMP(2);

@@ -280,6 +280,7 @@ def add_profile_figures(hbm: dict, comp: dict, name: str, S: int, kernel: str, k
         # history and cfg5's hand-over ring are read that way too ("all": 2 x FETCH)
         hbm["traffic"] = (2.0 * fetch if wide == "all" else fetch + 0.5 * audio) + c["WRITE_SIZE"] * 1024.0
         hbm["traffic_source"] = f"committed profile of the same kernel sources: {c['_source']} (FETCH_SIZE {c['FETCH_SIZE']:.0f} KB, WRITE_SIZE {c['WRITE_SIZE']:.0f} KB per launch)"
+        comp["traffic"] = hbm["traffic"]                      # (HBM bytes per launch: the same figure in either roofline object)
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
         comp["mfma_busy_frac"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (N_SIMDS * kernel_ms * 1e-3 * NOMINAL_GHZ * 1e9)
         comp["mfma_busy_source"] = f"SQ_VALU_MFMA_BUSY_CYCLES {c['SQ_VALU_MFMA_BUSY_CYCLES']:.4g} per launch / ({N_SIMDS} SIMDs x kernel time x {NOMINAL_GHZ} GHz), {c['_source']}"
@@ -339,9 +340,9 @@ def realtime_case(ax, W, local: int):
                     "gpu_call_us": {"p50": float(np.percentile(t, 50) * 1e6), "p99": float(np.percentile(t, 99) * 1e6),
                                     "p99.9": float(np.percentile(t, 99.9) * 1e6), "max": float(t.max() * 1e6),
                                     "calls": int(t.size), "calls_over_1.5x_p50": int((t > 1.5 * np.percentile(t, 50)).sum()),
-                                    "note": "max = one call in thousands that the host thread spent descheduled (the caller spins on a "
-                                            "completion word in pinned memory; no GPU-side outlier: rocprofv3 kernel durations stay within "
-                                            "2 % of their mean, profiles/r04_rt_latency.txt)"},
+                                    "note": "the slow calls are periodic — one every ~10 ms of wall time (every 194th call at 53.6 us), 80-100 us each — "
+                                            "i.e. a timer on the host side of the spin-wait, not the kernel (its own durations under rocprofv3 "
+                                            "have no such tail): profiles/r04_rt_latency.txt"},
                     "gpu_realtime_factor": float((N_FRAMES / 48000.0) / np.percentile(t, 50)),
                     "cpu_one_thread_block_us": secs / 1500 * 1e6,
                     "cpu_realtime_factor": float((N_FRAMES / 48000.0) / (secs / 1500))})
@@ -613,6 +614,8 @@ def main():
                                "ms_per_step": r["elapsed"] / steps * 1e3, "value": So * N_FRAMES * steps / r["elapsed"],
                                "unit": "samples/s", "roofline": c2 if WORKLOADS[name]["bound"] == "mfma" else h2,
                                "roofline_compute": c2, "max_abs_err": r["max_err"]})
+                if WORKLOADS[name]["bound"] == "mfma":
+                    others[-1]["roofline_hbm"] = h2
                 if not args.no_cpu_baseline:
                     others[-1]["cpu_baseline"] = cpu_baseline(W, r["json"], name, target_s=3.0)
             out["other_workloads"] = others

@@ -1636,6 +1636,10 @@ __device__ __forceinline__ void ls_body(const LaunchArgs& a, const MfmaDesc& d, 
     for (int i = tid; i < 2 * kFrag; i += NT) below[i] = u32x4{ 0u, 0u, 0u, 0u };
     // where a lane's h values go in the fragments: unit u = 4T + q -> k-step u / 32, lane row (u % 32) / 8, element u % 8
     auto publish_tile = [&](u32x4* dst, int tl) {
+#ifdef AIDAX_LS_NOPUBLISH                                            // (measurement build, wrong results: what split + fragment writes cost)
+        (void)dst; (void)tl;
+        return;
+#endif
         const int u = 4 * (wave * TPW + tl) + q;
         uint16_t* p16 = reinterpret_cast<uint16_t*>(dst + (u >> 5) * 64 + ((u & 31) >> 3) * 16 + (lane & 15)) + (u & 7);
         float r = hv[tl];
@@ -1658,6 +1662,10 @@ __device__ __forceinline__ void ls_body(const LaunchArgs& a, const MfmaDesc& d, 
     CellTmp ct[TPW];
     auto cell_step = [&](int tl, int k, const f32x4& g, u32x4* h_dst) {
         CellTmp& t = ct[tl];
+#ifdef AIDAX_LS_NOCELL                                               // (measurement build, wrong results: what the cell update costs)
+        if (k == NSTEP - 1) { hv[tl] = g.x * 1e-9f; publish_tile(h_dst, tl); }
+        return;
+#endif
         if constexpr (CELL == 0) {                          // LSTM: g = (i, f, g, o), the sigmoid rows carrying -log2 e
             switch (k) {
             case 0: t.x = tanh_rat_clamp(g.z); t.u = t.x * t.x; t.e0 = __builtin_amdgcn_exp2f(g.x); break;
@@ -1691,19 +1699,31 @@ __device__ __forceinline__ void ls_body(const LaunchArgs& a, const MfmaDesc& d, 
     // whose shadow the cell update issues in) and leave at the head of the next one, so that every store has a whole tick to
     // drain before the barrier that precedes its publication.
     auto ship_h = [&](const u32x4* h_src, int Fprev) {
+#ifndef AIDAX_LS_NOSHIP                                              // (measurement build without the ring's stores: what the hand-over costs the lower layer)
         const uint32_t slot_off = (uint32_t)(((base_out + (uint32_t)Fprev) % kLpRing) * kSlot * sizeof(float));
         for (int i = tid; i < kFrag; i += NT) lp_store16(rs_out, slot_off + (uint32_t)i * 16u, __builtin_bit_cast(f32x4, h_src[i]));
+#else
+        (void)h_src; (void)Fprev;
+#endif
     };
     auto ship_started = [&](const f32x4 (&pacc)[MA], int Fprev) {
+#ifndef AIDAX_LS_NOSHIP
         const uint32_t slot_off = (uint32_t)(((base_out + (uint32_t)Fprev) % kLpRing) * kSlot * sizeof(float));
 #pragma unroll
         for (int tl = 0; tl < MW; ++tl)
             lp_store16(rs_out, slot_off + (uint32_t)(kFrag * 16) + (uint32_t)(((wave * M + tl) * kWave + lane) * 16), pacc[tl]);
+#else
+        (void)pacc; (void)Fprev;
+#endif
     };
     auto no_valu = [](int) {};
     auto own_w = [&](int tl, int ks, int tw) -> bf16x8 { return wq[tl][ks][tw]; };
     // the segments nobody waits for: x = tile (first layer: the tiles started for the layer above) / tile - MW (others)
+#ifdef AIDAX_LS_NOXW                                                 // (measurement build, wrong results: what reading the LDS-resident terms at use costs)
+    auto x_w = [&](int x, int ks, int tw) -> bf16x8 { (void)tw; return wx[x][ks]; };
+#else
     auto x_w = [&](int x, int ks, int tw) -> bf16x8 { return tw == 0 ? wx[x][ks] : __builtin_bit_cast(bf16x8, w2x[((x * KS2 + ks) * 2 + tw - 1) * 64]); };
+#endif
     auto up_w = [&](int tl, int ks, int tw) -> bf16x8 { return x_w(tl, ks, tw); };
     auto below_w = [&](int tl, int ks, int tw) -> bf16x8 { return x_w(tl - MW, ks, tw); };
     auto bias_of = [&](int tl, bool above) { return *reinterpret_cast<const f32x4*>(biasL + (above ? H * 4 : 0) + 4 * (4 * (wave * TPW + tl) + q)); };
@@ -1899,11 +1919,15 @@ __device__ __forceinline__ void ls_body(const LaunchArgs& a, const MfmaDesc& d, 
                 LS_STAMP(2);
                 ls_gates<KS2, NPROD, 0, HALF, TPW>(acc, hb, own_w, no_valu);
                 LS_STAMP(3);
+#ifndef AIDAX_LS_STASH_LATE
                 if constexpr (!first) {
                     // frame F+2's fragments (requested at the head of the tick) go where frame F's were: their product was taken
-                    // a tick ago, and the registers they travelled in are free for the phases below
+                    // a tick ago, and the registers they travelled in are free for the phases below. (At the END of the tick —
+                    // AIDAX_LS_STASH_LATE — the load has the whole tick to arrive: measured the same for LSTM-96 x 2, 712.5
+                    // against 713.3 us, and 3 % slower for LSTM-64 x 2.)
                     if (more2) stash_below(tick & 1);
                 }
+#endif
                 // phase B: ... the second half, the first half's cell update in its shadow
                 if constexpr (HALF < TPW) ls_gates<KS2, NPROD, HALF, TPW, TPW>(acc, hb, own_w, [&](int g) { deal(0, HALF, g); });
                 else {
@@ -1939,6 +1963,9 @@ __device__ __forceinline__ void ls_body(const LaunchArgs& a, const MfmaDesc& d, 
                     }
                 }
                 LS_STAMP(5);
+#ifdef AIDAX_LS_STASH_LATE
+                if constexpr (!first) { if (more2) stash_below(tick & 1); }
+#endif
                 par = wr;
                 if (!last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's ring stores (issued at the head of the tick) have left before the barrier (G16)
                 LS_STAMP(6);

@@ -62,6 +62,15 @@ ManyForm many_streams_form(int cell, int hidden, uint32_t n, int cus)
     // the whole run() in one launch; up to two workgroups per CU): GRU-64 326 us flat up to 4096 streams, 595 us at 8192,
     // 1 140 us at 16384 against 257 / 408 / 859 us for k_nn at 2048 / 3072 / 8192; GRU-40 277-287 us up to 4096 against
     // 300 (k_nn) / 278 (k_quad) at 3072 and 303 (k_quad) at 4096, 492 / 562 at 8192.
+    // Round 4: with the recurrent product on the bf16 matrix pipe (k_gru_gs) the kernel costs 190 us (GRU-64) / 186 us (GRU-40) per
+    // 256-frame block whatever the stream count up to a full round, and the crossovers moved (scratch/gs_threshold.py,
+    // profiles/r04_gs_threshold.txt): GRU-64 wins from 256 streams on (k_quad 197 us at 256 - 1024, k_nn 225 at 1536 - 2048);
+    // GRU-40 from the point where k_nn needs a second round of waves (2048 streams: 174 us; 2560: 279). AIDAX_GRU_GM=f32 (the
+    // fp32 MFMA kernel, 305 us) keeps round 3's thresholds.
+    static const bool gm_f32 = [] { const char* e = std::getenv("AIDAX_GRU_GM"); return e && e[0] == 'f'; }();
+    if (!lstm && cus > 0 && !gm_f32 &&
+        ((hidden == 64 && groups * 16 >= static_cast<uint32_t>(cus)) || (hidden == 40 && groups * 2 > static_cast<uint32_t>(cus))))
+        return MANY_MFMA;
     if (!lstm && cus > 0 && ((hidden == 64 && groups * 8 >= static_cast<uint32_t>(cus) * 5) || (hidden == 40 && groups * 8 >= static_cast<uint32_t>(cus) * 7)))
         return MANY_MFMA;
     if (hidden <= 32) return n >= 4096 ? MANY_QUAD : MANY_NONE;

@@ -165,6 +165,7 @@ struct ModelSlot {
     uint32_t* d_counters = nullptr;  // k_mfma_lp: frames produced / consumed per (group, layer boundary)
     const void* lp_owner = nullptr;  // the pool whose hold on the device's LpGate this slot shares (d_ring != nullptr)
     bool lp_fused = false;           // k_mfma_lp runs the DSP chain too (one-layer models, helper waves): one launch per block
+    uint32_t lp_round_streams = 0;   // k_mfma_ls on a pool larger than one resident grid: streams per launch (a pass is several launches over stream ranges); 0: one launch
     int lp_split = 0;                // stacked models: k_mfma_ls serves the passes (contractions as bf16 term products of split operands): 6 or 9 products; 0: k_mfma_lp (fp32 MFMAs)
     bool gru_gm = false;             // one-layer GRU: k_gru_gm (gate-major tiles, the whole run() in one launch) serves the passes
     int gru_gs = 0;                  // ... as k_gru_gs (recurrent product on the bf16 matrix pipe, operands split into three bf16 terms): 6 or 9 term products; 0: the fp32 kernel
@@ -416,10 +417,24 @@ struct aidax_pool {
                 lp_off.store(true, std::memory_order_relaxed);
                 return true;
             };
+            // k_mfma_ls over the pass's streams: one launch, or one per range of lp_round_streams streams (every range a resident grid)
+            auto launch_ls = [&](bool fused) {
+                if (!m.lp_round_streams || a.n_streams <= m.lp_round_streams)
+                    return launch_mfma_ls_kernel(a, m.mdesc, m.d_ring, m.d_counters, hd_lp_fault, m.lp_split, s, fused);
+                for (uint32_t s0 = 0; s0 < a.n_streams; s0 += m.lp_round_streams) {
+                    LaunchArgs b = a;
+                    b.n_streams = std::min(m.lp_round_streams, a.n_streams - s0);
+                    b.ctl = a.ctl + s0; b.st = a.st + s0; b.nn = a.nn + static_cast<size_t>(s0) * a.nn_stride;
+                    if (a.in) b.in = a.in + static_cast<size_t>(s0) * a.n_frames;
+                    b.out = a.out + static_cast<size_t>(s0) * a.n_frames;
+                    const hipError_t e = launch_mfma_ls_kernel(b, m.mdesc, m.d_ring, m.d_counters, hd_lp_fault, m.lp_split, s, fused);
+                    if (e != hipSuccess) return e;      // (a refusal can only come from the first range: the ranges are one size or smaller)
+                }
+                return hipSuccess;
+            };
             auto model_kernel = [&]() {
                 if (lp_in_use(m) && a.mode == MODE_CHAIN) {
-                    const hipError_t e = m.lp_split ? launch_mfma_ls_kernel(a, m.mdesc, m.d_ring, m.d_counters, hd_lp_fault, m.lp_split, s)
-                                                    : launch_mfma_lp_kernel(a, m.mdesc, m.d_ring, m.d_counters, hd_lp_fault, s);
+                    const hipError_t e = m.lp_split ? launch_ls(false) : launch_mfma_lp_kernel(a, m.mdesc, m.d_ring, m.d_counters, hd_lp_fault, s);
                     if (!refused(e)) return e;
                 }
                 return launch_mfma_kernel(a, m.mdesc, s);
@@ -427,8 +442,7 @@ struct aidax_pool {
             if (a.mode != MODE_CHAIN) return model_kernel();
             if (m.gru_gm && a.n_frames != 0) return m.gru_gs ? launch_gru_gs_kernel(a, m.mdesc, m.gru_gs, s) : launch_gru_gm_kernel(a, m.mdesc, s);
             if (m.lp_fused && lp_in_use(m) && a.n_frames != 0) {
-                const hipError_t e = m.lp_split ? launch_mfma_ls_kernel(a, m.mdesc, m.d_ring, m.d_counters, hd_lp_fault, m.lp_split, s, true)
-                                                : launch_mfma_lp_kernel(a, m.mdesc, m.d_ring, m.d_counters, hd_lp_fault, s, true);
+                const hipError_t e = m.lp_split ? launch_ls(true) : launch_mfma_lp_kernel(a, m.mdesc, m.d_ring, m.d_counters, hd_lp_fault, s, true);
                 if (!refused(e)) return e;
             }
             hipError_t e = launch_chain_pass(true, a, s);
@@ -627,18 +641,33 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
     // (one-layer models of <= 48 units in the one-launch form: also in several rounds of workgroups — nothing waits for anything,
     // and LSTM-40 at 8192 streams measures 521 us against 583 us for k_mfma; profiles/r03_cfg3_forms.txt)
     const bool lp_rounds_ok = ms.kind == ModelSlot::MFMA && ms.mdesc.n_layers == 1 && ms.mdesc.hidden <= 48 && mfma_lp_fused_serves(ms.mdesc, p.max_frames);
-    const bool lp_pays = lp ? lp[0] != '0' : (lp_rounds_ok || lp_groups * static_cast<size_t>(ms.mdesc.n_layers) <= static_cast<size_t>(cus));
     // (a one-layer model has no hand-over and nothing to wait for: no hold on the device's gate needed)
     const bool lp_chained = ms.mdesc.n_layers >= 2;
+    // Round 4: k_mfma_ls is fast enough to pay in SEVERAL rounds too — a pass over more streams than one resident grid holds goes
+    // out as one launch per range of streams (each a resident, cooperative grid; same ring, the counters are per group):
+    // LSTM-96 x 2 at 4096 streams 2 x 0.71 ms against 2.48 ms on k_mfma, at 16 384 streams 8 x 0.71 against 9.42 ms.
+    const char* sp_env = std::getenv("AIDAX_LP_SPLIT");
+    const bool ls_ok = ms.kind == ModelSlot::MFMA && lp_chained && mfma_ls_serves(ms.mdesc) && !(sp_env && sp_env[0] == '0') &&
+                       mfma_ls_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024;
+    const char* rg_env = std::getenv("AIDAX_LP_ROUND_GROUPS");      // (tests: ranges of this many stream groups, so that a small pool goes out in several)
+    const size_t round_groups = rg_env && std::atoi(rg_env) > 0
+                                    ? static_cast<size_t>(std::atoi(rg_env))
+                                    : static_cast<size_t>(cus) / static_cast<size_t>(ms.mdesc.n_layers > 0 ? ms.mdesc.n_layers : 1) / 8 * 8;      // workgroup ids come in eights
+    // ... where k_mfma_ls's time per resident grid beats k_mfma's rate on a full chip (profiles/r04_ls_rounds_ab.txt): 64 units and
+    // more — LSTM-96 x 2 x1.65 / GRU-96 x 2 x1.64, 64 units x 2 x1.17..1.19, x 3 x1.10..1.16, GRU-80 x1.03; below 64 units k_mfma
+    // wins by x1.4..1.65, and LSTM-80 (the four-wave geometry) pays up to two grids' worth of streams only
+    const bool ranges_pay = rg_env || (ms.mdesc.hidden >= 64 && (ms.mdesc.hidden != 80 || ms.mdesc.L[0].cell != 0 || lp_groups <= static_cast<size_t>(cus)));
+    const bool ls_rounds = ls_ok && ranges_pay && round_groups >= (rg_env ? 1u : 8u) && lp_groups > round_groups && !(lp && lp[0] == '1');
+    const bool lp_pays = lp ? lp[0] != '0' : (lp_rounds_ok || ls_rounds || lp_groups * static_cast<size_t>(ms.mdesc.n_layers) <= static_cast<size_t>(cus));
     if (ms.kind == ModelSlot::MFMA && mfma_lp_serves(ms.mdesc) && lp_pays && !(lp_chained && p.lp_off.load()) &&
         mfma_lp_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024 && (!lp_chained || lp_gate().acquire(p.device, &p, &p.lp_off))) {
         if (lp_chained) ms.lp_owner = &p;
         // stacked models whose split fragments fit the register file: the same hand-over with the contractions on the bf16 matrix
         // pipe (k_mfma_ls; AIDAX_LP_SPLIT=0: the fp32 kernel, =9: every term product instead of six — A/B runs)
-        const char* sp = std::getenv("AIDAX_LP_SPLIT");
-        ms.lp_split = lp_chained && mfma_ls_serves(ms.mdesc) && !(sp && sp[0] == '0') && mfma_ls_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024
-                          ? (sp && sp[0] == '9' ? 9 : 6) : 0;
-        const size_t ring_bytes = ms.lp_split ? mfma_ls_ring_bytes(ms.mdesc, p.n_streams) : mfma_lp_ring_bytes(ms.mdesc, p.n_streams);
+        ms.lp_split = ls_ok ? (sp_env && sp_env[0] == '9' ? 9 : 6) : 0;
+        ms.lp_round_streams = ls_rounds ? static_cast<uint32_t>(round_groups) * kMfmaStreams : 0u;
+        const uint32_t ring_streams = ms.lp_round_streams ? ms.lp_round_streams : p.n_streams;
+        const size_t ring_bytes = ms.lp_split ? mfma_ls_ring_bytes(ms.mdesc, ring_streams) : mfma_lp_ring_bytes(ms.mdesc, p.n_streams);
         HIP_TRY(hipMalloc(&ms.d_ring, ring_bytes));
         HIP_TRY(hipMalloc(&ms.d_counters, mfma_lp_counter_bytes(ms.mdesc, p.n_streams)));
         HIP_TRY(hipMemsetAsync(ms.d_counters, 0, mfma_lp_counter_bytes(ms.mdesc, p.n_streams), p.wq));

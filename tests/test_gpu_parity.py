@@ -1244,6 +1244,44 @@ def test_split_stack_geometries_match_the_oracle(kind, hidden, n_rnn, isz, tmp_p
             pos += n
         pool.close()
 
+@pytest.mark.parametrize("kind,hidden,n_rnn,max_frames", [("lstm", 96, 2, 256), ("gru", 48, 3, 1024)])
+def test_split_stack_in_several_ranges_is_bit_identical_to_one_launch(kind, hidden, n_rnn, max_frames, tmp_path, monkeypatch):
+    """A stacked pool larger than one resident grid of k_mfma_ls goes out as one launch per range of streams (aidax_pool.cpp,
+    lp_round_streams). Ranges forced small here (AIDAX_LP_ROUND_GROUPS=8: 300 streams = 19 groups = ranges of 8, 8 and a ragged 3):
+    outputs and state bit-identical to the one-launch pass, and within the NN bar of the oracle — one-launch form (256-frame pool)
+    and three-launch form (1024-frame pool), ragged blocks incl. 0 and 1."""
+    path, spec = _model_file(tmp_path, f"lsr_{kind}{hidden}x{n_rnn}", kind=kind, hidden=hidden, input_size=1, seed=77 + hidden, n_rnn=n_rnn)
+    S = 300
+    sizes = [max_frames, 1, 0, 37, 255] if max_frames == 256 else [700, 16, 3, 513]
+    x = modelgen.signal(S, sum(sizes), seed=35)
+    cg, co = _ctl_pair(param1=0.4, param2=0.7, pregain_db=-1.0)
+    outs, states = {}, {}
+    for form in ("one", "ranges"):
+        monkeypatch.delenv("AIDAX_LP_ROUND_GROUPS", raising=False)
+        if form == "ranges":
+            monkeypatch.setenv("AIDAX_LP_ROUND_GROUPS", "8")
+        pool = ax.Pool(S, max_frames)
+        pool.set_model(ax.Model(path))
+        assert pool.kernel_name == ("k_mfma_ls" if max_frames == 256 else "k_chain+k_mfma_ls"), pool.kernel_name
+        pool.set_controls(cg)
+        got, pos = [], 0
+        for n in sizes:
+            got.append(pool.process(np.ascontiguousarray(x[:, pos:pos + n])))
+            pos += n
+        outs[form] = np.concatenate(got, axis=1)
+        states[form] = [pool.read_state(stream=s_, layer=n_rnn - 1, hidden=128) for s_ in (0, 127, 128, 255, 256, S - 1)]
+        pool.close()
+    assert np.array_equal(outs["one"].view(np.uint32), outs["ranges"].view(np.uint32))
+    for a_, b_ in zip(states["one"], states["ranges"]):
+        for u, v in zip(a_, b_):
+            assert np.array_equal(np.asarray(u).view(np.uint32), np.asarray(v).view(np.uint32))
+    for s_ in (0, 127, 128, 256, S - 1):                      # first / last stream of a range, the ragged tail
+        pl = O.OraclePlugin()
+        pl.set_model(O.OracleModel(spec))
+        want = pl.run(co, x[s_])
+        errlog.bound(np.abs(outs["ranges"][s_] - want).max(), 2e-6, "gpu_parity:ls_ranges")
+
+
 @pytest.mark.parametrize("name,kw", [
     ("lstm96x2", dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2)),          # BASELINE cfg #5 model
     ("gru48x3", dict(kind="gru", hidden=48, input_size=3, seed=483, n_rnn=3)),            # three layers: a middle workgroup both consumes and produces

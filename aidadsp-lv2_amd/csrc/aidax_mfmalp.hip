@@ -1381,22 +1381,23 @@ __global__ __launch_bounds__((UT + NHELP) * kWave) void k_gru_gs(LaunchArgs a, M
 // waves — one per SIMD, 512 registers each (the fragments are MFMA operands only and may live in AGPRs) — with half of the
 // upper layer's tiles started below, so that both workgroups of a group issue the same number of MFMAs (LSTM-96 x 2: six
 // tiles per wave, nine resident segments of 36 registers, 162 bf16 MFMAs per wave and frame in either layer).
-struct LsGeo { int nw, tpw, m; };
+struct LsGeo { int nw, tpw, m, nx; };      // nx: resident tile segments of a wave besides its own-h ones (the larger role's; none for a lone layer)
 __host__ __device__ constexpr int ls_ks2(int hidden) { return (hidden + 31) / 32; }
 __host__ __device__ constexpr int ls_frag_vecs(int hidden) { return 3 * ls_ks2(hidden) * 64; }      // 16-byte vectors of one h buffer
 __host__ __device__ constexpr int ls_segments(int tpw, int m) { return tpw + (tpw - m > m ? tpw - m : m); }      // resident tile segments of a wave (the larger role)
 __host__ __device__ constexpr LsGeo ls_geo(int n_layers, int hidden)
 {
-    if (hidden < 16 || hidden % 16 != 0 || n_layers < 2) return LsGeo{ 0, 0, 0 };
+    if (hidden < 16 || hidden % 16 != 0 || n_layers < 1) return LsGeo{ 0, 0, 0, 0 };
 #ifndef AIDAX_LS_M96
 #define AIDAX_LS_M96 2      // LSTM-96 x 2 on eight waves: tiles per wave the lower layer starts for the upper one (1: 32 / 40 tile segments per workgroup, 2: 40 / 32)
 #endif
     // registers a wave spends on resident fragments: all three terms of its own-h segments, term 0 of the others
     const int nw = mfma_waves(hidden), tpw = hidden / 4 / nw, m = lp_moved_tiles(n_layers, tpw, nw) == 2 ? AIDAX_LS_M96 : lp_moved_tiles(n_layers, tpw, nw);
-    if (tpw * ls_ks2(hidden) * 12 + (ls_segments(tpw, m) - tpw) * ls_ks2(hidden) * 4 <= 140) return LsGeo{ nw, tpw, m };
-    const int tpw4 = hidden / 16, m4 = n_layers == 2 ? tpw4 / 2 : 0;
-    if (n_layers == 2 && tpw4 * ls_ks2(hidden) * 12 + (ls_segments(tpw4, m4) - tpw4) * ls_ks2(hidden) * 4 <= 330) return LsGeo{ 4, tpw4, m4 };
-    return LsGeo{ 0, 0, 0 };
+    const int nx = n_layers == 1 ? 0 : ls_segments(tpw, m) - tpw;
+    if (tpw * ls_ks2(hidden) * 12 + nx * ls_ks2(hidden) * 4 <= 140) return LsGeo{ nw, tpw, m, nx };
+    const int tpw4 = hidden / 16, m4 = n_layers == 2 ? tpw4 / 2 : 0, nx4 = n_layers == 1 ? 0 : ls_segments(tpw4, m4) - tpw4;
+    if (n_layers <= 2 && tpw4 * ls_ks2(hidden) * 12 + nx4 * ls_ks2(hidden) * 4 <= 330) return LsGeo{ 4, tpw4, m4, nx4 };
+    return LsGeo{ 0, 0, 0, 0 };
 }
 __host__ __device__ inline size_t ls_lds_floats(int hidden, int n_frames, LsGeo g)
 {
@@ -1408,7 +1409,7 @@ __host__ __device__ inline size_t ls_lds_floats(int hidden, int n_frames, LsGeo 
          + (size_t)((hidden + 1 + 3) & ~3)                    /* Dense weights + bias (last layer)                         */
          + kMfmaStreams                                       /* live flags                                                */
          + 2 * 8 * kMfmaStreams                               /* Dense partial sums [parity][wave][n]                      */
-         + (size_t)g.nw * (ls_segments(g.tpw, g.m) - g.tpw) * ls_ks2(hidden) * 2 * 64 * 4;      /* second- and third-term fragments of the segments nobody waits for */
+         + (size_t)g.nw * g.nx * ls_ks2(hidden) * 2 * 64 * 4;      /* second- and third-term fragments of the segments nobody waits for */
 }
 // one frame in the ring: the h fragments, then (M > 0) the started tiles [wave][tile][lane] x 4 gate rows
 __host__ __device__ constexpr size_t ls_slot_floats(int hidden, int waves, int m) { return (size_t)ls_frag_vecs(hidden) * 4 + (size_t)waves * m * kWave * 4; }
@@ -1484,7 +1485,7 @@ __device__ __forceinline__ void ls_body(const LaunchArgs& a, const MfmaDesc& d, 
     constexpr int MA = MW > 0 ? MW : 1;
     constexpr size_t kSlot = ls_slot_floats(H, NW, M);      // floats of one ring frame
     constexpr bool chain = CHAIN, first = FIRST, last = LAST;
-    static_assert(!(FIRST && LAST), "stacked models only");
+    static_assert(!(FIRST && LAST) || M == 0, "a lone layer starts no tiles for a layer above");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1748,7 +1749,7 @@ __device__ __forceinline__ void ls_body(const LaunchArgs& a, const MfmaDesc& d, 
             }
         };
         // ---- audio rows of this chunk: the first layer reads them as input, the last for in_skip and to deliver
-        if constexpr (chain && last) {
+        if constexpr (chain && last && !first) {
             // one-launch form: the rows in a.out are the pre pass's, stored (write-through, drained) by the FIRST layer's
             // workgroup before it computed its first frame — once frames exist below, the rows are there
             if (tid == 0) wait_below(done + 3);
@@ -2082,6 +2083,26 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_ls(LaunchArgs a, MfmaDesc d
     }
 }
 
+// A LONE layer on the same body (first and last role at once: no ring, nobody waits, a workgroup per 16 streams): the one-layer
+// models of the reference's table at stream counts where a matrix-core form pays — LSTM-64 / 80, GRU-80, ... (GRU-40 / 64 have
+// k_gru_gs). CHAIN: the DSP chain passes on waves 0 and 1 around the body, the whole run() in the launch.
+template <int TPW, int NW, bool CHAIN, int NPROD>
+__global__ __launch_bounds__(NW * kWave) void k_mfma_ls1(LaunchArgs a, MfmaDesc d, float* ring, uint32_t* counters, uint32_t* fault)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int grp = (int)blockIdx.x;
+    if constexpr (CHAIN) {
+        lp_chain_rows<true>(a, smem, grp, true);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    if (d.L[0].cell == 0) ls_body<TPW, NW, 0, true, true, CHAIN, NPROD, 0>(a, d, ring, counters, fault, smem, grp, 0);
+    else ls_body<TPW, NW, 0, true, true, CHAIN, NPROD, 1>(a, d, ring, counters, fault, smem, grp, 0);
+    if constexpr (CHAIN) {
+        __syncthreads();
+        lp_chain_rows<false>(a, smem, grp, true);
+    }
+}
+
 // ---------------------------------------------------------------- host side
 typedef void (*LpFn)(LaunchArgs, MfmaDesc, float*, uint32_t*, uint32_t*);
 // Helper waves of the one-launch form: a third wave per SIMD must fit next to the main waves' registers (512 per SIMD
@@ -2245,7 +2266,12 @@ static LpFn ls_fn_for(bool chain, int nprod)
 {
     constexpr LsGeo g = ls_geo(NL, HID);
     if constexpr (g.nw == 0) return nullptr;
-    else if constexpr (ls_segments(g.tpw, g.m) * ls_ks2(HID) * 12 > 150)      // the 512-register geometries: six products only (nine spill)
+    else if constexpr (NL == 1) {
+        if constexpr (g.tpw * ls_ks2(HID) * 12 > 150) return chain ? k_mfma_ls1<g.tpw, g.nw, true, 6> : k_mfma_ls1<g.tpw, g.nw, false, 6>;
+        else return chain ? (nprod == 9 ? k_mfma_ls1<g.tpw, g.nw, true, 9> : k_mfma_ls1<g.tpw, g.nw, true, 6>)
+                          : (nprod == 9 ? k_mfma_ls1<g.tpw, g.nw, false, 9> : k_mfma_ls1<g.tpw, g.nw, false, 6>);
+    }
+    else if constexpr ((g.tpw + g.nx) * ls_ks2(HID) * 12 > 150)      // the 512-register geometries: six products only (nine spill)
         return chain ? k_mfma_ls<g.tpw, g.nw, g.m, true, 6> : k_mfma_ls<g.tpw, g.nw, g.m, false, 6>;
     else return chain ? (nprod == 9 ? k_mfma_ls<g.tpw, g.nw, g.m, true, 9> : k_mfma_ls<g.tpw, g.nw, g.m, true, 6>)
                       : (nprod == 9 ? k_mfma_ls<g.tpw, g.nw, g.m, false, 9> : k_mfma_ls<g.tpw, g.nw, g.m, false, 6>);
@@ -2253,7 +2279,7 @@ static LpFn ls_fn_for(bool chain, int nprod)
 static LpFn ls_fn(int hidden, int n_layers, bool chain, int nprod)
 {
     switch (hidden) {                                       // (two layers: tiles started below; deeper stacks: none — the same body with M = 0)
-#define AIDAX_LS_CASE(HID) case HID: return n_layers == 2 ? ls_fn_for<HID, 2>(chain, nprod) : ls_fn_for<HID, 3>(chain, nprod);
+#define AIDAX_LS_CASE(HID) case HID: return n_layers == 2 ? ls_fn_for<HID, 2>(chain, nprod) : n_layers == 1 ? ls_fn_for<HID, 1>(chain, nprod) : ls_fn_for<HID, 3>(chain, nprod);
     AIDAX_LS_CASE(16) AIDAX_LS_CASE(32) AIDAX_LS_CASE(48) AIDAX_LS_CASE(64) AIDAX_LS_CASE(80) AIDAX_LS_CASE(96)
 #undef AIDAX_LS_CASE
     default: return nullptr;
@@ -2261,7 +2287,7 @@ static LpFn ls_fn(int hidden, int n_layers, bool chain, int nprod)
 }
 bool mfma_ls_serves(const MfmaDesc& d)
 {
-    return d.n_layers >= 2 && d.ls_off != 0 && ls_geo(d.n_layers, d.hidden).nw != 0 && ls_fn(d.hidden, d.n_layers, false, 6) != nullptr;
+    return d.n_layers >= 1 && d.ls_off != 0 && ls_geo(d.n_layers, d.hidden).nw != 0 && ls_fn(d.hidden, d.n_layers, false, 6) != nullptr;
 }
 size_t mfma_ls_lds_bytes(const MfmaDesc& d, uint32_t n_frames, bool fused)
 {
@@ -2288,7 +2314,7 @@ hipError_t launch_mfma_ls_kernel(const LaunchArgs& a, const MfmaDesc& d, float* 
         if (e != hipSuccess) return e;
     }
     const uint32_t groups = (a.n_streams + kMfmaStreams - 1) / kMfmaStreams;
-    const uint32_t blocks = ((groups + 7) / 8) * 8 * (uint32_t)d.n_layers;
+    const uint32_t blocks = d.n_layers == 1 ? groups : ((groups + 7) / 8) * 8 * (uint32_t)d.n_layers;
     return lp_launch(fn, blocks, (uint32_t)(ls_geo(d.n_layers, d.hidden).nw * kWave), lds, stream, a, d, ring, counters, fault);
 }
 

@@ -339,7 +339,7 @@ std::vector<float> pack_mfma(const aidax_model& m, MfmaDesc* d, uint32_t* state_
     // every fp32 weight split exactly into three bf16 terms (split_bf16x3; why: see the gs record above). Same tiles (four units
     // x their four gate rows), same scale factors. Per layer: [wave][tile][segment: h of the layer below (layers >= 1) | own
     // h(t-1)][ceil(H/32) k-steps][3 terms][64 lanes][8 bf16]; lane supplies row (lane & 15), columns k = 32 ks + 8 (lane >> 4) + i.
-    if (m.n_rnn >= 2) {
+    if (m.n_rnn >= 1) {
         while (out.size() % 4) out.push_back(0.f);
         d->ls_off = static_cast<uint32_t>(out.size());
         const int KS2 = (H + 31) / 32;

@@ -52,10 +52,32 @@ constexpr uint32_t kMaxFrames = 8192;           // LDS block buffer bound (32 Ki
 // machine in one round, and beats every other form when that round is (nearly) full — LSTM-32 209 us against 231,
 // GRU-32 197 / 211, LSTM-40 338 / 346, GRU-64 434 / 468 at 4096 streams on 256 CUs; at 3072 streams the others win.
 enum ManyForm { MANY_NONE = 0, MANY_QUAD = 1, MANY_MFMA = 2 };
+// One-layer models on k_mfma_ls1 (k_mfma_ls's body for a lone layer: the recurrent product as bf16 term products, a workgroup per
+// 16 streams): where it beats every other form at 256-frame blocks on 256 CUs (scratch/ls1_ab.py, profiles/r04_ls1_ab.txt) —
+// LSTM-64 from 2048 streams (4096: 306 us against 417 on k_mfma_lp, 16 384: 1 228 against 1 609 on k_mfma), LSTM-80 / GRU-80 from
+// 1024 (4096: 540 / 458 against 716 / 669), LSTM-40 beyond 4096 (8192: 427 against 526), 32 units beyond 6144 (8192: 286 / 248
+// against 345 / 289 on k_quad). GRU-40 / 64 have k_gru_gs (190 us per round of 4096 streams against 244 .. 275 here); 16 units never.
+bool lone_split_pays(int cell, int hidden, uint32_t n, int cus)
+{
+    static const bool off = [] { const char* e = std::getenv("AIDAX_LP_SPLIT"); return e && e[0] == '0'; }();
+    if (off || cus <= 0) return false;
+    const bool lstm = cell == AIDAX_CELL_LSTM;
+    const uint32_t groups = (n + kMfmaStreams - 1) / kMfmaStreams, c = static_cast<uint32_t>(cus);
+    switch (hidden) {
+    case 32: return groups * 2 > c * 3;
+    case 40: return lstm && groups > c;
+    case 64: return lstm && groups * 2 > c;
+    case 80: return groups * 4 > c;
+    default: return false;
+    }
+}
+
 ManyForm many_streams_form(int cell, int hidden, uint32_t n, int cus)
 {
     const bool lstm = cell == AIDAX_CELL_LSTM;
     const uint32_t groups = (n + kMfmaStreams - 1) / kMfmaStreams;
+    static const bool ls1_off = [] { const char* e = std::getenv("AIDAX_LS1"); return e && e[0] == '0'; }();
+    if (!ls1_off && lone_split_pays(cell, hidden, n, cus)) return MANY_MFMA;
     const bool full_round = cus > 0 && groups <= static_cast<uint32_t>(cus) && groups * 8 > static_cast<uint32_t>(cus) * 7;
     if (full_round && (hidden == 32 || hidden == 64 || (hidden == 40 && lstm))) return MANY_MFMA;
     // One-layer GRUs of 40 (run as 48) / 64 units have k_gru_gm (gate-major tiles: three quarters of the matrix-core work,
@@ -647,7 +669,10 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
     // out as one launch per range of streams (each a resident, cooperative grid; same ring, the counters are per group):
     // LSTM-96 x 2 at 4096 streams 2 x 0.71 ms against 2.48 ms on k_mfma, at 16 384 streams 8 x 0.71 against 9.42 ms.
     const char* sp_env = std::getenv("AIDAX_LP_SPLIT");
-    const bool ls_ok = ms.kind == ModelSlot::MFMA && lp_chained && mfma_ls_serves(ms.mdesc) && !(sp_env && sp_env[0] == '0') &&
+    // (a lone layer on k_mfma_ls: AIDAX_LS1=1 / 0 forces it on / off)
+    const char* ls1_env = std::getenv("AIDAX_LS1");
+    const bool ls1 = !lp_chained && (ls1_env ? ls1_env[0] != '0' : lone_split_pays(m->cell, m->hidden, p.n_streams, cus));
+    const bool ls_ok = ms.kind == ModelSlot::MFMA && (lp_chained || ls1) && mfma_ls_serves(ms.mdesc) && !(sp_env && sp_env[0] == '0') &&
                        mfma_ls_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024;
     const char* rg_env = std::getenv("AIDAX_LP_ROUND_GROUPS");      // (tests: ranges of this many stream groups, so that a small pool goes out in several)
     const size_t round_groups = rg_env && std::atoi(rg_env) > 0
@@ -658,7 +683,7 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
     // wins by x1.4..1.65, and LSTM-80 (the four-wave geometry) pays up to two grids' worth of streams only
     const bool ranges_pay = rg_env || (ms.mdesc.hidden >= 64 && (ms.mdesc.hidden != 80 || ms.mdesc.L[0].cell != 0 || lp_groups <= static_cast<size_t>(cus)));
     const bool ls_rounds = ls_ok && ranges_pay && round_groups >= (rg_env ? 1u : 8u) && lp_groups > round_groups && !(lp && lp[0] == '1');
-    const bool lp_pays = lp ? lp[0] != '0' : (lp_rounds_ok || ls_rounds || lp_groups * static_cast<size_t>(ms.mdesc.n_layers) <= static_cast<size_t>(cus));
+    const bool lp_pays = lp ? lp[0] != '0' : (lp_rounds_ok || ls_rounds || (ls_ok && !lp_chained) || lp_groups * static_cast<size_t>(ms.mdesc.n_layers) <= static_cast<size_t>(cus));
     if (ms.kind == ModelSlot::MFMA && mfma_lp_serves(ms.mdesc) && lp_pays && !(lp_chained && p.lp_off.load()) &&
         mfma_lp_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024 && (!lp_chained || lp_gate().acquire(p.device, &p, &p.lp_off))) {
         if (lp_chained) ms.lp_owner = &p;
@@ -1330,7 +1355,7 @@ AIDAX_API const char* aidax_pool_kernel_name(const aidax_pool* p)
     if (!(p && p->cur.has_model)) return "k_nomodel";
     const ModelSlot& m = p->cur;
     if (m.kind == ModelSlot::STACK) return "k_stack";
-    if (m.kind == ModelSlot::MFMA) return m.gru_gm ? (m.gru_gs ? "k_gru_gs" : "k_gru_gm") : !p->lp_in_use(m) ? "k_chain+k_mfma" : m.lp_split ? (m.lp_fused ? "k_mfma_ls" : "k_chain+k_mfma_ls") : m.lp_fused ? "k_mfma_lp" : "k_chain+k_mfma_lp";
+    if (m.kind == ModelSlot::MFMA) return m.gru_gm ? (m.gru_gs ? "k_gru_gs" : "k_gru_gm") : !p->lp_in_use(m) ? "k_chain+k_mfma" : m.lp_split ? (m.mdesc.n_layers == 1 ? (m.lp_fused ? "k_mfma_ls1" : "k_chain+k_mfma_ls1") : m.lp_fused ? "k_mfma_ls" : "k_chain+k_mfma_ls") : m.lp_fused ? "k_mfma_lp" : "k_chain+k_mfma_lp";
     if (m.kind == ModelSlot::QUAD) return "k_chain+k_quad";
     if (m.kind == ModelSlot::CONV) return m.conv_fused ? "k_conv_mfma" : m.conv_mfma ? "k_chain+k_conv_mfma" : "k_conv";
     const int form = p->chain_form(m);

@@ -562,6 +562,13 @@ def test_long_run_drift_lstm96x2_on_the_fp32_layer_pipelined_kernel(tmp_path, mo
               kernel="k_mfma_lp", tag="gpu_parity:drift_lstm96x2_lp", tol=4e-6)
 
 
+def test_long_run_drift_lstm64_on_the_lone_layer_split_kernel(tmp_path):
+    """LSTM-64 (the widest LSTM of the reference's table with GRU-80's neighbours) at 4096 streams — where the pool picks
+    k_mfma_ls1 by itself — over 48 128 samples with PARAM1 ramping."""
+    _long_run(tmp_path, "drift_lstm64", dict(kind="lstm", hidden=64, input_size=2, seed=64), S=4096, distinct=8,
+              kernel="k_mfma_ls1", tag="gpu_parity:drift_lstm64_ls1", tol=4e-6, ramp=True)
+
+
 def test_long_run_drift_small_gru_on_the_pipeline_kernel(tmp_path):
     """The three-wave pipeline's GRU cell (the exp-form candidate went into every GRU kernel) over 48 128 samples,
     PARAM1 ramping."""
@@ -577,8 +584,10 @@ def test_long_run_drift_small_gru_on_the_pipeline_kernel(tmp_path):
     ("cfg3", dict(kind="gru", hidden=64, input_size=3, seed=64), 4096, _EQ_POST, "k_gru_gs"),                     # one launch: gate-major tiles, the chain on the helper waves
     ("cfg4", dict(kind="conv", hidden=16, input_size=1, seed=1608), 1024, {}, "k_conv_mfma"),
     ("cfg5", dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2), 2048, {}, "k_mfma_ls"),
-    ("lstm80-2k", dict(kind="lstm", hidden=80, input_size=2, seed=80), 2048, dict(param1=0.7), "k_chain+k_quad"),
-    ("lstm80-4k", dict(kind="lstm", hidden=80, input_size=2, seed=80), 4096, dict(param1=0.7), "k_mfma_lp"),
+    ("lstm80-1k", dict(kind="lstm", hidden=80, input_size=2, seed=80), 1024, dict(param1=0.7), "k_chain+k_quad"),
+    ("lstm80-2k", dict(kind="lstm", hidden=80, input_size=2, seed=80), 2048, dict(param1=0.7), "k_mfma_ls1"),      # a lone layer on k_mfma_ls's body
+    ("gru80-4k", dict(kind="gru", hidden=80, input_size=2, seed=81), 4096, dict(param1=0.7), "k_mfma_ls1"),
+    ("lstm40-4k", dict(kind="lstm", hidden=40, input_size=2, seed=40), 4096, dict(param1=0.7), "k_mfma_lp"),       # the fp32 one-launch form keeps what it wins
     ("gru16-4k", dict(kind="gru", hidden=16, input_size=3, seed=16), 4096, dict(param1=0.2, param2=0.9), "k_chain+k_quad"),
 ])
 def test_full_size_properties(name, kw, S, ckw, kernel, tmp_path):
@@ -1243,6 +1252,48 @@ def test_split_stack_geometries_match_the_oracle(kind, hidden, n_rnn, isz, tmp_p
                     errlog.bound(np.abs(got[s_] - want).max(), 2e-6, "gpu_parity:ls_geometries")
             pos += n
         pool.close()
+
+@pytest.mark.parametrize("kind,hidden,isz", [
+    ("lstm", 64, 1),       # eight waves, two tiles per wave
+    ("lstm", 80, 2),       # four waves x 512 registers, five tiles per wave
+    ("gru", 80, 3),
+    ("lstm", 40, 1),       # 40 units run zero-padded to 48: four waves, three tiles
+    ("lstm", 32, 3),       # one tile per wave: no second phase for the cell update to hide in
+    ("gru", 16, 2),
+    ("lstm", 96, 1),       # wider than the reference's table
+])
+def test_lone_layer_on_the_split_kernel_matches_the_oracle(kind, hidden, isz, tmp_path, monkeypatch):
+    """k_mfma_ls1 (aidax_mfmalp.hip): ONE layer on k_mfma_ls's body — first and last role at once, no ring. Forced (AIDAX_KERNEL=mfma,
+    AIDAX_LS1=1) so that every geometry runs whatever the pool's table says: ragged blocks incl. 0 and 1, 40 streams (the last
+    group ragged), PARAM moves, in_skip, against per-stream oracle plugins; the one-launch form on a 256-frame pool and the
+    three-launch form on a 1024-frame pool."""
+    monkeypatch.setenv("AIDAX_KERNEL", "mfma")
+    monkeypatch.setenv("AIDAX_LS1", "1")
+    monkeypatch.setenv("AIDAX_GRU_GM", "0")
+    path, spec = _model_file(tmp_path, f"ls1_{kind}{hidden}", kind=kind, hidden=hidden, input_size=isz, seed=700 + hidden + isz, in_skip=isz == 1)
+    S = 40
+    for max_frames, sizes, name in ((256, [256, 1, 0, 37, 255, 64], "k_mfma_ls1"), (1024, [700, 16, 3, 513], "k_chain+k_mfma_ls1")):
+        x = modelgen.signal(S, sum(sizes), seed=34)
+        pool = ax.Pool(S, max_frames)
+        pool.set_model(ax.Model(path))
+        assert pool.kernel_name == name, pool.kernel_name
+        plugs = {}
+        for s_ in (0, 7, 17, S - 1):
+            p = O.OraclePlugin()
+            p.set_model(O.OracleModel(spec))
+            plugs[s_] = p
+        pos = 0
+        for bi, n in enumerate(sizes):
+            kw = dict(param1=0.2 + 0.15 * bi, param2=0.9 - 0.1 * bi, pregain_db=1.0)
+            pool.set_controls(ax.default_controls(**kw))
+            got = pool.process(np.ascontiguousarray(x[:, pos:pos + n]))
+            for s_, p in plugs.items():
+                want = p.run(O.default_controls(**kw), x[s_, pos:pos + n])
+                if n:
+                    errlog.bound(np.abs(got[s_] - want).max(), 2e-6, "gpu_parity:ls1_geometries")
+            pos += n
+        pool.close()
+
 
 @pytest.mark.parametrize("kind,hidden,n_rnn,max_frames", [("lstm", 96, 2, 256), ("gru", 48, 3, 1024)])
 def test_split_stack_in_several_ranges_is_bit_identical_to_one_launch(kind, hidden, n_rnn, max_frames, tmp_path, monkeypatch):

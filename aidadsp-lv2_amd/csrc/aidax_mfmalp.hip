@@ -1865,6 +1865,11 @@ __device__ __forceinline__ void ls_body(const LaunchArgs& a, const MfmaDesc& d, 
                     }
                 }
             }
+            // (a lone layer: the tick's fragment reads are requested before the Dense, whose 340 cycles then pass while they arrive —
+            // 48 KiB for the eight waves of LSTM-64, 384 cycles of the LDS port; the stacked roles have no registers to spare for that)
+            constexpr bool early_frags = first && last;
+            LsFrags<KS2> hb;                                // own h(t-1)
+            if constexpr (early_frags) { if (body) ls_load_frags(hb, hT + rd * kFrag, lane); }
             // ---- Dense(H,1) of frame tick-1 from the lanes' own h(tick-1): this wave's units, summed in a fixed order
             if (last && tick >= 1 && tick <= cnt) {
                 float y = wdu[0] * hv[0];
@@ -1877,7 +1882,7 @@ __device__ __forceinline__ void ls_body(const LaunchArgs& a, const MfmaDesc& d, 
                 if (lane < NS) dpart[((tick & 1) * NW + wave) * NS + lane] = y;
             }
             // ---- ... and of frame tick-2: the NW partial sums, bias, skip, output gain (wave 0, one lane per stream)
-            if (last && tick >= 2 && wave == 0 && lane < NS) {
+            if (last && tick >= 2 && wave == (early_frags && NW > 1 ? 1 : 0) && lane < NS) {      // (lone layer: not on the wave that writes the model inputs)
                 const int fd = tick - 2;
                 float y = wdl[H];
 #pragma unroll
@@ -1892,8 +1897,7 @@ __device__ __forceinline__ void ls_body(const LaunchArgs& a, const MfmaDesc& d, 
             if (body) {
                 const u32x4* h_rd = hT + rd * kFrag;
                 u32x4* h_wr = hT + wr * kFrag;
-                LsFrags<KS2> hb;                            // own h(t-1): requested first, on its way while the frame before goes up the ring
-                ls_load_frags(hb, h_rd, lane);
+                if constexpr (!early_frags) ls_load_frags(hb, h_rd, lane);      // requested first, on its way while the frame before goes up the ring
                 if (!last && F >= 1) ship_h(h_rd, F - 1);              // h_rd = h(F-1)
                 if constexpr (first) {
                     if (MW > 0 && F >= 2) ship_started(held, F - 2);

@@ -49,6 +49,10 @@ hipError_t launch_gru_gm_kernel(const LaunchArgs& a, const MfmaDesc& d, hipStrea
 bool gru_gs_serves(const MfmaDesc& d);
 size_t gru_gs_lds_bytes(const MfmaDesc& d, uint32_t n_frames);
 hipError_t launch_gru_gs_kernel(const LaunchArgs& a, const MfmaDesc& d, int n_products, hipStream_t stream);
+// k_lstm_gs (aidax_mfmalp.hip): the same structure for one-layer LSTMs of 40 (run as 48) / 64 units (pack_mfma's LSTM record at gs_off)
+bool lstm_gs_serves(const MfmaDesc& d);
+size_t lstm_gs_lds_bytes(const MfmaDesc& d, uint32_t n_frames);
+hipError_t launch_lstm_gs_kernel(const LaunchArgs& a, const MfmaDesc& d, int n_products, hipStream_t stream);
 hipError_t launch_mfma_lp_kernel(const LaunchArgs& a, const MfmaDesc& d, float* ring, uint32_t* counters, uint32_t* fault, hipStream_t stream, bool fused = false);
 // k_mfma_ls (aidax_mfmalp.hip): k_mfma_lp's stacked models with the contractions as bf16 MFMAs of operands split exactly into
 // three bf16 terms (n_products: 6 or 9); same ring protocol, its own ring geometry (a frame is the h fragments)

@@ -1362,6 +1362,199 @@ __global__ __launch_bounds__((UT + NHELP) * kWave) void k_gru_gs(LaunchArgs a, M
 }
 
 
+// ================================================================ k_lstm_gs: k_gru_gs's structure for one-layer LSTMs
+// UT main waves, one per 16 units (the four gate tiles i | f | g | o of those units: a lane's accumulator quads are the four gates of
+// four ADJACENT units of one stream), NHELP helper waves with the whole DSP chain, the model inputs and the Dense's tail
+// (lp_helper) — the whole run() in one launch. Per frame and main wave: 4 fp32 MFMAs (the model inputs' k-step), 4 x KS2 x NPROD
+// bf16 MFMAs (48 for 64 units) — i and g first, two accumulators in turn with the Dense's steps behind them, then f and o with
+// sigmoid(i), tanh(g) and their product dealt out in their shadow (bf16 MFMAs leave the VALU free, profiles/r04_overlap.txt) —
+// then the rest of the cell update (the same operations in the same order as k_mfma_ls's cell_step: sigmoid_pre, tanh_rat),
+// the split of the four new h values (gs_split4) and three 8-byte fragment writes, one barrier. The record: pack_mfma, gs_off.
+template <int UT, int NHELP, int NPROD>
+__global__ __launch_bounds__((UT + NHELP) * kWave) void k_lstm_gs(LaunchArgs a, MfmaDesc d)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int H = 16 * UT, NW = UT, NS = kMfmaStreams, NT = NW * kWave;
+    constexpr int KS2 = (H + 31) / 32;
+    constexpr int kFrag = 3 * KS2 * 64;
+    static_assert(NPROD == 6 || NPROD == 9, "six products (to fp32 rounding) or all nine");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = (int)a.n_frames;
+    const int grp = (int)blockIdx.x;
+    const int s_base = grp * NS;
+    const int Ht = d.hidden_true;
+    const int chunk = n < kLpChunk ? n : kLpChunk;
+    const int nP = (chunk + 3) & ~3;
+    float* xb    = smem;                                    // [NS][nP] audio rows
+    float* xin   = xb + NS * nP;                            // [2][4][NS] model inputs of a frame
+    u32x4* hB    = reinterpret_cast<u32x4*>(xin + 2 * 64);  // [2][3][KS2][64] h(t-1) as B fragments of the bf16 k-steps
+    float* wdl   = reinterpret_cast<float*>(hB + 2 * kFrag);// Dense weights, bias at [H]
+    float* livef = wdl + ((H + 1 + 3) & ~3);                // [NS]
+    float* dpart = livef + NS;                              // [2][8][NS] Dense partial sums of the waves
+    float* hands = dpart + 2 * 8 * NS;
+    if (wave >= NW) {
+        lp_helper<H, NW, NHELP>(a, xb, xin, wdl, livef, dpart, hands, grp, nP);
+        return;
+    }
+    const float* W = a.wpack;
+    const MfmaLayer& L = d.L[0];
+    const int q = lane >> 4, c = lane & 15;
+    for (int i = tid; i < H + 1; i += NT) wdl[i] = W[d.wd_off + i];
+    constexpr size_t kRecFloats = 4 * kWave + 4 * kWave * 4 + (size_t)4 * KS2 * 3 * kWave * 4;      // per wave: input k-step, bias quads, split fragments
+    const float* rec = W + d.gs_off + (size_t)wave * kRecFloats;
+    float w_in[4];
+    f32x4 bias[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        w_in[g] = rec[g * kWave + lane];
+        bias[g] = *reinterpret_cast<const f32x4*>(rec + 4 * kWave + (g * kWave + lane) * 4);
+    }
+    bf16x8 wq[4][KS2][3];
+    {
+        const u32x4* sp = reinterpret_cast<const u32x4*>(rec + 4 * kWave + 4 * kWave * 4) + lane;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) wq[g][ks][t] = __builtin_bit_cast(bf16x8, sp[((g * KS2 + ks) * 3 + t) * kWave]);
+    }
+    // h(t-1) and c(t-1) of this lane's four units (16 wave + 4q + e) of stream s_base + c: registers for the launch
+    const int sg = s_base + c;
+    const bool valid = sg < (int)a.n_streams;
+    const float* stp = a.nn + (size_t)(valid ? sg : 0) * a.nn_stride + L.state_off;
+    float hreg[4], creg[4], dw[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int u = 16 * wave + 4 * q + e;
+        hreg[e] = (valid && u < Ht) ? stp[u] : 0.f;         // padded units rest at 0
+        creg[e] = (valid && u < Ht) ? stp[Ht + u] : 0.f;
+        dw[e] = W[d.wd_off + u];                            // (zero for padded units)
+    }
+    const int my_slot = (wave >> 1) * 64 + (2 * (wave & 1) + (q >> 1)) * 16 + c;      // (k_gru_gs: where a lane's four values sit in the fragments)
+    const int my_half = q & 1;
+    auto publish = [&](int parity) {
+        u32x2 t[3];
+        gs_split4(hreg, t);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            reinterpret_cast<u32x2*>(hB + parity * kFrag + k * KS2 * 64 + my_slot)[my_half] = t[k];
+    };
+    if constexpr (H % 32 != 0) {                            // columns H .. 32 KS2 - 1 of the last k-step are nobody's: zero, for good
+        for (int i = tid; i < 2 * 3 * 32; i += NT)
+            hB[(i / 32) * KS2 * 64 + (KS2 - 1) * 64 + 32 + (i & 31)] = u32x4{ 0u, 0u, 0u, 0u };
+    }
+    publish(0);
+    __syncthreads();                                        // (1)
+
+    int par = 0;
+    for (int base = 0; base < n; base += kLpChunk) {
+        const int cnt = n - base < kLpChunk ? n - base : kLpChunk;
+        for (int sl = wave; sl < NS; sl += NW) {            // every valid row: the chains run on net-off streams too
+            const int s2 = s_base + sl;
+            const bool lv = s2 < (int)a.n_streams;
+            float* row = xb + sl * nP;
+            const float* src = a.in + (size_t)(lv ? s2 : 0) * n + base;
+            if (lv && ((n | base) & 3) == 0) load_block(row, src, cnt, lane);
+            else for (int t = lane; t < cnt; t += kWave) row[t] = lv ? src[t] : 0.f;
+        }
+        __syncthreads();                                    // (2)
+        __syncthreads();                                    // (3) the helpers have run the head of the pre pass and written frame 0's inputs
+        const int ticks = cnt + 2;
+        for (int tick = 0; tick < ticks; ++tick) {
+            float dy = 0.f;
+            Pair dp = { 0.f, 0.f };
+            const bool dense_on = tick >= 1 && tick <= cnt;
+            auto dense_step = [&](int k) {                  // (k_gru_gs: the Dense of frame tick-1 from the lane's own h(tick-1), nine steps)
+                switch (k) {
+                case 0: dy = dw[0] * hreg[0]; break;
+                case 1: dy = __builtin_fmaf(dw[1], hreg[1], dy); break;
+                case 2: dy = __builtin_fmaf(dw[2], hreg[2], dy); break;
+                case 3: dy = __builtin_fmaf(dw[3], hreg[3], dy); break;
+                case 4: dp = share_rows(dy); break;
+                case 5: dy = dp.lo + dp.hi; break;
+                case 6: dp = share_halves(dy); break;
+                case 7: dy = dp.lo + dp.hi; break;
+                case 8: if (dense_on && lane < NS) dpart[((tick & 1) * NW + wave) * NS + lane] = dy; break;
+                default: break;
+                }
+            };
+            if (tick < cnt) {
+                const u32x4* h_rd = hB + par * kFrag + lane;
+                constexpr int P9[9][2] = { {2, 2}, {1, 2}, {2, 1}, {0, 2}, {1, 1}, {2, 0}, {0, 1}, {1, 0}, {0, 0} };      // (weight term, h term), smallest first
+                bf16x8 hb[KS2][3];
+#pragma unroll
+                for (int t = 2; t >= 0; --t)
+#pragma unroll
+                    for (int ks = 0; ks < KS2; ++ks) hb[ks][t] = __builtin_bit_cast(bf16x8, h_rd[(t * KS2 + ks) * 64]);
+                f32x4 acc[4] = { bias[0], bias[1], bias[2], bias[3] };
+                const float bx = xin[(tick & 1) * 64 + lane];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_in[g], bx, acc[g], 0, 0, 0);
+                // i and g first, two accumulators in turn, the Dense's steps behind them ...
+#pragma unroll
+                for (int j = 0; j < NPROD * KS2; ++j) {
+                    const int pi = 9 - NPROD + j / KS2, ks = j % KS2;
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[0][ks][P9[pi][0]], hb[ks][P9[pi][1]], acc[0], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[2][ks][P9[pi][0]], hb[ks][P9[pi][1]], acc[2], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    dense_step(j);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // ... then f and o, with sigmoid(i) * tanh(g) of the four units in their shadow: six steps per unit (sigmoid_pre: the
+                // sigmoid rows carry -log2 e; tanh_rat: the odd rational x P(x^2) / Q(x^2))
+                float ig[4], tx[4], tu[4], tp[4], tq[4], te[4];
+                auto ig_step = [&](int e, int k) {
+                    switch (k) {
+                    case 0: tx[e] = tanh_rat_clamp(acc[2][e]); tu[e] = tx[e] * tx[e]; te[e] = __builtin_amdgcn_exp2f(acc[0][e]); break;
+                    case 1: tp[e] = __builtin_fmaf(kTanhP[6], tu[e], kTanhP[5]); tp[e] = __builtin_fmaf(tp[e], tu[e], kTanhP[4]); tp[e] = __builtin_fmaf(tp[e], tu[e], kTanhP[3]); break;
+                    case 2: tp[e] = __builtin_fmaf(tp[e], tu[e], kTanhP[2]); tp[e] = __builtin_fmaf(tp[e], tu[e], kTanhP[1]); tp[e] = __builtin_fmaf(tp[e], tu[e], kTanhP[0]); break;
+                    case 3: tq[e] = __builtin_fmaf(kTanhQ[3], tu[e], kTanhQ[2]); tq[e] = __builtin_fmaf(tq[e], tu[e], kTanhQ[1]); tq[e] = __builtin_fmaf(tq[e], tu[e], kTanhQ[0]); break;
+                    case 4: te[e] = __builtin_amdgcn_rcpf(1.0f + te[e]); tq[e] = __builtin_amdgcn_rcpf(tq[e]); break;
+                    case 5: ig[e] = te[e] * ((tp[e] * tx[e]) * tq[e]); break;
+                    default: break;
+                    }
+                };
+#pragma unroll
+                for (int j = 0; j < NPROD * KS2; ++j) {
+                    const int pi = 9 - NPROD + j / KS2, ks = j % KS2;
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[1][ks][P9[pi][0]], hb[ks][P9[pi][1]], acc[1], 0, 0, 0);
+                    acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[3][ks][P9[pi][0]], hb[ks][P9[pi][1]], acc[3], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (j < 12) { ig_step((2 * j) & 3, (2 * j) >> 2); ig_step((2 * j + 1) & 3, (2 * j + 1) >> 2); }      // 24 steps: the units advance together
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float f = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[1][e]));
+                    const float o = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[3][e]));
+                    creg[e] = __builtin_fmaf(f, creg[e], ig[e]);
+                    hreg[e] = o * tanh_rat(creg[e]);
+                }
+                par ^= 1;
+                publish(par);
+            } else if (dense_on) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) dense_step(k);
+            }
+            __syncthreads();                                // the tick's barrier
+        }
+        __syncthreads();                                    // (4) the helpers have stored the rows
+    }
+    __syncthreads();                                        // (5)
+    if (valid && livef[c] != 0.f) {
+        float* dst = a.nn + (size_t)sg * a.nn_stride + L.state_off;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int u = 16 * wave + 4 * q + e;
+            if (u < Ht) { dst[u] = hreg[e]; dst[Ht + u] = creg[e]; }
+        }
+    }
+}
+
+
 // ================================================================ k_mfma_ls: k_mfma_lp with the contractions on the bf16 matrix pipe
 // The layer-pipelined kernel above (one workgroup per (16 streams, layer), the layer's fragments resident in registers, h on
 // its way up through a ring in global memory, every wait bounded) with every fp32 product W . h computed as NPROD bf16 term
@@ -2255,6 +2448,31 @@ hipError_t launch_gru_gs_kernel(const LaunchArgs& a, const MfmaDesc& d, int n_pr
     GmFn fn = gs_fn(d.hidden, n_products);
     if (!fn || !gru_gs_serves(d) || a.mode != MODE_CHAIN || a.n_frames == 0) return hipErrorInvalidValue;
     const size_t lds = gru_gs_lds_bytes(d, a.n_frames);
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const uint32_t groups = (a.n_streams + kMfmaStreams - 1) / kMfmaStreams;
+    hipLaunchKernelGGL(fn, dim3(groups), dim3((d.hidden / 16 + kLpHelpers) * kWave), lds, stream, a, d);
+    return hipGetLastError();
+}
+
+// k_lstm_gs: one-layer LSTMs of 48 (LSTM-40 padded) / 64 units — as many main waves as a CU has SIMDs or one fewer, 256 registers each
+static GmFn lgs_fn(int hidden, int nprod)
+{
+    switch (hidden) {
+    case 48: return nprod == 9 ? k_lstm_gs<3, kLpHelpers, 9> : k_lstm_gs<3, kLpHelpers, 6>;
+    case 64: return nprod == 9 ? k_lstm_gs<4, kLpHelpers, 9> : k_lstm_gs<4, kLpHelpers, 6>;
+    default: return nullptr;
+    }
+}
+bool lstm_gs_serves(const MfmaDesc& d) { return d.n_layers == 1 && d.L[0].cell == 0 && d.gs_off != 0 && lgs_fn(d.hidden, 6) != nullptr; }
+size_t lstm_gs_lds_bytes(const MfmaDesc& d, uint32_t n_frames) { return gs_lds_floats(d.hidden, (int)n_frames, kLpHelpers) * sizeof(float); }
+hipError_t launch_lstm_gs_kernel(const LaunchArgs& a, const MfmaDesc& d, int n_products, hipStream_t stream)
+{
+    GmFn fn = lgs_fn(d.hidden, n_products);
+    if (!fn || !lstm_gs_serves(d) || a.mode != MODE_CHAIN || a.n_frames == 0) return hipErrorInvalidValue;
+    const size_t lds = lstm_gs_lds_bytes(d, a.n_frames);
     if (lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

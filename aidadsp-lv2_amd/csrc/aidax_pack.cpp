@@ -335,6 +335,37 @@ std::vector<float> pack_mfma(const aidax_model& m, MfmaDesc* d, uint32_t* state_
                                 out.push_back(f);
                             }
     }
+    // One-layer LSTM: the record of k_lstm_gs at gs_off — unit-major tiles like the GRU's gs record (wave w owns units 16w .. 16w+15
+    // as four tiles, one per gate i | f | g | o; a lane's accumulator quad is one gate of four ADJACENT units, so that the new h
+    // leaves as one 8-byte write per term). Per wave: [4 gates][64] input k-step (lane 16 k + r: unit 16w + r, input k), then
+    // [4 gates][64 lanes][4] bias quads (lane's units 16w + 4 (lane >> 4) + e), then [4 gates][ceil(H/32) k-steps][3 terms][64 lanes]
+    // [8 bf16] recurrent weights split exactly into three bf16 terms. Same scale factors as every other record (mfma_weight).
+    if (m.n_rnn == 1 && m.layers[0].type == Layer::LSTM) {
+        while (out.size() % 4) out.push_back(0.f);
+        d->gs_off = static_cast<uint32_t>(out.size());
+        const int KS2 = (H + 31) / 32;
+        for (int w = 0; w < H / 16; ++w) {
+            for (int g = 0; g < 4; ++g)
+                for (int lane = 0; lane < kWave; ++lane) out.push_back(mfma_weight(m, 0, SEG_IN, 16 * w + (lane & 15), g, lane >> 4));
+            for (int g = 0; g < 4; ++g)
+                for (int lane = 0; lane < kWave; ++lane)
+                    for (int e = 0; e < 4; ++e) out.push_back(mfma_weight(m, 0, SEG_BIAS, 16 * w + 4 * (lane >> 4) + e, g, 0));
+            for (int g = 0; g < 4; ++g)
+                for (int ks = 0; ks < KS2; ++ks)
+                    for (int term = 0; term < 3; ++term)
+                        for (int lane = 0; lane < kWave; ++lane)
+                            for (int i = 0; i < 8; i += 2) {
+                                const int u = 16 * w + (lane & 15), k = 32 * ks + 8 * (lane >> 4) + i;
+                                uint16_t t0[3], t1[3];
+                                split_bf16x3(k < H ? mfma_weight(m, 0, SEG_REC, u, g, k) : 0.f, t0);
+                                split_bf16x3(k + 1 < H ? mfma_weight(m, 0, SEG_REC, u, g, k + 1) : 0.f, t1);
+                                const uint32_t pair = static_cast<uint32_t>(t0[term]) | (static_cast<uint32_t>(t1[term]) << 16);
+                                float f;
+                                std::memcpy(&f, &pair, sizeof f);
+                                out.push_back(f);
+                            }
+        }
+    }
     // Stacked models: the k-step groups of every layer once more, for k_mfma_ls — as A fragments of v_mfma_f32_16x16x32_bf16 with
     // every fp32 weight split exactly into three bf16 terms (split_bf16x3; why: see the gs record above). Same tiles (four units
     // x their four gate rows), same scale factors. Per layer: [wave][tile][segment: h of the layer below (layers >= 1) | own

@@ -59,7 +59,7 @@ enum ManyForm { MANY_NONE = 0, MANY_QUAD = 1, MANY_MFMA = 2 };
 // against 345 / 289 on k_quad). GRU-40 / 64 have k_gru_gs (190 us per round of 4096 streams against 244 .. 275 here); 16 units never.
 bool lone_split_pays(int cell, int hidden, uint32_t n, int cus)
 {
-    static const bool off = [] { const char* e = std::getenv("AIDAX_LP_SPLIT"); return e && e[0] == '0'; }();
+    const bool off = [] { const char* e = std::getenv("AIDAX_LP_SPLIT"); return e && e[0] == '0'; }();
     if (off || cus <= 0) return false;
     const bool lstm = cell == AIDAX_CELL_LSTM;
     const uint32_t groups = (n + kMfmaStreams - 1) / kMfmaStreams, c = static_cast<uint32_t>(cus);
@@ -72,11 +72,28 @@ bool lone_split_pays(int cell, int hidden, uint32_t n, int cus)
     }
 }
 
+// ... and k_lstm_gs (k_gru_gs's structure for one-layer LSTMs: unit-major tiles, a main wave per 16 units, the chain on helper
+// waves): LSTM-64 265 us per round of 4096 streams — ahead of k_quad from 1025 streams on (289 us at 2048) and of k_mfma_ls1
+// throughout (308 / 616 / 1 234 us at 4096 / 8192 / 16 384 against 265 / 528 / 1 057); LSTM-40 265 us, between k_quad (223 us at
+// 2048) and k_mfma_ls1 (two workgroups per CU: 418 us at 8192 against 527) — profiles/r04_ls1_ab.txt. AIDAX_LSTM_GS=0 / 1: never / wherever it serves.
+bool lstm_gs_pays(int cell, int hidden, uint32_t n, int cus)
+{
+    // (read on every call — the worker thread's, at model load: tests switch forms within one process)
+    const int forced = [] { const char* e = std::getenv("AIDAX_LSTM_GS"); return !e ? -1 : e[0] != '0' ? 1 : 0; }();
+    const bool f32 = [] { const char* e = std::getenv("AIDAX_GRU_GM"); return e && e[0] == 'f'; }();
+    if (cell != AIDAX_CELL_LSTM || (hidden != 40 && hidden != 64) || forced == 0 || f32) return false;
+    if (forced == 1) return true;
+    if (cus <= 0) return false;
+    const uint32_t groups = (n + kMfmaStreams - 1) / kMfmaStreams, c = static_cast<uint32_t>(cus);
+    return hidden == 64 ? groups * 4 > c : groups * 2 > c && groups <= c;
+}
+
 ManyForm many_streams_form(int cell, int hidden, uint32_t n, int cus)
 {
+    if (lstm_gs_pays(cell, hidden, n, cus)) return MANY_MFMA;
     const bool lstm = cell == AIDAX_CELL_LSTM;
     const uint32_t groups = (n + kMfmaStreams - 1) / kMfmaStreams;
-    static const bool ls1_off = [] { const char* e = std::getenv("AIDAX_LS1"); return e && e[0] == '0'; }();
+    const bool ls1_off = [] { const char* e = std::getenv("AIDAX_LS1"); return e && e[0] == '0'; }();
     if (!ls1_off && lone_split_pays(cell, hidden, n, cus)) return MANY_MFMA;
     const bool full_round = cus > 0 && groups <= static_cast<uint32_t>(cus) && groups * 8 > static_cast<uint32_t>(cus) * 7;
     if (full_round && (hidden == 32 || hidden == 64 || (hidden == 40 && lstm))) return MANY_MFMA;
@@ -89,7 +106,7 @@ ManyForm many_streams_form(int cell, int hidden, uint32_t n, int cus)
     // profiles/r04_gs_threshold.txt): GRU-64 wins from 256 streams on (k_quad 197 us at 256 - 1024, k_nn 225 at 1536 - 2048);
     // GRU-40 from the point where k_nn needs a second round of waves (2048 streams: 174 us; 2560: 279). AIDAX_GRU_GM=f32 (the
     // fp32 MFMA kernel, 305 us) keeps round 3's thresholds.
-    static const bool gm_f32 = [] { const char* e = std::getenv("AIDAX_GRU_GM"); return e && e[0] == 'f'; }();
+    const bool gm_f32 = [] { const char* e = std::getenv("AIDAX_GRU_GM"); return e && e[0] == 'f'; }();
     if (!lstm && cus > 0 && !gm_f32 &&
         ((hidden == 64 && groups * 16 >= static_cast<uint32_t>(cus)) || (hidden == 40 && groups * 2 > static_cast<uint32_t>(cus))))
         return MANY_MFMA;
@@ -190,6 +207,7 @@ struct ModelSlot {
     uint32_t lp_round_streams = 0;   // k_mfma_ls on a pool larger than one resident grid: streams per launch (a pass is several launches over stream ranges); 0: one launch
     int lp_split = 0;                // stacked models: k_mfma_ls serves the passes (contractions as bf16 term products of split operands): 6 or 9 products; 0: k_mfma_lp (fp32 MFMAs)
     bool gru_gm = false;             // one-layer GRU: k_gru_gm (gate-major tiles, the whole run() in one launch) serves the passes
+    int lstm_gs = 0;                 // one-layer LSTM-40 / 64 on k_lstm_gs (k_gru_gs's structure): 6 or 9 term products; 0: not
     int gru_gs = 0;                  // ... as k_gru_gs (recurrent product on the bf16 matrix pipe, operands split into three bf16 terms): 6 or 9 term products; 0: the fp32 kernel
 
     float p_den() const { return 0.1f * model_sr; }      // LinearValueSmoother tau * sampleRate (:1053-1054)
@@ -462,6 +480,7 @@ struct aidax_pool {
                 return launch_mfma_kernel(a, m.mdesc, s);
             };
             if (a.mode != MODE_CHAIN) return model_kernel();
+            if (m.lstm_gs && a.n_frames != 0) return launch_lstm_gs_kernel(a, m.mdesc, m.lstm_gs, s);
             if (m.gru_gm && a.n_frames != 0) return m.gru_gs ? launch_gru_gs_kernel(a, m.mdesc, m.gru_gs, s) : launch_gru_gm_kernel(a, m.mdesc, s);
             if (m.lp_fused && lp_in_use(m) && a.n_frames != 0) {
                 const hipError_t e = m.lp_split ? launch_ls(true) : launch_mfma_lp_kernel(a, m.mdesc, m.d_ring, m.d_counters, hd_lp_fault, s, true);
@@ -705,6 +724,8 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
         const char* gm = std::getenv("AIDAX_GRU_GM");        // (=0: the four-rows-per-unit kernels; =f32: k_gru_gm with fp32 MFMAs — A/B runs)
         ms.gru_gm = gru_gm_serves(ms.mdesc) && !(gm && gm[0] == '0') && gru_gm_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024;
         const char* np = std::getenv("AIDAX_GS_PRODUCTS");   // (=9: every term product of the split operands instead of six)
+        ms.lstm_gs = lstm_gs_serves(ms.mdesc) && lstm_gs_pays(m->cell, m->hidden, p.n_streams, cus) && lstm_gs_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024
+                         ? (np && np[0] == '9' ? 9 : 6) : 0;
         ms.gru_gs = ms.gru_gm && gru_gs_serves(ms.mdesc) && !(gm && gm[0] == 'f') && gru_gs_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024
                         ? (np && np[0] == '9' ? 9 : 6) : 0;
     }
@@ -1355,6 +1376,7 @@ AIDAX_API const char* aidax_pool_kernel_name(const aidax_pool* p)
     if (!(p && p->cur.has_model)) return "k_nomodel";
     const ModelSlot& m = p->cur;
     if (m.kind == ModelSlot::STACK) return "k_stack";
+    if (m.kind == ModelSlot::MFMA && m.lstm_gs) return "k_lstm_gs";
     if (m.kind == ModelSlot::MFMA) return m.gru_gm ? (m.gru_gs ? "k_gru_gs" : "k_gru_gm") : !p->lp_in_use(m) ? "k_chain+k_mfma" : m.lp_split ? (m.mdesc.n_layers == 1 ? (m.lp_fused ? "k_mfma_ls1" : "k_chain+k_mfma_ls1") : m.lp_fused ? "k_mfma_ls" : "k_chain+k_mfma_ls") : m.lp_fused ? "k_mfma_lp" : "k_chain+k_mfma_lp";
     if (m.kind == ModelSlot::QUAD) return "k_chain+k_quad";
     if (m.kind == ModelSlot::CONV) return m.conv_fused ? "k_conv_mfma" : m.conv_mfma ? "k_chain+k_conv_mfma" : "k_conv";

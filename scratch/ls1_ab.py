@@ -6,7 +6,7 @@ sys.path.insert(0, os.getcwd())
 ax = importlib.import_module("aidadsp-lv2_amd")
 W = ax.workloads
 def run(env, kind, hidden, S, n=256, steps=40):
-    for k in ("AIDAX_KERNEL", "AIDAX_LS1", "AIDAX_GRU_GM"): os.environ.pop(k, None)
+    for k in ("AIDAX_KERNEL", "AIDAX_LS1", "AIDAX_GRU_GM", "AIDAX_LSTM_GS"): os.environ.pop(k, None)
     os.environ.update(env)
     p = W.write_model(W.make_model(kind, hidden, 1, seed=hidden), os.path.join(tempfile.mkdtemp(), "m.json"))
     pool = ax.Pool(S, n); pool.set_model(ax.Model(p))
@@ -28,7 +28,7 @@ if os.environ.get("LS1_SHAPES"): shapes = [tuple(s.split("-")) for s in os.envir
 for kind, hidden in shapes:
     for S in (256, 1024, 2048, 4096, 8192, 16384):
         cells = []
-        for tag, env in (("auto", {}), ("mfma", {"AIDAX_KERNEL": "mfma", "AIDAX_GRU_GM": "0"}), ("ls1", {"AIDAX_KERNEL": "mfma", "AIDAX_LS1": "1", "AIDAX_GRU_GM": "0"})):
+        for tag, env in (("auto", {}), ("mfma", {"AIDAX_KERNEL": "mfma", "AIDAX_GRU_GM": "0"}), ("ls1", {"AIDAX_KERNEL": "mfma", "AIDAX_LS1": "1", "AIDAX_GRU_GM": "0"})) + ((("lgs", {"AIDAX_KERNEL": "mfma", "AIDAX_LSTM_GS": "1"}),) if kind == "lstm" and hidden in (40, 64) else ()):
             name, us = run(env, kind, hidden, S)
             cells.append("%s=%s: %7.1f" % (tag, name, us))
         print("%s%-3d S=%6d: %s" % (kind, hidden, S, " | ".join(cells)), flush=True)

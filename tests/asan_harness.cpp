@@ -87,7 +87,35 @@ int main(int argc, char** argv)
                     use(wp);
                     // k_gru_gs's record: the three bf16 terms of every fragment entry add up to the fp32 weight k_gru_gm
                     // multiplies with — exactly — and shrink by 2^-8 per term (split_bf16x3)
-                    if (d.gs_off != 0) {
+                    if (d.gs_off != 0 && d.gm_off == 0) {
+                        // k_lstm_gs's record (one-layer LSTM, unit-major tiles): per wave [4][64] input k-step, [4][64][4] bias quads,
+                        // [4 gates][KS2][3 terms][64 lanes][8 bf16] — the terms against the fp32 weight of the tile record k_mfma reads
+                        const int H = d.hidden, KS2 = (H + 31) / 32;
+                        const size_t per_wave = 4 * kWave + 4 * kWave * 4 + static_cast<size_t>(4) * KS2 * 3 * kWave * 4;
+                        auto widen = [](uint32_t half) { const uint32_t u = half << 16; float f; std::memcpy(&f, &u, sizeof f); return f; };
+                        for (int w = 0; w < H / 16; ++w)
+                            for (int g = 0; g < 4; ++g)
+                                for (int ks = 0; ks < KS2; ++ks)
+                                    for (int lane = 0; lane < kWave; ++lane)
+                                        for (int i = 0; i < 8; ++i) {
+                                            const int u = 16 * w + (lane & 15), k = 32 * ks + 8 * (lane >> 4) + i;
+                                            float term[3];
+                                            for (int t = 0; t < 3; ++t) {
+                                                uint32_t pair;
+                                                std::memcpy(&pair, &wp[d.gs_off + w * per_wave + 4 * kWave + 4 * kWave * 4 + ((((static_cast<size_t>(g) * KS2 + ks) * 3 + t) * kWave + lane) * 4) + i / 2], sizeof pair);
+                                                term[t] = widen((pair >> (16 * (i & 1))) & 0xffffu);
+                                            }
+                                            const int T = u / 4, r = (u % 4) * 4 + g, kk = k / 4;
+                                            const float want = k < H ? wp[d.L[0].w_big_off + ((((static_cast<size_t>(T / d.tpw) * (H / 16) + kk / 4) * kWave + (r | (k & 3) << 4)) * 4 + kk % 4) * d.tpw + T % d.tpw)] : 0.f;
+                                            const float sum = (term[2] + term[1]) + term[0];
+                                            if (std::isfinite(want) && std::fabs(want) < 1e38f && (sum != want || std::fabs(term[1]) > std::fabs(want) / 256.f + 1e-38f || std::fabs(term[2]) > std::fabs(want) / 65536.f + 1e-38f)) {
+                                                std::fprintf(stderr, "%s: LSTM split record differs at wave %d gate %d k %d unit %d: %.9g + %.9g + %.9g vs %.9g\n", argv[i], w, g, k, u, term[0], term[1], term[2], want);
+                                                aidax_model_free(m);
+                                                return 3;
+                                            }
+                                        }
+                    }
+                    if (d.gs_off != 0 && d.gm_off != 0) {
                         const int H = d.hidden, KS = H / 4, KS2 = (H + 31) / 32;
                         auto widen = [](uint32_t half) { const uint32_t u = half << 16; float f; std::memcpy(&f, &u, sizeof f); return f; };
                         for (int w = 0; w < H / 16; ++w)

@@ -562,10 +562,16 @@ def test_long_run_drift_lstm96x2_on_the_fp32_layer_pipelined_kernel(tmp_path, mo
               kernel="k_mfma_lp", tag="gpu_parity:drift_lstm96x2_lp", tol=4e-6)
 
 
-def test_long_run_drift_lstm64_on_the_lone_layer_split_kernel(tmp_path):
-    """LSTM-64 (the widest LSTM of the reference's table with GRU-80's neighbours) at 4096 streams — where the pool picks
-    k_mfma_ls1 by itself — over 48 128 samples with PARAM1 ramping."""
+def test_long_run_drift_lstm64_on_the_unit_major_split_kernel(tmp_path):
+    """LSTM-64 at 4096 streams — where the pool picks k_lstm_gs by itself — over 48 128 samples with PARAM1 ramping."""
     _long_run(tmp_path, "drift_lstm64", dict(kind="lstm", hidden=64, input_size=2, seed=64), S=4096, distinct=8,
+              kernel="k_lstm_gs", tag="gpu_parity:drift_lstm64_gs", tol=4e-6, ramp=True)
+
+
+def test_long_run_drift_lstm64_on_the_lone_layer_split_kernel(tmp_path, monkeypatch):
+    """... and on k_mfma_ls1 (AIDAX_LSTM_GS=0: a lone layer on k_mfma_ls's body), the kernel LSTM-80 / GRU-80 pools get."""
+    monkeypatch.setenv("AIDAX_LSTM_GS", "0")
+    _long_run(tmp_path, "drift_lstm64b", dict(kind="lstm", hidden=64, input_size=2, seed=64), S=4096, distinct=8,
               kernel="k_mfma_ls1", tag="gpu_parity:drift_lstm64_ls1", tol=4e-6, ramp=True)
 
 
@@ -587,7 +593,9 @@ def test_long_run_drift_small_gru_on_the_pipeline_kernel(tmp_path):
     ("lstm80-1k", dict(kind="lstm", hidden=80, input_size=2, seed=80), 1024, dict(param1=0.7), "k_chain+k_quad"),
     ("lstm80-2k", dict(kind="lstm", hidden=80, input_size=2, seed=80), 2048, dict(param1=0.7), "k_mfma_ls1"),      # a lone layer on k_mfma_ls's body
     ("gru80-4k", dict(kind="gru", hidden=80, input_size=2, seed=81), 4096, dict(param1=0.7), "k_mfma_ls1"),
-    ("lstm40-4k", dict(kind="lstm", hidden=40, input_size=2, seed=40), 4096, dict(param1=0.7), "k_mfma_lp"),       # the fp32 one-launch form keeps what it wins
+    ("lstm40-4k", dict(kind="lstm", hidden=40, input_size=2, seed=40), 4096, dict(param1=0.7), "k_lstm_gs"),       # unit-major tiles, chain on helper waves
+    ("lstm64-2k", dict(kind="lstm", hidden=64, input_size=3, seed=65), 2048, dict(param1=0.7, param2=0.1), "k_lstm_gs"),
+    ("gru32-4k", dict(kind="gru", hidden=32, input_size=2, seed=33), 4096, dict(param1=0.7), "k_mfma_lp"),         # the fp32 one-launch form keeps what it wins
     ("gru16-4k", dict(kind="gru", hidden=16, input_size=3, seed=16), 4096, dict(param1=0.2, param2=0.9), "k_chain+k_quad"),
 ])
 def test_full_size_properties(name, kw, S, ckw, kernel, tmp_path):
@@ -1292,6 +1300,46 @@ def test_lone_layer_on_the_split_kernel_matches_the_oracle(kind, hidden, isz, tm
                 if n:
                     errlog.bound(np.abs(got[s_] - want).max(), 2e-6, "gpu_parity:ls1_geometries")
             pos += n
+        pool.close()
+
+
+@pytest.mark.parametrize("hidden,isz,nprod", [(64, 1, 6), (64, 3, 9), (40, 2, 6)])
+def test_one_layer_lstm_on_the_unit_major_split_kernel_matches_the_oracle(hidden, isz, nprod, tmp_path, monkeypatch):
+    """k_lstm_gs (aidax_mfmalp.hip): k_gru_gs's structure for one-layer LSTMs of 40 (run as 48) / 64 units — unit-major tiles, one
+    main wave per 16 units, the DSP chain on helper waves, the whole run() in the launch. Forced (AIDAX_KERNEL=mfma, AIDAX_LSTM_GS=1):
+    ragged blocks incl. 0 and 1 and blocks longer than a staging chunk, 40 streams (the last group ragged), PARAM moves, in_skip,
+    EQ in circuit, against per-stream oracle plugins; copies of a stream stay bitwise identical."""
+    monkeypatch.setenv("AIDAX_KERNEL", "mfma")
+    monkeypatch.setenv("AIDAX_LSTM_GS", "1")
+    if nprod == 9:
+        monkeypatch.setenv("AIDAX_GS_PRODUCTS", "9")
+    path, spec = _model_file(tmp_path, f"lgs_{hidden}", kind="lstm", hidden=hidden, input_size=isz, seed=300 + hidden + isz, in_skip=isz == 1)
+    S = 40
+    for max_frames, sizes in ((256, [256, 1, 0, 37, 255, 64]), (1024, [700, 16, 3, 513])):
+        base = modelgen.signal(8, sum(sizes), seed=36)
+        idx = (np.arange(S) * 3) % 8
+        pool = ax.Pool(S, max_frames)
+        pool.set_model(ax.Model(path))
+        assert pool.kernel_name == "k_lstm_gs", pool.kernel_name
+        plugs = []
+        for _ in range(8):
+            p = O.OraclePlugin()
+            p.set_model(O.OracleModel(spec))
+            plugs.append(p)
+        pos = 0
+        for bi, n in enumerate(sizes):
+            kw = dict(_EQ_POST, param1=0.2 + 0.15 * bi, param2=0.9 - 0.1 * bi, pregain_db=1.0)
+            pool.set_controls(ax.default_controls(**kw))
+            got = pool.process(np.ascontiguousarray(base[idx, pos:pos + n]))
+            for k, p in enumerate(plugs):
+                want = p.run(O.default_controls(**kw), base[k, pos:pos + n])
+                rows = got[idx == k]
+                assert np.all(rows == rows[0])
+                if n:
+                    errlog.bound(np.abs(rows[0] - want).max(), 2e-6, f"gpu_parity:lstm_gs{nprod}")
+            pos += n
+        h, c = pool.read_state(stream=S - 1, layer=0, hidden=128)
+        assert h.size == hidden and np.abs(c).max() > 1e-4
         pool.close()
 
 

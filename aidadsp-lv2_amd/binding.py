@@ -4,6 +4,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import re
+import weakref
 from typing import Optional
 
 import numpy as np
@@ -258,6 +259,11 @@ class Model:
             pass
 
 
+# the pools and hubs that are open (test harnesses close what a failed test left behind: a pool that holds a device's right to
+# the chained kernels would otherwise change the kernel every later pool of the process gets)
+live_handles = weakref.WeakSet()
+
+
 class Pool:
     """aidax_pool: N plugin instances' DSP state on one GPU."""
 
@@ -265,6 +271,7 @@ class Pool:
         h = C.c_void_p()
         _check(lib().aidax_pool_create(n_streams, max_frames, samplerate, device, C.byref(h)))
         self.h = h
+        live_handles.add(self)
         self.n_streams = n_streams
         self.max_frames = max_frames
 
@@ -371,6 +378,7 @@ class Hub:
         h = C.c_void_p()
         _check(lib().aidax_hub_create(max_instances, max_frames, samplerate, device, C.byref(h)))
         self.h = h
+        live_handles.add(self)
 
     def set_model(self, m: Optional[Model], start_mode: int = START_WARMUP):
         _check(lib().aidax_hub_set_model(self.h, m.h if m is not None else None, start_mode))

@@ -23,6 +23,26 @@ def pytest_configure(config):
             subprocess.run(["make", "-j8", "all"], cwd=ROOT, check=False, stdout=subprocess.DEVNULL)
 
 
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_makereport(item, call):
+    """A failed GPU test may leave pools and hubs open (the traceback keeps them alive) — among them one that holds a device's
+    right to the chained kernels (LpGate), after which every later stacked pool of the session would get k_mfma and fail on its
+    kernel name: one failure would read as ten. Close what a failed test left behind."""
+    outcome = yield
+    rep = outcome.get_result()
+    if rep.when == "call" and rep.failed and "gpu" in item.keywords:
+        try:
+            import importlib
+            binding = importlib.import_module("aidadsp-lv2_amd.binding")
+            for obj in list(binding.live_handles):
+                try:
+                    obj.close()
+                except Exception:
+                    pass
+        except Exception:
+            pass
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -409,10 +409,15 @@ def test_worker_thread_prepares_while_the_audio_thread_processes(tmp_path):
             failure.append(e)
 
     t = threading.Thread(target=worker)
-    t.start()
     swaps, names = 0, set()
     try:
         for b in range(blocks):
+            if b == 1:
+                # The worker starts once the first block has run: a prepared model inherits the PARAM targets the PLAYING model
+                # holds at the time of its preparation (rt-neural-generic.cpp:1053-1061), and those are the controls' only after the
+                # first run() has read the ports. (Started ahead of block 0, a host whose first prepare beats its first block —
+                # two cores for both threads are enough — hands the new model targets of 0: 3e-3 off the oracle, decaying.)
+                t.start()
             try:
                 mi, sg = ready.get_nowait()
             except queue.Empty:
@@ -434,7 +439,8 @@ def test_worker_thread_prepares_while_the_audio_thread_processes(tmp_path):
                 break
     finally:
         stop.set()
-        t.join()
+        if t.is_alive():
+            t.join()
         while not ready.empty():
             pool.staged_free(ready.get()[1])
     assert not failure, failure

@@ -10,7 +10,10 @@ blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 rs = np.random.RandomState(int(os.environ.get("SOAK_SEED", "2026")))
 d = tempfile.mkdtemp()
 models = []
-for kind, H, I, L in (("lstm", 32, 1, 1), ("gru", 16, 3, 1), ("lstm", 12, 2, 1), ("gru", 64, 1, 1), ("lstm", 32, 2, 2), ("conv", 16, 1, 1)):
+SHAPES = (("lstm", 32, 1, 1), ("gru", 16, 3, 1), ("lstm", 12, 2, 1), ("gru", 64, 1, 1), ("lstm", 32, 2, 2), ("conv", 16, 1, 1))
+if os.environ.get("SOAK_MODELS") == "wide":       # the wide one-layer cells and stacks: at ~4200 streams k_lstm_gs, k_mfma_ls1, k_gru_gs, k_mfma_ls (in ranges)
+    SHAPES = (("lstm", 64, 1, 1), ("lstm", 80, 2, 1), ("gru", 80, 3, 1), ("lstm", 40, 2, 1), ("gru", 64, 3, 1), ("lstm", 96, 1, 2), ("lstm", 12, 2, 1))
+for kind, H, I, L in SHAPES:
     # the last two are extensions — a stacked model (k_mfma_lp) and a conv stack (k_conv_mfma, chain passes inside the
     # launch) — so swaps also cross kernel families
     # the GRU-16 file carries a numeric samplerate: its PARAM smoothers run at the model's rate, not the host's (:1053-1060)

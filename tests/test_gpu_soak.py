@@ -32,6 +32,18 @@ def test_random_host_behaviour_many_streams():
     assert r.returncode == 0 and "soak ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_random_host_behaviour_wide_models_many_streams():
+    """... and with the wide one-layer cells and stacks as the models swapped between (SOAK_MODELS=wide: LSTM-64 / 80 / 40, GRU-80 / 64,
+    LSTM-96 x 2) at 4200 streams: k_lstm_gs, k_mfma_ls1, k_gru_gs, k_mfma_ls in ranges of streams."""
+    env = dict(os.environ)
+    env.pop("AIDAX_KERNEL", None)
+    env["SOAK_STREAMS"] = "4200"
+    env["SOAK_MODELS"] = "wide"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "soak.py"), "200"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "soak ok" in r.stdout and "k_lstm_gs" in r.stdout and "k_mfma_ls1" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_random_hub_host():
     """tests/soak_hub.py: attach / detach / skipped instances / block-size changes inside a period / model swaps of the
     hub, every delivered block against the instance's own oracle plugin one period late, pass count against the

@@ -2438,11 +2438,15 @@ static GmFn gs_fn(int hidden, int nprod)
     switch (hidden) {
     case 48: return nprod == 9 ? k_gru_gs<3, kLpHelpers, 9> : k_gru_gs<3, kLpHelpers, 6>;
     case 64: return nprod == 9 ? k_gru_gs<4, kLpHelpers, 9> : k_gru_gs<4, kLpHelpers, 6>;
+    // 80 units: five main waves and TWO helpers (eight streams each) — seven waves, two per SIMD at most, 256 registers each;
+    // one SIMD carries two main waves (no fp32 twin: k_gru_gm stays with 48 / 64 units)
+    case 80: return nprod == 9 ? k_gru_gs<5, 2, 9> : k_gru_gs<5, 2, 6>;
     default: return nullptr;
     }
 }
-bool gru_gs_serves(const MfmaDesc& d) { return gru_gm_serves(d) && d.gs_off != 0; }
-size_t gru_gs_lds_bytes(const MfmaDesc& d, uint32_t n_frames) { return gs_lds_floats(d.hidden, (int)n_frames, kLpHelpers) * sizeof(float); }
+static int gs_helpers(int hidden) { return hidden == 80 ? 2 : kLpHelpers; }
+bool gru_gs_serves(const MfmaDesc& d) { return d.n_layers == 1 && d.L[0].cell == 1 && d.gm_off != 0 && d.gs_off != 0 && gs_fn(d.hidden, 6) != nullptr; }
+size_t gru_gs_lds_bytes(const MfmaDesc& d, uint32_t n_frames) { return gs_lds_floats(d.hidden, (int)n_frames, gs_helpers(d.hidden)) * sizeof(float); }
 hipError_t launch_gru_gs_kernel(const LaunchArgs& a, const MfmaDesc& d, int n_products, hipStream_t stream)
 {
     GmFn fn = gs_fn(d.hidden, n_products);
@@ -2453,7 +2457,7 @@ hipError_t launch_gru_gs_kernel(const LaunchArgs& a, const MfmaDesc& d, int n_pr
         if (e != hipSuccess) return e;
     }
     const uint32_t groups = (a.n_streams + kMfmaStreams - 1) / kMfmaStreams;
-    hipLaunchKernelGGL(fn, dim3(groups), dim3((d.hidden / 16 + kLpHelpers) * kWave), lds, stream, a, d);
+    hipLaunchKernelGGL(fn, dim3(groups), dim3((d.hidden / 16 + gs_helpers(d.hidden)) * kWave), lds, stream, a, d);
     return hipGetLastError();
 }
 

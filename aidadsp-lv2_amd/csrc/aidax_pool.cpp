@@ -57,6 +57,8 @@ enum ManyForm { MANY_NONE = 0, MANY_QUAD = 1, MANY_MFMA = 2 };
 // LSTM-64 from 2048 streams (4096: 306 us against 417 on k_mfma_lp, 16 384: 1 228 against 1 609 on k_mfma), LSTM-80 / GRU-80 from
 // 1024 (4096: 540 / 458 against 716 / 669), LSTM-40 beyond 4096 (8192: 427 against 526), 32 units beyond 6144 (8192: 286 / 248
 // against 345 / 289 on k_quad). GRU-40 / 64 have k_gru_gs (190 us per round of 4096 streams against 244 .. 275 here); 16 units never.
+// (A GRU-80 pool this rule sends to the matrix-core forms runs k_gru_gs<5, 2> — 324 us per 4096 streams against 436 here — and LSTM-40 / 64
+// have k_lstm_gs, below; k_mfma_ls1 then serves LSTM-80, 32 units at many streams, and the A/B runs.)
 bool lone_split_pays(int cell, int hidden, uint32_t n, int cus)
 {
     const bool off = [] { const char* e = std::getenv("AIDAX_LP_SPLIT"); return e && e[0] == '0'; }();
@@ -726,8 +728,10 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
         const char* np = std::getenv("AIDAX_GS_PRODUCTS");   // (=9: every term product of the split operands instead of six)
         ms.lstm_gs = lstm_gs_serves(ms.mdesc) && lstm_gs_pays(m->cell, m->hidden, p.n_streams, cus) && lstm_gs_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024
                          ? (np && np[0] == '9' ? 9 : 6) : 0;
-        ms.gru_gs = ms.gru_gm && gru_gs_serves(ms.mdesc) && !(gm && gm[0] == 'f') && gru_gs_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024
+        ms.gru_gs = gru_gs_serves(ms.mdesc) && !(gm && (gm[0] == 'f' || gm[0] == '0')) && gru_gs_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024
                         ? (np && np[0] == '9' ? 9 : 6) : 0;
+        if (ms.gru_gs) ms.gru_gm = true;                       // (80 units: the split kernel only — the flag says "one-launch gate-major form")
+        else if (!gru_gm_serves(ms.mdesc)) ms.gru_gm = false;
     }
     HIP_TRY(hipMemcpyAsync(ms.d_wpack, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice, p.wq));
     std::vector<float> wq4;                                // (lives until the stream has been waited for below)

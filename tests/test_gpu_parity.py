@@ -598,7 +598,7 @@ def test_long_run_drift_small_gru_on_the_pipeline_kernel(tmp_path):
     ("cfg5", dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2), 2048, {}, "k_mfma_ls"),
     ("lstm80-1k", dict(kind="lstm", hidden=80, input_size=2, seed=80), 1024, dict(param1=0.7), "k_chain+k_quad"),
     ("lstm80-2k", dict(kind="lstm", hidden=80, input_size=2, seed=80), 2048, dict(param1=0.7), "k_mfma_ls1"),      # a lone layer on k_mfma_ls's body
-    ("gru80-4k", dict(kind="gru", hidden=80, input_size=2, seed=81), 4096, dict(param1=0.7), "k_mfma_ls1"),
+    ("gru80-4k", dict(kind="gru", hidden=80, input_size=2, seed=81), 4096, dict(param1=0.7), "k_gru_gs"),           # five main waves, two helpers
     ("lstm40-4k", dict(kind="lstm", hidden=40, input_size=2, seed=40), 4096, dict(param1=0.7), "k_lstm_gs"),       # unit-major tiles, chain on helper waves
     ("lstm64-2k", dict(kind="lstm", hidden=64, input_size=3, seed=65), 2048, dict(param1=0.7, param2=0.1), "k_lstm_gs"),
     ("gru32-4k", dict(kind="gru", hidden=32, input_size=2, seed=33), 4096, dict(param1=0.7), "k_mfma_lp"),         # the fp32 one-launch form keeps what it wins
@@ -1061,6 +1061,7 @@ def test_stacked_one_launch_form_is_bit_identical_to_the_three_launch_form(name,
         monkeypatch.setenv("AIDAX_LP_SPLIT", "0")             # k_mfma_lp (fp32 MFMAs) instead of k_mfma_ls
     if kw.get("n_rnn", 1) == 1:
         monkeypatch.setenv("AIDAX_KERNEL", "mfma")            # (40 streams of a table model would take k_quad)
+        monkeypatch.setenv("AIDAX_GRU_GM", "0")               # (... and GRU-80 on the matrix cores k_gru_gs: this is about k_mfma_lp's chain form)
     S = 40
     sizes = [256, 1, 0, 37, 16, 255, 64, 3, 256]
     x = modelgen.signal(S, sum(sizes), seed=41)
@@ -1307,6 +1308,49 @@ def test_lone_layer_on_the_split_kernel_matches_the_oracle(kind, hidden, isz, tm
                     errlog.bound(np.abs(got[s_] - want).max(), 2e-6, "gpu_parity:ls1_geometries")
             pos += n
         pool.close()
+
+
+@pytest.mark.parametrize("isz,nprod", [(3, 6), (1, 9)])
+def test_gru80_on_the_split_gate_major_kernel_with_two_helper_waves(isz, nprod, tmp_path, monkeypatch):
+    """k_gru_gs<5, 2>: GRU-80 — five main waves (one SIMD carries two) and two helper waves with eight streams each. Forced
+    (AIDAX_KERNEL=mfma): ragged blocks incl. 0 and 1 and blocks longer than a staging chunk, 70 streams, per-stream bypass /
+    disable / EQ, PARAM moves, against per-stream oracle plugins; the state against k_mfma_lp's (fp32 MFMAs) to rounding."""
+    monkeypatch.setenv("AIDAX_KERNEL", "mfma")
+    path, spec = _model_file(tmp_path, f"gs80_{isz}", kind="gru", hidden=80, input_size=isz, seed=880 + isz, in_skip=isz == 1)
+    S = 70
+    sizes = [256, 1, 0, 37, 700, 16, 255, 513, 3]
+    x = modelgen.signal(S, sum(sizes), seed=37)
+    kws = [dict(param1=0.3, param2=0.8), dict(enabled=0.0), dict(net_bypass=1.0), dict(eq_position=1.0, bass_boost_db=5.0, mid_type=1.0),
+           dict(dc_blocker=0.0, in_lpf_pc=0.0, eq_bypass=1.0, param1=1.0), dict(pregain_db=6.0, master_db=-6.0, treble_boost_db=4.0, param2=0.1)]
+    outs, states = {}, {}
+    for form, env in (("gs", {"AIDAX_GS_PRODUCTS": str(nprod)}), ("lp", {"AIDAX_GRU_GM": "0", "AIDAX_LS1": "0"})):
+        for k in ("AIDAX_GRU_GM", "AIDAX_GS_PRODUCTS", "AIDAX_LS1"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pool = ax.Pool(S, 1024)
+        pool.set_model(ax.Model(path))
+        assert pool.kernel_name == {"gs": "k_gru_gs", "lp": "k_chain+k_mfma_lp"}[form], pool.kernel_name
+        for s_ in range(S):
+            pool.set_controls(ax.default_controls(**kws[s_ % len(kws)]), stream=s_)
+        got, pos = np.empty_like(x), 0
+        for n in sizes:
+            got[:, pos:pos + n] = pool.process(np.ascontiguousarray(x[:, pos:pos + n]))
+            pos += n
+        outs[form] = got
+        states[form] = [pool.read_state(stream=s_, layer=0, hidden=128)[0].copy() for s_ in (0, 5, S - 1)]
+        pool.close()
+    for s_ in range(0, S, 5):
+        plug = O.OraclePlugin()
+        plug.set_model(O.OracleModel(spec))
+        kw = kws[s_ % len(kws)]
+        want = np.concatenate([plug.run(O.default_controls(**kw), x[s_, p0:p0 + n]) for p0, n in zip(np.cumsum([0] + sizes[:-1]), sizes)])
+        if kw.get("enabled") == 0.0 or kw.get("net_bypass") == 1.0:
+            assert np.array_equal(outs["gs"][s_], want), s_
+        else:
+            errlog.bound(np.abs(outs["gs"][s_] - want).max(), 2e-6, f"gpu_parity:gru80_gs{nprod}")
+    for a, b in zip(states["gs"], states["lp"]):
+        errlog.bound(np.abs(a - b).max(), 2e-6, "gpu_parity:gru80_gs_state_vs_lp")
 
 
 @pytest.mark.parametrize("hidden,isz,nprod", [(64, 1, 6), (64, 3, 9), (40, 2, 6)])

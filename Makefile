@@ -23,7 +23,7 @@ HIPFLAGS := --offload-arch=$(ARCH) $(CXXFLAGS) -fno-slp-vectorize
 
 HOST_SRCS := $(SRC)/aidax_model.cpp $(SRC)/aidax_dsp_host.cpp $(SRC)/aidax_pack.cpp $(SRC)/aidax_pool.cpp $(SRC)/aidax_hub.cpp
 HOST_OBJS := $(patsubst $(SRC)/%.cpp,$(OBJDIR)/%.o,$(HOST_SRCS))
-KERN_OBJS := $(OBJDIR)/aidax_kernels.o $(OBJDIR)/aidax_stack.o $(OBJDIR)/aidax_mfma.o $(OBJDIR)/aidax_mfmalp.o $(OBJDIR)/aidax_convm.o $(OBJDIR)/aidax_quad.o $(OBJDIR)/aidax_q4.o
+KERN_OBJS := $(OBJDIR)/aidax_kernels.o $(OBJDIR)/aidax_stack.o $(OBJDIR)/aidax_mfma.o $(OBJDIR)/aidax_mfmalp_p1.o $(OBJDIR)/aidax_mfmalp_p2.o $(OBJDIR)/aidax_mfmalp_p3.o $(OBJDIR)/aidax_mfmalp_p4.o $(OBJDIR)/aidax_convm.o $(OBJDIR)/aidax_quad.o $(OBJDIR)/aidax_q4.o
 HDRS      := $(wildcard $(SRC)/*.h) include/aidax.h
 
 LV2SO := $(PKG)/lv2/rt-neural-generic.so
@@ -42,6 +42,12 @@ $(OBJDIR)/%.o $(OBJDIR)/%.remarks &: $(SRC)/%.hip $(HDRS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $(OBJDIR)/$*.o 2> $(OBJDIR)/$*.remarks || (cat $(OBJDIR)/$*.remarks; exit 1)
 	@grep -A3 -E "warning:" $(OBJDIR)/$*.remarks >&2 || true
+
+# aidax_mfmalp.hip in four objects, each with its share of the template instantiations (see the file's host section)
+$(OBJDIR)/aidax_mfmalp_p%.o $(OBJDIR)/aidax_mfmalp_p%.remarks &: $(SRC)/aidax_mfmalp.hip $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -DAIDAX_MFMALP_PART=$* -Rpass-analysis=kernel-resource-usage -c $< -o $(OBJDIR)/aidax_mfmalp_p$*.o 2> $(OBJDIR)/aidax_mfmalp_p$*.remarks || (cat $(OBJDIR)/aidax_mfmalp_p$*.remarks; exit 1)
+	@grep -A3 -E "warning:" $(OBJDIR)/aidax_mfmalp_p$*.remarks >&2 || true
 
 $(OBJDIR)/scratch.ok: $(KERN_OBJS) $(KERN_OBJS:.o=.remarks) tools/check_scratch.py
 	python3 tools/check_scratch.py $(KERN_OBJS:.o=.remarks)

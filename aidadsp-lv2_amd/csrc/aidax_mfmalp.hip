@@ -2301,10 +2301,40 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_ls1(LaunchArgs a, MfmaDesc 
 }
 
 // ---------------------------------------------------------------- host side
+// The file compiles as three objects (Makefile: -DAIDAX_MFMALP_PART=1 .. 4), each instantiating its own share of the kernel
+// templates above — 1: k_mfma_lp, k_gru_gm; 2 and 4: k_mfma_ls, k_mfma_ls1; 3: k_gru_gs, k_lstm_gs — so that a clean build does not wait
+// four minutes for one translation unit (part 4: the two-layer instantiations of k_mfma_ls, the largest group). Without the macro everything lands in one object (the measurement builds of scratch/).
+#ifndef AIDAX_MFMALP_PART
+#define AIDAX_MFMALP_PART 0
+#endif
+#define AIDAX_PART(n) (AIDAX_MFMALP_PART == 0 || AIDAX_MFMALP_PART == (n))
 typedef void (*LpFn)(LaunchArgs, MfmaDesc, float*, uint32_t*, uint32_t*);
+typedef void (*GmFn)(LaunchArgs, MfmaDesc);
+[[maybe_unused]] constexpr int kLpHelpers = 4;
+// The chained kernels (two or more layers: workgroups that wait for each other) go out through hipLaunchCooperativeKernel: the
+// runtime REFUSES a grid that cannot be co-resident on the device (hipErrorCooperativeLaunchTooLarge — the pool then serves the
+// model with k_mfma at once, aidax_pool.cpp) and schedules the grid as a gang, so that another process's kernels cannot sit
+// between its workgroups: next to a process that keeps every CU busy a cfg5 block took 7.8 ms through the plain launch and
+// 0.71 ms through this one; alone it costs 15 us per block (698 -> 713 us, profiles/r04_lp_coop.txt). AIDAX_LP_COOP=0: the
+// plain launch (A/B runs).
+[[maybe_unused]] static bool lp_coop_launch()
+{
+    static const bool on = [] { const char* e = std::getenv("AIDAX_LP_COOP"); return !(e && e[0] == '0'); }();
+    return on;
+}
+[[maybe_unused]] static hipError_t lp_launch(LpFn fn, uint32_t blocks, uint32_t threads, size_t lds, hipStream_t stream, LaunchArgs a, MfmaDesc d,
+                            float* ring, uint32_t* counters, uint32_t* fault)
+{
+    if (lp_coop_launch() && d.n_layers >= 2) {
+        void* args[] = { &a, &d, &ring, &counters, &fault };
+        return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fn), dim3(blocks), dim3(threads), args, (unsigned)lds, stream);
+    }
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(threads), lds, stream, a, d, ring, counters, fault);
+    return hipGetLastError();
+}
+#if AIDAX_PART(1)
 // Helper waves of the one-launch form: a third wave per SIMD must fit next to the main waves' registers (512 per SIMD
 // lane: H <= 64 at <= 160 registers; H = 80 / 96 hold 256 / 233 and keep the three-launch form).
-constexpr int kLpHelpers = 4;
 static int lp_helpers(int hidden) { return hidden == 16 || hidden == 32 || hidden == 48 || hidden == 64 ? kLpHelpers : 0; }
 static LpFn lp_fn_fused(int hidden)
 {
@@ -2334,27 +2364,6 @@ static LpFn lp_fn(int hidden, int n_layers)
 #undef AIDAX_LP_CASE
     default: return nullptr;                               // wider stacks keep the fragment-streaming kernel
     }
-}
-// The chained kernels (two or more layers: workgroups that wait for each other) go out through hipLaunchCooperativeKernel: the
-// runtime REFUSES a grid that cannot be co-resident on the device (hipErrorCooperativeLaunchTooLarge — the pool then serves the
-// model with k_mfma at once, aidax_pool.cpp) and schedules the grid as a gang, so that another process's kernels cannot sit
-// between its workgroups: next to a process that keeps every CU busy a cfg5 block took 7.8 ms through the plain launch and
-// 0.71 ms through this one; alone it costs 15 us per block (698 -> 713 us, profiles/r04_lp_coop.txt). AIDAX_LP_COOP=0: the
-// plain launch (A/B runs).
-static bool lp_coop_launch()
-{
-    static const bool on = [] { const char* e = std::getenv("AIDAX_LP_COOP"); return !(e && e[0] == '0'); }();
-    return on;
-}
-static hipError_t lp_launch(LpFn fn, uint32_t blocks, uint32_t threads, size_t lds, hipStream_t stream, LaunchArgs a, MfmaDesc d,
-                            float* ring, uint32_t* counters, uint32_t* fault)
-{
-    if (lp_coop_launch() && d.n_layers >= 2) {
-        void* args[] = { &a, &d, &ring, &counters, &fault };
-        return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fn), dim3(blocks), dim3(threads), args, (unsigned)lds, stream);
-    }
-    hipLaunchKernelGGL(fn, dim3(blocks), dim3(threads), lds, stream, a, d, ring, counters, fault);
-    return hipGetLastError();
 }
 static int lp_m(const MfmaDesc& d) { return lp_moved_tiles(d.n_layers, d.hidden / 4 / mfma_waves(d.hidden), mfma_waves(d.hidden)); }
 
@@ -2407,7 +2416,6 @@ hipError_t launch_mfma_lp_kernel(const LaunchArgs& a, const MfmaDesc& d, float* 
 // k_gru_gm: one-layer GRU models with three or four main waves (48 / 64 units after rounding up to 16). Narrower ones would
 // leave SIMDs without a main wave — GRU-32 at 4096 streams: 245 us here against 197 us on k_mfma_lp's one-launch form,
 // whose eight waves share one tile row each.
-typedef void (*GmFn)(LaunchArgs, MfmaDesc);
 static GmFn gm_fn(int hidden)
 {
     switch (hidden) {
@@ -2432,6 +2440,8 @@ hipError_t launch_gru_gm_kernel(const LaunchArgs& a, const MfmaDesc& d, hipStrea
     return hipGetLastError();
 }
 
+#endif      // part 1
+#if AIDAX_PART(3)
 // k_gru_gs: the same models as k_gru_gm, recurrent product on the bf16 matrix pipe (operands split into three bf16 terms)
 static GmFn gs_fn(int hidden, int nprod)
 {
@@ -2486,6 +2496,8 @@ hipError_t launch_lstm_gs_kernel(const LaunchArgs& a, const MfmaDesc& d, int n_p
     return hipGetLastError();
 }
 
+#endif      // part 3
+#if AIDAX_PART(2) || AIDAX_PART(4)
 // k_mfma_ls: the stacked models k_mfma_lp serves whose resident split fragments fit the register file (ls_geo)
 template <int HID, int NL>
 static LpFn ls_fn_for(bool chain, int nprod)
@@ -2502,10 +2514,25 @@ static LpFn ls_fn_for(bool chain, int nprod)
     else return chain ? (nprod == 9 ? k_mfma_ls<g.tpw, g.nw, g.m, true, 9> : k_mfma_ls<g.tpw, g.nw, g.m, true, 6>)
                       : (nprod == 9 ? k_mfma_ls<g.tpw, g.nw, g.m, false, 9> : k_mfma_ls<g.tpw, g.nw, g.m, false, 6>);
 }
+#endif
+LpFn ls_fn_two_layers(int hidden, bool chain, int nprod);      // (an object of its own: part 4)
+#if AIDAX_PART(4)
+LpFn ls_fn_two_layers(int hidden, bool chain, int nprod)
+{
+    switch (hidden) {                                       // two layers: tiles started below
+#define AIDAX_LS_CASE(HID) case HID: return ls_fn_for<HID, 2>(chain, nprod);
+    AIDAX_LS_CASE(16) AIDAX_LS_CASE(32) AIDAX_LS_CASE(48) AIDAX_LS_CASE(64) AIDAX_LS_CASE(80) AIDAX_LS_CASE(96)
+#undef AIDAX_LS_CASE
+    default: return nullptr;
+    }
+}
+#endif
+#if AIDAX_PART(2)
 static LpFn ls_fn(int hidden, int n_layers, bool chain, int nprod)
 {
-    switch (hidden) {                                       // (two layers: tiles started below; deeper stacks: none — the same body with M = 0)
-#define AIDAX_LS_CASE(HID) case HID: return n_layers == 2 ? ls_fn_for<HID, 2>(chain, nprod) : n_layers == 1 ? ls_fn_for<HID, 1>(chain, nprod) : ls_fn_for<HID, 3>(chain, nprod);
+    if (n_layers == 2) return ls_fn_two_layers(hidden, chain, nprod);
+    switch (hidden) {                                       // (a lone layer; deeper stacks: no tiles started below — the same body with M = 0)
+#define AIDAX_LS_CASE(HID) case HID: return n_layers == 1 ? ls_fn_for<HID, 1>(chain, nprod) : ls_fn_for<HID, 3>(chain, nprod);
     AIDAX_LS_CASE(16) AIDAX_LS_CASE(32) AIDAX_LS_CASE(48) AIDAX_LS_CASE(64) AIDAX_LS_CASE(80) AIDAX_LS_CASE(96)
 #undef AIDAX_LS_CASE
     default: return nullptr;
@@ -2543,5 +2570,6 @@ hipError_t launch_mfma_ls_kernel(const LaunchArgs& a, const MfmaDesc& d, float* 
     const uint32_t blocks = d.n_layers == 1 ? groups : ((groups + 7) / 8) * 8 * (uint32_t)d.n_layers;
     return lp_launch(fn, blocks, (uint32_t)(ls_geo(d.n_layers, d.hidden).nw * kWave), lds, stream, a, d, ring, counters, fault);
 }
+#endif      // part 2
 
 }  // namespace aidax

@@ -2477,11 +2477,12 @@ static GmFn lgs_fn(int hidden, int nprod)
     switch (hidden) {
     case 48: return nprod == 9 ? k_lstm_gs<3, kLpHelpers, 9> : k_lstm_gs<3, kLpHelpers, 6>;
     case 64: return nprod == 9 ? k_lstm_gs<4, kLpHelpers, 9> : k_lstm_gs<4, kLpHelpers, 6>;
+    case 80: return k_lstm_gs<5, 2, 6>;                      // (five main waves, two helpers: as k_gru_gs for 80 units; nine products do not fit the registers)
     default: return nullptr;
     }
 }
 bool lstm_gs_serves(const MfmaDesc& d) { return d.n_layers == 1 && d.L[0].cell == 0 && d.gs_off != 0 && lgs_fn(d.hidden, 6) != nullptr; }
-size_t lstm_gs_lds_bytes(const MfmaDesc& d, uint32_t n_frames) { return gs_lds_floats(d.hidden, (int)n_frames, kLpHelpers) * sizeof(float); }
+size_t lstm_gs_lds_bytes(const MfmaDesc& d, uint32_t n_frames) { return gs_lds_floats(d.hidden, (int)n_frames, gs_helpers(d.hidden)) * sizeof(float); }
 hipError_t launch_lstm_gs_kernel(const LaunchArgs& a, const MfmaDesc& d, int n_products, hipStream_t stream)
 {
     GmFn fn = lgs_fn(d.hidden, n_products);
@@ -2492,7 +2493,7 @@ hipError_t launch_lstm_gs_kernel(const LaunchArgs& a, const MfmaDesc& d, int n_p
         if (e != hipSuccess) return e;
     }
     const uint32_t groups = (a.n_streams + kMfmaStreams - 1) / kMfmaStreams;
-    hipLaunchKernelGGL(fn, dim3(groups), dim3((d.hidden / 16 + kLpHelpers) * kWave), lds, stream, a, d);
+    hipLaunchKernelGGL(fn, dim3(groups), dim3((d.hidden / 16 + gs_helpers(d.hidden)) * kWave), lds, stream, a, d);
     return hipGetLastError();
 }
 

@@ -77,17 +77,18 @@ bool lone_split_pays(int cell, int hidden, uint32_t n, int cus)
 // ... and k_lstm_gs (k_gru_gs's structure for one-layer LSTMs: unit-major tiles, a main wave per 16 units, the chain on helper
 // waves): LSTM-64 265 us per round of 4096 streams — ahead of k_quad from 1025 streams on (289 us at 2048) and of k_mfma_ls1
 // throughout (308 / 616 / 1 234 us at 4096 / 8192 / 16 384 against 265 / 528 / 1 057); LSTM-40 265 us, between k_quad (223 us at
-// 2048) and k_mfma_ls1 (two workgroups per CU: 418 us at 8192 against 527) — profiles/r04_ls1_ab.txt. AIDAX_LSTM_GS=0 / 1: never / wherever it serves.
+// 2048) and k_mfma_ls1 (two workgroups per CU: 418 us at 8192 against 527) — profiles/r04_ls1_ab.txt. AIDAX_LSTM_GS=0 / 1: never / wherever it serves
+// (LSTM-80 is served too — five main waves, two helpers — but only 4 % ahead of k_mfma_ls1, 483 against 503 us per 4096 streams: not in the rule).
 bool lstm_gs_pays(int cell, int hidden, uint32_t n, int cus)
 {
     // (read on every call — the worker thread's, at model load: tests switch forms within one process)
     const int forced = [] { const char* e = std::getenv("AIDAX_LSTM_GS"); return !e ? -1 : e[0] != '0' ? 1 : 0; }();
     const bool f32 = [] { const char* e = std::getenv("AIDAX_GRU_GM"); return e && e[0] == 'f'; }();
-    if (cell != AIDAX_CELL_LSTM || (hidden != 40 && hidden != 64) || forced == 0 || f32) return false;
+    if (cell != AIDAX_CELL_LSTM || (hidden != 40 && hidden != 64 && hidden != 80) || forced == 0 || f32) return false;
     if (forced == 1) return true;
     if (cus <= 0) return false;
     const uint32_t groups = (n + kMfmaStreams - 1) / kMfmaStreams, c = static_cast<uint32_t>(cus);
-    return hidden == 64 ? groups * 4 > c : groups * 2 > c && groups <= c;
+    return hidden == 64 ? groups * 4 > c : hidden == 80 ? false : groups * 2 > c && groups <= c;
 }
 
 ManyForm many_streams_form(int cell, int hidden, uint32_t n, int cus)

@@ -28,7 +28,7 @@ if os.environ.get("LS1_SHAPES"): shapes = [tuple(s.split("-")) for s in os.envir
 for kind, hidden in shapes:
     for S in (256, 1024, 2048, 4096, 8192, 16384):
         cells = []
-        for tag, env in (("auto", {}), ("mfma", {"AIDAX_KERNEL": "mfma", "AIDAX_GRU_GM": "0"}), ("ls1", {"AIDAX_KERNEL": "mfma", "AIDAX_LS1": "1", "AIDAX_GRU_GM": "0"})) + ((("lgs", {"AIDAX_KERNEL": "mfma", "AIDAX_LSTM_GS": "1"}),) if kind == "lstm" and hidden in (40, 64) else (("gs", {"AIDAX_KERNEL": "mfma"}),) if kind == "gru" and hidden == 80 else ()):
+        for tag, env in (("auto", {}), ("mfma", {"AIDAX_KERNEL": "mfma", "AIDAX_GRU_GM": "0"}), ("ls1", {"AIDAX_KERNEL": "mfma", "AIDAX_LS1": "1", "AIDAX_GRU_GM": "0"})) + ((("lgs", {"AIDAX_KERNEL": "mfma", "AIDAX_LSTM_GS": "1"}),) if kind == "lstm" and hidden in (40, 64, 80) else (("gs", {"AIDAX_KERNEL": "mfma"}),) if kind == "gru" and hidden == 80 else ()):
             name, us = run(env, kind, hidden, S)
             cells.append("%s=%s: %7.1f" % (tag, name, us))
         print("%s%-3d S=%6d: %s" % (kind, hidden, S, " | ".join(cells)), flush=True)

@@ -1353,7 +1353,7 @@ def test_gru80_on_the_split_gate_major_kernel_with_two_helper_waves(isz, nprod, 
         errlog.bound(np.abs(a - b).max(), 2e-6, "gpu_parity:gru80_gs_state_vs_lp")
 
 
-@pytest.mark.parametrize("hidden,isz,nprod", [(64, 1, 6), (64, 3, 9), (40, 2, 6)])
+@pytest.mark.parametrize("hidden,isz,nprod", [(64, 1, 6), (64, 3, 9), (40, 2, 6), (80, 2, 6)])
 def test_one_layer_lstm_on_the_unit_major_split_kernel_matches_the_oracle(hidden, isz, nprod, tmp_path, monkeypatch):
     """k_lstm_gs (aidax_mfmalp.hip): k_gru_gs's structure for one-layer LSTMs of 40 (run as 48) / 64 units — unit-major tiles, one
     main wave per 16 units, the DSP chain on helper waves, the whole run() in the launch. Forced (AIDAX_KERNEL=mfma, AIDAX_LSTM_GS=1):

@@ -92,6 +92,8 @@ def lib() -> C.CDLL:
     L.aidax_lpf_fc.restype = C.c_float
     L.aidax_device_count.argtypes = [C.POINTER(C.c_int)]
     L.aidax_pick_device.argtypes = [C.c_char_p, C.c_int, C.POINTER(u32), C.POINTER(C.c_int)]
+    L.aidax_many_streams_form.argtypes = [C.c_int, C.c_int, u32, C.c_int]
+    L.aidax_many_streams_form.restype = C.c_int
     L.aidax_pool_create.argtypes = [u32, u32, C.c_double, C.c_int, C.POINTER(vp)]
     L.aidax_pool_destroy.argtypes = [vp]
     L.aidax_pool_destroy.restype = None
@@ -196,6 +198,11 @@ def pick_device(spec: Optional[str], count: int, load=None) -> int:
     out = C.c_int(-1)
     _check(lib().aidax_pick_device(spec.encode() if spec is not None else None, count, arr, C.byref(out)))
     return out.value
+
+
+def many_streams_form(cell: int, hidden: int, n_streams: int, compute_units: int = 256) -> int:
+    """The launch-form rule for one-layer table models (pure): 0 none, 1 k_quad, 2 the 16-stream matrix-core kernels."""
+    return int(lib().aidax_many_streams_form(cell, hidden, n_streams, compute_units))
 
 
 def db_to_coeff(db: float) -> float:

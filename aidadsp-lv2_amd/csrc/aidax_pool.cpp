@@ -1376,6 +1376,11 @@ AIDAX_API int aidax_pool_read_state(aidax_pool* p, uint32_t stream, int layer, f
     });
 }
 
+AIDAX_API int aidax_many_streams_form(int cell, int hidden, uint32_t n_streams, int compute_units)
+{
+    return static_cast<int>(many_streams_form(cell, hidden, n_streams, compute_units));
+}
+
 AIDAX_API const char* aidax_pool_kernel_name(const aidax_pool* p)
 {
     if (!(p && p->cur.has_model)) return "k_nomodel";

@@ -131,6 +131,15 @@ AIDAX_API float aidax_lpf_fc(float percent);
 AIDAX_API int aidax_device_count(int* count);
 AIDAX_API int aidax_pick_device(const char* spec, int device_count, const uint32_t* load, int* device_out);
 
+/* ------------------------------------------------------- launch-form rule (diagnostic)
+ * Which kernel family a pool of n_streams instances of a ONE-layer model of the reference's table (cell: AIDAX_CELL_LSTM /
+ * AIDAX_CELL_GRU, hidden units) takes on a device with compute_units CUs, beyond the per-stream forms: 0 none (the wavefront /
+ * pipeline / split forms, chosen by residency at pool creation), 1 four streams per workgroup on the 4x4 matrix instruction
+ * (k_quad), 2 sixteen streams per workgroup on the 16x16 ones (k_gru_gs, k_lstm_gs, k_mfma_ls1, k_mfma_lp, k_mfma). A pure
+ * function (no HIP call, environment switches apply): the decision table of csrc/aidax_pool.cpp, measured at 256-frame blocks on
+ * 256 CUs; exported so that hosts and tests can see what a pool size will run on. */
+AIDAX_API int aidax_many_streams_form(int cell, int hidden, uint32_t n_streams, int compute_units);
+
 /* -------------------------------------------------------------------- pool */
 typedef struct aidax_pool aidax_pool;
 

@@ -141,6 +141,34 @@ def test_control_defaults_match_ttl():
 
 
 
+def test_launch_form_rule_for_one_layer_table_models(monkeypatch):
+    """aidax_many_streams_form — the decision table that sends a pool of a one-layer table model to k_quad (1) or to the
+    16-stream matrix-core kernels (2) — is a pure function of (cell, hidden, streams, CUs): the measured crossovers of
+    profiles/r03_cfg3_forms.txt, r04_gs_threshold.txt and r04_ls1_ab.txt pinned on CPU, the thresholds moving with the CU count
+    (they are counted in rounds of workgroups), the environment switches taking effect per call."""
+    ax = importlib.import_module("aidadsp-lv2_amd")
+    for k in ("AIDAX_LSTM_GS", "AIDAX_LS1", "AIDAX_LP_SPLIT", "AIDAX_GRU_GM"):
+        monkeypatch.delenv(k, raising=False)
+    f, LSTM, GRU = ax.many_streams_form, 0, 1
+    # small cells: per-stream forms up to 4095 streams, k_quad from 4096; 32 units on the split kernel beyond 6144
+    assert [f(LSTM, 16, n) for n in (1, 1024, 4095, 4096, 16384)] == [0, 0, 0, 1, 1]
+    assert [f(GRU, 32, n) for n in (2048, 4096, 6144, 6145, 16384)] == [0, 2, 1, 2, 2]          # (4096: one full round of k_mfma_lp's one-launch form)
+    # LSTM-64: k_quad up to 1024 streams, k_lstm_gs beyond; LSTM-40: k_lstm_gs from 2049 to 4096, k_mfma_ls1 beyond
+    assert [f(LSTM, 64, n) for n in (64, 1024, 1025, 4096, 16384)] == [1, 1, 2, 2, 2]
+    assert [f(LSTM, 40, n) for n in (256, 512, 2048, 2049, 4096, 8192)] == [0, 1, 1, 2, 2, 2]
+    # GRU-64 on k_gru_gs from sixteen stream groups (241 streams), GRU-40 from 2049; the 80-unit cells on the matrix cores beyond 1024 streams
+    assert [f(GRU, 64, n) for n in (240, 241, 4096)] == [1, 2, 2]          # (sixteen stream groups of 16)
+    assert [f(GRU, 40, n) for n in (2048, 2049)] == [0, 2]
+    assert [f(GRU, 80, n) for n in (1024, 1025)] == [1, 2] and [f(LSTM, 80, n) for n in (1024, 1025)] == [1, 2]
+    # half the CUs (a partitioned device): the stream counts of the crossovers halve
+    assert [f(LSTM, 64, n, 128) for n in (512, 513)] == [1, 2] and [f(GRU, 80, n, 128) for n in (512, 513)] == [1, 2]
+    # switches: read per call
+    monkeypatch.setenv("AIDAX_LSTM_GS", "0")
+    assert f(LSTM, 64, 2048) == 1 and f(LSTM, 64, 2049) == 2          # k_mfma_ls1's rule takes over (beyond 2048 streams)
+    monkeypatch.setenv("AIDAX_LP_SPLIT", "0")
+    assert f(LSTM, 64, 3584) == 1 and f(LSTM, 64, 3585) == 2          # round 3's table: k_mfma_lp where its one round is at least seven eighths full
+
+
 def test_placement_rule_picks_the_least_loaded_candidate():
     """aidax_pick_device — how the LV2 shell spreads instances / hubs over the GPUs of a node (one instance = one stream,
     rt-neural-generic.cpp:244-333) — is a pure function: the device count and the loads are injected here."""

@@ -47,8 +47,14 @@ namespace aidax {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kLpChunk = 256;            // frames of audio staged in LDS at a time
-constexpr int kLpRing = 32;              // frames of h in flight between two layers
-constexpr int kLpBatch = 8;              // frames per counter update (a release costs ~2-6 us, an acquire ~1.7 us: MI355X_MICROARCH.md)
+#ifndef AIDAX_LP_RING
+#define AIDAX_LP_RING 32                 // (measurement builds: -DAIDAX_LP_RING=16 -DAIDAX_LP_BATCH=4, scratch/mkvariant_lp.sh)
+#endif
+#ifndef AIDAX_LP_BATCH
+#define AIDAX_LP_BATCH 8
+#endif
+constexpr int kLpRing = AIDAX_LP_RING;   // frames of h in flight between two layers
+constexpr int kLpBatch = AIDAX_LP_BATCH; // frames per counter update (a release costs ~2-6 us, an acquire ~1.7 us: MI355X_MICROARCH.md)
 // A waiting workgroup gives up after kLpGiveUpTicks of the 100 MHz wall clock (250 ms: far beyond any wait that co-tenant
 // kernels can cause while the partner still gets a CU — a launch must end even if its partner never runs). The pass is then
 // wrong; the workgroup says so in the pool's fault word (pinned host memory), the pool reports AIDAX_ERR_DEVICE for it
@@ -96,17 +102,23 @@ constexpr int kLpCounterStride = 32;     // uint32 per (group, boundary): produc
 // compiler keeps track of their completion (vmcnt) like of any other load.
 typedef unsigned lp_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kLpDeviceScope = 17;                         // aux bits: sc0 | sc1
+#ifndef AIDAX_LP_LOAD_AUX
+#define AIDAX_LP_LOAD_AUX kLpDeviceScope                   // (measurement builds: the ring's loads / stores at another scope — 16 = sc1, 1 = sc0, 0 = none)
+#endif
+#ifndef AIDAX_LP_STORE_AUX
+#define AIDAX_LP_STORE_AUX kLpDeviceScope
+#endif
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t lp_rsrc(const float* base, size_t bytes)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
 }
 __device__ __forceinline__ f32x4 lp_load16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off)
 {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, kLpDeviceScope));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, AIDAX_LP_LOAD_AUX));
 }
 __device__ __forceinline__ void lp_store16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, f32x4 v)
 {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lp_u32x4, v), r, byte_off, 0, kLpDeviceScope);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lp_u32x4, v), r, byte_off, 0, AIDAX_LP_STORE_AUX);
 }
 
 __device__ __forceinline__ float lp_row_sum16(float v)
@@ -2254,6 +2266,13 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_ls(LaunchArgs a, MfmaDesc d
     const int l = adjacent ? blk % NL : (blk / 8) % NL;
     const int n_groups = ((int)a.n_streams + kMfmaStreams - 1) / kMfmaStreams;
     if (grp >= n_groups) return;
+    // (measurement, AIDAX_TUNE bit 4096: where this workgroup ran and when — XCC_ID, HW_ID, the 100 MHz clock at its start and end — into
+    // the pool's pinned fault page behind the fault word; scratch/r05_modes.py reads it)
+    const bool stamp = (a.tune & 4096) && blk < 500 && threadIdx.x == 0;
+    if (stamp) {
+        fault[16 + 3 * blk] = (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) | (__builtin_amdgcn_s_getreg((31 << 11) | 4) << 4);
+        fault[17 + 3 * blk] = (uint32_t)wall_clock64();
+    }
     if (l == 0) {
         if constexpr (CHAIN) {
             lp_chain_rows<true>(a, smem, grp, true);
@@ -2278,6 +2297,7 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_ls(LaunchArgs a, MfmaDesc d
         if (d.L[l].cell == 0) ls_body<TPW, NW, M, false, false, CHAIN, NPROD, 0>(a, d, ring, counters, fault, smem, grp, l);
         else ls_body<TPW, NW, M, false, false, CHAIN, NPROD, 1>(a, d, ring, counters, fault, smem, grp, l);
     }
+    if (stamp) fault[18 + 3 * blk] = (uint32_t)wall_clock64();
 }
 
 // A LONE layer on the same body (first and last role at once: no ring, nobody waits, a workgroup per 16 streams): the one-layer

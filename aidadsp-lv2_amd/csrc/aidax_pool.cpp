@@ -546,11 +546,9 @@ struct aidax_pool {
         if (cur.d_ring) (void)hipFree(cur.d_ring);
         if (cur.d_counters) (void)hipFree(cur.d_counters);
         if (cur.lp_owner) { lp_gate().release(device, cur.lp_owner); cur.lp_owner = nullptr; }
-#ifdef AIDAX_LP_TRACE
-        if (h_lp_fault)
+        if (h_lp_fault)                                      // (measurement builds / AIDAX_TUNE bit 4096: the stamps behind the fault word)
             if (const char* f = std::getenv("AIDAX_LP_TRACE_FILE"))
                 if (FILE* fp = std::fopen(f, "wb")) { std::fwrite(h_lp_fault + 16, 4, 1536, fp); std::fclose(fp); }
-#endif
         if (h_lp_fault) (void)hipHostFree(h_lp_fault);
         h_lp_fault = nullptr;
         for (const HostRange& r : host_ranges) (void)hipHostUnregister(r.base);
@@ -870,11 +868,7 @@ AIDAX_API int aidax_pool_create(uint32_t n_streams, uint32_t max_frames, double 
             HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
             HIP_TRY(hipStreamCreateWithPriority(&p->q, hipStreamNonBlocking, prio_greatest));
             HIP_TRY(hipStreamCreateWithPriority(&p->wq, hipStreamNonBlocking, prio_least));
-#ifdef AIDAX_LP_TRACE
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_lp_fault), 8192, hipHostMallocDefault));     // + the time stamps of scratch/lp_trace.py
-#else
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_lp_fault), 64, hipHostMallocDefault));
-#endif
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_lp_fault), 8192, hipHostMallocDefault));     // the fault word + the time stamps of scratch/lp_trace.py, r05_modes.py
             HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->hd_lp_fault), p->h_lp_fault, 0));
             *p->h_lp_fault = 0;
             HIP_TRY(hipEventCreateWithFlags(&p->ev_x, hipEventDisableTiming));

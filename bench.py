@@ -30,6 +30,10 @@ Prints ONE json line (rank 0) with the driver's contract keys plus
                     aidax_pool_process call (pinned staging + launch + wait) next to the CPU oracle on one thread
   cpu_baseline      the CPU oracle (a port, not RTNeural) timed on this host's cores on a bounded sample of
                     the same workload (N=1, rank 0 only)
+  max_abs_err       of the TIMED pool's first blocks (sixteen streams spread over it) against the CPU oracle, with the kernel that
+                    produced it (max_abs_err_kernel, parity{...}); every other_workloads entry carries its own
+  per_launch_us     one HIP event pair per launch after the timed region: min / p50 / p95 / max, launches over 1.2 x p50
+  gpu_state_while_running   shader clock / socket power read by rocm-smi while the workload's kernel runs
   roofline.traffic  HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE: two child runs of this
                     script under the profiler, N = 1 only); when the profiler is not usable, the committed profile of
                     the same kernel sources (hash-checked), else null
@@ -78,6 +82,7 @@ WORKLOADS = {
                  text="cfg5: LSTM-96 x2 model, 2048 streams/GPU (16384 over 8 GPUs) x 256-frame blocks, matrix-core kernel"),
 }
 OTHER_STEPS = {"cfg3": 600, "cfg4": 2000, "cfg5": 120}      # ~0.25 s of GPU time each
+DIST_STEPS = {"cfg2": 1000, "cfg3": 400, "cfg4": 1000, "cfg5": 300}    # launches timed one by one after a workload's timed region
 
 
 def dist_env():
@@ -196,7 +201,7 @@ def measure_traffic_live(workload: str, kernel_name: str, wide_read_bytes: float
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="aidax_pmc_")
         cmd = [prof, "--output-format", "csv", "--pmc", ctr, "-d", d, "-o", "r", "--", sys.executable, os.path.abspath(__file__),
-               "--workload", workload, "--steps", "200", "--warmup", "20", "--no-cpu-baseline", "--no-check", "--no-others", "--no-traffic"]
+               "--workload", workload, "--steps", "200", "--warmup", "20", "--no-cpu-baseline", "--no-check", "--no-others", "--no-traffic", "--no-dist"]
         env = dict(os.environ, TMPDIR="/tmp")
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
@@ -349,7 +354,7 @@ def realtime_case(ax, W, local: int):
     return out
 
 
-def measure(ax, W, torch, name, S, steps, warmup, rank, world, local, check, launch_stream, preroll_s=PREROLL_S):
+def measure(ax, W, torch, name, S, steps, warmup, rank, world, local, check, launch_stream, preroll_s=PREROLL_S, dist_steps=True):
     """One timed region of one workload on this rank. Returns a dict with the local elapsed time, the average pass
     duration from HIP events on the launch stream, the pool's kernel name, the parity spot-check and the json."""
     import numpy as np
@@ -371,19 +376,24 @@ def measure(ax, W, torch, name, S, steps, warmup, rank, world, local, check, lau
         k = i % RING
         pool.process_device(d_in[k].data_ptr(), d_out[k].data_ptr(), N_FRAMES, stream)
 
-    # parity spot-check on the first blocks (outside the timed region)
-    max_err = None
+    # parity spot-check (outside the timed region) on the pool that is timed, through the kernel that is timed: its first blocks,
+    # sixteen streams spread over the pool, against the CPU oracle on the same inputs
+    max_err, parity = None, None
     if rank == 0 and check:
         from oracle import oracle as O
-        chk = ax.Pool(16, N_FRAMES, 48000.0, device=local)
-        chk.set_model(model, ax.START_WARMUP)
-        chk.set_controls(ax.default_controls(**wl["controls"]))
         nb = 4 if name != "cfg5" else 2
-        xs = np.concatenate([b[:16] for b in host_ring[:nb]], axis=1)
-        got = np.concatenate([chk.process(np.ascontiguousarray(xs[:, k * N_FRAMES:(k + 1) * N_FRAMES])) for k in range(nb)], axis=1)
+        rows = sorted(set(int(round(k * (S - 1) / 15.0)) for k in range(16)))
+        got = []
+        for k in range(nb):
+            step(k)
+            launch_stream.synchronize()
+            got.append(d_out[k][rows].cpu().numpy())
+        got = np.concatenate(got, axis=1)
+        xs = np.concatenate([b[rows] for b in host_ring[:nb]], axis=1)
         want = O.run_streams(O.parse_model(j), O.default_controls(**wl["controls"]), xs, N_FRAMES)
         max_err = float(np.abs(got - want).max())
-        chk.close()
+        parity = {"max_abs_err": max_err, "kernel": pool.kernel_name, "pool": "the timed pool (its first blocks, before the pre-roll)",
+                  "streams_checked": rows, "blocks": nb, "against": "CPU oracle (oracle/), same inputs", "bar": 1e-5}
 
     # clock pre-roll: un-timed, not part of `warmup`; a short driver run then sees the same clocks as a long one
     t0 = time.perf_counter()
@@ -417,8 +427,76 @@ def measure(ax, W, torch, name, S, steps, warmup, rank, world, local, check, lau
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / max(steps, 1)            # avg pass duration on the launch stream
     kernel = pool.kernel_name
+    if parity is not None and parity["kernel"] != kernel:
+        raise SystemExit(f"bench.py: the parity check ran on {parity['kernel']}, the timed region on {kernel}")
+    per_launch = launch_distribution(torch, step, launch_stream, DIST_STEPS.get(name, 200)) if dist_steps else None
+    gpu_state = gpu_state_while(step, launch_stream) if (dist_steps and rank == 0) else None
     pool.close()
-    return dict(elapsed=elapsed, kernel_ms=kernel_ms, kernel=kernel, max_err=max_err, json=j, preroll_ms=preroll_ms)
+    return dict(elapsed=elapsed, kernel_ms=kernel_ms, kernel=kernel, max_err=max_err, parity=parity, json=j, preroll_ms=preroll_ms,
+                per_launch_us=per_launch, gpu_state=gpu_state)
+
+
+def launch_distribution(torch, step, launch_stream, n):
+    """One HIP event pair PER LAUNCH (n + 1 events on the launch stream, back to back: a launch's figure is the time from the end of
+    the launch before it to its own end), after the timed region: min / p50 / p95 / max and the launches over 1.2 x p50. A kernel
+    with a second operating point shows here; an average hides it."""
+    import numpy as np
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    ev[0].record(launch_stream)
+    for i in range(n):
+        step(i)
+        ev[i + 1].record(launch_stream)
+    torch.cuda.synchronize()
+    t = np.array([ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(n)])
+    p50 = float(np.percentile(t, 50))
+    return {"n": n, "min": float(t.min()), "p50": p50, "p95": float(np.percentile(t, 95)), "max": float(t.max()),
+            "over_1.2x_p50": int((t > 1.2 * p50).sum()), "mean": float(t.mean())}
+
+
+def gpu_state_while(step, launch_stream, busy_s=0.6):
+    """Shader clock and socket power WHILE this workload's kernel runs (rocm-smi from a thread, the launches from this one): cfg5
+    draws the board's whole power budget, and a box that caps it earlier runs that kernel — and only that one — slower
+    (profiles/r05_cfg5_modes.txt). None when rocm-smi is not there."""
+    import re
+    import shutil
+    import threading
+    if not shutil.which("rocm-smi"):
+        return None
+    seen = {}
+
+    def sample():
+        time.sleep(0.1)
+        try:
+            r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp", "--csv"], capture_output=True, text=True, timeout=20)
+            rows = [ln.split(",") for ln in r.stdout.strip().splitlines() if ln.strip()]
+            if len(rows) >= 2:
+                for k, v in zip(rows[0], rows[1]):
+                    m = re.search(r"[-0-9.]+", v)
+                    if k.startswith("sclk clock speed") and m:
+                        seen["sclk_mhz"] = float(m.group(0))
+                    elif k.startswith("mclk clock speed") and m:
+                        seen["mclk_mhz"] = float(m.group(0))
+                    elif k.startswith("fclk clock speed") and m:
+                        seen["fclk_mhz"] = float(m.group(0))
+                    elif "Power" in k and m:
+                        seen["socket_power_w"] = float(m.group(0))
+                    elif "junction" in k and m:
+                        seen["junction_c"] = float(m.group(0))
+        except Exception:
+            pass
+    th = threading.Thread(target=sample)
+    th.start()
+    t0 = time.perf_counter()
+    i = 0
+    while th.is_alive() or time.perf_counter() - t0 < 0.2:
+        for _ in range(16):
+            step(i)
+            i += 1
+        launch_stream.synchronize()
+        if time.perf_counter() - t0 > 25.0:
+            break
+    th.join()
+    return seen or None
 
 
 def rooflines(name, S, kernel_ms, kernel):
@@ -499,6 +577,7 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the short cfg3/cfg4/cfg5 regions and the one-stream case")
     ap.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic (the two rocprofv3 --pmc child runs)")
+    ap.add_argument("--no-dist", action="store_true", help="skip the per-launch distribution and the clock / power sample after each timed region")
     ap.add_argument("--dry-run", action="store_true", help="CPU stand-in for the rank plumbing (gloo, no GPU): tests only")
     ap.add_argument("--share-device", action="store_true",
                     help="rank plumbing with the real kernels on a box with fewer GPUs than ranks: every rank runs on device 0, "
@@ -540,7 +619,8 @@ def main():
     launch_stream = torch.cuda.Stream()              # a real (non-null) HIP stream: the events sit on it too
     torch.cuda.set_stream(launch_stream)
 
-    m = measure(ax, W, torch, args.workload, S, args.steps, args.warmup, rank, world, local, not args.no_check, launch_stream)
+    m = measure(ax, W, torch, args.workload, S, args.steps, args.warmup, rank, world, local, not args.no_check, launch_stream,
+                dist_steps=not args.no_dist)
     samples = float(S) * N_FRAMES * args.steps
     red_dev = "cpu" if args.share_device else "cuda"
     elapsed_max, samples_all = reduce_results(m["elapsed"], samples, world, backend_device=red_dev, force=use_dist)
@@ -561,7 +641,7 @@ def main():
                 continue
             So, steps = WORKLOADS[name]["streams"], OTHER_STEPS[name]
             r = measure(ax, W, torch, name, So, steps, max(10, steps // 10), rank, world, local, not args.no_check, launch_stream,
-                        preroll_s=0.15)
+                        preroll_s=0.15, dist_steps=not args.no_dist)
             e_max, n_all = reduce_results(r["elapsed"], float(So) * N_FRAMES * steps, world, backend_device=red_dev, force=use_dist)
             multi_others.append((name, So, steps, r, e_max, n_all))
 
@@ -591,7 +671,8 @@ def main():
             "roofline": comp if wl["bound"] == "mfma" else hbm,
             "roofline_compute": comp,
             "preroll_ms": m["preroll_ms"],
-            "max_abs_err": m["max_err"],
+            "max_abs_err": m["max_err"], "max_abs_err_kernel": m["parity"]["kernel"] if m["parity"] else None, "parity": m["parity"],
+            "per_launch_us": m["per_launch_us"], "gpu_state_while_running": m["gpu_state"],
             "ranks": {"world_size": world, "backend": ("gloo" if args.share_device else "nccl (RCCL)") if use_dist else None,
                       "elapsed_s": rank_elapsed, "collective": "all_reduce MAX(elapsed) + SUM(samples), all_gather(elapsed): after the timed region only"},
         }
@@ -607,13 +688,15 @@ def main():
                     continue
                 So, steps = WORKLOADS[name]["streams"], OTHER_STEPS[name]
                 r = measure(ax, W, torch, name, So, steps, max(10, steps // 10), 0, 1, local, not args.no_check, launch_stream,
-                            preroll_s=0.15)
+                            preroll_s=0.15, dist_steps=not args.no_dist)
                 h2, c2 = rooflines(name, So, r["kernel_ms"], r["kernel"])
                 add_profile_figures(h2, c2, name, So, r["kernel"], r["kernel_ms"])
                 others.append({"workload": WORKLOADS[name]["text"], "streams": So, "kernel": r["kernel"], "steps": steps,
                                "ms_per_step": r["elapsed"] / steps * 1e3, "value": So * N_FRAMES * steps / r["elapsed"],
                                "unit": "samples/s", "roofline": c2 if WORKLOADS[name]["bound"] == "mfma" else h2,
-                               "roofline_compute": c2, "max_abs_err": r["max_err"]})
+                               "roofline_compute": c2, "max_abs_err": r["max_err"],
+                               "max_abs_err_kernel": r["parity"]["kernel"] if r["parity"] else None, "parity": r["parity"],
+                               "per_launch_us": r["per_launch_us"], "gpu_state_while_running": r["gpu_state"]})
                 if WORKLOADS[name]["bound"] == "mfma":
                     others[-1]["roofline_hbm"] = h2
                 if not args.no_cpu_baseline:
@@ -624,7 +707,7 @@ def main():
                 # on their SIMDs and throughput, not latency, is what is measured (the pool picks the form per size)
                 sweep = []
                 for So, steps in ((4096, 400), (16384, 120)):
-                    r = measure(ax, W, torch, "cfg2", So, steps, max(10, steps // 10), 0, 1, local, False, launch_stream, preroll_s=0.1)
+                    r = measure(ax, W, torch, "cfg2", So, steps, max(10, steps // 10), 0, 1, local, False, launch_stream, preroll_s=0.1, dist_steps=False)
                     sweep.append({"streams": So, "kernel": r["kernel"], "steps": steps, "ms_per_step": r["elapsed"] / steps * 1e3,
                                   "value": So * N_FRAMES * steps / r["elapsed"], "unit": "samples/s"})
                 out["stream_sweep"] = sweep
@@ -639,7 +722,9 @@ def main():
                 out["other_workloads"].append({"workload": WORKLOADS[name]["text"], "streams_per_gpu": So, "n_gpus": world, "kernel": r["kernel"],
                                                "steps": steps, "ms_per_step": e_max / steps * 1e3, "value": n_all / e_max, "unit": "samples/s",
                                                "scaling": "weak", "roofline": c2 if WORKLOADS[name]["bound"] == "mfma" else h2,
-                                               "roofline_compute": c2, "max_abs_err": r["max_err"]})
+                                               "roofline_compute": c2, "max_abs_err": r["max_err"],
+                                               "max_abs_err_kernel": r["parity"]["kernel"] if r["parity"] else None, "parity": r["parity"],
+                                               "per_launch_us": r["per_launch_us"], "gpu_state_while_running": r["gpu_state"]})
 
     if use_dist:
         dist.destroy_process_group()       # RCCL prints its banner on teardown: keep the JSON line last

@@ -82,6 +82,30 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did():
     assert 1.0 <= out["ms_per_step"] < 20.0
 
 
+def test_eight_ranks_as_the_driver_launches_them():
+    """The 8-GPU line before there is an 8-GPU node: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...` — the driver's own command — with --dry-run (a sleep for the
+    pass, gloo for RCCL). Eight contiguous stream ranges that tile cfg2's 8192 streams, ONE line (rank 0's), whole-job value =
+    all ranks' samples over the slowest rank's time. And cfg4 / cfg5, BASELINE's 8-GPU workloads: 8 x 1024 = 8192 and
+    8 x 2048 = 16 384 streams."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    for workload, per_gpu in (("cfg2", 1024), ("cfg4", 1024), ("cfg5", 2048)):
+        run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                              "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "4",
+                              "--warmup", "1", "--workload", workload], env=env, capture_output=True, text=True, timeout=600)
+        assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-3000:]
+        lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, lines
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["steps"] == 4 and out["dry_run"] is True
+        assert out["config"]["stream_ranges"] == [[r * per_gpu, (r + 1) * per_gpu] for r in range(8)]
+        assert out["value"] == pytest.approx(8 * per_gpu * 256 * 4 / (out["ms_per_step"] * 4e-3))
+        if workload != "cfg2":
+            break_even = out["config"]["stream_ranges"][-1][1]
+            assert break_even == {"cfg4": 8192, "cfg5": 16384}[workload]          # BASELINE.json configs[3], configs[4]
+
+
 def test_bench_single_rank_dry_run_needs_no_launcher_and_fails_loudly_when_a_rank_dies():
     import json
     import subprocess

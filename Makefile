@@ -27,8 +27,17 @@ KERN_OBJS := $(OBJDIR)/aidax_kernels.o $(OBJDIR)/aidax_stack.o $(OBJDIR)/aidax_m
 HDRS      := $(wildcard $(SRC)/*.h) include/aidax.h
 
 LV2SO := $(PKG)/lv2/rt-neural-generic.so
+# Two builds of the library from the same sources (aidax_layout.h: AIDAX_TEST_HOOKS):
+#   $(PKG)/lib/libaidax_hip.so        the SHIPPED one — bench.py, smoke(), the LV2 shell, the bundle. No test or measurement switch in it.
+#   $(PKG)/lib/hooks/libaidax_hip.so  the same with -DAIDAX_TEST_HOOKS: what tests/conftest.py points AIDAX_LIB at (the suite forces
+#                                     kernel forms, injects faults, ...) and what scratch/ measures with.
+HOOKS_LIBDIR := $(PKG)/lib/hooks
+HOOKS_OBJDIR := build/obj_hooks
 
-all: $(LIBDIR)/libaidax_hip.so $(LV2SO) oracle
+all: $(LIBDIR)/libaidax_hip.so hooks $(LV2SO) oracle
+
+hooks:
+	$(MAKE) OBJDIR=$(HOOKS_OBJDIR) LIBDIR=$(HOOKS_LIBDIR) EXTRA="-DAIDAX_TEST_HOOKS $(EXTRA)" $(HOOKS_LIBDIR)/libaidax_hip.so
 
 $(OBJDIR)/%.o: $(SRC)/%.cpp $(HDRS)
 	@mkdir -p $(OBJDIR)
@@ -55,7 +64,7 @@ $(OBJDIR)/scratch.ok: $(KERN_OBJS) $(KERN_OBJS:.o=.remarks) tools/check_scratch.
 
 $(LIBDIR)/libaidax_hip.so: $(HOST_OBJS) $(KERN_OBJS) $(OBJDIR)/scratch.ok
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(HOST_OBJS) $(KERN_OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -Wl,-soname,libaidax_hip.so -o $@ $(HOST_OBJS) $(KERN_OBJS)
 
 # The LV2 plugin shell (no lib prefix, like the reference's binary: rt-neural-generic/CMakeLists.txt:47)
 $(LV2SO): $(PKG)/lv2/rt_neural_generic_lv2.cpp $(PKG)/lv2/lv2_min.h include/aidax.h $(LIBDIR)/libaidax_hip.so
@@ -80,7 +89,7 @@ oracle:
 	$(MAKE) -s -C oracle _ref
 
 clean:
-	rm -rf build $(LIBDIR) $(LV2SO)
+	rm -rf build $(LIBDIR) $(HOOKS_LIBDIR) $(LV2SO)
 	$(MAKE) -s -C oracle clean
 
-.PHONY: all oracle bundle clean asan
+.PHONY: all hooks oracle bundle clean asan

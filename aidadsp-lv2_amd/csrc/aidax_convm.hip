@@ -302,7 +302,7 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
     // post pass — a lone wave — ended the launch with the rest of the CU idle (scratch/conv_trace.py; 67.5 -> 64.6 us for
     // BASELINE cfg4; a priority fixed per workgroup id is worse than none, 66.5 us). AIDAX_TUNE bit 2048 switches it off.
     auto set_prio = [&](int phase) {
-        if (!FUSED || (a.tune & 2048)) return;
+        if (!FUSED || (AIDAX_TUNE(a) & 2048)) return;
         switch (phase & 3) {
         case 0: __builtin_amdgcn_s_setprio(3); break;
         case 1: __builtin_amdgcn_s_setprio(2); break;
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(kConvmThreads, 4) void k_conv_mfma(LaunchArgs a, Co
     else if constexpr (FUSED) { if (wave == chain_wave) post_begin(); }
     if constexpr (FUSED) {
         lds_barrier();                                        // the row is complete, the staging area is free again
-        if (!(a.tune & 2048)) __builtin_amdgcn_s_setprio(0);  // (the post pass: measured the same at priority 0 and 3)
+        if (!(AIDAX_TUNE(a) & 2048)) __builtin_amdgcn_s_setprio(0);  // (the post pass: measured the same at priority 0 and 3)
         if (wave == chain_wave) CV_STAMP(9);
         if (wave == chain_wave) {
             chain_epilogue_run(a.st[sg], post_ctx, post_pass, a.out + (size_t)sg * rstride, pl + Hb, n, lane, wst);

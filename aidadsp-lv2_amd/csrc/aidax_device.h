@@ -544,8 +544,8 @@ __device__ __forceinline__ void chain_wave_pass(const LaunchArgs& a, int stream0
         const int n_full = n & ~(kChainPackBlock - 1);
         // the longest cascade among the wave's running streams: without EQ on this side it is one stage, and the
         // sweep needs no fill / drain steps at all
-        const int depth = (a.tune & 8) || __builtin_amdgcn_ballot_w64(run && stage > 0) != 0 ? 6 : 1;
-        if (n_full != 0) chain_sweep_blocked<kChainPackBlock, kWave>(c, stage, run, depth, row, hand, n_full, lane, (a.tune & 8) != 0);
+        const int depth = (AIDAX_TUNE(a) & 8) || __builtin_amdgcn_ballot_w64(run && stage > 0) != 0 ? 6 : 1;
+        if (n_full != 0) chain_sweep_blocked<kChainPackBlock, kWave>(c, stage, run, depth, row, hand, n_full, lane, (AIDAX_TUNE(a) & 8) != 0);
         if (n_full != n) chain_sweep<1>(c, stage, run, depth, row + n_full, row + n_full, n - n_full);
         __builtin_amdgcn_wave_barrier();
     }

@@ -703,7 +703,7 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
     } else if (wave == 1) {               // ---- N prologue
         // the recurrent wave is the critical path of the workgroup and of its SIMD, which it shares with helper
         // waves of other streams: it issues first (measured 95 -> 84 us per cfg2 block)
-        if (!(a.tune & 1)) __builtin_amdgcn_s_setprio(3);
+        if (!(AIDAX_TUNE(a) & 1)) __builtin_amdgcn_s_setprio(3);
         if (net_on) {
             cell.load(a.wpack, nnst, lane);
             cell.publish_h(hh + (kRing - 1) * HS);       // h(-1): the row "before" frame 0

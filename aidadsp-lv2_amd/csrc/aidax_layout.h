@@ -13,6 +13,20 @@
 
 #include <cstdint>
 
+// Test and measurement switches (AIDAX_TUNE, AIDAX_KERNEL, AIDAX_LP_COOP, ... and the kernels' LaunchArgs::tune bits) exist only in a
+// library built with -DAIDAX_TEST_HOOKS: the build the test suite and scratch/ load (make all -> lib/hooks/libaidax_hip.so). The shipped
+// library (lib/libaidax_hip.so: bench.py, smoke(), the LV2 shell, the bundle) compiles AIDAX_HOOK_ENV to a null pointer and AIDAX_TUNE
+// to 0: none of the names is in its strings, none of the switched code in its kernels. What the shipped library does read from the
+// environment is configuration, documented in INTEGRATION.md: AIDAX_ZEROCOPY, AIDAX_SPIN_WAIT (pool), AIDAX_DEVICE, AIDAX_HUB,
+// AIDAX_HUB_FRAMES, AIDAX_HUB_DEADLINE_US, AIDAX_STRICT_REFERENCE_SET (LV2 shell / loader).
+#ifdef AIDAX_TEST_HOOKS
+#define AIDAX_HOOK_ENV(name) std::getenv(name)
+#define AIDAX_TUNE(a) ((a).tune)
+#else
+#define AIDAX_HOOK_ENV(name) (static_cast<const char*>(nullptr))
+#define AIDAX_TUNE(a) 0
+#endif
+
 namespace aidax {
 
 constexpr int kWave = 64;

@@ -170,7 +170,7 @@ __device__ __forceinline__ void lp_gates(f32x4 (&acc)[NACC], const f32x4 (&wres)
 }
 
 #ifdef AIDAX_LP_TRACE
-#define LP_STAMP(k) do { if ((int)blockIdx.x == ((a.tune >> 16) & 0xff) && tick >= kTraceT0 && tick < kTraceT0 + 8) {                         \
+#define LP_STAMP(k) do { if ((int)blockIdx.x == ((AIDAX_TUNE(a) >> 16) & 0xff) && tick >= kTraceT0 && tick < kTraceT0 + 8) {                         \
         __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = clock64(); __builtin_amdgcn_sched_barrier(0); \
         if ((threadIdx.x & 63) == 0) trace[((tick - kTraceT0) * 12 + (threadIdx.x >> 6)) * 8 + (k)] = t_; } } while (0)
 #else
@@ -196,7 +196,7 @@ __device__ __forceinline__ void lp_helper(const LaunchArgs& a, float* xb, float*
     constexpr int NS = kMfmaStreams;
     constexpr int SPH = NS / NHELP;                        // streams per helper wave
     static_assert(SPH * NHELP == NS && SPH <= 8, "eight lanes per stream");
-    if (!(a.tune & 1024)) __builtin_amdgcn_s_setprio(3);   // (measurement: AIDAX_TUNE bit 1024 leaves the helpers at the main waves' priority)
+    if (!(AIDAX_TUNE(a) & 1024)) __builtin_amdgcn_s_setprio(3);   // (measurement: AIDAX_TUNE bit 1024 leaves the helpers at the main waves' priority)
     const int lane = threadIdx.x & 63;
     const int hw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) - NW;
     const int gl = lane >> 3, stage = lane & 7;
@@ -266,7 +266,7 @@ __device__ __forceinline__ void lp_helper(const LaunchArgs& a, float* xb, float*
         Q.g.arm(master_mem0, master_tgt, ctl.master_coef);
     }
     const bool run_p = live && stage < P.K, run_q = live && stage < Q.K;
-    const bool general = (a.tune & 8) != 0;
+    const bool general = (AIDAX_TUNE(a) & 8) != 0;
     const int depth_p = general || __builtin_amdgcn_ballot_w64(run_p && stage > 0) != 0 ? 6 : 1;
     const int depth_q = general || __builtin_amdgcn_ballot_w64(run_q && stage > 0) != 0 ? 6 : 1;
     float* row = xb + sl * nP;
@@ -350,7 +350,7 @@ __device__ __forceinline__ void lp_helper(const LaunchArgs& a, float* xb, float*
         __syncthreads();                                   // (4) the rows may be overwritten
     }
 #ifdef AIDAX_LP_TRACE
-    if ((int)blockIdx.x == ((a.tune >> 16) & 0xff)) __syncthreads();
+    if ((int)blockIdx.x == ((AIDAX_TUNE(a) >> 16) & 0xff)) __syncthreads();
 #endif
     __syncthreads();                                       // (5)
     if (!valid) return;
@@ -528,7 +528,7 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
     uint32_t* cnt_out = last ? nullptr : counters + ((size_t)grp * (NL - 1) + l) * kLpCounterStride;
     uint32_t* cnt_in = first ? nullptr : counters + ((size_t)grp * (NL - 1) + (l - 1)) * kLpCounterStride;
     auto give_up = [&]() { __hip_atomic_fetch_add(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
-    if ((a.tune & 16) && blk == 0 && tid == 0) give_up();      // test hook: report a give-up that did not happen
+    if ((AIDAX_TUNE(a) & 16) && blk == 0 && tid == 0) give_up();      // test hook: report a give-up that did not happen
     // every thread needs the bases (they place a frame in the ring); the running counts are thread 0's business
     const uint32_t base_out = cnt_out ? __hip_atomic_load(cnt_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     const uint32_t base_in = cnt_in ? __hip_atomic_load(cnt_in + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
@@ -825,7 +825,7 @@ __device__ __forceinline__ void lp_body(const LaunchArgs& a, const MfmaDesc& d, 
     }
 
 #ifdef AIDAX_LP_TRACE
-    if ((int)blockIdx.x == ((a.tune >> 16) & 0xff)) { __syncthreads(); for (int i = tid; i < 2 * 768; i += NT) fault[16 + i] = reinterpret_cast<const uint32_t*>(trace)[i]; }
+    if ((int)blockIdx.x == ((AIDAX_TUNE(a) >> 16) & 0xff)) { __syncthreads(); for (int i = tid; i < 2 * 768; i += NT) fault[16 + i] = reinterpret_cast<const uint32_t*>(trace)[i]; }
 #endif
     // ---- recurrent state and smoother memories back to HBM for the streams that ran
 #pragma unroll
@@ -913,7 +913,7 @@ __global__ __launch_bounds__((NW + NHELP) * kWave) void k_mfma_lp(LaunchArgs a, 
     // tests can exercise the cross-XCD hand-over too.)
     const int NL = d.n_layers;
     const int blk = (int)blockIdx.x;
-    const bool adjacent = (a.tune & 2) != 0;
+    const bool adjacent = (AIDAX_TUNE(a) & 2) != 0;
     const int grp = adjacent ? blk / NL : (blk / (8 * NL)) * 8 + (blk & 7);
     const int l = adjacent ? blk % NL : (blk / 8) % NL;
     const int n_groups = ((int)a.n_streams + kMfmaStreams - 1) / kMfmaStreams;
@@ -930,7 +930,7 @@ __global__ __launch_bounds__((NW + NHELP) * kWave) void k_mfma_lp(LaunchArgs a, 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");           // (the body's loads of the rows: from L2, see lp_body)
             lp_body<TPW, NW, M, true, false, 0, true>(a, d, ring, counters, fault, smem, grp, l);
         } else if (l == NL - 1) {
-            if (a.tune & 8192) {                                          // test hook: this workgroup starts 100 us late
+            if (AIDAX_TUNE(a) & 8192) {                                          // test hook: this workgroup starts 100 us late
                 const uint64_t t0 = wall_clock64();
                 while (wall_clock64() - t0 < 10000) __builtin_amdgcn_s_sleep(64);
             }
@@ -1092,7 +1092,7 @@ __global__ __launch_bounds__((UT + NHELP) * kWave) void k_gru_gm(LaunchArgs a, M
         __syncthreads();                                    // (4) the helpers have stored the rows
     }
 #ifdef AIDAX_LP_TRACE
-    if ((int)blockIdx.x == ((a.tune >> 16) & 0xff)) __syncthreads();      // (lp_helper's extra barrier of the measurement build)
+    if ((int)blockIdx.x == ((AIDAX_TUNE(a) >> 16) & 0xff)) __syncthreads();      // (lp_helper's extra barrier of the measurement build)
 #endif
     __syncthreads();                                        // (5)
     if (valid && livef[c] != 0.f) {
@@ -1356,11 +1356,11 @@ __global__ __launch_bounds__((UT + NHELP) * kWave) void k_gru_gs(LaunchArgs a, M
         __syncthreads();                                    // (4) the helpers have stored the rows
     }
 #ifdef AIDAX_LP_TRACE
-    if ((int)blockIdx.x == ((a.tune >> 16) & 0xff)) __syncthreads();
+    if ((int)blockIdx.x == ((AIDAX_TUNE(a) >> 16) & 0xff)) __syncthreads();
 #endif
     __syncthreads();                                        // (5)
 #ifdef AIDAX_LP_TRACE
-    if ((int)blockIdx.x == ((a.tune >> 16) & 0xff))
+    if ((int)blockIdx.x == ((AIDAX_TUNE(a) >> 16) & 0xff))
         for (int i = tid; i < 2 * 768; i += NT) a.out[(size_t)s_base * n + i] = reinterpret_cast<const float*>(trace)[i];
 #endif
     if (valid && livef[c] != 0.f) {
@@ -1668,7 +1668,7 @@ __host__ __device__ constexpr int ls_gate_groups(int ks2, int nprod) { return np
 #ifdef AIDAX_LP_TRACE
 // measurement build (scratch/ls_trace.py): the workgroups of stream group (tune >> 16 & 0xff) stamp the shader clock at eight points
 // of ticks 96..103 on every wave, straight into the pinned fault buffer: [layer is last][tick][wave][stamp] u64 behind word 16
-#define LS_STAMP(k) do { if (grp == ((a.tune >> 16) & 0xff) && tick >= 96 && tick < 104) {                                       \
+#define LS_STAMP(k) do { if (grp == ((AIDAX_TUNE(a) >> 16) & 0xff) && tick >= 96 && tick < 104) {                                       \
         __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = clock64(); __builtin_amdgcn_sched_barrier(0);            \
         if (lane == 0) reinterpret_cast<unsigned long long*>(fault + 16)[(((last ? 1 : 0) * 8 + (tick - 96)) * 4 + (wave & 3)) * 8 + (k)] = t_; } } while (0)
 #else
@@ -1824,7 +1824,7 @@ __device__ __forceinline__ void ls_body(const LaunchArgs& a, const MfmaDesc& d, 
     uint32_t* cnt_out = last ? nullptr : counters + ((size_t)grp * (NL - 1) + l) * kLpCounterStride;
     uint32_t* cnt_in = first ? nullptr : counters + ((size_t)grp * (NL - 1) + (l - 1)) * kLpCounterStride;
     auto give_up = [&]() { __hip_atomic_fetch_add(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
-    if ((a.tune & 16) && blk == 0 && tid == 0) give_up();      // test hook: report a give-up that did not happen
+    if ((AIDAX_TUNE(a) & 16) && blk == 0 && tid == 0) give_up();      // test hook: report a give-up that did not happen
     const uint32_t base_out = cnt_out ? __hip_atomic_load(cnt_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     const uint32_t base_in = cnt_in ? __hip_atomic_load(cnt_in + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     uint32_t known_free = kLpRing;                         // frames of this launch the ring above is known to have room for
@@ -2261,14 +2261,14 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_ls(LaunchArgs a, MfmaDesc d
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int NL = d.n_layers;
     const int blk = (int)blockIdx.x;
-    const bool adjacent = (a.tune & 2) != 0;
+    const bool adjacent = (AIDAX_TUNE(a) & 2) != 0;
     const int grp = adjacent ? blk / NL : (blk / (8 * NL)) * 8 + (blk & 7);
     const int l = adjacent ? blk % NL : (blk / 8) % NL;
     const int n_groups = ((int)a.n_streams + kMfmaStreams - 1) / kMfmaStreams;
     if (grp >= n_groups) return;
     // (measurement, AIDAX_TUNE bit 4096: where this workgroup ran and when — XCC_ID, HW_ID, the 100 MHz clock at its start and end — into
     // the pool's pinned fault page behind the fault word; scratch/r05_modes.py reads it)
-    const bool stamp = (a.tune & 4096) && blk < 500 && threadIdx.x == 0;
+    const bool stamp = (AIDAX_TUNE(a) & 4096) && blk < 500 && threadIdx.x == 0;
     if (stamp) {
         fault[16 + 3 * blk] = (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) | (__builtin_amdgcn_s_getreg((31 << 11) | 4) << 4);
         fault[17 + 3 * blk] = (uint32_t)wall_clock64();
@@ -2282,7 +2282,7 @@ __global__ __launch_bounds__(NW * kWave) void k_mfma_ls(LaunchArgs a, MfmaDesc d
         else ls_body<TPW, NW, M, true, false, CHAIN, NPROD, 1>(a, d, ring, counters, fault, smem, grp, l);
     } else if (l == NL - 1) {
         if constexpr (CHAIN) {
-            if (a.tune & 8192) {                                          // test hook: this workgroup starts 100 us late
+            if (AIDAX_TUNE(a) & 8192) {                                          // test hook: this workgroup starts 100 us late
                 const uint64_t t0 = wall_clock64();
                 while (wall_clock64() - t0 < 10000) __builtin_amdgcn_s_sleep(64);
             }
@@ -2339,7 +2339,7 @@ typedef void (*GmFn)(LaunchArgs, MfmaDesc);
 // plain launch (A/B runs).
 [[maybe_unused]] static bool lp_coop_launch()
 {
-    static const bool on = [] { const char* e = std::getenv("AIDAX_LP_COOP"); return !(e && e[0] == '0'); }();
+    static const bool on = [] { const char* e = AIDAX_HOOK_ENV("AIDAX_LP_COOP"); return !(e && e[0] == '0'); }();
     return on;
 }
 [[maybe_unused]] static hipError_t lp_launch(LpFn fn, uint32_t blocks, uint32_t threads, size_t lds, hipStream_t stream, LaunchArgs a, MfmaDesc d,

@@ -61,7 +61,7 @@ enum ManyForm { MANY_NONE = 0, MANY_QUAD = 1, MANY_MFMA = 2 };
 // have k_lstm_gs, below; k_mfma_ls1 then serves LSTM-80, 32 units at many streams, and the A/B runs.)
 bool lone_split_pays(int cell, int hidden, uint32_t n, int cus)
 {
-    const bool off = [] { const char* e = std::getenv("AIDAX_LP_SPLIT"); return e && e[0] == '0'; }();
+    const bool off = [] { const char* e = AIDAX_HOOK_ENV("AIDAX_LP_SPLIT"); return e && e[0] == '0'; }();
     if (off || cus <= 0) return false;
     const bool lstm = cell == AIDAX_CELL_LSTM;
     const uint32_t groups = (n + kMfmaStreams - 1) / kMfmaStreams, c = static_cast<uint32_t>(cus);
@@ -82,8 +82,8 @@ bool lone_split_pays(int cell, int hidden, uint32_t n, int cus)
 bool lstm_gs_pays(int cell, int hidden, uint32_t n, int cus)
 {
     // (read on every call — the worker thread's, at model load: tests switch forms within one process)
-    const int forced = [] { const char* e = std::getenv("AIDAX_LSTM_GS"); return !e ? -1 : e[0] != '0' ? 1 : 0; }();
-    const bool f32 = [] { const char* e = std::getenv("AIDAX_GRU_GM"); return e && e[0] == 'f'; }();
+    const int forced = [] { const char* e = AIDAX_HOOK_ENV("AIDAX_LSTM_GS"); return !e ? -1 : e[0] != '0' ? 1 : 0; }();
+    const bool f32 = [] { const char* e = AIDAX_HOOK_ENV("AIDAX_GRU_GM"); return e && e[0] == 'f'; }();
     if (cell != AIDAX_CELL_LSTM || (hidden != 40 && hidden != 64 && hidden != 80) || forced == 0 || f32) return false;
     if (forced == 1) return true;
     if (cus <= 0) return false;
@@ -96,7 +96,7 @@ ManyForm many_streams_form(int cell, int hidden, uint32_t n, int cus)
     if (lstm_gs_pays(cell, hidden, n, cus)) return MANY_MFMA;
     const bool lstm = cell == AIDAX_CELL_LSTM;
     const uint32_t groups = (n + kMfmaStreams - 1) / kMfmaStreams;
-    const bool ls1_off = [] { const char* e = std::getenv("AIDAX_LS1"); return e && e[0] == '0'; }();
+    const bool ls1_off = [] { const char* e = AIDAX_HOOK_ENV("AIDAX_LS1"); return e && e[0] == '0'; }();
     if (!ls1_off && lone_split_pays(cell, hidden, n, cus)) return MANY_MFMA;
     const bool full_round = cus > 0 && groups <= static_cast<uint32_t>(cus) && groups * 8 > static_cast<uint32_t>(cus) * 7;
     if (full_round && (hidden == 32 || hidden == 64 || (hidden == 40 && lstm))) return MANY_MFMA;
@@ -109,7 +109,7 @@ ManyForm many_streams_form(int cell, int hidden, uint32_t n, int cus)
     // profiles/r04_gs_threshold.txt): GRU-64 wins from 256 streams on (k_quad 197 us at 256 - 1024, k_nn 225 at 1536 - 2048);
     // GRU-40 from the point where k_nn needs a second round of waves (2048 streams: 174 us; 2560: 279). AIDAX_GRU_GM=f32 (the
     // fp32 MFMA kernel, 305 us) keeps round 3's thresholds.
-    const bool gm_f32 = [] { const char* e = std::getenv("AIDAX_GRU_GM"); return e && e[0] == 'f'; }();
+    const bool gm_f32 = [] { const char* e = AIDAX_HOOK_ENV("AIDAX_GRU_GM"); return e && e[0] == 'f'; }();
     if (!lstm && cus > 0 && !gm_f32 &&
         ((hidden == 64 && groups * 16 >= static_cast<uint32_t>(cus)) || (hidden == 40 && groups * 2 > static_cast<uint32_t>(cus))))
         return MANY_MFMA;
@@ -547,7 +547,7 @@ struct aidax_pool {
         if (cur.d_counters) (void)hipFree(cur.d_counters);
         if (cur.lp_owner) { lp_gate().release(device, cur.lp_owner); cur.lp_owner = nullptr; }
         if (h_lp_fault)                                      // (measurement builds / AIDAX_TUNE bit 4096: the stamps behind the fault word)
-            if (const char* f = std::getenv("AIDAX_LP_TRACE_FILE"))
+            if (const char* f = AIDAX_HOOK_ENV("AIDAX_LP_TRACE_FILE"))
                 if (FILE* fp = std::fopen(f, "wb")) { std::fwrite(h_lp_fault + 16, 4, 1536, fp); std::fclose(fp); }
         if (h_lp_fault) (void)hipHostFree(h_lp_fault);
         h_lp_fault = nullptr;
@@ -629,7 +629,7 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
         // chain passes inside the conv launch while every workgroup of the pool is resident at once (their serial
         // latency is then paid once per block; in a second round of workgroups it would be paid again, and the packed
         // k_chain launches around the kernel are cheaper). AIDAX_CONV_FUSED=1 / 0 forces the form.
-        const char* fused = std::getenv("AIDAX_CONV_FUSED");
+        const char* fused = AIDAX_HOOK_ENV("AIDAX_CONV_FUSED");
         ms.conv_fused = ms.conv_mfma && (fused ? fused[0] != '0'
                                                : static_cast<int>(p.n_streams) <= convm_resident_streams(ms.cdesc, p.ext_chunk(), p.device));
         if (ms.conv_mfma && p.max_frames > 256) ms.conv_fused = true;      // long blocks go through in time slices: the one-launch form only
@@ -676,7 +676,7 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
     // parallelism, i.e. while every (group, layer) workgroup gets a CU of its own (2048 streams for two layers on 256
     // CUs: 1.9x over one workgroup per group; beyond, where the CUs are full either way, a second round of workgroups
     // costs what the resident weights save: 4096 streams 2.49 against 2.45 ms). AIDAX_MFMA_LP=1 / 0 forces it on / off.
-    const char* lp = std::getenv("AIDAX_MFMA_LP");
+    const char* lp = AIDAX_HOOK_ENV("AIDAX_MFMA_LP");
     int cus = 0;
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p.device));
     const size_t lp_groups = (p.n_streams + kMfmaStreams - 1) / kMfmaStreams;
@@ -688,13 +688,13 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
     // Round 4: k_mfma_ls is fast enough to pay in SEVERAL rounds too — a pass over more streams than one resident grid holds goes
     // out as one launch per range of streams (each a resident, cooperative grid; same ring, the counters are per group):
     // LSTM-96 x 2 at 4096 streams 2 x 0.71 ms against 2.48 ms on k_mfma, at 16 384 streams 8 x 0.71 against 9.42 ms.
-    const char* sp_env = std::getenv("AIDAX_LP_SPLIT");
+    const char* sp_env = AIDAX_HOOK_ENV("AIDAX_LP_SPLIT");
     // (a lone layer on k_mfma_ls: AIDAX_LS1=1 / 0 forces it on / off)
-    const char* ls1_env = std::getenv("AIDAX_LS1");
+    const char* ls1_env = AIDAX_HOOK_ENV("AIDAX_LS1");
     const bool ls1 = !lp_chained && (ls1_env ? ls1_env[0] != '0' : lone_split_pays(m->cell, m->hidden, p.n_streams, cus));
     const bool ls_ok = ms.kind == ModelSlot::MFMA && (lp_chained || ls1) && mfma_ls_serves(ms.mdesc) && !(sp_env && sp_env[0] == '0') &&
                        mfma_ls_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024;
-    const char* rg_env = std::getenv("AIDAX_LP_ROUND_GROUPS");      // (tests: ranges of this many stream groups, so that a small pool goes out in several)
+    const char* rg_env = AIDAX_HOOK_ENV("AIDAX_LP_ROUND_GROUPS");      // (tests: ranges of this many stream groups, so that a small pool goes out in several)
     const size_t round_groups = rg_env && std::atoi(rg_env) > 0
                                     ? static_cast<size_t>(std::atoi(rg_env))
                                     : static_cast<size_t>(cus) / static_cast<size_t>(ms.mdesc.n_layers > 0 ? ms.mdesc.n_layers : 1) / 8 * 8;      // workgroup ids come in eights
@@ -716,15 +716,15 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
         HIP_TRY(hipMalloc(&ms.d_ring, ring_bytes));
         HIP_TRY(hipMalloc(&ms.d_counters, mfma_lp_counter_bytes(ms.mdesc, p.n_streams)));
         HIP_TRY(hipMemsetAsync(ms.d_counters, 0, mfma_lp_counter_bytes(ms.mdesc, p.n_streams), p.wq));
-        const char* fu = std::getenv("AIDAX_LP_FUSED");      // (=0: packed k_chain launches around the kernel, A/B runs)
+        const char* fu = AIDAX_HOOK_ENV("AIDAX_LP_FUSED");      // (=0: packed k_chain launches around the kernel, A/B runs)
         ms.lp_fused = !(fu && fu[0] == '0') &&
                       (ms.lp_split ? mfma_ls_fused_serves(ms.mdesc, p.max_frames) && mfma_ls_lds_bytes(ms.mdesc, p.max_frames, true) <= 160 * 1024
                                    : mfma_lp_fused_serves(ms.mdesc, p.max_frames) && mfma_lp_lds_bytes(ms.mdesc, p.max_frames, true) <= 160 * 1024);
     }
     if (ms.kind == ModelSlot::MFMA) {
-        const char* gm = std::getenv("AIDAX_GRU_GM");        // (=0: the four-rows-per-unit kernels; =f32: k_gru_gm with fp32 MFMAs — A/B runs)
+        const char* gm = AIDAX_HOOK_ENV("AIDAX_GRU_GM");        // (=0: the four-rows-per-unit kernels; =f32: k_gru_gm with fp32 MFMAs — A/B runs)
         ms.gru_gm = gru_gm_serves(ms.mdesc) && !(gm && gm[0] == '0') && gru_gm_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024;
-        const char* np = std::getenv("AIDAX_GS_PRODUCTS");   // (=9: every term product of the split operands instead of six)
+        const char* np = AIDAX_HOOK_ENV("AIDAX_GS_PRODUCTS");   // (=9: every term product of the split operands instead of six)
         ms.lstm_gs = lstm_gs_serves(ms.mdesc) && lstm_gs_pays(m->cell, m->hidden, p.n_streams, cus) && lstm_gs_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024
                          ? (np && np[0] == '9' ? 9 : 6) : 0;
         ms.gru_gs = gru_gs_serves(ms.mdesc) && !(gm && (gm[0] == 'f' || gm[0] == '0')) && gru_gs_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024
@@ -857,9 +857,9 @@ AIDAX_API int aidax_pool_create(uint32_t n_streams, uint32_t max_frames, double 
         p->max_frames = max_frames;
         p->host_sr = host_samplerate;
         p->gain_coef = exp_smoother_coef(static_cast<float>(host_samplerate), 0.1f);
-        if (const char* f = std::getenv("AIDAX_KERNEL"))
+        if (const char* f = AIDAX_HOOK_ENV("AIDAX_KERNEL"))
             p->force_form = std::strcmp(f, "wave") == 0 ? 1 : std::strcmp(f, "pipe") == 0 ? 2 : std::strcmp(f, "split") == 0 ? 3 : std::strcmp(f, "valu") == 0 ? 4 : std::strcmp(f, "mfma") == 0 ? 5 : std::strcmp(f, "quad") == 0 ? 6 : std::strcmp(f, "q4") == 0 ? 7 : 0;
-        if (const char* t = std::getenv("AIDAX_TUNE")) p->tune = std::atoi(t);
+        if (const char* t = AIDAX_HOOK_ENV("AIDAX_TUNE")) p->tune = std::atoi(t);
         try {
             HIP_TRY(hipSetDevice(device_id));
             HIP_TRY(hipDeviceGetAttribute(&p->cus, hipDeviceAttributeMultiprocessorCount, device_id));

@@ -170,12 +170,12 @@ __global__ __launch_bounds__(kQ4Waves * kWave) void k_lstm_q4(LaunchArgs a)
         float hcur = upd ? nnst[u] : 0.f;
         if (!hi) hh[((kQ4HRing - 1) * kQ4Streams + j) * HS + u] = hcur;      // h(-1): the slot "before" frame 0
         const float in_gain = a.in_gain;
-        if (!(a.tune & 1)) __builtin_amdgcn_s_setprio(3);
+        if (!(AIDAX_TUNE(a) & 1)) __builtin_amdgcn_s_setprio(3);
         // LDS addresses of the lane, per ring slot (the frame loop is unrolled over the four slots of the h ring)
         const float* hrd = hh + j * HS + 16 * q;            // + slot * 4 * HS: the 16 columns of h(t-1) this K-half contracts
         float* hwr = hh + j * HS + u;                       // + slot * 4 * HS: where h(t) of this lane's unit goes
         const float* xrd = xq + j;                          // + (t & 15) * 4
-        const bool work = !(a.tune & 64);
+        const bool work = !(AIDAX_TUNE(a) & 64);
         // one frame; SLOT = t & 3 at compile time. `x` arrives prefetched (frame t), the next frame's is fetched here.
         auto frame = [&](int t, auto slot_c, float& x) {
             constexpr int SLOT = decltype(slot_c)::value, PREV = (SLOT + kQ4HRing - 1) & (kQ4HRing - 1);
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(kQ4Waves * kWave) void k_lstm_q4(LaunchArgs a)
         for (int s = 0; s < steps; ++s) {
             const float head = head_next;
             head_next = row[s + 1 < n ? s + 1 : n - 1];     // a step ahead: the read's latency is off the step's path
-            if (!(a.tune & (32 | 256)) && q4_chain_step(cp, stage, run, head, carry, s, n) && writer)
+            if (!(AIDAX_TUNE(a) & (32 | 256)) && q4_chain_step(cp, stage, run, head, carry, s, n) && writer)
                 xq[((s - stage) & (kQ4XRing - 1)) * kQ4Streams + j] = carry;
             q4_barrier();
         }
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(kQ4Waves * kWave) void k_lstm_q4(LaunchArgs a)
                 hv_next = *reinterpret_cast<const float2*>(hh + ((tn & (kQ4HRing - 1)) * kQ4Streams + j) * HS + 2 * stage);
                 xin_next = xq[(tn & (kQ4XRing - 1)) * kQ4Streams + j];
             }
-            if (tq >= 0 && tq < n && !(a.tune & (32 | 128))) {
+            if (tq >= 0 && tq < n && !(AIDAX_TUNE(a) & (32 | 128))) {
                 const float part = __builtin_fmaf(wd1, hv.y, wd0 * hv.x);
                 const float y = q4_row_sum16(part) + bd;
                 const float xg = xin * in_gain;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(kQ4Waves * kWave) void k_lstm_q4(LaunchArgs a)
                 o = o * out_gain;                            // out[i] *= output_gain
                 if (!net_on) o = xin;                        // :631-632: the model is not in circuit
             }
-            if (!(a.tune & (32 | 128)) && q4_chain_step(cp, stage, run, o, carry, tq, n) && writer) row[tq - stage] = carry;
+            if (!(AIDAX_TUNE(a) & (32 | 128)) && q4_chain_step(cp, stage, run, o, carry, tq, n) && writer) row[tq - stage] = carry;
             q4_barrier();
         }
         if (run && cp.active) { st.z[slot][0] = cp.z1; st.z[slot][1] = cp.z2; }

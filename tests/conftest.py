@@ -7,6 +7,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The suite runs on the library built with -DAIDAX_TEST_HOOKS (lib/hooks/): it forces kernel forms, injects faults and reads measurement
+# stamps through environment switches that the shipped library (lib/libaidax_hip.so: bench.py, smoke(), the LV2 shell, the bundle) does not
+# have. Same sources, same kernels. (An explicit AIDAX_LIB — an A/B build — wins; subprocesses inherit it.)
+SHIP_LIB = os.path.join(ROOT, "aidadsp-lv2_amd", "lib", "libaidax_hip.so")
+HOOKS_LIB = os.path.join(ROOT, "aidadsp-lv2_amd", "lib", "hooks", "libaidax_hip.so")
+os.environ.setdefault("AIDAX_LIB", HOOKS_LIB)
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 MODELS = os.path.join(GOLDEN, "models")
 
@@ -16,7 +23,7 @@ def pytest_configure(config):
     # a fresh checkout has no binaries (they are git-ignored): build once, like __graft_entry__.build()
     lib = os.path.join(ROOT, "aidadsp-lv2_amd", "lib", "libaidax_hip.so")
     orc = os.path.join(ROOT, "oracle", "_build", "libaidax_oracle.so")
-    if not (os.path.exists(lib) and os.path.exists(orc)):
+    if not (os.path.exists(lib) and os.path.exists(HOOKS_LIB) and os.path.exists(orc)):
         import shutil
         import subprocess
         if shutil.which("hipcc") and shutil.which("make"):

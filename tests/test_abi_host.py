@@ -13,6 +13,7 @@ import pytest
 from oracle import oracle as O
 from tests import modelgen
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ax = importlib.import_module("aidadsp-lv2_amd")
 
 
@@ -27,12 +28,14 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 def test_no_torch_types_and_no_oracle_in_the_product():
     """The boundary is plain C; the product never links or opens the oracle."""
-    with open(os.path.join(os.path.dirname(ax.lib_path()), "..", "..", "include", "aidax.h")) as f:
+    with open(os.path.join(ROOT, "include", "aidax.h")) as f:
         hdr = f.read()
     assert "torch" not in hdr and "at::" not in hdr
-    out = os.popen(f"ldd '{ax.lib_path()}'").read()
-    assert "oracle" not in out and "libamdhip64" in out
-    csrc = os.path.join(os.path.dirname(ax.lib_path()), "..", "csrc")
+    from tests.conftest import HOOKS_LIB, SHIP_LIB
+    for path in (SHIP_LIB, HOOKS_LIB):
+        out = os.popen(f"ldd '{path}'").read()
+        assert "oracle" not in out and "libamdhip64" in out
+    csrc = os.path.join(ROOT, "aidadsp-lv2_amd", "csrc")
     for fn in os.listdir(csrc):
         with open(os.path.join(csrc, fn)) as f:
             assert "oracle/" not in f.read().replace("vs the CPU oracle", ""), fn
@@ -224,3 +227,27 @@ def test_header_is_plain_c_and_a_c_program_links(tmp_path, bundled_models):
     import torch
     if not torch.cuda.is_available():
         assert "pool_create rc=-5 pool=null" in run.stdout
+
+
+def test_the_shipped_library_has_no_test_or_measurement_switch():
+    """Two builds of one source tree (Makefile, aidax_layout.h: AIDAX_TEST_HOOKS): the shipped library — bench.py, smoke(), the LV2
+    shell, the bundle — reads only its documented configuration from the environment; every switch that forces a kernel form, injects a
+    fault or selects a measurement path exists only in lib/hooks/, which this suite loads (tests/conftest.py)."""
+    import re
+    import subprocess
+    from tests.conftest import HOOKS_LIB, SHIP_LIB
+
+    def names(path):
+        out = subprocess.run(["strings", "-a", path], capture_output=True, text=True, check=True).stdout
+        return set(re.findall(r"AIDAX_[A-Z0-9_]+", out))
+    ship, hooks = names(SHIP_LIB), names(HOOKS_LIB)
+    assert ship == {"AIDAX_SPIN_WAIT", "AIDAX_ZEROCOPY", "AIDAX_STRICT_REFERENCE_SET"}, ship
+    assert {"AIDAX_TUNE", "AIDAX_KERNEL", "AIDAX_LP_COOP", "AIDAX_MFMA_LP", "AIDAX_LP_SPLIT"} <= hooks
+    shell = names(os.path.join(ROOT, "aidadsp-lv2_amd", "lv2", "rt-neural-generic.so"))
+    assert shell == {"AIDAX_DEVICE", "AIDAX_HUB", "AIDAX_HUB_FRAMES", "AIDAX_HUB_DEADLINE_US", "AIDAX_STRICT_REFERENCE_SET"}, shell
+    assert os.path.samefile(ax.lib_path(), HOOKS_LIB)          # what this process runs on
+    # both export everything include/aidax.h declares
+    import ctypes
+    for path in (SHIP_LIB, HOOKS_LIB):
+        L = ctypes.CDLL(path)
+        assert not [n for n in ax.declared_symbols() if not hasattr(L, n)], path

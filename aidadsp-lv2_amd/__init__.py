@@ -10,7 +10,7 @@ The directory name carries a hyphen, so import it with
 """
 from .binding import (  # noqa: F401
     AidaxError, Controls, StreamDsp, Hub, Model, ModelInfo, Pool, lib, lib_path, default_controls,
-    biquad_design, db_to_coeff, lpf_fc, declared_symbols, device_count, pick_device, many_streams_form,
+    biquad_design, db_to_coeff, lpf_fc, declared_symbols, device_count, pick_device, pick_hub, many_streams_form,
     ALL_STREAMS, START_WARMUP, START_RESET,
 )
 from . import workloads  # noqa: F401,E402

@@ -92,6 +92,8 @@ def lib() -> C.CDLL:
     L.aidax_lpf_fc.restype = C.c_float
     L.aidax_device_count.argtypes = [C.POINTER(C.c_int)]
     L.aidax_pick_device.argtypes = [C.c_char_p, C.c_int, C.POINTER(u32), C.POINTER(C.c_int)]
+    L.aidax_pick_hub.argtypes = [C.POINTER(C.c_int), C.POINTER(u32), C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(u32),
+                                 C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.aidax_many_streams_form.argtypes = [C.c_int, C.c_int, u32, C.c_int]
     L.aidax_many_streams_form.restype = C.c_int
     L.aidax_pool_create.argtypes = [u32, u32, C.c_double, C.c_int, C.POINTER(vp)]
@@ -145,6 +147,8 @@ def lib() -> C.CDLL:
     L.aidax_hub_launches.restype = C.c_uint64
     L.aidax_hub_deadline_launches.argtypes = [vp]
     L.aidax_hub_deadline_launches.restype = C.c_uint64
+    L.aidax_hub_faults_unmapped.argtypes = [vp]
+    L.aidax_hub_faults_unmapped.restype = C.c_uint64
     L.aidax_hub_set_deadline_us.argtypes = [vp, C.c_int64]
     L.aidax_hub_flush.argtypes = [vp]
     _lib = L
@@ -198,6 +202,18 @@ def pick_device(spec: Optional[str], count: int, load=None) -> int:
     out = C.c_int(-1)
     _check(lib().aidax_pick_device(spec.encode() if spec is not None else None, count, arr, C.byref(out)))
     return out.value
+
+
+def pick_hub(hub_devices, hub_free_seats, current_device: int, spec: Optional[str], count: int, load=None):
+    """-> (index of the hub to join or -1 = open a new one, device)"""
+    n = len(hub_devices)
+    dev = (C.c_int * max(n, 1))(*hub_devices)
+    free = (C.c_uint32 * max(n, 1))(*hub_free_seats)
+    arr = (C.c_uint32 * count)(*load) if load is not None else None
+    idx, out = C.c_int(-2), C.c_int(-1)
+    _check(lib().aidax_pick_hub(dev, free, n, current_device, spec.encode() if spec is not None else None, count, arr,
+                                C.byref(idx), C.byref(out)))
+    return idx.value, out.value
 
 
 def many_streams_form(cell: int, hidden: int, n_streams: int, compute_units: int = 256) -> int:

@@ -214,4 +214,22 @@ AIDAX_API int aidax_pick_device(const char* spec, int device_count, const uint32
     return AIDAX_OK;
 }
 
+AIDAX_API int aidax_pick_hub(const int* hub_device, const uint32_t* hub_free_seats, int n_hubs, int current_device,
+                             const char* spec, int device_count, const uint32_t* load, int* index_out, int* device_out)
+{
+    if (!index_out || !device_out || n_hubs < 0 || (n_hubs > 0 && (!hub_device || !hub_free_seats))) return aidax::fail(AIDAX_ERR_ARG, "pick_hub: null argument");
+    if (current_device >= device_count) return aidax::fail(AIDAX_ERR_ARG, "pick_hub: current device out of range");
+    *index_out = -1;
+    if (current_device >= 0) {
+        // a playing instance keeps its device: its DSP state moves seat to seat on the device (aidax_hub_adopt)
+        for (int i = 0; i < n_hubs; ++i)
+            if (hub_device[i] == current_device && hub_free_seats[i] > 0) { *index_out = i; break; }
+        *device_out = current_device;
+        return AIDAX_OK;
+    }
+    for (int i = 0; i < n_hubs; ++i)
+        if (hub_free_seats[i] > 0) { *index_out = i; *device_out = hub_device[i]; return AIDAX_OK; }
+    return aidax_pick_device(spec, device_count, load, device_out);
+}
+
 }  // extern "C"

@@ -54,6 +54,7 @@ struct aidax_hub {
     uint64_t launches = 0, deadline_launches = 0;
     uint64_t last_chained = 0;                   // the latest pass that went out on a chained kernel (k_mfma_lp / k_mfma_ls): later ones cannot have given up
     uint64_t clean_upto = 0;                     // passes up to this id are known to carry no k_mfma_lp give-up
+    uint64_t faults_unmapped = 0;                // give-up reports that mapped to no chained pass (nothing to silence; counted so that none vanishes)
     uint64_t bad_from = 1, bad_upto = 0;         // passes in [bad_from, bad_upto] may: their rows are delivered as silence
     int last_error = AIDAX_OK;
     float* h_in[kHubBuffers] = {};               // pinned staging, rows packed at the period's block length
@@ -479,6 +480,7 @@ AIDAX_API int aidax_hub_run(aidax_hub* h, int32_t slot, const float* in, float* 
             if (pool_take_lp_fault(h->pool)) {              // some pass in (clean_upto, launches] gave up a layer hand-over ...
                 h->bad_from = h->clean_upto + 1;
                 h->bad_upto = std::min(h->launches, h->last_chained);      // ... and only one that ran on a chained kernel can have
+                if (h->bad_upto < h->bad_from) ++h->faults_unmapped;       // (a report that maps to no pass still counts: aidax_hub_faults_unmapped)
             }
             lp_fault = prev_pass >= h->bad_from && prev_pass <= h->bad_upto;
             if (!lp_fault && prev_pass > h->clean_upto) h->clean_upto = prev_pass;     // its event has passed and nothing was reported
@@ -494,6 +496,7 @@ AIDAX_API int aidax_hub_run(aidax_hub* h, int32_t slot, const float* in, float* 
             if (pool_take_lp_fault(h->pool)) {
                 h->bad_from = h->clean_upto + 1;
                 h->bad_upto = std::min(h->launches, h->last_chained);
+                if (h->bad_upto < h->bad_from) ++h->faults_unmapped;
             }
         }
         if (!delivered) std::memset(out, 0, sizeof(float) * n_frames);
@@ -514,5 +517,6 @@ AIDAX_API uint32_t aidax_hub_max_frames(const aidax_hub* h) { return h ? h->max_
 AIDAX_API uint32_t aidax_hub_attached(const aidax_hub* h) { return hub_read<uint32_t>(h, [](aidax_hub& x) { return x.n_attached; }); }
 AIDAX_API uint64_t aidax_hub_launches(const aidax_hub* h) { return hub_read<uint64_t>(h, [](aidax_hub& x) { return x.launches; }); }
 AIDAX_API uint64_t aidax_hub_deadline_launches(const aidax_hub* h) { return hub_read<uint64_t>(h, [](aidax_hub& x) { return x.deadline_launches; }); }
+AIDAX_API uint64_t aidax_hub_faults_unmapped(const aidax_hub* h) { return hub_read<uint64_t>(h, [](aidax_hub& x) { return x.faults_unmapped; }); }
 
 }  // extern "C"

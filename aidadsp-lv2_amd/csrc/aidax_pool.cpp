@@ -208,6 +208,8 @@ struct ModelSlot {
     const void* lp_owner = nullptr;  // the pool whose hold on the device's LpGate this slot shares (d_ring != nullptr)
     bool lp_fused = false;           // k_mfma_lp runs the DSP chain too (one-layer models, helper waves): one launch per block
     uint32_t lp_round_streams = 0;   // k_mfma_ls on a pool larger than one resident grid: streams per launch (a pass is several launches over stream ranges); 0: one launch
+    mutable bool lp_refused = false; // the runtime refused this model's chained grid (cooperative launch: not co-resident on this device): k_mfma serves it — this
+                                     // model only; another model of the pool, with a smaller grid, may still fit (set on the launch path, hence mutable)
     int lp_split = 0;                // stacked models: k_mfma_ls serves the passes (contractions as bf16 term products of split operands): 6 or 9 products; 0: k_mfma_lp (fp32 MFMAs)
     bool gru_gm = false;             // one-layer GRU: k_gru_gm (gate-major tiles, the whole run() in one launch) serves the passes
     int lstm_gs = 0;                 // one-layer LSTM-40 / 64 on k_lstm_gs (k_gru_gs's structure): 6 or 9 term products; 0: not
@@ -266,6 +268,7 @@ struct aidax_pool {
     uint32_t* hd_lp_fault = nullptr;
     mutable std::atomic<bool> lp_off{false};      // (mutable: set from the launch path, a const member function)
     std::atomic<uint32_t> lp_faults{0};
+    mutable std::atomic<uint32_t> lp_refusals{0}; // chained grids the runtime refused (the text is in aidax_last_error(); kernel_name says k_mfma from then on)
     bool take_lp_fault()
     {
         if (!h_lp_fault) return false;
@@ -360,7 +363,7 @@ struct aidax_pool {
         }
     }
 
-    bool lp_in_use(const ModelSlot& m) const { return m.d_ring != nullptr && !(m.mdesc.n_layers >= 2 && lp_off.load(std::memory_order_relaxed)); }
+    bool lp_in_use(const ModelSlot& m) const { return m.d_ring != nullptr && !m.lp_refused && !(m.mdesc.n_layers >= 2 && lp_off.load(std::memory_order_relaxed)); }
 
     static size_t lds_bytes(const ModelSlot& m, uint32_t n_frames)
     {
@@ -457,7 +460,9 @@ struct aidax_pool {
             auto refused = [&](hipError_t e) {
                 if (e != hipErrorCooperativeLaunchTooLarge) return false;
                 (void)hipGetLastError();
-                lp_off.store(true, std::memory_order_relaxed);
+                m.lp_refused = true;                          // this model's grid; a pool-wide lp_off is for give-ups (co-tenants)
+                lp_refusals.fetch_add(1, std::memory_order_relaxed);
+                set_error("a chained grid cannot be co-resident on this device (cooperative launch refused): the model is served by k_mfma");
                 return true;
             };
             // k_mfma_ls over the pass's streams: one launch, or one per range of lp_round_streams streams (every range a resident grid)
@@ -703,7 +708,10 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
     // wins by x1.4..1.65, and LSTM-80 (the four-wave geometry) pays up to two grids' worth of streams only
     const bool ranges_pay = rg_env || (ms.mdesc.hidden >= 64 && (ms.mdesc.hidden != 80 || ms.mdesc.L[0].cell != 0 || lp_groups <= static_cast<size_t>(cus)));
     const bool ls_rounds = ls_ok && ranges_pay && round_groups >= (rg_env ? 1u : 8u) && lp_groups > round_groups && !(lp && lp[0] == '1');
-    const bool lp_pays = lp ? lp[0] != '0' : (lp_rounds_ok || ls_rounds || (ls_ok && !lp_chained) || lp_groups * static_cast<size_t>(ms.mdesc.n_layers) <= static_cast<size_t>(cus));
+    // (the grid a chained launch asks for: workgroup ids come in eights, so the group count is rounded up — the padded workgroups return
+    // at once, but a cooperative launch counts them: 85 groups x 3 layers are 264 workgroups, not 255)
+    const size_t lp_blocks = (lp_groups + 7) / 8 * 8 * static_cast<size_t>(ms.mdesc.n_layers);
+    const bool lp_pays = lp ? lp[0] != '0' : (lp_rounds_ok || ls_rounds || (ls_ok && !lp_chained) || lp_blocks <= static_cast<size_t>(cus));
     if (ms.kind == ModelSlot::MFMA && mfma_lp_serves(ms.mdesc) && lp_pays && !(lp_chained && p.lp_off.load()) &&
         mfma_lp_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024 && (!lp_chained || lp_gate().acquire(p.device, &p, &p.lp_off))) {
         if (lp_chained) ms.lp_owner = &p;

@@ -28,6 +28,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/aidax.h"
 #include "lv2_min.h"
@@ -152,15 +153,34 @@ bool hub_join(Plugin* self, const aidax_model* model, aidax_hub** hub_out, int32
 {
     const std::string key = aidax_model_path(model);
     std::lock_guard<std::mutex> g(g_hub_mu);
-    // a hub of this file with a free seat (the one this instance sits in now counts: its seat is given back after the swap);
-    // none: a new hub on the least-loaded device AIDAX_DEVICE allows — that is how the instances of one file spread over GPUs
+    // Which hub (aidax_pick_hub, a pure rule tested with injected devices): an instance that already plays stays on ITS device — the
+    // first hub of this file there with a free seat (the one it sits in now counts: its seat is given back after the swap), else a new
+    // hub there — because work_response() carries its biquad memories and gain smoothers into the new seat with a device-side copy
+    // (aidax_hub_adopt; the reference keeps them across a swap, rt-neural-generic.cpp:868-875). A first join takes any hub of the file
+    // with a free seat, else opens one on the least-loaded device AIDAX_DEVICE allows — how the instances of one file spread over GPUs.
+    int current_device = -1;
+    if (self->hub)
+        for (const auto& kv : g_hubs)
+            if (kv.second.hub == self->hub) { current_device = kv.second.device; break; }
     auto range = g_hubs.equal_range(key);
-    auto it = g_hubs.end();
-    for (auto k = range.first; k != range.second; ++k)
-        if (k->second.refs < self->hub_capacity || k->second.hub == self->hub) { it = k; break; }
+    std::vector<decltype(g_hubs)::iterator> cand;
+    std::vector<int> cand_dev;
+    std::vector<uint32_t> cand_free;
+    for (auto k = range.first; k != range.second; ++k) {
+        cand.push_back(k);
+        cand_dev.push_back(k->second.device);
+        cand_free.push_back(k->second.hub == self->hub ? 1u : k->second.refs < self->hub_capacity ? static_cast<uint32_t>(self->hub_capacity - k->second.refs) : 0u);
+    }
+    int count = 0, index = -1, device = -1;
+    if (aidax_device_count(&count) != AIDAX_OK) return false;
+    {
+        std::lock_guard<std::mutex> gd(g_dev_mu);
+        if (aidax_pick_hub(cand_dev.data(), cand_free.data(), static_cast<int>(cand.size()), current_device, std::getenv("AIDAX_DEVICE"), count,
+                           g_dev_load, &index, &device) != AIDAX_OK)
+            return false;
+    }
+    auto it = index >= 0 ? cand[static_cast<size_t>(index)] : g_hubs.end();
     if (it == g_hubs.end()) {
-        const int device = place_on_device(0);
-        if (device < 0) return false;
         aidax_hub* hub = nullptr;
         const char* fr = std::getenv("AIDAX_HUB_FRAMES");
         const uint32_t max_frames = fr ? static_cast<uint32_t>(std::atoi(fr)) : 2048u;
@@ -468,6 +488,11 @@ void run(LV2_Handle instance, uint32_t n_samples)
                 while (n_samples % k != 0) ++k;                                                // k <= n_samples: ends
                 self->sliced_n = n_samples;
                 self->slice_len = n_samples / k;
+                // (said once per block length, not per call: a length with no divisor between 32 frames and the hub's block costs a
+                // pass per few frames — correct, one slice late, and far from real time)
+                if (self->slice_len < 32u)
+                    plog(self, uris->log_Note, "aidax: hub mode: a host block of %u frames goes through in %u slices of %u (no larger divisor fits the hub's %u-frame blocks): "
+                         "use a block length with a divisor in [32, %u] or raise AIDAX_HUB_FRAMES\n", n_samples, k, self->slice_len, cap, cap);
             }
             const uint32_t slice = self->slice_len;
             for (uint32_t done = 0; done < n_samples && rc == AIDAX_OK; done += slice)

@@ -345,12 +345,27 @@ def realtime_case(ax, W, local: int):
                     "gpu_call_us": {"p50": float(np.percentile(t, 50) * 1e6), "p99": float(np.percentile(t, 99) * 1e6),
                                     "p99.9": float(np.percentile(t, 99.9) * 1e6), "max": float(t.max() * 1e6),
                                     "calls": int(t.size), "calls_over_1.5x_p50": int((t > 1.5 * np.percentile(t, 50)).sum()),
-                                    "note": "the slow calls are periodic — one every ~10 ms of wall time (every 194th call at 53.6 us), 80-100 us each — "
-                                            "i.e. a timer on the host side of the spin-wait, not the kernel (its own durations under rocprofv3 "
-                                            "have no such tail): profiles/r04_rt_latency.txt"},
+                                    **slow_call_pattern(t)},
                     "gpu_realtime_factor": float((N_FRAMES / 48000.0) / np.percentile(t, 50)),
                     "cpu_one_thread_block_us": secs / 1500 * 1e6,
                     "cpu_realtime_factor": float((N_FRAMES / 48000.0) / (secs / 1500))})
+    return out
+
+
+def slow_call_pattern(t):
+    """What THIS run's slow calls (over 1.5 x p50) look like: how far apart (in calls and in wall time) and how long — measured, not
+    quoted. A fixed spacing in wall time points at a timer on the host side of the spin-wait (profiles/r04_rt_latency.txt found one
+    every ~10 ms on that box), a random one at the scheduler."""
+    import numpy as np
+    p50 = float(np.percentile(t, 50))
+    idx = np.nonzero(t > 1.5 * p50)[0]
+    out = {"slow_calls_us_p50": float(np.median(t[idx]) * 1e6) if idx.size else None}
+    if idx.size >= 3:
+        gaps = np.diff(idx)
+        start = np.concatenate([[0.0], np.cumsum(t)[:-1]])
+        wall = np.diff(start[idx])
+        out.update({"slow_call_gap_calls_p50": float(np.median(gaps)), "slow_call_gap_ms_p50": float(np.median(wall) * 1e3),
+                    "slow_call_gap_ms_iqr": [float(np.percentile(wall, 25) * 1e3), float(np.percentile(wall, 75) * 1e3)]})
     return out
 
 

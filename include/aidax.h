@@ -130,6 +130,16 @@ AIDAX_API float aidax_lpf_fc(float percent);
  * resp. when it opens a hub. */
 AIDAX_API int aidax_device_count(int* count);
 AIDAX_API int aidax_pick_device(const char* spec, int device_count, const uint32_t* load, int* device_out);
+/* aidax_pick_hub: which of the n hubs that serve one model file an instance joins (hub mode of the LV2 shell), a pure function too.
+ * hub_device[i] / hub_free_seats[i] describe hub i; current_device is the device of the hub the instance plays in NOW (a model-file
+ * swap: work() -> work_response(), rt-neural-generic.cpp:807-893), or -1 for an instance that joins its first hub. An instance
+ * that already plays STAYS ON ITS DEVICE — its seven biquad memories and both gain smoothers are carried into the new seat by a
+ * device-side copy (aidax_hub_adopt; the reference keeps them across a swap, :868-875), which two pools on different devices
+ * cannot do. *index_out: the first hub on that device with a free seat, or -1 = open a new hub, on *device_out. For a first join:
+ * the first hub with a free seat whatever its device; else a new hub on the device aidax_pick_device(spec, ...) names.
+ * AIDAX_ERR_ARG as for aidax_pick_device, or when current_device is not below device_count. */
+AIDAX_API int aidax_pick_hub(const int* hub_device, const uint32_t* hub_free_seats, int n_hubs, int current_device,
+                             const char* spec, int device_count, const uint32_t* load, int* index_out, int* device_out);
 
 /* ------------------------------------------------------- launch-form rule (diagnostic)
  * Which kernel family a pool of n_streams instances of a ONE-layer model of the reference's table (cell: AIDAX_CELL_LSTM /
@@ -347,6 +357,9 @@ AIDAX_API uint32_t aidax_hub_max_frames(const aidax_hub* h);
 AIDAX_API uint64_t aidax_hub_launches(const aidax_hub* h);
 /* ... of which were launched by the deadline with somebody missing */
 AIDAX_API uint64_t aidax_hub_deadline_launches(const aidax_hub* h);
+/* Diagnostic: hand-over give-ups of the stacked-model kernel (see aidax_pool_sync) that the hub could attribute to no pass of a chained
+ * kernel — nothing was silenced for them; a non-zero count on a healthy system is a bug report. */
+AIDAX_API uint64_t aidax_hub_faults_unmapped(const aidax_hub* h);
 
 #ifdef __cplusplus
 }

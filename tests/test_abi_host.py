@@ -195,6 +195,40 @@ def test_placement_rule_picks_the_least_loaded_candidate():
         with pytest.raises(ax.AidaxError):
             pick(bad, n)
 
+def test_hub_rule_keeps_a_playing_instance_on_its_device():
+    """aidax_pick_hub with injected devices (no GPU involved): a model-file swap of an instance that already plays must land on the
+    device it plays on — work_response() carries the biquad memories and gain smoothers seat to seat with a device-side copy
+    (rt-neural-generic.cpp:868-875 keeps them), which pools on two devices cannot do — whatever the loads say; a FIRST join spreads."""
+    ax = importlib.import_module("aidadsp-lv2_amd")
+    pick = ax.pick_hub
+    # first join, no hub of the file yet: a new hub on the least-loaded candidate
+    assert pick([], [], -1, "auto", 4, [2, 1, 0, 3]) == (-1, 2)
+    assert pick([], [], -1, None, 4, [9, 0, 0, 0]) == (-1, 0)                       # AIDAX_DEVICE unset: device 0
+    # first join, hubs of the file exist: the first with a free seat, wherever it is
+    assert pick([1, 3], [0, 2], -1, "auto", 4, [0, 5, 0, 5]) == (1, 3)
+    assert pick([1, 3], [0, 0], -1, "auto", 4, [4, 5, 1, 5]) == (-1, 2)             # all full: a new hub, least-loaded device
+    # a playing instance (device 1): hubs elsewhere do not count, however idle those devices are
+    assert pick([0, 2, 1], [8, 8, 1], 1, "auto", 4, [0, 9, 0, 0]) == (2, 1)
+    assert pick([0, 2, 1], [8, 8, 0], 1, "auto", 4, [0, 9, 0, 0]) == (-1, 1)        # its device's hub is full: a NEW hub there
+    assert pick([0, 2], [8, 8], 1, "auto", 4, [0, 9, 0, 0]) == (-1, 1)              # the file has no hub on its device yet
+    assert pick([], [], 3, "0", 4) == (-1, 3)                                       # ... even when AIDAX_DEVICE now names another
+    # twenty swaps of instances spread over four devices: nobody ever changes device
+    hubs_dev, hubs_free = [0, 1, 2, 3], [1, 1, 1, 1]
+    for k in range(20):
+        cur = k % 4
+        idx, dev = pick(hubs_dev, hubs_free, cur, "auto", 4, [k, 0, 0, 0])
+        assert dev == cur and (idx == -1 or hubs_dev[idx] == cur)
+        if idx >= 0:
+            hubs_free[idx] -= 1
+        else:
+            hubs_dev.append(dev)
+            hubs_free.append(3)
+    with pytest.raises(ax.AidaxError):
+        pick([], [], 4, "auto", 4)                                                  # current device beyond the machine
+    with pytest.raises(ax.AidaxError):
+        pick([], [], -1, "7", 4)                                                    # a first join still needs a valid AIDAX_DEVICE
+
+
 def test_device_calls_fail_loudly_without_a_gpu():
     import torch
     if torch.cuda.is_available():

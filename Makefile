@@ -23,7 +23,7 @@ HIPFLAGS := --offload-arch=$(ARCH) $(CXXFLAGS) -fno-slp-vectorize
 
 HOST_SRCS := $(SRC)/aidax_model.cpp $(SRC)/aidax_dsp_host.cpp $(SRC)/aidax_pack.cpp $(SRC)/aidax_pool.cpp $(SRC)/aidax_hub.cpp
 HOST_OBJS := $(patsubst $(SRC)/%.cpp,$(OBJDIR)/%.o,$(HOST_SRCS))
-KERN_OBJS := $(OBJDIR)/aidax_kernels.o $(OBJDIR)/aidax_stack.o $(OBJDIR)/aidax_mfma.o $(OBJDIR)/aidax_mfmalp_p1.o $(OBJDIR)/aidax_mfmalp_p2.o $(OBJDIR)/aidax_mfmalp_p3.o $(OBJDIR)/aidax_mfmalp_p4.o $(OBJDIR)/aidax_convm.o $(OBJDIR)/aidax_quad.o $(OBJDIR)/aidax_q4.o
+KERN_OBJS := $(OBJDIR)/aidax_kernels.o $(OBJDIR)/aidax_stack.o $(OBJDIR)/aidax_mfma.o $(OBJDIR)/aidax_mfmalp_p1.o $(OBJDIR)/aidax_mfmalp_p2.o $(OBJDIR)/aidax_mfmalp_p3.o $(OBJDIR)/aidax_mfmalp_p4.o $(OBJDIR)/aidax_convm.o $(OBJDIR)/aidax_convs.o $(OBJDIR)/aidax_quad.o $(OBJDIR)/aidax_q4.o
 HDRS      := $(wildcard $(SRC)/*.h) include/aidax.h
 
 LV2SO := $(PKG)/lv2/rt-neural-generic.so

@@ -423,7 +423,7 @@ __device__ __forceinline__ void chain_load(ChainPass& c, const StreamCtl& ctl, c
 // Measurement build only (make EXTRA=-DAIDAX_CONV_TRACE ..., scratch/conv_trace.py): shader-clock stamps of the fused conv
 // kernel's chain wave, left in the first floats of the stream's output row.
 #ifdef AIDAX_CONV_TRACE
-__device__ __forceinline__ unsigned long long* cv_trace() { __shared__ unsigned long long t[16]; return t; }
+__device__ __forceinline__ unsigned long long* cv_trace() { __shared__ unsigned long long t[32]; return t; }
 #define CV_STAMP(k) do { if ((threadIdx.x & 63) == 0) cv_trace()[k] = clock64(); } while (0)
 #else
 #define CV_STAMP(k) do { } while (0)

@@ -78,5 +78,7 @@ void split_bf16x3(float x, uint16_t (&terms)[3]);     // x = t0 + t1 + t2 exactl
 std::vector<float> pack_quad(const aidax_model& m, uint32_t* bias_off, uint32_t* dense_off);   // table models only
 std::vector<float> pack_q4(const aidax_model& m);       // LSTM-32, one input: the record k_lstm_q4 reads
 std::vector<float> pack_conv(const aidax_model& m, ConvDesc* d, uint32_t* state_floats);
+int  conv_ms_tap(int ksize, int pos);
+bool conv_ms_shape_ok(const ConvDesc& d);
 
 }  // namespace aidax

@@ -73,6 +73,10 @@ size_t convm_lds_bytes(const ConvDesc& d, uint32_t n_frames);
 int convm_resident_streams(const ConvDesc& d, uint32_t n_frames, int device);                 // workgroups of the fused form resident at once
 hipError_t launch_conv_mfma_kernel(const LaunchArgs& a, const ConvDesc& d, bool fused, hipStream_t stream);   // n_frames <= 256; fused: whole run()
 hipError_t launch_conv_kernel(const LaunchArgs& a, const ConvDesc& d, hipStream_t stream);
+// k_conv_ms (aidax_convs.hip): the conv stacks conv_ms_shape_ok admits, as bf16 term products; its own history layout (ConvDesc::ms_*)
+size_t convs_lds_bytes();
+int convs_resident_streams(int device);
+hipError_t launch_conv_ms_kernel(const LaunchArgs& a, const ConvDesc& d, bool fused, hipStream_t stream);   // n_frames <= 256; fused: whole run()
 hipError_t launch_set_pending(StreamState* st, uint32_t n_streams, int32_t stream, uint32_t bits, hipStream_t q);
 hipError_t launch_init_streams(StreamState* st, uint32_t n, hipStream_t q);
 hipError_t launch_stage_params(const StreamState* live, StreamState* staged, uint32_t n, hipStream_t q);

@@ -230,7 +230,21 @@ struct ConvLayer {
     // Both carry the factor 2 log2(e) on tanh layers: tanh(x) = 1 - 2 / (1 + 2^(x 2 log2 e)) then costs four instructions.
     uint32_t wf_full_off;
     uint32_t bs_off;       // [16]
+    // k_conv_ms (aidax_convs.hip): the layer as bf16 term products on v_mfma_f32_16x16x32_bf16 with the WEIGHTS as the A operand —
+    // [ms_ksteps][3 terms][64 lanes] fragments of 8 bf16: lane supplies row (lane & 15) = cout, columns 8 (lane >> 4) .. + 7 of a
+    // k-step of 32 = two taps x sixteen input channels (quarter q: tap ms_tap[ks][q >> 1], channels 8 (q & 1) ..); every weight
+    // (times 2 log2 e on tanh layers, like the records above) split exactly into three bf16 terms. ms_shift[ks][h]: frames back
+    // of the tap in half h of k-step ks, -1 = padding (zero weights). ms_state_off: this layer's input history in the stream's nn
+    // state in the layout of the kernel's activation plane ([3 terms][2 channel halves][hist frames][8 bf16]; layer 0: fp32 [hist]).
+    uint32_t ms_w_off;
+    int32_t  ms_ksteps;
+    int16_t  ms_shift[2][2];
+    uint32_t ms_state_off;
 };
+// k_conv_ms's activation plane: per (term, channel half) a strip of kConvsPF frames x 16 bytes — kConvsHist frames of history in
+// front of the block's 256. A layer whose history is longer reads the part beyond it straight from HBM (as B fragments).
+constexpr int kConvsHist = 128, kConvsFrames = 256, kConvsPF = kConvsHist + kConvsFrames;
+constexpr int kConvsX0 = 16;             // frames of layer 0's (scalar, fp32) input history in front of the audio row
 // k_conv_mfma's activation plane: frames per channel row = history (rounded to 4) + block (rounded to whole tiles), then up to
 // 16 (mod 64) floats (the four cin groups of an A fragment on disjoint banks)
 constexpr int kConvmFullFrames = 256;
@@ -253,6 +267,8 @@ struct ConvDesc {
     int32_t n_layers, channels, max_hist, max_k_steps;
     ConvLayer L[kMaxConvLayers];
     uint32_t wd_off, bd_off;
+    int32_t  ms_ok;             // k_conv_ms serves this stack (pack_conv: conv_ms_shape_ok)
+    uint32_t ms_state_floats;   // ... with this much state per stream (its history layout differs from k_conv's / k_conv_mfma's)
 };
 
 struct LaunchArgs {

@@ -516,6 +516,38 @@ std::vector<float> pack_q4(const aidax_model& m)
     return out;
 }
 
+// k_conv_ms (aidax_convs.hip): which tap sits at position `pos` (k-step pos / 2, channel half pos & 1) of a layer with `ksize` taps —
+// taps in pairs, the oldest first; an odd count leaves the first k-step half empty ([tap 0 | padding], then [1 | 2], ...), so that the
+// oldest tap, the one that may reach beyond the plane's history, has a k-step of its own. -1: padding (zero weights).
+int conv_ms_tap(int ksize, int pos)
+{
+    if (!(ksize & 1)) return pos < ksize ? pos : -1;
+    return pos == 0 ? 0 : pos == 1 ? -1 : pos - 1 < ksize ? pos - 1 : -1;
+}
+// Which conv stacks k_conv_ms serves: layer 0 takes the one scalar input into sixteen channels with a history of at most kConvsX0
+// frames; every other layer is sixteen channels into sixteen with two to four taps; a history reaches at most kConvsFrames frames
+// beyond the plane's kConvsHist (a source frame is then either in the plane or in the layer's history in HBM), and of a wave's
+// four frame tiles at most two (tile, k-step) pairs read from beyond the plane (they travel in registers).
+bool conv_ms_shape_ok(const ConvDesc& d)
+{
+    if (d.channels != 16 || d.n_layers < 2) return false;
+    for (int l = 0; l < d.n_layers; ++l) {
+        const ConvLayer& C = d.L[l];
+        if (C.out_ch != 16 || C.in_ch != (l == 0 ? 1 : 16) || C.ksize < 1 || C.dilation < 1 || C.activation < 0 || C.activation > 3) return false;
+        if (l == 0) { if (C.hist > kConvsX0 || C.ksize > 4) return false; continue; }
+        if (C.ksize < 2 || C.ksize > 4 || C.hist > kConvsHist + kConvsFrames) return false;
+        // pairs that reach beyond the plane, of wave 0 (tiles 0, 4, 8, 12: the earliest tiles reach furthest back): the kernel carries two
+        // register sets for them, owned by (k-step 0, j = 0) and (k-step 0, j = 1)
+        for (int ks = 0; ks < (C.ksize + 1) / 2; ++ks)
+            for (int j = 0; j < 4; ++j)
+                for (int h = 0; h < 2; ++h) {
+                    const int tap = conv_ms_tap(C.ksize, 2 * ks + h);
+                    if (tap >= 0 && 16 * (4 * j) - (C.ksize - 1 - tap) * C.dilation < -kConvsHist && (ks != 0 || j > 1)) return false;
+                }
+    }
+    return true;
+}
+
 std::vector<float> pack_conv(const aidax_model& m, ConvDesc* d, uint32_t* state_floats)
 {
     std::vector<float> out;
@@ -579,6 +611,51 @@ std::vector<float> pack_conv(const aidax_model& m, ConvDesc* d, uint32_t* state_
                 out.push_back(f);
             }
         }
+    }
+    // k_conv_ms's records (ConvLayer::ms_*), for the stacks it serves: one scalar input into sixteen channels, then sixteen into
+    // sixteen; up to four taps (two bf16 k-steps); histories the kernel's plane + at most two deep fragment pairs per wave can hold.
+    d->ms_ok = conv_ms_shape_ok(*d) ? 1 : 0;
+    if (d->ms_ok) {
+        uint32_t mst = 0;
+        for (int l = 0; l < m.n_rnn; ++l) {
+            const Layer& L = m.layers[l];
+            ConvLayer& C = d->L[l];
+            C.ms_state_off = mst;
+            mst += l == 0 ? ((static_cast<uint32_t>(C.hist) + 3u) & ~3u) : static_cast<uint32_t>(C.hist) * 24u;      // 96 bytes per frame of history
+            C.ms_ksteps = 0; C.ms_w_off = 0;
+            for (auto& r : C.ms_shift) for (auto& v : r) v = -1;
+            if (l == 0) continue;                                   // layer 0 is a few FMAs per output: the fp32 records above serve it
+            // taps in pairs, the oldest first; an odd count leaves the FIRST k-step half empty (the oldest tap — the one that may
+            // reach beyond the plane's history — then has a k-step of its own)
+            int taps[2][2] = { { -1, -1 }, { -1, -1 } };
+            const int odd = C.ksize & 1;
+            C.ms_ksteps = (C.ksize + 1) / 2;
+            for (int pos = 0; pos < 2 * C.ms_ksteps; ++pos) taps[pos / 2][pos & 1] = conv_ms_tap(C.ksize, pos);
+            (void)odd;
+            for (int ks = 0; ks < C.ms_ksteps; ++ks)
+                for (int h = 0; h < 2; ++h) C.ms_shift[ks][h] = taps[ks][h] < 0 ? int16_t(-1) : static_cast<int16_t>((C.ksize - 1 - taps[ks][h]) * C.dilation);
+            const float scale = C.activation == 1 ? kTwoLog2e : 1.0f;
+            while (out.size() % 4) out.push_back(0.f);
+            C.ms_w_off = static_cast<uint32_t>(out.size());
+            for (int ks = 0; ks < C.ms_ksteps; ++ks)
+                for (int term = 0; term < 3; ++term)
+                    for (int lane = 0; lane < kWave; ++lane) {
+                        const int co = lane & 15, q = lane >> 4, tap = taps[ks][q >> 1];
+                        for (int i = 0; i < 8; i += 2) {
+                            uint16_t t0[3] = { 0, 0, 0 }, t1[3] = { 0, 0, 0 };
+                            if (tap >= 0) {
+                                const int ci = 8 * (q & 1) + i;
+                                split_bf16x3(scale * L.w0[((size_t)tap * C.in_ch + ci) * C.out_ch + co], t0);
+                                split_bf16x3(scale * L.w0[((size_t)tap * C.in_ch + ci + 1) * C.out_ch + co], t1);
+                            }
+                            const uint32_t pair = static_cast<uint32_t>(t0[term]) | (static_cast<uint32_t>(t1[term]) << 16);
+                            float f;
+                            std::memcpy(&f, &pair, sizeof f);
+                            out.push_back(f);
+                        }
+                    }
+        }
+        d->ms_state_floats = mst;
     }
     const Layer& D = m.layers[m.n_rnn];
     d->wd_off = static_cast<uint32_t>(out.size());

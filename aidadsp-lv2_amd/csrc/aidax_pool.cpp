@@ -193,6 +193,7 @@ struct ModelSlot {
     MfmaDesc mdesc{};
     ConvDesc cdesc{};
     bool conv_mfma = false;          // conv stacks on the matrix cores (blocks of <= 256 frames), else k_conv
+    bool conv_ms = false;            // ... as bf16 term products (k_conv_ms: the stacks conv_ms_shape_ok admits; its own history layout)
     bool conv_fused = false;         // ... with the DSP chain inside the same launch (AIDAX_CONV_FUSED=0: packed k_chain launches around it)
     const KernelEntry* kernel = nullptr;
     int cell = 0, input_size = 1, input_skip = 0, hidden = 0;
@@ -508,24 +509,27 @@ struct aidax_pool {
         }
         if (m.has_model && m.kind == ModelSlot::STACK) return launch_stack_kernel(a, m.sdesc, s);
         if (m.has_model && m.kind == ModelSlot::CONV && m.conv_mfma) {
-            if (a.mode != MODE_CHAIN) return launch_conv_mfma_kernel(a, m.cdesc, false, s);
+            auto conv_launch = [&](const LaunchArgs& b, bool fused) {
+                return m.conv_ms ? launch_conv_ms_kernel(b, m.cdesc, fused, s) : launch_conv_mfma_kernel(b, m.cdesc, fused, s);
+            };
+            if (a.mode != MODE_CHAIN) return conv_launch(a, false);
             if (m.conv_fused) {
                 // the whole run() in one launch; a block longer than the kernel's 256 frames goes through in time slices,
                 // each the whole run() of its slice (the rows keep the block's pitch)
                 const uint32_t chunk = ext_chunk();
-                if (a.n_frames <= chunk) return launch_conv_mfma_kernel(a, m.cdesc, true, s);
+                if (a.n_frames <= chunk) return conv_launch(a, true);
                 hipError_t e = hipSuccess;
                 for (uint32_t done = 0; done < a.n_frames && e == hipSuccess; done += chunk) {
                     LaunchArgs b = a;
                     b.in = a.in + done; b.out = a.out + done;
                     b.n_frames = std::min(chunk, a.n_frames - done);
                     b.row_stride = a.n_frames;
-                    e = launch_conv_mfma_kernel(b, m.cdesc, true, s);
+                    e = conv_launch(b, true);
                 }
                 return e;
             }
             hipError_t e = launch_chain_pass(true, a, s);
-            if (e == hipSuccess && a.n_frames != 0) e = launch_conv_mfma_kernel(a, m.cdesc, false, s);
+            if (e == hipSuccess && a.n_frames != 0) e = conv_launch(a, false);
             if (e == hipSuccess) e = launch_chain_pass(false, a, s);
             return e;
         }
@@ -631,12 +635,18 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
         ms.kind = ModelSlot::CONV;
         wp = pack_conv(*m, &ms.cdesc, &state_floats);
         ms.conv_mfma = p.force_form != 4 && convm_lds_bytes(ms.cdesc, p.ext_chunk()) <= 160 * 1024;
+        // the stacks k_conv_ms admits run there (the contraction as bf16 term products: BASELINE cfg4 60 -> see profiles/r05_cfg4_*); its
+        // per-layer histories live in the stream's state in ITS layout, so the choice holds for the life of the model in this pool
+        // (warm-up, bare-model modes and passes all run the one kernel). AIDAX_CONV_MS=0 (test build): k_conv_mfma, the fp32 partner.
+        const char* cms = AIDAX_HOOK_ENV("AIDAX_CONV_MS");
+        ms.conv_ms = ms.conv_mfma && ms.cdesc.ms_ok && !(cms && cms[0] == '0');
+        if (ms.conv_ms) state_floats = ms.cdesc.ms_state_floats;
         // chain passes inside the conv launch while every workgroup of the pool is resident at once (their serial
         // latency is then paid once per block; in a second round of workgroups it would be paid again, and the packed
         // k_chain launches around the kernel are cheaper). AIDAX_CONV_FUSED=1 / 0 forces the form.
         const char* fused = AIDAX_HOOK_ENV("AIDAX_CONV_FUSED");
         ms.conv_fused = ms.conv_mfma && (fused ? fused[0] != '0'
-                                               : static_cast<int>(p.n_streams) <= convm_resident_streams(ms.cdesc, p.ext_chunk(), p.device));
+                                               : static_cast<int>(p.n_streams) <= (ms.conv_ms ? convs_resident_streams(p.device) : convm_resident_streams(ms.cdesc, p.ext_chunk(), p.device)));
         if (ms.conv_mfma && p.max_frames > 256) ms.conv_fused = true;      // long blocks go through in time slices: the one-launch form only
         if (!ms.conv_mfma && conv_lds_bytes(ms.cdesc, p.max_frames) > 160 * 1024)
             return fail(AIDAX_ERR_ARG, "conv model: pool max_frames too large for the LDS activation planes");
@@ -1391,7 +1401,7 @@ AIDAX_API const char* aidax_pool_kernel_name(const aidax_pool* p)
     if (m.kind == ModelSlot::MFMA && m.lstm_gs) return "k_lstm_gs";
     if (m.kind == ModelSlot::MFMA) return m.gru_gm ? (m.gru_gs ? "k_gru_gs" : "k_gru_gm") : !p->lp_in_use(m) ? "k_chain+k_mfma" : m.lp_split ? (m.mdesc.n_layers == 1 ? (m.lp_fused ? "k_mfma_ls1" : "k_chain+k_mfma_ls1") : m.lp_fused ? "k_mfma_ls" : "k_chain+k_mfma_ls") : m.lp_fused ? "k_mfma_lp" : "k_chain+k_mfma_lp";
     if (m.kind == ModelSlot::QUAD) return "k_chain+k_quad";
-    if (m.kind == ModelSlot::CONV) return m.conv_fused ? "k_conv_mfma" : m.conv_mfma ? "k_chain+k_conv_mfma" : "k_conv";
+    if (m.kind == ModelSlot::CONV) return m.conv_ms ? (m.conv_fused ? "k_conv_ms" : "k_chain+k_conv_ms") : m.conv_fused ? "k_conv_mfma" : m.conv_mfma ? "k_chain+k_conv_mfma" : "k_conv";
     const int form = p->chain_form(m);
     return form == 3 ? "k_lstm_q4<32>" : form == 1 ? m.kernel->name_pipe : form == 2 ? m.kernel->name_split : m.kernel->name;
 }

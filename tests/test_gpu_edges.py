@@ -191,7 +191,8 @@ def test_extreme_levels_denormal_silence_and_full_scale(tmp_path):
 
 
 @pytest.mark.parametrize("kw,max_frames,kernel", [
-    (dict(kind="conv", hidden=16, input_size=1, seed=3, conv_layers=5), 512, "k_conv_mfma"),         # blocks > 256: time slices of the one-launch form
+    (dict(kind="conv", hidden=16, input_size=1, seed=3, conv_layers=5), 512, "k_conv_ms"),           # blocks > 256: time slices of the one-launch form
+    (dict(kind="conv", hidden=16, input_size=1, seed=3, conv_layers=5), 512, "k_conv_mfma"),         # ... the fp32 partner (AIDAX_CONV_MS=0)
     (dict(kind="conv", hidden=16, input_size=1, seed=3, conv_layers=5), 512, "k_conv"),              # ... and the VALU conv with the whole block in LDS (AIDAX_KERNEL=valu)
     (dict(kind="lstm", hidden=48, input_size=2, seed=4, n_rnn=2), 2048, "k_chain+k_mfma_ls"),             # longest block of the packed chains
     (dict(kind="lstm", hidden=20, input_size=1, seed=5, n_rnn=2), 256, "k_mfma_ls"),                      # 20 units run zero-padded to 32 (one launch: blocks of one staging chunk)
@@ -203,6 +204,8 @@ def test_extension_fallback_kernels_for_long_blocks(kw, max_frames, kernel, tmp_
     import importlib
     if kernel == "k_conv":
         monkeypatch.setenv("AIDAX_KERNEL", "valu")
+    if kernel == "k_conv_mfma":
+        monkeypatch.setenv("AIDAX_CONV_MS", "0")
     ax = importlib.import_module("aidadsp-lv2_amd")
     j = modelgen.make_model(**kw)
     path = modelgen.write_model(j, str(tmp_path / "m.json"))

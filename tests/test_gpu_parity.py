@@ -41,7 +41,7 @@ def _ctl_pair(**kw):
 def _canon(kernel_name):
     """Stacked models run on k_mfma_ls (contractions as bf16 term products) where their split fragments fit the register file,
     else on k_mfma_lp (fp32 MFMAs; AIDAX_LP_SPLIT=0 forces it): the same launch forms, named alike here."""
-    return kernel_name.replace("k_mfma_ls", "k_mfma_lp")
+    return kernel_name.replace("k_mfma_ls", "k_mfma_lp").replace("k_conv_ms", "k_conv_mfma")      # (... and the conv stacks k_conv_ms admits run there, bf16 term products too)
 
 
 def _run_gpu(pool, x, block):
@@ -317,8 +317,9 @@ def test_activate_and_model_swap_semantics(tmp_path, bundled_models):
 
 @pytest.mark.parametrize("first,env", [
     (dict(kind="lstm", hidden=16, input_size=1, seed=3), {}),                             # table kernel, no PARAM input
-    (dict(kind="conv", hidden=16, input_size=1, seed=4), {}),                             # k_conv_mfma, chain passes inside
-    (dict(kind="conv", hidden=16, input_size=1, seed=4), {"AIDAX_CONV_FUSED": "0"}),      # k_chain + k_conv_mfma + k_chain
+    (dict(kind="conv", hidden=16, input_size=1, seed=4), {}),                             # k_conv_ms, chain passes inside
+    (dict(kind="conv", hidden=16, input_size=1, seed=4), {"AIDAX_CONV_FUSED": "0"}),      # k_chain + k_conv_ms + k_chain
+    (dict(kind="conv", hidden=16, input_size=1, seed=4), {"AIDAX_CONV_MS": "0"}),         # k_conv_mfma (fp32 MFMAs)
     (dict(kind="conv", hidden=16, input_size=1, seed=4), {"AIDAX_KERNEL": "valu"}),       # k_conv
     (dict(kind="lstm", hidden=32, input_size=1, seed=5, n_rnn=2), {}),                    # k_mfma_lp
 ])
@@ -594,7 +595,7 @@ def test_long_run_drift_small_gru_on_the_pipeline_kernel(tmp_path):
 @pytest.mark.parametrize("name,kw,S,ckw,kernel", [
     ("cfg2", dict(kind="lstm", hidden=32, input_size=1, seed=32), 1024, {}, "k_lstm_pipe<32>"),
     ("cfg3", dict(kind="gru", hidden=64, input_size=3, seed=64), 4096, _EQ_POST, "k_gru_gs"),                     # one launch: gate-major tiles, the chain on the helper waves
-    ("cfg4", dict(kind="conv", hidden=16, input_size=1, seed=1608), 1024, {}, "k_conv_mfma"),
+    ("cfg4", dict(kind="conv", hidden=16, input_size=1, seed=1608), 1024, {}, "k_conv_ms"),
     ("cfg5", dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2), 2048, {}, "k_mfma_ls"),
     ("lstm80-1k", dict(kind="lstm", hidden=80, input_size=2, seed=80), 1024, dict(param1=0.7), "k_chain+k_quad"),
     ("lstm80-2k", dict(kind="lstm", hidden=80, input_size=2, seed=80), 2048, dict(param1=0.7), "k_mfma_ls1"),      # a lone layer on k_mfma_ls's body
@@ -731,14 +732,21 @@ def test_random_conv_architectures(seed, tmp_path, monkeypatch):
     x = modelgen.signal(S, sum(sizes), seed=300 + seed)
     cg, co = _ctl_pair(pregain_db=1.5, bass_boost_db=-2.0)
     want = O.run_streams(spec, co, x, 256)
-    for env, name in (({}, "k_conv_mfma"), ({"AIDAX_CONV_FUSED": "0"}, "k_chain+k_conv_mfma"), ({"AIDAX_KERNEL": "valu"}, "k_conv")):
-        for k_, v in (("AIDAX_CONV_FUSED", None), ("AIDAX_KERNEL", None)):
+    seen = set()
+    for env, name in (({}, "k_conv_mfma"), ({"AIDAX_CONV_MS": "0"}, "k_conv_mfma"), ({"AIDAX_CONV_FUSED": "0"}, "k_chain+k_conv_mfma"), ({"AIDAX_KERNEL": "valu"}, "k_conv")):
+        for k_, v in (("AIDAX_CONV_FUSED", None), ("AIDAX_KERNEL", None), ("AIDAX_CONV_MS", None)):
             monkeypatch.delenv(k_, raising=False)
         for k_, v in env.items():
             monkeypatch.setenv(k_, v)
         pool = ax.Pool(S, 256)
         pool.set_model(ax.Model(path))
-        assert pool.kernel_name == name, (pool.kernel_name, name, C_, nl, k)
+        # (the stacks k_conv_ms admits — sixteen channels, two to four taps, histories its plane holds — run there unless AIDAX_CONV_MS=0)
+        assert _canon(pool.kernel_name) == name, (pool.kernel_name, name, C_, nl, k)
+        assert not ("k_conv_ms" in pool.kernel_name and env.get("AIDAX_CONV_MS") == "0")
+        if pool.kernel_name in seen:
+            pool.close()
+            continue
+        seen.add(pool.kernel_name)
         pool.set_controls(cg)
         got = np.empty_like(x)
         pos = 0
@@ -805,7 +813,7 @@ def test_conv_stack_on_a_pool_with_long_blocks(tmp_path):
     cg, co = _ctl_pair(bass_boost_db=3.0, pregain_db=2.0, eq_position=1.0)
     big = ax.Pool(S, 2048)
     big.set_model(ax.Model(path))
-    assert big.kernel_name == "k_conv_mfma"
+    assert big.kernel_name == "k_conv_ms"
     big.set_controls(cg)
     got = np.empty_like(x)
     pos = 0
@@ -828,7 +836,8 @@ def test_conv_stack_on_a_pool_with_long_blocks(tmp_path):
     assert np.array_equal(got, ref)
 
 
-def test_conv_fused_launch_is_bit_identical_to_split_launches(tmp_path, monkeypatch):
+@pytest.mark.parametrize("ms", ["1", "0"])
+def test_conv_fused_launch_is_bit_identical_to_split_launches(ms, tmp_path, monkeypatch):
     """The conv stack's one-launch form (chain passes inside k_conv_mfma) against packed k_chain launches around the
     same kernel: same operations per sample in the same order, so every output sample and the carried state agree
     to the bit — ragged blocks incl. 0 and 1 frames, per-stream disable / model bypass / EQ position / bandpass."""
@@ -843,9 +852,11 @@ def test_conv_fused_launch_is_bit_identical_to_split_launches(tmp_path, monkeypa
     for fused, tune in (("1", "0"), ("0", "0"), ("1", "2048")):
         monkeypatch.setenv("AIDAX_CONV_FUSED", fused)
         monkeypatch.setenv("AIDAX_TUNE", tune)
+        monkeypatch.setenv("AIDAX_CONV_MS", ms)
         pool = ax.Pool(S, 256)
         pool.set_model(ax.Model(path))
-        assert pool.kernel_name == ("k_conv_mfma" if fused == "1" else "k_chain+k_conv_mfma")
+        base = "k_conv_ms" if ms == "1" else "k_conv_mfma"
+        assert pool.kernel_name == (base if fused == "1" else "k_chain+" + base)
         got = np.empty_like(x)
         pos = 0
         for bi, n in enumerate(sizes):

@@ -96,6 +96,8 @@ def lib() -> C.CDLL:
                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.aidax_many_streams_form.argtypes = [C.c_int, C.c_int, u32, C.c_int]
     L.aidax_many_streams_form.restype = C.c_int
+    L.aidax_many_streams_form_at.argtypes = [C.c_int, C.c_int, u32, C.c_int, u32]
+    L.aidax_many_streams_form_at.restype = C.c_int
     L.aidax_pool_create.argtypes = [u32, u32, C.c_double, C.c_int, C.POINTER(vp)]
     L.aidax_pool_destroy.argtypes = [vp]
     L.aidax_pool_destroy.restype = None
@@ -216,9 +218,9 @@ def pick_hub(hub_devices, hub_free_seats, current_device: int, spec: Optional[st
     return idx.value, out.value
 
 
-def many_streams_form(cell: int, hidden: int, n_streams: int, compute_units: int = 256) -> int:
-    """The launch-form rule for one-layer table models (pure): 0 none, 1 k_quad, 2 the 16-stream matrix-core kernels."""
-    return int(lib().aidax_many_streams_form(cell, hidden, n_streams, compute_units))
+def many_streams_form(cell: int, hidden: int, n_streams: int, compute_units: int = 256, max_frames: int = 256) -> int:
+    """aidax_many_streams_form_at: 0 per-stream forms, 1 k_quad, 2 the 16-stream matrix-core kernels"""
+    return int(lib().aidax_many_streams_form_at(cell, hidden, n_streams, compute_units, max_frames))
 
 
 def db_to_coeff(db: float) -> float:

@@ -59,14 +59,18 @@ enum ManyForm { MANY_NONE = 0, MANY_QUAD = 1, MANY_MFMA = 2 };
 // against 345 / 289 on k_quad). GRU-40 / 64 have k_gru_gs (190 us per round of 4096 streams against 244 .. 275 here); 16 units never.
 // (A GRU-80 pool this rule sends to the matrix-core forms runs k_gru_gs<5, 2> — 324 us per 4096 streams against 436 here — and LSTM-40 / 64
 // have k_lstm_gs, below; k_mfma_ls1 then serves LSTM-80, 32 units at many streams, and the A/B runs.)
-bool lone_split_pays(int cell, int hidden, uint32_t n, int cus)
+// Round 5 (profiles/r05_blocklen_forms*.txt: the table re-measured at 64- and 128-frame blocks, what a host's period really is): the
+// crossovers hold at every block length but two, both wrong at 256 frames too — see many_streams_form — and ONE moves with the block:
+// LSTM-32 at 5632 .. 6144 streams is k_mfma_ls1's from 192-frame blocks (268 against 278 us on k_nn), k_nn's below (84 / 149 us at 64 /
+// 128 frames against 93 / 152). `max_frames` is the pool's block length.
+bool lone_split_pays(int cell, int hidden, uint32_t n, int cus, uint32_t max_frames)
 {
     const bool off = [] { const char* e = AIDAX_HOOK_ENV("AIDAX_LP_SPLIT"); return e && e[0] == '0'; }();
     if (off || cus <= 0) return false;
     const bool lstm = cell == AIDAX_CELL_LSTM;
     const uint32_t groups = (n + kMfmaStreams - 1) / kMfmaStreams, c = static_cast<uint32_t>(cus);
     switch (hidden) {
-    case 32: return groups * 2 > c * 3;
+    case 32: return groups * 2 > c * 3 || (lstm && max_frames >= 192 && groups * 8 >= c * 11);
     case 40: return lstm && groups > c;
     case 64: return lstm && groups * 2 > c;
     case 80: return groups * 4 > c;
@@ -91,13 +95,17 @@ bool lstm_gs_pays(int cell, int hidden, uint32_t n, int cus)
     return hidden == 64 ? groups * 4 > c : hidden == 80 ? false : groups * 2 > c && groups <= c;
 }
 
-ManyForm many_streams_form(int cell, int hidden, uint32_t n, int cus)
+ManyForm many_streams_form(int cell, int hidden, uint32_t n, int cus, uint32_t max_frames)
 {
     if (lstm_gs_pays(cell, hidden, n, cus)) return MANY_MFMA;
     const bool lstm = cell == AIDAX_CELL_LSTM;
     const uint32_t groups = (n + kMfmaStreams - 1) / kMfmaStreams;
     const bool ls1_off = [] { const char* e = AIDAX_HOOK_ENV("AIDAX_LS1"); return e && e[0] == '0'; }();
-    if (!ls1_off && lone_split_pays(cell, hidden, n, cus)) return MANY_MFMA;
+    if (!ls1_off && lone_split_pays(cell, hidden, n, cus, max_frames)) return MANY_MFMA;
+    // Round 5: LSTM-32 between one and one and a half rounds of stream groups (4097 .. 6144 streams on 256 CUs) was k_quad's by the
+    // rule below — which nothing measured there ever supported: k_nn (the split form) is 5 .. 16 % ahead of it at every block length
+    // (5120 streams: 77 / 135 / 249 us at 64 / 128 / 256 frames against 84 / 146 / 271), and k_mfma_ls1 takes over above (lone_split_pays).
+    if (lstm && hidden == 32 && cus > 0 && groups > static_cast<uint32_t>(cus) && groups * 2 <= static_cast<uint32_t>(cus) * 3) return MANY_NONE;
     const bool full_round = cus > 0 && groups <= static_cast<uint32_t>(cus) && groups * 8 > static_cast<uint32_t>(cus) * 7;
     if (full_round && (hidden == 32 || hidden == 64 || (hidden == 40 && lstm))) return MANY_MFMA;
     // One-layer GRUs of 40 (run as 48) / 64 units have k_gru_gm (gate-major tiles: three quarters of the matrix-core work,
@@ -110,8 +118,10 @@ ManyForm many_streams_form(int cell, int hidden, uint32_t n, int cus)
     // GRU-40 from the point where k_nn needs a second round of waves (2048 streams: 174 us; 2560: 279). AIDAX_GRU_GM=f32 (the
     // fp32 MFMA kernel, 305 us) keeps round 3's thresholds.
     const bool gm_f32 = [] { const char* e = AIDAX_HOOK_ENV("AIDAX_GRU_GM"); return e && e[0] == 'f'; }();
-    if (!lstm && cus > 0 && !gm_f32 &&
-        ((hidden == 64 && groups * 16 >= static_cast<uint32_t>(cus)) || (hidden == 40 && groups * 2 > static_cast<uint32_t>(cus))))
+    // Round 5: GRU-64 is k_gru_gs's at EVERY pool size, the one-stream pool of an LV2 instance included — 49.9 / 93.1 / 179 us per block
+    // of 64 / 128 / 256 frames at one stream against 55.4 / 99.1 / 187 on k_quad, 54 / 99 / 188 against 64 / 108 / 197 at 16 .. 192 streams
+    // (the 256-stream threshold of round 4 was measured at 256 frames only, where the gap is 4 %; at a 64-frame period it is 19 %).
+    if (!lstm && cus > 0 && !gm_f32 && (hidden == 64 || (hidden == 40 && groups * 2 > static_cast<uint32_t>(cus))))
         return MANY_MFMA;
     if (!lstm && cus > 0 && ((hidden == 64 && groups * 8 >= static_cast<uint32_t>(cus) * 5) || (hidden == 40 && groups * 8 >= static_cast<uint32_t>(cus) * 7)))
         return MANY_MFMA;
@@ -338,12 +348,12 @@ struct aidax_pool {
     bool quad_for_table_model(int cell_kind, int hidden_units) const
     {
         if (force_form == 6) return true;
-        return force_form == 0 && many_streams_form(cell_kind, hidden_units, n_streams, cus) == MANY_QUAD;
+        return force_form == 0 && many_streams_form(cell_kind, hidden_units, n_streams, cus, max_frames) == MANY_QUAD;
     }
     bool mfma_for_table_model(int cell_kind, int hidden_units) const
     {
         if (force_form == 5) return true;
-        return force_form == 0 && many_streams_form(cell_kind, hidden_units, n_streams, cus) == MANY_MFMA;
+        return force_form == 0 && many_streams_form(cell_kind, hidden_units, n_streams, cus, max_frames) == MANY_MFMA;
     }
     bool use_pipe(const ModelSlot& m) const
     {
@@ -706,7 +716,7 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
     const char* sp_env = AIDAX_HOOK_ENV("AIDAX_LP_SPLIT");
     // (a lone layer on k_mfma_ls: AIDAX_LS1=1 / 0 forces it on / off)
     const char* ls1_env = AIDAX_HOOK_ENV("AIDAX_LS1");
-    const bool ls1 = !lp_chained && (ls1_env ? ls1_env[0] != '0' : lone_split_pays(m->cell, m->hidden, p.n_streams, cus));
+    const bool ls1 = !lp_chained && (ls1_env ? ls1_env[0] != '0' : lone_split_pays(m->cell, m->hidden, p.n_streams, cus, p.max_frames));
     const bool ls_ok = ms.kind == ModelSlot::MFMA && (lp_chained || ls1) && mfma_ls_serves(ms.mdesc) && !(sp_env && sp_env[0] == '0') &&
                        mfma_ls_lds_bytes(ms.mdesc, p.max_frames) <= 160 * 1024;
     const char* rg_env = AIDAX_HOOK_ENV("AIDAX_LP_ROUND_GROUPS");      // (tests: ranges of this many stream groups, so that a small pool goes out in several)
@@ -1390,7 +1400,11 @@ AIDAX_API int aidax_pool_read_state(aidax_pool* p, uint32_t stream, int layer, f
 
 AIDAX_API int aidax_many_streams_form(int cell, int hidden, uint32_t n_streams, int compute_units)
 {
-    return static_cast<int>(many_streams_form(cell, hidden, n_streams, compute_units));
+    return static_cast<int>(many_streams_form(cell, hidden, n_streams, compute_units, 256));
+}
+AIDAX_API int aidax_many_streams_form_at(int cell, int hidden, uint32_t n_streams, int compute_units, uint32_t max_frames)
+{
+    return static_cast<int>(many_streams_form(cell, hidden, n_streams, compute_units, max_frames));
 }
 
 AIDAX_API const char* aidax_pool_kernel_name(const aidax_pool* p)

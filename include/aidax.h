@@ -149,6 +149,10 @@ AIDAX_API int aidax_pick_hub(const int* hub_device, const uint32_t* hub_free_sea
  * function (no HIP call, environment switches apply): the decision table of csrc/aidax_pool.cpp, measured at 256-frame blocks on
  * 256 CUs; exported so that hosts and tests can see what a pool size will run on. */
 AIDAX_API int aidax_many_streams_form(int cell, int hidden, uint32_t n_streams, int compute_units);
+/* ... for a pool made for blocks of max_frames frames (the reference's run() is called with the HOST's period, rt-neural-generic.cpp:484:
+ * 64 or 128 frames on MOD devices and low-latency set-ups). The table was re-measured at 64 / 128 / 256 frames (profiles/r05_blocklen_forms*.txt):
+ * one crossover moves with the block length (LSTM-32 at 5632 .. 6144 streams); aidax_many_streams_form is this function at 256 frames. */
+AIDAX_API int aidax_many_streams_form_at(int cell, int hidden, uint32_t n_streams, int compute_units, uint32_t max_frames);
 
 /* -------------------------------------------------------------------- pool */
 typedef struct aidax_pool aidax_pool;

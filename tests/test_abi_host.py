@@ -160,9 +160,16 @@ def test_launch_form_rule_for_one_layer_table_models(monkeypatch):
     assert [f(LSTM, 64, n) for n in (64, 1024, 1025, 4096, 16384)] == [1, 1, 2, 2, 2]
     assert [f(LSTM, 40, n) for n in (256, 512, 2048, 2049, 4096, 8192)] == [0, 1, 1, 2, 2, 2]
     # GRU-64 on k_gru_gs from sixteen stream groups (241 streams), GRU-40 from 2049; the 80-unit cells on the matrix cores beyond 1024 streams
-    assert [f(GRU, 64, n) for n in (240, 241, 4096)] == [1, 2, 2]          # (sixteen stream groups of 16)
+    assert [f(GRU, 64, n) for n in (1, 240, 241, 4096)] == [2, 2, 2, 2]    # round 5: at every size, the one-stream pool included (profiles/r05_blocklen_forms3.txt)
     assert [f(GRU, 40, n) for n in (2048, 2049)] == [0, 2]
     assert [f(GRU, 80, n) for n in (1024, 1025)] == [1, 2] and [f(LSTM, 80, n) for n in (1024, 1025)] == [1, 2]
+    # round 5, the table at the block lengths a host really uses (rt-neural-generic.cpp:484: run() gets the host's period): LSTM-32 between
+    # one and one and a half rounds of stream groups belongs to the split form (k_nn), not to k_quad; from 352 groups (5617 streams) and
+    # 192-frame blocks to k_mfma_ls1 — the one crossover that moves with the block length
+    assert [f(LSTM, 32, n) for n in (4096, 4097, 5120, 5616, 5617, 6144, 6145)] == [2, 0, 0, 0, 2, 2, 2]
+    assert [f(LSTM, 32, n, 256, 64) for n in (4096, 4097, 5120, 5616, 5617, 6144, 6145)] == [2, 0, 0, 0, 0, 0, 2]
+    assert [f(LSTM, 32, n, 256, 128) for n in (5617, 6144, 6145)] == [0, 0, 2] and [f(LSTM, 32, n, 256, 192) for n in (5617, 6144)] == [2, 2]
+    assert [f(GRU, 64, n, 256, 64) for n in (1, 64, 4096)] == [2, 2, 2] and [f(LSTM, 64, n, 256, 64) for n in (1024, 1025)] == [1, 2]
     # half the CUs (a partitioned device): the stream counts of the crossovers halve
     assert [f(LSTM, 64, n, 128) for n in (512, 513)] == [1, 2] and [f(GRU, 80, n, 128) for n in (512, 513)] == [1, 2]
     # switches: read per call

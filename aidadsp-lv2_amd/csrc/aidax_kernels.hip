@@ -767,6 +767,12 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
                     // frame loop is unrolled, so a frame's only LDS traffic is h (one write, H/4 broadcast reads issued
                     // straight behind it) and nothing but the recurrence sits between two frames
                     float xr[kSB];
+                    // The unrolled stage — ~1800 instructions issued by a lone wave, one per ~5 cycles — starts on a 64-byte boundary.
+                    // Where it falls is otherwise an accident of everything in front of it in the code object: the shipped build of
+                    // round 5 (the kernels' tune tests compiled out: a few instructions fewer in front) ran cfg2 at 68.5 - 68.9 us, the
+                    // test build of the SAME loop at 66.2 - 66.5; with the boundary both run 66.4 - 66.7 (any start inside the line measures
+                    // the same: profiles/r05_cfg2_alignment.txt).
+                    asm volatile(".p2align 6");
 #pragma unroll
                     for (int q = 0; q < kSB / 4; ++q) {
                         const float4 v = reinterpret_cast<const float4*>(stage)[q];

@@ -12,7 +12,7 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
 py=$(command -v python3)
-bench="$root/bench.py --workload $wl --steps $steps --warmup 50 --no-cpu-baseline --no-check --no-others --no-traffic"
+bench="$root/bench.py --workload $wl --steps $steps --warmup 50 --no-cpu-baseline --no-check --no-others --no-traffic --no-dist"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o r -- $py $bench > "$out/trace.log" 2>&1
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$out/pmc_fetch" -o r -- $py $bench > "$out/pmc_fetch.log" 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$out/pmc_write" -o r -- $py $bench > "$out/pmc_write.log" 2>&1

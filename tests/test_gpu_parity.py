@@ -758,6 +758,62 @@ def test_random_conv_architectures(seed, tmp_path, monkeypatch):
         pool.close()
 
 
+_MS_STACKS = [
+    # (layer 0: taps, dilation), then (taps, dilation, activation) per sixteen-channel layer — what k_conv_ms admits (conv_ms_shape_ok), corners first
+    ("cfg4-like", (3, 1), [(3, 2, "tanh"), (3, 4, "tanh"), (3, 8, "tanh"), (3, 16, "tanh"), (3, 32, "tanh"), (3, 64, "tanh"), (3, 128, "tanh")]),   # last layer: 256 frames back, beyond the plane
+    ("two taps, one deep", (2, 3), [(2, 200, "relu"), (2, 1, "tanh")]),                                   # 200 frames back: tiles 0 .. 4 read the history in HBM
+    ("four taps, two deep taps in one k-step", (4, 5), [(4, 85, "tanh"), (4, 1, "sigmoid"), (4, 7, "")]),      # shifts 255 / 170 share k-step 0: per-lane sources
+    ("four taps, 64 apart", (1, 1), [(4, 64, "tanh"), (4, 42, "relu")]),                                 # shift 192: tiles 0 .. 3 deep; layer 0 with ONE tap
+    ("odd dilations", (3, 8), [(3, 3, "tanh"), (3, 9, "tanh"), (3, 27, ""), (3, 81, "tanh"), (2, 127, "sigmoid")]),   # shifts that are no multiples of 16: unaligned reads
+    ("history = the plane's", (2, 16), [(3, 64, "tanh"), (2, 128, "tanh"), (4, 42, "tanh")]),            # 128 frames back: the last in-plane frame
+]
+
+
+@pytest.mark.parametrize("name,l0,rest", _MS_STACKS, ids=[s[0] for s in _MS_STACKS])
+def test_conv_stacks_on_the_split_kernel_corners(name, l0, rest, tmp_path, monkeypatch):
+    """k_conv_ms at the corners of what it admits — two to four taps (one or two bf16 k-steps, the first half empty for odd counts), histories
+    up to and beyond the 128 frames its plane holds (fragments straight from the history in HBM, lanes of one fragment from different
+    sources), dilations that are no multiples of sixteen, every activation — against the oracle and against k_conv_mfma (fp32 MFMAs) on ragged
+    blocks: short blocks on deep layers move old history up in HBM; 0- and 1-frame blocks; the split-launch form too."""
+    import zlib
+    rs = np.random.RandomState(zlib.crc32(name.encode()))
+    layers = [modelgen.conv_layer(rs, 1, 16, l0[0], l0[1], "tanh")]
+    for k, dil, act in rest:
+        layers.append(modelgen.conv_layer(rs, 16, 16, k, dil, act))
+    layers.append(modelgen.dense_layer(rs, 16))
+    j = {"in_shape": [None, None, 1], "layers": layers, "metadata": {"name": name, "samplerate": "48000"},
+         "in_skip": 1, "in_gain": -1.0, "out_gain": 2.0}
+    path = modelgen.write_model(j, str(tmp_path / "ms.json"))
+    spec = O.parse_model(j)
+    S = 6
+    sizes = [256, 100, 1, 255, 0, 64, 256, 17, 130, 3, 256, 256]
+    x = modelgen.signal(S, sum(sizes), seed=41)
+    cg, co = _ctl_pair(pregain_db=1.0, treble_boost_db=2.0)
+    want = O.run_streams(spec, co, x, 256)
+    scale = max(1.0, float(np.abs(want).max()))
+    outs = {}
+    for env, kname in (({}, "k_conv_ms"), ({"AIDAX_CONV_FUSED": "0"}, "k_chain+k_conv_ms"), ({"AIDAX_CONV_MS": "0"}, "k_conv_mfma")):
+        for k_ in ("AIDAX_CONV_FUSED", "AIDAX_CONV_MS"):
+            monkeypatch.delenv(k_, raising=False)
+        for k_, v in env.items():
+            monkeypatch.setenv(k_, v)
+        pool = ax.Pool(S, 256)
+        pool.set_model(ax.Model(path))
+        assert pool.kernel_name == kname, (name, pool.kernel_name)
+        pool.set_controls(cg)
+        got = np.empty_like(x)
+        pos = 0
+        for n in sizes:
+            got[:, pos:pos + n] = pool.process(np.ascontiguousarray(x[:, pos:pos + n]))
+            pos += n
+        pool.close()
+        assert np.isfinite(got).all()
+        errlog.bound(np.abs(got - want).max() / scale, 3e-6, "gpu_parity:conv_ms_corners")
+        outs[kname] = got
+    assert np.array_equal(outs["k_conv_ms"], outs["k_chain+k_conv_ms"])      # one launch or three: the same bits
+    errlog.bound(np.abs(outs["k_conv_ms"] - outs["k_conv_mfma"]).max() / scale, 2e-6, "gpu_parity:conv_ms_vs_mfma")
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_random_recurrent_stacks(seed, tmp_path, monkeypatch):
     """Stacked / wide recurrent models drawn at random — LSTM or GRU, 2..4 layers or one layer wider than the table,

@@ -57,7 +57,7 @@ RING = 8                  # distinct input blocks cycled through HBM
 HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: vector FP32 peak = v_mfma_f32_16x16x4_f32 peak (64 FLOP/clk/SIMD)
 BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA peak (~2.5 PFLOP/s)
-SPLIT_PRODUCTS = 6        # k_gru_gs / k_mfma_ls: bf16 term products issued per fp32 product (operands split exactly into three bf16 terms)
+SPLIT_PRODUCTS = 6        # k_gru_gs / k_mfma_ls / k_conv_ms: bf16 term products issued per fp32 product (operands split exactly into three bf16 terms)
 N_SIMDS = 1024            # 256 CUs x 4
 NOMINAL_GHZ = 2.4
 ALGO_BYTES_PER_SAMPLE = 8
@@ -75,7 +75,7 @@ WORKLOADS = {
                  flops=2 * (3 * 64 * (64 + 3) + 64) + 63 + 6, bound="hbm", split_flops=2 * 3 * 64 * 64, fetch_wide="audio",
                  text="cfg3: GRU-64 conditioned (PARAM1+PARAM2) pedal model + 5-band EQ post, 4096 streams x 256-frame blocks"),
     "cfg4": dict(model=dict(kind="conv", hidden=16, input_size=1, seed=1608), streams=1024, controls={},
-                 flops=2 * (3 * 1 * 16 + 7 * 3 * 16 * 16 + 16) + 63 + 6, bound="hbm", fetch_wide="all",
+                 flops=2 * (3 * 1 * 16 + 7 * 3 * 16 * 16 + 16) + 63 + 6, bound="hbm", split_flops=2 * 7 * 3 * 16 * 16, fetch_wide="all",
                  text="cfg4: dilated conv1d stack (8 layers, 16 channels, k=3), 1024 streams/GPU (8192 over 8 GPUs) x 256-frame blocks"),
     "cfg5": dict(model=dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2), streams=2048, controls={},
                  flops=2 * (384 * (1 + 96) + 384 * (96 + 96) + 96), bound="mfma", split_flops=2 * (384 * 96 + 384 * 192), fetch_wide="all",
@@ -527,7 +527,7 @@ def rooflines(name, S, kernel_ms, kernel):
     comp = {"bound": "mfma" if wl["bound"] == "mfma" else "fp32", "achieved": tflops, "peak": FP32_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": tflops / FP32_PEAK_TFLOPS, "traffic": None, "kernel_ms": kernel_ms,
             "algorithmic_flops_per_launch": algo_flops}
-    if ("k_gru_gs" in kernel or "k_mfma_ls" in kernel) and wl.get("split_flops"):
+    if ("k_gru_gs" in kernel or "k_mfma_ls" in kernel or "k_conv_ms" in kernel) and wl.get("split_flops"):
         # The contraction runs on the bf16 matrix pipe: every fp32 product as SPLIT_PRODUCTS bf16 term products of operands
         # split exactly into three bf16 terms (fp32 MFMAs run at the vector rate on gfx950 and stall the VALU beside them,
         # profiles/r04_overlap.txt). What binds the kernel is then the bf16 MFMA peak against the matrix flops it EXECUTES

@@ -509,13 +509,506 @@ __global__ __launch_bounds__(kCsThreads, 4) void k_conv_ms(LaunchArgs a, ConvDes
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// k_conv_st: the same run() of the same stack as a STREAM — tile-major instead of layer-major. k_conv_ms's workgroup starts with the
+// pre pass (a lone wave, 8 us), ends with the post pass (10 us) and shares its CU's SIMDs with three other workgroups doing the same at
+// the same moments: 18 of a workgroup's 47 us are one wave per SIMD issuing dependent fp64 instructions with nothing beside it. Here the
+// block moves through the stack sixteen frames (one MFMA column tile) at a time, a TICK per tile and pipeline stage, one barrier per
+// tick:
+//     wave 0   both chain passes AT ONCE: the pre pass on lanes 0 .. 5, the post pass on lanes 6 .. 11 of the same instructions
+//              (chain_macro_step: a stage per lane, eight frames per hand-over, two steps per tick) — tile j of the input at tick j, tile j
+//              of the output d1 + 4 ticks later; then layer 7, Dense + skip / gain of the tile between them;
+//     wave 1   layer 0 (fp32 FMAs), layers 1, 2         wave 2   layers 3, 4         wave 3   layers 5, 6,
+// each a tick behind the one in front of it (FOUR waves: a fifth would put two of a workgroup's waves on one SIMD, and the CU does not then
+// take four workgroups — measured: 768 of cfg4's 1024 resident), a wave's layers back to back on the same tile (LDS runs a wave's accesses in order). A
+// layer's input lives in a RING of its own in LDS — its history plus the tiles in flight, in k_conv_ms's [term][channel half][frame]
+// vectors — so nothing is copied between layers, no history goes out and in through HBM per layer pass, and a wave keeps the A fragments
+// of its two layers in registers for the whole launch. 23 tiles of rings = 34.5 KiB: four workgroups per CU as before. What does not
+// fit comes from HBM as B fragments, requested a tick ahead: layer 6's oldest tap (128 frames back) and both old taps of layer 7
+// (256, 128) — out of the layer's history where the frame belongs to the block before (k_conv_ms's layout: the two kernels share the
+// state, ragged blocks and the split form go through k_conv_ms), out of what this launch has written where it belongs to this one
+// (layer 7's history IS the block; layer 6's takes the block's second half, the first goes to 12 KiB of scratch per stream). The new
+// histories leave as the tiles pass: the wave that reads a tile's newest tap has the very vectors the history consists of in registers.
+// Same fragments, same MFMA order, same epilogue arithmetic as k_conv_ms: the outputs are bit-identical to it.
+// Serves: exactly eight layers of three taps, dilation 2^l (BASELINE cfg4's stack; conv_st_shape_ok), blocks of exactly 256 frames, the fused form.
+constexpr int kStThreads = 256;
+// tiles of the ring in front of layer l: history / 16 + 1, + 1 where producer and consumer are different waves
+__host__ __device__ constexpr int st_nt(int l) { return l == 1 || l == 2 || l == 7 ? 2 : l == 3 || l == 4 ? 3 : l == 5 ? 6 : l == 6 ? 5 : 0; }
+__host__ __device__ constexpr int st_len(int l) { return 16 * st_nt(l); }
+__host__ __device__ constexpr int st_off(int l) { int o = 0; for (int i = 1; i < l; ++i) o += 6 * st_len(i); return o; }      // in 16-byte vectors
+constexpr int kStRingVecs = st_off(8);
+constexpr int kStStageVecs = 3 * 2 * 16;                      // [term][channel half][frame]
+// The chain moves in blocks of EIGHT frames, two steps per tick (a six-stage cascade then trails the tiles by two and a half ticks, not five:
+// the launch ends with the post pass's last stage, alone). d1 = ticks between a tile entering the pre pass and layer 0 reading it.
+constexpr int kStChainBlock = 8;
+__device__ __forceinline__ int st_d1(int Kp) { return Kp / 2 + 1; }
+__device__ __forceinline__ int st_ticks(int Kp, int Kq) { return (31 + (Kq - 1) + 2 * (st_d1(Kp) + 4)) / 2 + 1; }
+constexpr int kStHandLanes = 12;                           // pre pass: lanes 0 .. 5, post pass: lanes 6 .. 11
+constexpr int kStHandFloats = 2 * kStHandLanes * kStChainBlock;                   
+__host__ __device__ constexpr size_t convst_lds_floats()
+{
+    return (size_t)kStRingVecs * 4 + kConvsX0 + kConvsFrames /* the audio row, layer 0's input history in front */
+         + 20 /* Dense */ + 64 /* layer 0: [3 taps][16] + bias */ + 7 * 16 /* biases of layers 1 .. 7 */ + kStHandFloats
+         + kStStageVecs * 4 /* layer 6's oldest tap of the tile to come, straight from HBM (global_load_lds) */;
+}
+static_assert(convst_lds_floats() * 4 <= 40 * 1024, "four workgroups per CU");
+
+// A lane's place in a ring WALKS: frame f sits at f mod LEN, a tile later the lane reads / writes sixteen frames on — one add and a wrap
+// per tile and place (computed from the tile number every time — two taps, the writer — the ring arithmetic was ~75 scalar instructions
+// per tile and layer: a third of what a wave issued).
+template <int L> __device__ __forceinline__ int st_place0(int nl, int shift) { return (nl - shift + 16 * st_len(L)) % st_len(L); }
+template <int L> __device__ __forceinline__ void st_walk(int& p) { p += 16; p = p >= st_len(L) ? p - st_len(L) : p; }
+// the places a lane reads layer L's two k-steps from (tile 0): k-step 0 = [oldest tap | padding: the lane's own frame], k-step 1 = [middle tap | newest tap]
+struct StRead { int p0, p1; };
+template <int L> __device__ __forceinline__ StRead st_read0(int q, int nl)
+{
+    constexpr int D = 1 << L;
+    const bool lo = q < 2;
+    return StRead{ st_place0<L>(nl, lo && L <= 5 ? 2 * D : 0), st_place0<L>(nl, lo && L <= 6 ? D : 0) };
+}
+// one vector of layer L's history -> its place in the ring (v-th of the 6 hl the ring takes: strip v / hl, frame v % hl - hl)
+template <int L> __device__ __forceinline__ cs_u32x4 st_ring_fetch(const cs_u32x4* h, int v)
+{
+    constexpr int hl = L == 6 ? 64 : 2 << L, H = 2 << L;
+    if (v >= 6 * hl) return cs_u32x4{ 0u, 0u, 0u, 0u };
+    const int strip = v / hl, kf = v % hl;
+    return h[strip * H + H - hl + kf];
+}
+template <int L> __device__ __forceinline__ void st_ring_put(cs_u32x4* pl, int v, const cs_u32x4& hv)
+{
+    constexpr int hl = L == 6 ? 64 : 2 << L, LEN = st_len(L);
+    if (v >= 6 * hl) return;
+    const int strip = v / hl, f = v % hl - hl;
+    pl[st_off(L) + strip * LEN + (f + 16 * LEN) % LEN] = hv;
+}
+// the activated outputs of layer LR - 1 (a lane: channels 4q .. 4q+3 of frame 16 t + nl) -> the ring in front of layer LR, at the lane's place po
+template <int LR> __device__ __forceinline__ void st_emit(cs_u32x4* pl, int q, int& po, const f32x4& v)
+{
+    constexpr int LEN = st_len(LR);
+    cs_u32x2 tm[3];
+    cs_split4(v, tm);
+    cs_u32x2* dst = reinterpret_cast<cs_u32x2*>(pl + st_off(LR) + (q >> 1) * LEN + po) + (q & 1);
+#pragma unroll
+    for (int term = 0; term < 3; ++term) dst[term * 4 * LEN] = tm[term];
+    st_walk<LR>(po);
+}
+// One tile of layer L on the matrix cores: tile t of its input ring (+ g0 / g1: the taps that come from HBM) -> the activated outputs.
+// k-step 0 = [oldest tap | padding: the lane's own frame], k-step 1 = [middle tap | newest tap] (conv_ms_tap, three taps).
+// The new history leaves from the newest tap's registers; hist = this layer's history in HBM, scratch = layer 6's first half block.
+template <int L>
+__device__ __forceinline__ f32x4 st_tile(cs_u32x4* pl, const float* biasl, int t, const cs_u32x4 (&afr)[2][3], int q, int nl, int activation, StRead& rd,
+                                         cs_u32x4* hist, cs_u32x4* scratch, const cs_u32x4* g0, const cs_u32x4* g1, int stage_vec = 0)
+{
+    constexpr int D = 1 << L, H = 2 * D, LEN = st_len(L);
+    const cs_u32x4* ring = pl + st_off(L) + (q & 1) * LEN;
+    const bool lo = q < 2;
+    const int i0 = rd.p0, i1 = rd.p1;
+    st_walk<L>(rd.p0);
+    st_walk<L>(rd.p1);
+    // (layers 6, 7: the padding lanes of k-step 0 read what the newest tap's lanes of k-step 1 read — the lane's own frame — so the fragment
+    // that comes from HBM is completed in place, in the registers it arrived in, and nothing is read twice)
+    cs_u32x4 b0[3], b1[3];
+    if constexpr (L == 6) {
+        // the oldest tap sits in the staging area ([term][half][frame], where the wave's LDS-DMA put it a tick ago): one read per term with a
+        // per-lane base and term stride (tap lanes: the staging area; padding lanes: the ring)
+        const int a0 = lo ? stage_vec + q * 16 + nl : st_off(L) + (q & 1) * LEN + i0;
+        const int ts = lo ? 32 : 2 * LEN;
+#pragma unroll
+        for (int term = 0; term < 3; ++term) { b0[term] = pl[a0 + term * ts]; b1[term] = ring[term * 2 * LEN + i1]; }
+    } else {
+#pragma unroll
+        for (int term = 0; term < 3; ++term) {
+            b1[term] = ring[term * 2 * LEN + i1];
+            if constexpr (L <= 5) b0[term] = ring[term * 2 * LEN + i0];
+            else b0[term] = lo ? g0[term] : b1[term];
+            if constexpr (L == 7) b1[term] = lo ? g1[term] : b1[term];
+        }
+    }
+    f32x4 acc = *reinterpret_cast<const f32x4*>(biasl + (L - 1) * 16 + 4 * q);
+    // (all seven reads are on their way before the first product: left alone the compiler asks for a fragment right where it is used, and a
+    // tile pays the LDS round trip four times in a row — the wave that sets the tick has two or three tiles per tick)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int th = 0; th < 3; ++th)
+#pragma unroll
+            for (int tw = 0; tw < 3 - th; ++tw)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cs_bf16x8, afr[ks][tw]), __builtin_bit_cast(cs_bf16x8, ks == 0 ? b0[th] : b1[th]), acc, 0, 0, 0);
+    // the history: the last H frames of the block, as the vectors they are (lanes q >= 2 of k-step 1: term, half q & 1, frame 16 t + nl)
+    const int f = 16 * t + nl;
+    if constexpr (L <= 5) {
+        if (16 * t + 15 >= kConvsFrames - H && !lo && f >= kConvsFrames - H) {
+#pragma unroll
+            for (int term = 0; term < 3; ++term) hist[(term * 2 + (q & 1)) * H + f - (kConvsFrames - H)] = b1[term];
+        }
+    } else if constexpr (L == 6) {
+        if (!lo) {
+            cs_u32x4* dst = t < 8 ? scratch + f : hist + (f - 128);
+#pragma unroll
+            for (int term = 0; term < 3; ++term) dst[(term * 2 + (q & 1)) * 128] = b1[term];
+        }
+    } else {
+        if (!lo) {
+#pragma unroll
+            for (int term = 0; term < 3; ++term) hist[(term * 2 + (q & 1)) * 256 + f] = b1[term];
+        }
+    }
+    return cs_activate(acc, activation);
+}
+
+__global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDesc d)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int sg = blockIdx.x;
+    // (Which role on which wave does not matter for the SIMDs' balance: the CU rotates the wave -> SIMD assignment from one of its
+    // workgroups to the next — every SIMD carries one wave of each role as it is. Rotating the roles as well cancels that: 62.9 against
+    // 51.8 us, scratch/st_trace.py.)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, nl = lane & 15;
+    constexpr int n = kConvsFrames;
+    const size_t rstride = a.row_stride ? a.row_stride : (size_t)n;
+    cs_u32x4* pl = reinterpret_cast<cs_u32x4*>(smem);
+    float* xbuf = smem + (size_t)kStRingVecs * 4;
+    float* xrow = xbuf + kConvsX0;
+    float* wdl = xrow + kConvsFrames;                         // Dense weights [16] + bias
+    float* l0w = wdl + 20;                                    // layer 0: [tap][16] (tanh: times 2 log2 e), then its bias
+    float* biasl = l0w + 64;                                  // [layer - 1][16]
+    float* hand = biasl + 7 * 16;
+    const float* W = a.wpack;
+    float* st_base = a.nn + (size_t)sg * a.nn_stride;
+    const StreamCtl& ctl = a.ctl[sg];
+    StreamState& st = a.st[sg];
+    const float* in_row = a.in + (size_t)sg * rstride;
+    float* out_row = a.out + (size_t)sg * rstride;
+
+#ifdef AIDAX_CONV_TRACE
+    // measurement build (scratch/st_trace.py): per wave and tick, (cycles from the kernel's start to the tick's work) / 16 << 16 | cycles of work,
+    // in 256 words behind the scratch; the chain wave copies them into the output row at the end
+    uint32_t* trace = reinterpret_cast<uint32_t*>(st_base + d.st_scratch_off + 6 * 128 * 4);
+    const unsigned long long t_start = clock64();
+    const unsigned long long w_start = wall_clock64();
+    unsigned long long t_tick = t_start;
+    { unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); if (lane == 0) trace[128 + wave] = hwid; }
+#define ST_TICK_BEGIN() do { t_tick = clock64(); } while (0)
+#define ST_TICK_END(tick) do { const unsigned long long now = clock64(); if (lane == 0) trace[wave * 32 + (tick)] = (uint32_t)(((t_tick - t_start) >> 4) << 16) | (uint32_t)((now - t_tick) & 0xffff); if ((tick) + 1 == T) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+#else
+#define ST_TICK_BEGIN() do { } while (0)
+#define ST_TICK_END(tick) do { } while (0)
+#endif
+    // Everything the launch reads from memory before its first tick is requested HERE, in front of the control word the first branch depends
+    // on — reads only, whatever that branch decides: one trip to HBM instead of two or three in a row (the prologue was 5 us of a 45 us
+    // workgroup: scratch/st_trace.py). Wave 0: the audio row, the smoothers, both passes' coefficients and state by lane (a lane beyond
+    // its cascade holds some stage's numbers and does not run), layer 7's fragments; waves 1 .. 3: the rings' histories, two layers' fragments.
+    auto hist_of = [&](int l) { return reinterpret_cast<cs_u32x4*>(st_base + d.L[l].ms_state_off); };
+    auto fetch_afrags = [&](int l, cs_u32x4 (&afr)[2][3]) {
+        const cs_u32x4* rec = reinterpret_cast<const cs_u32x4*>(W + d.L[l].ms_w_off) + lane;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) afr[ks][t] = rec[(ks * 3 + t) * kWave];
+    };
+    const bool isQ = lane >= 6;
+    const int stage = isQ ? lane - 6 : lane;
+    const int slot = isQ ? post_slot(stage < 6 ? stage : 0) : pre_slot(stage < 6 ? stage : 0);
+    if (wave == 0) {
+        float4 rowv = float4{ 0.f, 0.f, 0.f, 0.f };
+        ChainPass c;
+        uint32_t pending = 0;
+        float pre_mem = 0.f, master_mem = 0.f, pre_tgt = 0.f, master_tgt = 0.f, pre_target = 0.f, master_target = 0.f, ramp_coef = 0.f;
+        cs_u32x4 afrA[2][3];
+        rowv = reinterpret_cast<const float4*>(in_row)[lane];
+        chain_load(c, ctl, st, slot, false);
+        pending = st.pending;
+        pre_mem = st.pre_mem; master_mem = st.master_mem; pre_tgt = st.pre_tgt; master_tgt = st.master_tgt;
+        pre_target = ctl.pre_target; master_target = ctl.master_target;
+        ramp_coef = isQ ? ctl.master_coef : ctl.pre_coef;
+        // (param_targets' reads: its verdict is written at the end of the launch — nothing in here waits for it)
+        const float pt0 = ctl.p_target[0], pt1 = ctl.p_target[1], p_den = ctl.p_den;
+        float ptg0 = st.p_tgt[0], ptg1 = st.p_tgt[1];
+        const float pm0 = st.p_mem[0], pm1 = st.p_mem[1];
+        fetch_afrags(7, afrA);
+        const uint32_t flags = ctl.flags;
+        if (!(flags & CTL_ENABLED) || !(flags & CTL_NET_ON)) {
+            // pre-run / bypass / the model out of circuit: the chain alone, k_conv_ms's own path for such a stream
+            if (wave != 0) return;
+            ChainCtx ctx = chain_prologue<true>(ctl, st, in_row, out_row, xrow, n, lane, hand);
+            if (!ctx.live) return;
+            chain_epilogue(ctl, st, ctx, out_row, xrow, n, lane, hand);
+            return;
+        }
+        const int Kp = (flags & CTL_EQ_PRE) ? 6 : 1, Kq = (flags & CTL_EQ_POST) ? 6 : 1;
+        const int d1 = st_d1(Kp), T = st_ticks(Kp, Kq);
+        // ---- the chain wave: lanes 0 .. 5 the pre pass's stages, lanes 6 .. 11 the post pass's (chain_prologue / chain_epilogue, side by side)
+        if (pending & PEND_ACTIVATE) { pre_mem = pre_tgt; master_mem = master_tgt; pending &= ~PEND_ACTIVATE; }
+        pre_tgt = pre_target;
+        master_tgt = master_target;
+        c.K = isQ ? Kq : Kp;
+        c.gain_lane = isQ ? Kq - 1 : 0;
+        c.active = stage == 0 ? (flags & (isQ ? CTL_DC_ON : CTL_LPF_ON)) != 0 : ((flags & CTL_EQ_BANDPASS) ? slot == BQ_MID : true);
+        c.g.arm(isQ ? master_mem : pre_mem, isQ ? master_tgt : pre_tgt, ramp_coef);
+        const bool run = lane < kStHandLanes && stage < c.K;
+        reinterpret_cast<float4*>(xrow)[lane] = rowv;
+        const double z1o = c.z1, z2o = c.z2;
+        ExpRamp g = c.g;
+        const bool is_gain = stage == c.gain_lane;
+        if (!is_gain) { g.mem = 1.f; g.coef = 1.f; g.tc = 0.f; }
+        const bool last = stage == c.K - 1;
+        const bool fussy = run && (!c.active || g.mem * g.coef + g.tc != g.mem);
+        const bool plain = __builtin_amdgcn_ballot_w64(fussy) == 0;
+        const int m0 = isQ ? 2 * (d1 + 4) : 0;
+        // ... and layer 7 (both old taps from its history in HBM, which is the block itself by the end) with the Dense(16, 1) + skip / output gain
+        const int actA = d.L[7].activation;
+        StRead rdA = st_read0<7>(q, nl);
+        cs_u32x4* h7 = hist_of(7);
+        cs_u32x4 g0[3] = { cs_u32x4{ 0u, 0u, 0u, 0u }, cs_u32x4{ 0u, 0u, 0u, 0u }, cs_u32x4{ 0u, 0u, 0u, 0u } };
+        cs_u32x4 g1[3] = { cs_u32x4{ 0u, 0u, 0u, 0u }, cs_u32x4{ 0u, 0u, 0u, 0u }, cs_u32x4{ 0u, 0u, 0u, 0u } };
+        auto fetch_g = [&](int t) {
+            if (q < 2 && t < 16) {
+                // frame f - 256: index f of the old history; frame f - 128: index f + 128 of the old history, or — the second half — f - 128 of the new
+                const cs_u32x4* s0 = h7 + (q & 1) * 256 + 16 * t + nl;
+                const cs_u32x4* s1 = h7 + (q & 1) * 256 + (t < 8 ? 16 * t + 128 : 16 * t - 128) + nl;
+#pragma unroll
+                for (int term = 0; term < 3; ++term) { g0[term] = s0[term * 2 * 256]; g1[term] = s1[term * 2 * 256]; }
+            }
+        };
+        fetch_g(0);
+        const float* wdq = wdl + 4 * q;
+        __builtin_amdgcn_s_setprio(3);
+        cs_lds_barrier();                                     // (the other waves' staging)
+        for (int tick = 0; tick < T; ++tick) {
+            ST_TICK_BEGIN();
+#pragma unroll
+            for (int hs = 0; hs < 2; ++hs) {
+                if (plain) chain_macro_step<true, kStChainBlock, kStHandLanes>(c, g, stage, run, last, xrow, hand, 32, 2 * tick + hs - m0, lane);
+                else chain_macro_step<false, kStChainBlock, kStHandLanes>(c, g, stage, run, last, xrow, hand, 32, 2 * tick + hs - m0, lane);
+            }
+            const int t = tick - d1 - 3;
+            if (t >= 0 && t < 16) {
+                const f32x4 v = st_tile<7>(pl, biasl, t, afrA, q, nl, actA, rdA, h7, nullptr, g0, g1);
+                fetch_g(t + 1);
+                float y = wdq[0] * v.x;                       // (:171-181; emit()'s arithmetic in k_conv_ms)
+                y = __builtin_fmaf(wdq[1], v.y, y);
+                y = __builtin_fmaf(wdq[2], v.z, y);
+                y = __builtin_fmaf(wdq[3], v.w, y);
+                const Pair r2 = share_rows(y);
+                y = r2.lo + r2.hi;
+                const Pair r4 = share_halves(y);
+                y = (r4.lo + r4.hi) + wdl[16];
+                const int f = 16 * t + nl;
+                const float x = xrow[f];
+                const float o = (a.input_skip ? x + y : y) * a.out_gain;
+                __builtin_amdgcn_wave_barrier();
+                if (q == 0) xrow[f] = o;
+            }
+            ST_TICK_END(tick);
+            cs_lds_barrier();
+        }
+        if (is_gain) c.g = g;
+        if (!run || !c.active) { c.z1 = z1o; c.z2 = z2o; }
+        if (run) { st.z[slot][0] = c.z1; st.z[slot][1] = c.z2; }
+        pre_mem = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c.g.mem), 0));
+        master_mem = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c.g.mem), 6 + Kq - 1));
+        reinterpret_cast<float4*>(out_row)[lane] = reinterpret_cast<const float4*>(xrow)[lane];
+#ifdef AIDAX_CONV_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int i = lane; i < 132; i += kWave) out_row[i] = __builtin_bit_cast(float, trace[i]);
+        if (lane == 0) { out_row[160] = __builtin_bit_cast(float, (uint32_t)(clock64() - t_start)); out_row[166] = __builtin_bit_cast(float, (uint32_t)blockIdx.x); out_row[161] = __builtin_bit_cast(float, (uint32_t)T);
+                         out_row[162] = __builtin_bit_cast(float, (uint32_t)(w_start & 0xffffffffu)); out_row[163] = __builtin_bit_cast(float, (uint32_t)(wall_clock64() & 0xffffffffu));
+                         unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                         out_row[164] = __builtin_bit_cast(float, hw); out_row[165] = __builtin_bit_cast(float, xcc); }
+#endif
+        if (lane == 0) {
+            // run() :634-640 for a model without PARAM inputs (param_targets, aidax_device.h): the smoothers' targets follow the controls,
+            // the first run after a load snaps them
+            if (__builtin_fabsf(ptg0 - pt0) >= FLT_EPSILON) { st.p_tgt[0] = pt0; st.p_step[0] = (pt0 - pm0) / p_den; ptg0 = pt0; }
+            if (__builtin_fabsf(ptg1 - pt1) >= FLT_EPSILON) { st.p_tgt[1] = pt1; st.p_step[1] = (pt1 - pm1) / p_den; ptg1 = pt1; }
+            if (pending & PEND_PARAM_FIRST) { pending &= ~PEND_PARAM_FIRST; st.p_mem[0] = ptg0; st.p_mem[1] = ptg1; }
+            st.pre_mem = pre_mem; st.master_mem = master_mem;
+            st.pre_tgt = pre_tgt; st.master_tgt = master_tgt;
+            st.pending = pending;
+        }
+        return;
+    }
+
+    // A layer wave loads the histories of ITS two rings — layer l's last hl frames (all of them; layer 6: the 64 its middle tap reaches), 6 hl
+    // vectors — and puts them into the rings right in front of its first tile, one to three ticks into the launch: the first tick waits for
+    // nobody's history (all of it behind the first barrier, the 18 MB the chip loads at once made a 5 us prologue).
+    // ---- waves 1 .. 3. Each is self-contained from here (no value of one role alive in another's code): its early reads, the control word,
+    // its share of the small staging — layer 0's input history and weights, the biases, the Dense: L2-resident weights —, its ticks.
+    auto out_of_circuit = [&](uint32_t flags) { return !(flags & CTL_ENABLED) || !(flags & CTL_NET_ON); };      // (wave 0 runs such a stream alone)
+    const int u = (wave - 1) * kWave + lane;                  // 0 .. 191
+    float sm_x = 0.f, sm_wd = 0.f, sm_l0 = 0.f, sm_b = 0.f;
+    {                                                         // (requested with the rest of the early reads; stored behind the control word)
+        const ConvLayer& L0 = d.L[0];
+        if (u < L0.hist) sm_x = st_base[L0.ms_state_off + u];
+        if (u < 17) sm_wd = u < 16 ? W[d.wd_off + u] : W[d.bd_off];
+        if (u >= 64 && u < 128) {
+            const int j = u - 64;
+            const float scale = L0.activation == 1 ? kTwoLog2e : 1.0f;
+            sm_l0 = j < 48 ? scale * W[L0.w_off + j] : W[L0.bs_off + j - 48];
+        }
+        if (u < 112) sm_b = W[d.L[1 + (u >> 4)].bs_off + (u & 15)];
+    }
+    auto stage_small = [&]() {
+        if (u < d.L[0].hist) xbuf[kConvsX0 - d.L[0].hist + u] = sm_x;
+        if (u < 17) wdl[u] = sm_wd;
+        if (u >= 64 && u < 128) l0w[u - 64] = sm_l0;
+        if (u < 112) biasl[u] = sm_b;
+    };
+    if (wave == 1) {
+        // ---- layer 0 (one scalar input, three taps, fp32 FMAs), layers 1, 2
+        cs_u32x4 hv[2], afrA[2][3], afrB[2][3];
+        hv[0] = st_ring_fetch<1>(hist_of(1), lane);
+        hv[1] = st_ring_fetch<2>(hist_of(2), lane);
+        fetch_afrags(1, afrA);
+        fetch_afrags(2, afrB);
+        const uint32_t flags = ctl.flags;
+        if (out_of_circuit(flags)) return;
+        const int Kp = (flags & CTL_EQ_PRE) ? 6 : 1, Kq = (flags & CTL_EQ_POST) ? 6 : 1, d1 = st_d1(Kp), T = st_ticks(Kp, Kq);
+        stage_small();
+        const ConvLayer& L0 = d.L[0];
+        const int act0 = L0.activation, act1 = d.L[1].activation, act2 = d.L[2].activation;
+        StRead rdA = st_read0<1>(q, nl), rdB = st_read0<2>(q, nl);
+        int po1 = nl, po2 = nl, po3 = nl;
+        cs_lds_barrier();
+        int tick = 0;
+        for (; tick < d1; ++tick) cs_lds_barrier();            // (nothing to do yet: the pipeline fills)
+        st_ring_put<1>(pl, lane, hv[0]);
+        st_ring_put<2>(pl, lane, hv[1]);
+        for (; tick < T; ++tick) {
+            const int t = tick - d1;
+            ST_TICK_BEGIN();
+            if (t < 16) {
+                // the tile of the model's input: x * in_gain, in place (the Dense's skip path and layer 0's history read it scaled)
+                if (lane < 16) xrow[16 * t + lane] = xrow[16 * t + lane] * a.in_gain;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                f32x4 v = *reinterpret_cast<const f32x4*>(l0w + 48 + 4 * q);
+#pragma unroll
+                for (int tap = 0; tap < 3; ++tap) {
+                    const float x = xrow[16 * t + nl - (2 - tap)];
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(l0w + tap * 16 + 4 * q);
+                    v.x = __builtin_fmaf(w.x, x, v.x); v.y = __builtin_fmaf(w.y, x, v.y);
+                    v.z = __builtin_fmaf(w.z, x, v.z); v.w = __builtin_fmaf(w.w, x, v.w);
+                }
+                if (t == 15 && lane >= 14 && lane < 16) st_base[L0.ms_state_off + lane - 14] = xrow[240 + lane];
+                st_emit<1>(pl, q, po1, cs_activate(v, act0));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                st_emit<2>(pl, q, po2, st_tile<1>(pl, biasl, t, afrA, q, nl, act1, rdA, hist_of(1), nullptr, nullptr, nullptr));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                st_emit<3>(pl, q, po3, st_tile<2>(pl, biasl, t, afrB, q, nl, act2, rdB, hist_of(2), nullptr, nullptr, nullptr));
+            }
+            ST_TICK_END(tick);
+            cs_lds_barrier();
+        }
+    } else if (wave == 2) {
+        cs_u32x4 hv[5], afrA[2][3], afrB[2][3];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) hv[r] = st_ring_fetch<3>(hist_of(3), lane + r * kWave);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) hv[2 + r] = st_ring_fetch<4>(hist_of(4), lane + r * kWave);
+        fetch_afrags(3, afrA);
+        fetch_afrags(4, afrB);
+        const uint32_t flags = ctl.flags;
+        if (out_of_circuit(flags)) return;
+        const int Kp = (flags & CTL_EQ_PRE) ? 6 : 1, Kq = (flags & CTL_EQ_POST) ? 6 : 1, d1 = st_d1(Kp), T = st_ticks(Kp, Kq);
+        stage_small();
+        const int actA = d.L[3].activation, actB = d.L[4].activation;
+        StRead rdA = st_read0<3>(q, nl), rdB = st_read0<4>(q, nl);
+        int po4 = nl, po5 = nl;
+        cs_lds_barrier();
+        int tick = 0;
+        for (; tick < d1 + 1; ++tick) cs_lds_barrier();            // (nothing to do yet: the pipeline fills)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) st_ring_put<3>(pl, lane + r * kWave, hv[r]);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) st_ring_put<4>(pl, lane + r * kWave, hv[2 + r]);
+        for (; tick < T; ++tick) {
+            const int t = tick - d1 - 1;
+            ST_TICK_BEGIN();
+            if (t < 16) {
+                st_emit<4>(pl, q, po4, st_tile<3>(pl, biasl, t, afrA, q, nl, actA, rdA, hist_of(3), nullptr, nullptr, nullptr));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                st_emit<5>(pl, q, po5, st_tile<4>(pl, biasl, t, afrB, q, nl, actB, rdB, hist_of(4), nullptr, nullptr, nullptr));
+            }
+            ST_TICK_END(tick);
+            cs_lds_barrier();
+        }
+    } else if (wave == 3) {
+        cs_u32x4 hv[12], afrA[2][3], afrB[2][3];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) hv[r] = st_ring_fetch<5>(hist_of(5), lane + r * kWave);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) hv[6 + r] = st_ring_fetch<6>(hist_of(6), lane + r * kWave);
+        fetch_afrags(5, afrA);
+        const uint32_t flags = ctl.flags;
+        if (out_of_circuit(flags)) return;
+        const int Kp = (flags & CTL_EQ_PRE) ? 6 : 1, Kq = (flags & CTL_EQ_POST) ? 6 : 1, d1 = st_d1(Kp), T = st_ticks(Kp, Kq);
+        stage_small();
+        const int actA = d.L[5].activation, actB = d.L[6].activation;
+        StRead rdA = st_read0<5>(q, nl), rdB = st_read0<6>(q, nl);
+        int po6 = nl, po7 = nl;
+        cs_u32x4* h6 = hist_of(6);
+        cs_u32x4* scratch = reinterpret_cast<cs_u32x4*>(st_base + d.st_scratch_off);
+        // layer 6's oldest tap (128 frames back) of tile t — out of the old history for the block's first half, out of the scratch for the
+        // second — goes from HBM into the staging area without passing through registers (the wave has none left: two layers' A fragments):
+        // lane (half, frame) of the low 32 lands at base + 16 lane, a term per instruction. Requested when the tile before has been read.
+        const int stage_vec = (int)(hand + kStHandFloats - smem) / 4;
+        auto fetch_g = [&](int t) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (the reads of the tile before have left the staging area)
+            if (q < 2 && t < 16) {
+                const cs_u32x4* src = (t < 8 ? h6 + 16 * t : scratch + 16 * (t - 8)) + (q & 1) * 128 + nl;
+#pragma unroll
+                for (int term = 0; term < 3; ++term) {
+                    unsigned keep;
+                    const unsigned dst = (unsigned)(size_t)(pl + stage_vec + term * 32);      // (LDS byte address: the low 32 bits of the pointer)
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(src + term * 2 * 128), "s"(dst) : "memory");
+                }
+            }
+        };
+        fetch_g(0);
+        cs_lds_barrier();
+        int tick = 0;
+        for (; tick < d1 + 2; ++tick) cs_lds_barrier();            // (nothing to do yet: the pipeline fills)
+#pragma unroll
+        for (int r = 0; r < 6; ++r) st_ring_put<5>(pl, lane + r * kWave, hv[r]);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) st_ring_put<6>(pl, lane + r * kWave, hv[6 + r]);
+        fetch_afrags(6, afrB);
+        for (; tick < T; ++tick) {
+            const int t = tick - d1 - 2;
+            ST_TICK_BEGIN();
+            if (t < 16) {
+                st_emit<6>(pl, q, po6, st_tile<5>(pl, biasl, t, afrA, q, nl, actA, rdA, hist_of(5), nullptr, nullptr, nullptr));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the staged tap has landed
+                const f32x4 v = st_tile<6>(pl, biasl, t, afrB, q, nl, actB, rdB, h6, scratch, nullptr, nullptr, stage_vec);
+                fetch_g(t + 1);
+                st_emit<7>(pl, q, po7, v);
+            }
+            ST_TICK_END(tick);
+            cs_lds_barrier();
+        }
+    }
+}
+
 size_t convs_lds_bytes() { return convs_lds_floats() * sizeof(float); }
 
-int convs_resident_streams(int device)
+
+int convs_resident_streams(int device, bool streaming_form)
 {
     int per_cu = 0, cus = 0;
     const void* fn = reinterpret_cast<const void*>(k_conv_ms<true, false>);      // (both instantiations have the same footprint)
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kCsThreads, convs_lds_bytes()) != hipSuccess) return 0;
+    if (streaming_form) {                                     // full blocks go through k_conv_st: both must be resident at the pool's size
+        int st = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&st, reinterpret_cast<const void*>(k_conv_st), kStThreads, convst_lds_floats() * sizeof(float)) != hipSuccess) return 0;
+        if (st < per_cu) per_cu = st;
+    }
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
     return per_cu * cus;
 }
@@ -525,6 +1018,10 @@ hipError_t launch_conv_ms_kernel(const LaunchArgs& a, const ConvDesc& d, bool fu
 {
     if (!d.ms_ok || a.n_frames > (uint32_t)kConvsFrames || (fused && a.mode != MODE_CHAIN)) return hipErrorInvalidValue;
     const bool full = a.n_frames == (uint32_t)kConvsFrames;
+    if (fused && full && d.st_ok) {
+        hipLaunchKernelGGL(k_conv_st, dim3(a.n_streams), dim3(kStThreads), convst_lds_floats() * sizeof(float), stream, a, d);
+        return hipGetLastError();
+    }
     typedef void (*Fn)(LaunchArgs, ConvDesc);
     const Fn fn = fused ? (full ? k_conv_ms<true, true> : k_conv_ms<true, false>) : (full ? k_conv_ms<false, true> : k_conv_ms<false, false>);
     hipLaunchKernelGGL(fn, dim3(a.n_streams), dim3(kCsThreads), convs_lds_bytes(), stream, a, d);

@@ -80,5 +80,6 @@ std::vector<float> pack_q4(const aidax_model& m);       // LSTM-32, one input: t
 std::vector<float> pack_conv(const aidax_model& m, ConvDesc* d, uint32_t* state_floats);
 int  conv_ms_tap(int ksize, int pos);
 bool conv_ms_shape_ok(const ConvDesc& d);
+bool conv_st_shape_ok(const ConvDesc& d);
 
 }  // namespace aidax

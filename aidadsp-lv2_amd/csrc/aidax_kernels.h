@@ -75,7 +75,7 @@ hipError_t launch_conv_mfma_kernel(const LaunchArgs& a, const ConvDesc& d, bool 
 hipError_t launch_conv_kernel(const LaunchArgs& a, const ConvDesc& d, hipStream_t stream);
 // k_conv_ms (aidax_convs.hip): the conv stacks conv_ms_shape_ok admits, as bf16 term products; its own history layout (ConvDesc::ms_*)
 size_t convs_lds_bytes();
-int convs_resident_streams(int device);
+int convs_resident_streams(int device, bool streaming_form);
 hipError_t launch_conv_ms_kernel(const LaunchArgs& a, const ConvDesc& d, bool fused, hipStream_t stream);   // n_frames <= 256; fused: whole run()
 hipError_t launch_set_pending(StreamState* st, uint32_t n_streams, int32_t stream, uint32_t bits, hipStream_t q);
 hipError_t launch_init_streams(StreamState* st, uint32_t n, hipStream_t q);

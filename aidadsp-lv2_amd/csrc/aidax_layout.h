@@ -269,6 +269,8 @@ struct ConvDesc {
     uint32_t wd_off, bd_off;
     int32_t  ms_ok;             // k_conv_ms serves this stack (pack_conv: conv_ms_shape_ok)
     uint32_t ms_state_floats;   // ... with this much state per stream (its history layout differs from k_conv's / k_conv_mfma's)
+    int32_t  st_ok;             // k_conv_st (the streaming form of full fused blocks) serves this stack (conv_st_shape_ok)
+    uint32_t st_scratch_off;    // ... with 6 x 128 vectors of scratch per stream behind the histories (layer 6's input, first half block)
 };
 
 struct LaunchArgs {

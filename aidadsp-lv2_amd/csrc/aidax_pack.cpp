@@ -548,6 +548,16 @@ bool conv_ms_shape_ok(const ConvDesc& d)
     return true;
 }
 
+// Which of them k_conv_st serves as well (full fused blocks as a stream of tiles; its ring geometry is compiled in): eight layers of
+// three taps, layer l dilated by 2^l — BASELINE cfg4's stack.
+bool conv_st_shape_ok(const ConvDesc& d)
+{
+    if (!conv_ms_shape_ok(d) || d.n_layers != 8) return false;
+    for (int l = 0; l < 8; ++l)
+        if (d.L[l].ksize != 3 || d.L[l].dilation != (1 << l)) return false;
+    return true;
+}
+
 std::vector<float> pack_conv(const aidax_model& m, ConvDesc* d, uint32_t* state_floats)
 {
     std::vector<float> out;
@@ -655,6 +665,11 @@ std::vector<float> pack_conv(const aidax_model& m, ConvDesc* d, uint32_t* state_
                         }
                     }
         }
+        d->st_ok = conv_st_shape_ok(*d) ? 1 : 0;
+        if (d->st_ok) { d->st_scratch_off = mst; mst += 6u * 128u * 4u; }
+#ifdef AIDAX_CONV_TRACE
+        if (d->st_ok) mst += 256u;                                  // the measurement build's stamps (k_conv_st)
+#endif
         d->ms_state_floats = mst;
     }
     const Layer& D = m.layers[m.n_rnn];

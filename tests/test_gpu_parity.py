@@ -41,7 +41,7 @@ def _ctl_pair(**kw):
 def _canon(kernel_name):
     """Stacked models run on k_mfma_ls (contractions as bf16 term products) where their split fragments fit the register file,
     else on k_mfma_lp (fp32 MFMAs; AIDAX_LP_SPLIT=0 forces it): the same launch forms, named alike here."""
-    return kernel_name.replace("k_mfma_ls", "k_mfma_lp").replace("k_conv_ms", "k_conv_mfma")      # (... and the conv stacks k_conv_ms admits run there, bf16 term products too)
+    return kernel_name.replace("k_mfma_ls", "k_mfma_lp").replace("k_conv_ms", "k_conv_mfma").replace("k_conv_st", "k_conv_mfma")      # (... and the conv stacks k_conv_ms admits run there, bf16 term products too; full blocks of the eight-layer stack as a stream of tiles: k_conv_st)
 
 
 def _run_gpu(pool, x, block):
@@ -595,7 +595,7 @@ def test_long_run_drift_small_gru_on_the_pipeline_kernel(tmp_path):
 @pytest.mark.parametrize("name,kw,S,ckw,kernel", [
     ("cfg2", dict(kind="lstm", hidden=32, input_size=1, seed=32), 1024, {}, "k_lstm_pipe<32>"),
     ("cfg3", dict(kind="gru", hidden=64, input_size=3, seed=64), 4096, _EQ_POST, "k_gru_gs"),                     # one launch: gate-major tiles, the chain on the helper waves
-    ("cfg4", dict(kind="conv", hidden=16, input_size=1, seed=1608), 1024, {}, "k_conv_ms"),
+    ("cfg4", dict(kind="conv", hidden=16, input_size=1, seed=1608), 1024, {}, "k_conv_st"),
     ("cfg5", dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2), 2048, {}, "k_mfma_ls"),
     ("lstm80-1k", dict(kind="lstm", hidden=80, input_size=2, seed=80), 1024, dict(param1=0.7), "k_chain+k_quad"),
     ("lstm80-2k", dict(kind="lstm", hidden=80, input_size=2, seed=80), 2048, dict(param1=0.7), "k_mfma_ls1"),      # a lone layer on k_mfma_ls's body
@@ -792,14 +792,16 @@ def test_conv_stacks_on_the_split_kernel_corners(name, l0, rest, tmp_path, monke
     want = O.run_streams(spec, co, x, 256)
     scale = max(1.0, float(np.abs(want).max()))
     outs = {}
-    for env, kname in (({}, "k_conv_ms"), ({"AIDAX_CONV_FUSED": "0"}, "k_chain+k_conv_ms"), ({"AIDAX_CONV_MS": "0"}, "k_conv_mfma")):
-        for k_ in ("AIDAX_CONV_FUSED", "AIDAX_CONV_MS"):
+    # (the first stack is the one k_conv_st serves: its full blocks run there — tile-major, the same bits — unless AIDAX_CONV_ST=0)
+    streamed = name == "cfg4-like"
+    for env, kname in (({}, "k_conv_ms"), ({"AIDAX_CONV_FUSED": "0"}, "k_chain+k_conv_ms"), ({"AIDAX_CONV_MS": "0"}, "k_conv_mfma"), ({"AIDAX_CONV_ST": "0"}, "k_conv_ms/all")):
+        for k_ in ("AIDAX_CONV_FUSED", "AIDAX_CONV_MS", "AIDAX_CONV_ST"):
             monkeypatch.delenv(k_, raising=False)
         for k_, v in env.items():
             monkeypatch.setenv(k_, v)
         pool = ax.Pool(S, 256)
         pool.set_model(ax.Model(path))
-        assert pool.kernel_name == kname, (name, pool.kernel_name)
+        assert pool.kernel_name == ("k_conv_st" if streamed and kname == "k_conv_ms" else kname.split("/")[0]), (name, pool.kernel_name)
         pool.set_controls(cg)
         got = np.empty_like(x)
         pos = 0
@@ -811,6 +813,7 @@ def test_conv_stacks_on_the_split_kernel_corners(name, l0, rest, tmp_path, monke
         errlog.bound(np.abs(got - want).max() / scale, 3e-6, "gpu_parity:conv_ms_corners")
         outs[kname] = got
     assert np.array_equal(outs["k_conv_ms"], outs["k_chain+k_conv_ms"])      # one launch or three: the same bits
+    assert np.array_equal(outs["k_conv_ms"], outs["k_conv_ms/all"])          # full blocks as a stream of tiles or layer by layer: the same bits
     errlog.bound(np.abs(outs["k_conv_ms"] - outs["k_conv_mfma"]).max() / scale, 2e-6, "gpu_parity:conv_ms_vs_mfma")
 
 
@@ -869,7 +872,7 @@ def test_conv_stack_on_a_pool_with_long_blocks(tmp_path):
     cg, co = _ctl_pair(bass_boost_db=3.0, pregain_db=2.0, eq_position=1.0)
     big = ax.Pool(S, 2048)
     big.set_model(ax.Model(path))
-    assert big.kernel_name == "k_conv_ms"
+    assert big.kernel_name == "k_conv_st"              # (full slices as a stream of tiles, ragged ones through k_conv_ms: one state)
     big.set_controls(cg)
     got = np.empty_like(x)
     pos = 0
@@ -905,14 +908,16 @@ def test_conv_fused_launch_is_bit_identical_to_split_launches(ms, tmp_path, monk
            dict(dc_blocker=0.0, in_lpf_pc=0.0, eq_bypass=1.0), dict(pregain_db=6.0, master_db=-6.0, treble_boost_db=4.0)]
     outs = []
     # (third run: the fused form without its issue priority by progress — AIDAX_TUNE bit 2048 — a scheduling hint, same bits)
-    for fused, tune in (("1", "0"), ("0", "0"), ("1", "2048")):
+    # (fourth run: full blocks through k_conv_ms too — AIDAX_CONV_ST=0 — instead of the streaming form k_conv_st: the same bits, the same state)
+    for fused, tune, st in (("1", "0", "1"), ("0", "0", "1"), ("1", "2048", "1"), ("1", "0", "0")):
         monkeypatch.setenv("AIDAX_CONV_FUSED", fused)
         monkeypatch.setenv("AIDAX_TUNE", tune)
         monkeypatch.setenv("AIDAX_CONV_MS", ms)
+        monkeypatch.setenv("AIDAX_CONV_ST", st)
         pool = ax.Pool(S, 256)
         pool.set_model(ax.Model(path))
         base = "k_conv_ms" if ms == "1" else "k_conv_mfma"
-        assert pool.kernel_name == (base if fused == "1" else "k_chain+" + base)
+        assert pool.kernel_name == (("k_conv_st" if ms == "1" and st == "1" else base) if fused == "1" else "k_chain+" + base)
         got = np.empty_like(x)
         pos = 0
         for bi, n in enumerate(sizes):
@@ -927,6 +932,7 @@ def test_conv_fused_launch_is_bit_identical_to_split_launches(ms, tmp_path, monk
         pool.close()
     assert np.array_equal(outs[0], outs[1])
     assert np.array_equal(outs[0], outs[2])
+    assert np.array_equal(outs[0], outs[3])
 
 
 @pytest.mark.parametrize("name,kw", [

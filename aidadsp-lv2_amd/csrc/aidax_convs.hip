@@ -558,6 +558,18 @@ static_assert(convst_lds_floats() * 4 <= 40 * 1024, "four workgroups per CU");
 // per tile and layer: a third of what a wave issued).
 template <int L> __device__ __forceinline__ int st_place0(int nl, int shift) { return (nl - shift + 16 * st_len(L)) % st_len(L); }
 template <int L> __device__ __forceinline__ void st_walk(int& p) { p += 16; p = p >= st_len(L) ? p - st_len(L) : p; }
+// Issue priority by progress (k_conv_ms's, for the same reason): a CU's four workgroups compete for its SIMDs, the arbiter favours the oldest
+// wave, and the workgroup dispatched last trails the first by microseconds — the launch ends with it, the CU three quarters idle. A wave's
+// priority steps down with every tick, cyclically over the four levels: of a CU's workgroups the ones behind go first.
+__device__ __forceinline__ void st_prio(int tick)
+{
+    switch (tick & 3) {
+    case 0: __builtin_amdgcn_s_setprio(3); break;
+    case 1: __builtin_amdgcn_s_setprio(2); break;
+    case 2: __builtin_amdgcn_s_setprio(1); break;
+    default: __builtin_amdgcn_s_setprio(0); break;
+    }
+}
 // the places a lane reads layer L's two k-steps from (tile 0): k-step 0 = [oldest tap | padding: the lane's own frame], k-step 1 = [middle tap | newest tap]
 struct StRead { int p0, p1; };
 template <int L> __device__ __forceinline__ StRead st_read0(int q, int nl)
@@ -776,9 +788,9 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
         };
         fetch_g(0);
         const float* wdq = wdl + 4 * q;
-        __builtin_amdgcn_s_setprio(3);
         cs_lds_barrier();                                     // (the other waves' staging)
         for (int tick = 0; tick < T; ++tick) {
+            if (!(AIDAX_TUNE(a) & 2048)) st_prio(tick);
             ST_TICK_BEGIN();
 #pragma unroll
             for (int hs = 0; hs < 2; ++hs) {
@@ -880,6 +892,7 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
         st_ring_put<2>(pl, lane, hv[1]);
         for (; tick < T; ++tick) {
             const int t = tick - d1;
+            if (!(AIDAX_TUNE(a) & 2048)) st_prio(tick);
             ST_TICK_BEGIN();
             if (t < 16) {
                 // the tile of the model's input: x * in_gain, in place (the Dense's skip path and layer 0's history read it scaled)
@@ -928,6 +941,7 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
         for (int r = 0; r < 3; ++r) st_ring_put<4>(pl, lane + r * kWave, hv[2 + r]);
         for (; tick < T; ++tick) {
             const int t = tick - d1 - 1;
+            if (!(AIDAX_TUNE(a) & 2048)) st_prio(tick);
             ST_TICK_BEGIN();
             if (t < 16) {
                 st_emit<4>(pl, q, po4, st_tile<3>(pl, biasl, t, afrA, q, nl, actA, rdA, hist_of(3), nullptr, nullptr, nullptr));
@@ -939,10 +953,6 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
         }
     } else if (wave == 3) {
         cs_u32x4 hv[12], afrA[2][3], afrB[2][3];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) hv[r] = st_ring_fetch<5>(hist_of(5), lane + r * kWave);
-#pragma unroll
-        for (int r = 0; r < 6; ++r) hv[6 + r] = st_ring_fetch<6>(hist_of(6), lane + r * kWave);
         fetch_afrags(5, afrA);
         const uint32_t flags = ctl.flags;
         if (out_of_circuit(flags)) return;
@@ -970,8 +980,15 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
                 }
             }
         };
-        fetch_g(0);
         cs_lds_barrier();
+        // This wave's histories are two thirds of what the launch reads at its start (12 of 18 KiB per stream), and its first tile is three
+        // ticks away: they are requested BEHIND the first barrier, when the chain wave's row and coefficients — which that barrier waits
+        // for — are home (all at once, the chip's 18 MB kept the first tick waiting for 4.5 us).
+#pragma unroll
+        for (int r = 0; r < 6; ++r) hv[r] = st_ring_fetch<5>(hist_of(5), lane + r * kWave);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) hv[6 + r] = st_ring_fetch<6>(hist_of(6), lane + r * kWave);
+        fetch_g(0);
         int tick = 0;
         for (; tick < d1 + 2; ++tick) cs_lds_barrier();            // (nothing to do yet: the pipeline fills)
 #pragma unroll
@@ -981,6 +998,7 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
         fetch_afrags(6, afrB);
         for (; tick < T; ++tick) {
             const int t = tick - d1 - 2;
+            if (!(AIDAX_TUNE(a) & 2048)) st_prio(tick);
             ST_TICK_BEGIN();
             if (t < 16) {
                 st_emit<6>(pl, q, po6, st_tile<5>(pl, biasl, t, afrA, q, nl, actA, rdA, hist_of(5), nullptr, nullptr, nullptr));

@@ -98,6 +98,8 @@ def lib() -> C.CDLL:
     L.aidax_many_streams_form.restype = C.c_int
     L.aidax_many_streams_form_at.argtypes = [C.c_int, C.c_int, u32, C.c_int, u32]
     L.aidax_many_streams_form_at.restype = C.c_int
+    L.aidax_model_conv_form.argtypes = [C.c_void_p]
+    L.aidax_model_conv_form.restype = C.c_int
     L.aidax_pool_create.argtypes = [u32, u32, C.c_double, C.c_int, C.POINTER(vp)]
     L.aidax_pool_destroy.argtypes = [vp]
     L.aidax_pool_destroy.restype = None
@@ -252,6 +254,11 @@ class Model:
     @property
     def path(self) -> str:
         return lib().aidax_model_path(self.h).decode()
+
+    @property
+    def conv_form(self) -> int:
+        """aidax_model_conv_form: 0 not a conv stack, 1 k_conv, 2 k_conv_mfma, 3 k_conv_ms, 4 k_conv_ms + k_conv_st for full blocks"""
+        return int(lib().aidax_model_conv_form(self.h))
 
     def golden(self):
         n = self.info.n_golden

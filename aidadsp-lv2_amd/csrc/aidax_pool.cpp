@@ -1411,6 +1411,16 @@ AIDAX_API int aidax_many_streams_form_at(int cell, int hidden, uint32_t n_stream
     return static_cast<int>(many_streams_form(cell, hidden, n_streams, compute_units, max_frames));
 }
 
+AIDAX_API int aidax_model_conv_form(const aidax_model* m)
+{
+    if (!m || !is_conv_model(*m)) return 0;
+    ConvDesc d;
+    uint32_t state_floats = 0;
+    (void)pack_conv(*m, &d, &state_floats);
+    if (convm_lds_bytes(d, 256) > 160 * 1024) return 1;
+    return d.st_ok ? 4 : d.ms_ok ? 3 : 2;
+}
+
 AIDAX_API const char* aidax_pool_kernel_name(const aidax_pool* p)
 {
     if (!(p && p->cur.has_model)) return "k_nomodel";

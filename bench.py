@@ -57,7 +57,7 @@ RING = 8                  # distinct input blocks cycled through HBM
 HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: vector FP32 peak = v_mfma_f32_16x16x4_f32 peak (64 FLOP/clk/SIMD)
 BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA peak (~2.5 PFLOP/s)
-SPLIT_PRODUCTS = 6        # k_gru_gs / k_mfma_ls / k_conv_ms: bf16 term products issued per fp32 product (operands split exactly into three bf16 terms)
+SPLIT_PRODUCTS = 6        # k_gru_gs / k_mfma_ls / k_conv_ms / k_conv_st: bf16 term products issued per fp32 product (operands split exactly into three bf16 terms)
 N_SIMDS = 1024            # 256 CUs x 4
 NOMINAL_GHZ = 2.4
 ALGO_BYTES_PER_SAMPLE = 8
@@ -527,7 +527,7 @@ def rooflines(name, S, kernel_ms, kernel):
     comp = {"bound": "mfma" if wl["bound"] == "mfma" else "fp32", "achieved": tflops, "peak": FP32_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": tflops / FP32_PEAK_TFLOPS, "traffic": None, "kernel_ms": kernel_ms,
             "algorithmic_flops_per_launch": algo_flops}
-    if ("k_gru_gs" in kernel or "k_mfma_ls" in kernel or "k_conv_ms" in kernel) and wl.get("split_flops"):
+    if ("k_gru_gs" in kernel or "k_mfma_ls" in kernel or "k_conv_ms" in kernel or "k_conv_st" in kernel) and wl.get("split_flops"):
         # The contraction runs on the bf16 matrix pipe: every fp32 product as SPLIT_PRODUCTS bf16 term products of operands
         # split exactly into three bf16 terms (fp32 MFMAs run at the vector rate on gfx950 and stall the VALU beside them,
         # profiles/r04_overlap.txt). What binds the kernel is then the bf16 MFMA peak against the matrix flops it EXECUTES

@@ -154,6 +154,14 @@ AIDAX_API int aidax_many_streams_form(int cell, int hidden, uint32_t n_streams, 
  * one crossover moves with the block length (LSTM-32 at 5632 .. 6144 streams); aidax_many_streams_form is this function at 256 frames. */
 AIDAX_API int aidax_many_streams_form_at(int cell, int hidden, uint32_t n_streams, int compute_units, uint32_t max_frames);
 
+/* ... and which kernel family a conv1d-stack model (an extension of the path: BASELINE config 4) takes, by its shape alone — the packer's
+ * rules (csrc/aidax_pack.cpp: conv_ms_shape_ok, conv_st_shape_ok), pure, no HIP call: 0 not a conv model, 1 k_conv (VALU, any stack the
+ * loader admits), 2 k_conv_mfma (fp32 matrix instructions: up to sixteen equal channels, a plane that fits LDS), 3 k_conv_ms (bf16 term
+ * products: exactly sixteen channels, two to four taps, histories its plane + two register fragments hold), 4 k_conv_ms with FULL 256-frame
+ * blocks of the fused form on k_conv_st, the streaming kernel (eight layers of three taps, dilation 2^l). Environment switches of the test
+ * build are not applied: this is the shape rule. */
+AIDAX_API int aidax_model_conv_form(const aidax_model* m);
+
 /* -------------------------------------------------------------------- pool */
 typedef struct aidax_pool aidax_pool;
 

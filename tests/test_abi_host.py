@@ -144,6 +144,28 @@ def test_control_defaults_match_ttl():
 
 
 
+def test_conv_stack_form_rule_by_shape(tmp_path):
+    """aidax_model_conv_form — which kernel family a conv1d stack runs on is a pure function of its shape (the packer's rules): BASELINE
+    cfg4's stack — eight layers of three taps, dilation 2^l, sixteen channels — is the one whose full blocks stream through k_conv_st (4);
+    other sixteen-channel stacks of two to four taps stay layer-major on k_conv_ms (3); narrower or wider-tap stacks on the fp32 matrix
+    kernel (2); recurrent models are not conv stacks (0)."""
+    from tests import modelgen
+    ax = importlib.import_module("aidadsp-lv2_amd")
+
+    def form(**kw):
+        return ax.Model(modelgen.write_model(modelgen.make_model(**kw), str(tmp_path / "m.json"))).conv_form
+    assert form(kind="conv", hidden=16, input_size=1, seed=1608) == 4                       # cfg4
+    assert form(kind="conv", hidden=16, input_size=1, seed=3, conv_layers=5) == 3           # the same taps and dilations, five layers
+    assert form(kind="conv", hidden=16, input_size=1, seed=3, conv_layers=8, conv_k=2) == 3 # eight layers of two taps
+    assert form(kind="conv", hidden=8, input_size=1, seed=85, conv_layers=4, conv_k=5) == 2 # eight channels, five taps
+    assert form(kind="lstm", hidden=32, input_size=1, seed=32) == 0
+    # dilations that are not 2^l: an eight-layer stack of three taps that k_conv_st does not take
+    rs = np.random.RandomState(5)
+    layers = [modelgen.conv_layer(rs, 1, 16, 3, 1, "tanh")] + [modelgen.conv_layer(rs, 16, 16, 3, 3 * (l + 1), "tanh") for l in range(7)] + [modelgen.dense_layer(rs, 16)]
+    j = {"in_shape": [None, None, 1], "layers": layers, "metadata": {"name": "odd", "samplerate": "48000"}, "in_skip": 0, "in_gain": 0.0, "out_gain": 0.0}
+    assert ax.Model(modelgen.write_model(j, str(tmp_path / "odd.json"))).conv_form == 3
+
+
 def test_launch_form_rule_for_one_layer_table_models(monkeypatch):
     """aidax_many_streams_form — the decision table that sends a pool of a one-layer table model to k_quad (1) or to the
     16-stream matrix-core kernels (2) — is a pure function of (cell, hidden, streams, CUs): the measured crossovers of

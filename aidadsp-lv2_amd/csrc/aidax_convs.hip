@@ -790,7 +790,7 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
         const float* wdq = wdl + 4 * q;
         cs_lds_barrier();                                     // (the other waves' staging)
         for (int tick = 0; tick < T; ++tick) {
-            if (!(AIDAX_TUNE(a) & 2048)) st_prio(tick);
+            if (!(AIDAX_TUNE(a) & 2048)) st_prio(tick);         // (this wave — the longest of the four — always on top instead: 42.8 against 42.3 us)
             ST_TICK_BEGIN();
 #pragma unroll
             for (int hs = 0; hs < 2; ++hs) {

@@ -185,6 +185,13 @@ __global__ __launch_bounds__(kCsThreads, 4) void k_conv_ms(LaunchArgs a, ConvDes
         const int s0 = L.ms_shift[ks][0], s1 = L.ms_shift[ks][1];
         return (s0 >= 0 && 16 * t - s0 < -Hh) || (s1 >= 0 && 16 * t - s1 < -Hh);
     };
+    // Where a lane's B fragment number i of k-step ks sits, in units of TS = the distance between two terms: term i — except in a PACKED first
+    // k-step (three taps: the lone oldest tap's six term products in three instructions, ConvLayer::ms_packed0), where instruction i takes
+    // term {0, 0, 1}[i] in the k-step's first half and {0, 1, 2}[i] in its second.
+    auto b_term_off = [&](const ConvLayer& L, int ks, int i, int TS) {
+        if (ks != 0 || !L.ms_packed0) return i * TS;
+        return i == 0 ? 0 : (i - 1) * TS + (q >= 2 ? TS : 0);
+    };
     // Deep B fragments of the next layer to run: only the FIRST k-step (the oldest taps) of a wave's first two tiles can reach beyond the
     // plane (conv_ms_shape_ok admits no other stack), so the two register sets have fixed owners — (k-step 0, tile j = 0) and (0, j = 1).
     cs_u32x4 dfr0[3], dfr1[3];
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(kCsThreads, 4) void k_conv_ms(LaunchArgs a, ConvDes
             const int hi = (f < -Hh && !pad) ? L.hist + f : 0;             // frame f of the history = index hist + f
 #pragma unroll
             for (int term = 0; term < 3; ++term) {
-                const cs_u32x4 v = src[(size_t)term * 2 * L.hist + hi];
+                const cs_u32x4 v = src[b_term_off(L, 0, term, 2 * L.hist) + hi];
                 if (j == 0) dfr0[term] = v; else dfr1[term] = v;
             }
         }
@@ -424,7 +431,7 @@ __global__ __launch_bounds__(kCsThreads, 4) void k_conv_ms(LaunchArgs a, ConvDes
                 const int idx = 16 * (wave + 4 * (p & 3)) - (p < 4 ? sh0 : sh1);      // this lane's source frame, less nl
                 const cs_u32x4* src = plq + (idx + nl + Hh > 0 ? idx : -(nl + Hh));
 #pragma unroll
-                for (int term = 0; term < 3; ++term) b[term] = src[(size_t)term * 2 * kCsStrip];
+                for (int term = 0; term < 3; ++term) b[term] = src[b_term_off(L, p >> 2, term, 2 * kCsStrip)];
             };
             auto mul_b = [&](int p, cs_u32x4 (&b)[3]) {
                 const int j = p & 3, ks = p >> 2;
@@ -435,6 +442,13 @@ __global__ __launch_bounds__(kCsThreads, 4) void k_conv_ms(LaunchArgs a, ConvDes
                         const cs_u32x4 dv = j == 0 ? dfr0[term] : dfr1[term];
                         if (mine) b[term] = dv;
                     }
+                }
+                if (ks == 0 && L.ms_packed0) {
+                    // the packed first k-step: [w0 | w1] x [x0 | x0], [w2 | w0] x [x0 | x1], [w1 | w0] x [x1 | x2] — fragments as the packer and load_b laid them
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cs_bf16x8, afr[0][i]), __builtin_bit_cast(cs_bf16x8, b[i]), acc[j], 0, 0, 0);
+                    return;
                 }
                 // (w0 w1 w2) x0 | (w0 w1) x1 | w0 x2: the six term products, the large ones first
 #pragma unroll
@@ -570,13 +584,14 @@ __device__ __forceinline__ void st_prio(int tick)
     default: __builtin_amdgcn_s_setprio(0); break;
     }
 }
-// the places a lane reads layer L's two k-steps from (tile 0): k-step 0 = [oldest tap | padding: the lane's own frame], k-step 1 = [middle tap | newest tap]
+// the places a lane reads layer L's two k-steps from (tile 0): k-step 0 = the oldest tap in both halves (the packed form: ConvLayer::ms_packed0),
+// k-step 1 = [middle tap | newest tap]. (Layers 6, 7: what comes from HBM has no place in the ring — the lane's own frame stands in.)
 struct StRead { int p0, p1; };
 template <int L> __device__ __forceinline__ StRead st_read0(int q, int nl)
 {
     constexpr int D = 1 << L;
     const bool lo = q < 2;
-    return StRead{ st_place0<L>(nl, lo && L <= 5 ? 2 * D : 0), st_place0<L>(nl, lo && L <= 6 ? D : 0) };
+    return StRead{ st_place0<L>(nl, L <= 5 ? 2 * D : 0), st_place0<L>(nl, lo && L <= 6 ? D : 0) };
 }
 // one vector of layer L's history -> its place in the ring (v-th of the 6 hl the ring takes: strip v / hl, frame v % hl - hl)
 template <int L> __device__ __forceinline__ cs_u32x4 st_ring_fetch(const cs_u32x4* h, int v)
@@ -617,36 +632,38 @@ __device__ __forceinline__ f32x4 st_tile(cs_u32x4* pl, const float* biasl, int t
     const int i0 = rd.p0, i1 = rd.p1;
     st_walk<L>(rd.p0);
     st_walk<L>(rd.p1);
-    // (layers 6, 7: the padding lanes of k-step 0 read what the newest tap's lanes of k-step 1 read — the lane's own frame — so the fragment
-    // that comes from HBM is completed in place, in the registers it arrived in, and nothing is read twice)
+    // k-step 0, packed: instruction i multiplies [w0 | w1], [w2 | w0], [w1 | w0] (the packer's fragments) by terms {0, 0, 1}[i] of the oldest tap in
+    // the k-step's first half and {0, 1, 2}[i] in its second: a lane's three reads are term 0, then one and two terms on from where its half starts
     cs_u32x4 b0[3], b1[3];
-    if constexpr (L == 6) {
-        // the oldest tap sits in the staging area ([term][half][frame], where the wave's LDS-DMA put it a tick ago): one read per term with a
-        // per-lane base and term stride (tap lanes: the staging area; padding lanes: the ring)
-        const int a0 = lo ? stage_vec + q * 16 + nl : st_off(L) + (q & 1) * LEN + i0;
-        const int ts = lo ? 32 : 2 * LEN;
-#pragma unroll
-        for (int term = 0; term < 3; ++term) { b0[term] = pl[a0 + term * ts]; b1[term] = ring[term * 2 * LEN + i1]; }
+    if constexpr (L <= 5) {
+        const int o1 = lo ? 0 : 2 * LEN;
+        b0[0] = ring[i0]; b0[1] = ring[o1 + i0]; b0[2] = ring[2 * LEN + o1 + i0];
+    } else if constexpr (L == 6) {
+        // ... out of the staging area ([term][half][frame], where the wave's LDS-DMA put it a tick ago)
+        const cs_u32x4* stg = pl + stage_vec + (q & 1) * 16 + nl;
+        const int o1 = lo ? 0 : 32;
+        b0[0] = stg[0]; b0[1] = stg[o1]; b0[2] = stg[32 + o1];
     } else {
 #pragma unroll
-        for (int term = 0; term < 3; ++term) {
-            b1[term] = ring[term * 2 * LEN + i1];
-            if constexpr (L <= 5) b0[term] = ring[term * 2 * LEN + i0];
-            else b0[term] = lo ? g0[term] : b1[term];
-            if constexpr (L == 7) b1[term] = lo ? g1[term] : b1[term];
-        }
+        for (int i = 0; i < 3; ++i) b0[i] = g0[i];             // ... as they came from HBM (fetch_g asks by the same rule)
+    }
+#pragma unroll
+    for (int term = 0; term < 3; ++term) {
+        b1[term] = ring[term * 2 * LEN + i1];
+        if constexpr (L == 7) b1[term] = lo ? g1[term] : b1[term];
     }
     f32x4 acc = *reinterpret_cast<const f32x4*>(biasl + (L - 1) * 16 + 4 * q);
     // (all seven reads are on their way before the first product: left alone the compiler asks for a fragment right where it is used, and a
     // tile pays the LDS round trip four times in a row — the wave that sets the tick has two or three tiles per tick)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int i = 0; i < 3; ++i)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cs_bf16x8, afr[0][i]), __builtin_bit_cast(cs_bf16x8, b0[i]), acc, 0, 0, 0);
 #pragma unroll
-        for (int th = 0; th < 3; ++th)
+    for (int th = 0; th < 3; ++th)
 #pragma unroll
-            for (int tw = 0; tw < 3 - th; ++tw)
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cs_bf16x8, afr[ks][tw]), __builtin_bit_cast(cs_bf16x8, ks == 0 ? b0[th] : b1[th]), acc, 0, 0, 0);
+        for (int tw = 0; tw < 3 - th; ++tw)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cs_bf16x8, afr[1][tw]), __builtin_bit_cast(cs_bf16x8, b1[th]), acc, 0, 0, 0);
     // the history: the last H frames of the block, as the vectors they are (lanes q >= 2 of k-step 1: term, half q & 1, frame 16 t + nl)
     const int f = 16 * t + nl;
     if constexpr (L <= 5) {
@@ -778,12 +795,17 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
         cs_u32x4 g0[3] = { cs_u32x4{ 0u, 0u, 0u, 0u }, cs_u32x4{ 0u, 0u, 0u, 0u }, cs_u32x4{ 0u, 0u, 0u, 0u } };
         cs_u32x4 g1[3] = { cs_u32x4{ 0u, 0u, 0u, 0u }, cs_u32x4{ 0u, 0u, 0u, 0u }, cs_u32x4{ 0u, 0u, 0u, 0u } };
         auto fetch_g = [&](int t) {
-            if (q < 2 && t < 16) {
-                // frame f - 256: index f of the old history; frame f - 128: index f + 128 of the old history, or — the second half — f - 128 of the new
+            if (t < 16) {
+                // frame f - 256 (k-step 0, every lane, terms by the packed rule): index f of the old history
                 const cs_u32x4* s0 = h7 + (q & 1) * 256 + 16 * t + nl;
-                const cs_u32x4* s1 = h7 + (q & 1) * 256 + (t < 8 ? 16 * t + 128 : 16 * t - 128) + nl;
+                const int o1 = q < 2 ? 0 : 2 * 256;
+                g0[0] = s0[0]; g0[1] = s0[o1]; g0[2] = s0[2 * 256 + o1];
+                if (q < 2) {
+                    // frame f - 128 (k-step 1's first half): index f + 128 of the old history, or — the block's second half — f - 128 of the new
+                    const cs_u32x4* s1 = h7 + (q & 1) * 256 + (t < 8 ? 16 * t + 128 : 16 * t - 128) + nl;
 #pragma unroll
-                for (int term = 0; term < 3; ++term) { g0[term] = s0[term * 2 * 256]; g1[term] = s1[term * 2 * 256]; }
+                    for (int term = 0; term < 3; ++term) g1[term] = s1[term * 2 * 256];
+                }
             }
         };
         fetch_g(0);

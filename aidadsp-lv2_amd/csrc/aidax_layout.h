@@ -239,6 +239,7 @@ struct ConvLayer {
     uint32_t ms_w_off;
     int32_t  ms_ksteps;
     int16_t  ms_shift[2][2];
+    int32_t  ms_packed0;   // three taps: k-step 0 is the oldest tap's six term products in three instructions (see pack_conv); B terms per half: {0,0,1} | {0,1,2}
     uint32_t ms_state_off;
 };
 // k_conv_ms's activation plane: per (term, channel half) a strip of kConvsPF frames x 16 bytes — kConvsHist frames of history in

@@ -641,7 +641,12 @@ std::vector<float> pack_conv(const aidax_model& m, ConvDesc* d, uint32_t* state_
             const int odd = C.ksize & 1;
             C.ms_ksteps = (C.ksize + 1) / 2;
             for (int pos = 0; pos < 2 * C.ms_ksteps; ++pos) taps[pos / 2][pos & 1] = conv_ms_tap(C.ksize, pos);
-            (void)odd;
+            // An odd count's lone first tap does not leave half of its k-step to padding: its SIX term products go out as THREE matrix
+            // instructions, two products side by side in the two halves of the k-step — [w0 | w1] x [x0 | x0], [w2 | w0] x [x0 | x1],
+            // [w1 | w0] x [x1 | x2] (ms_packed0: both halves read the tap's frame, a lane's B term depends on its half). Nine matrix
+            // instructions per tile and three-tap layer instead of twelve.
+            C.ms_packed0 = odd ? 1 : 0;
+            if (odd) taps[0][1] = taps[0][0];
             for (int ks = 0; ks < C.ms_ksteps; ++ks)
                 for (int h = 0; h < 2; ++h) C.ms_shift[ks][h] = taps[ks][h] < 0 ? int16_t(-1) : static_cast<int16_t>((C.ksize - 1 - taps[ks][h]) * C.dilation);
             const float scale = C.activation == 1 ? kTwoLog2e : 1.0f;
@@ -658,7 +663,10 @@ std::vector<float> pack_conv(const aidax_model& m, ConvDesc* d, uint32_t* state_
                                 split_bf16x3(scale * L.w0[((size_t)tap * C.in_ch + ci) * C.out_ch + co], t0);
                                 split_bf16x3(scale * L.w0[((size_t)tap * C.in_ch + ci + 1) * C.out_ch + co], t1);
                             }
-                            const uint32_t pair = static_cast<uint32_t>(t0[term]) | (static_cast<uint32_t>(t1[term]) << 16);
+                            // (the packed first k-step: record `term` is instruction `term` — weight term kPackedW[term][half of the k-step])
+                            static const int kPackedW[3][2] = { { 0, 1 }, { 2, 0 }, { 1, 0 } };
+                            const int wt = (ks == 0 && odd) ? kPackedW[term][q >> 1] : term;
+                            const uint32_t pair = static_cast<uint32_t>(t0[wt]) | (static_cast<uint32_t>(t1[wt]) << 16);
                             float f;
                             std::memcpy(&f, &pair, sizeof f);
                             out.push_back(f);

@@ -686,6 +686,9 @@ __device__ __forceinline__ f32x4 st_tile(cs_u32x4* pl, const float* biasl, int t
     return cs_activate(acc, activation);
 }
 
+// kTanh: every layer's activation is tanh (what a WaveNet-like stack has): the epilogue's switch on the layer's activation — a dozen scalar
+// instructions and branches per tile and layer — is compiled out.
+template <bool kTanh>
 __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDesc d)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -789,7 +792,7 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
         const bool plain = __builtin_amdgcn_ballot_w64(fussy) == 0;
         const int m0 = isQ ? 2 * (d1 + 4) : 0;
         // ... and layer 7 (both old taps from its history in HBM, which is the block itself by the end) with the Dense(16, 1) + skip / output gain
-        const int actA = d.L[7].activation;
+        const int actA = kTanh ? 1 : d.L[7].activation;
         StRead rdA = st_read0<7>(q, nl);
         cs_u32x4* h7 = hist_of(7);
         cs_u32x4 g0[3] = { cs_u32x4{ 0u, 0u, 0u, 0u }, cs_u32x4{ 0u, 0u, 0u, 0u }, cs_u32x4{ 0u, 0u, 0u, 0u } };
@@ -904,7 +907,7 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
         const int Kp = (flags & CTL_EQ_PRE) ? 6 : 1, Kq = (flags & CTL_EQ_POST) ? 6 : 1, d1 = st_d1(Kp), T = st_ticks(Kp, Kq);
         stage_small();
         const ConvLayer& L0 = d.L[0];
-        const int act0 = L0.activation, act1 = d.L[1].activation, act2 = d.L[2].activation;
+        const int act0 = kTanh ? 1 : L0.activation, act1 = kTanh ? 1 : d.L[1].activation, act2 = kTanh ? 1 : d.L[2].activation;
         StRead rdA = st_read0<1>(q, nl), rdB = st_read0<2>(q, nl);
         int po1 = nl, po2 = nl, po3 = nl;
         cs_lds_barrier();
@@ -951,7 +954,7 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
         if (out_of_circuit(flags)) return;
         const int Kp = (flags & CTL_EQ_PRE) ? 6 : 1, Kq = (flags & CTL_EQ_POST) ? 6 : 1, d1 = st_d1(Kp), T = st_ticks(Kp, Kq);
         stage_small();
-        const int actA = d.L[3].activation, actB = d.L[4].activation;
+        const int actA = kTanh ? 1 : d.L[3].activation, actB = kTanh ? 1 : d.L[4].activation;
         StRead rdA = st_read0<3>(q, nl), rdB = st_read0<4>(q, nl);
         int po4 = nl, po5 = nl;
         cs_lds_barrier();
@@ -980,7 +983,7 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
         if (out_of_circuit(flags)) return;
         const int Kp = (flags & CTL_EQ_PRE) ? 6 : 1, Kq = (flags & CTL_EQ_POST) ? 6 : 1, d1 = st_d1(Kp), T = st_ticks(Kp, Kq);
         stage_small();
-        const int actA = d.L[5].activation, actB = d.L[6].activation;
+        const int actA = kTanh ? 1 : d.L[5].activation, actB = kTanh ? 1 : d.L[6].activation;
         StRead rdA = st_read0<5>(q, nl), rdB = st_read0<6>(q, nl);
         int po6 = nl, po7 = nl;
         cs_u32x4* h6 = hist_of(6);
@@ -1046,7 +1049,7 @@ int convs_resident_streams(int device, bool streaming_form)
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kCsThreads, convs_lds_bytes()) != hipSuccess) return 0;
     if (streaming_form) {                                     // full blocks go through k_conv_st: both must be resident at the pool's size
         int st = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&st, reinterpret_cast<const void*>(k_conv_st), kStThreads, convst_lds_floats() * sizeof(float)) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&st, reinterpret_cast<const void*>(k_conv_st<false>), kStThreads, convst_lds_floats() * sizeof(float)) != hipSuccess) return 0;
         if (st < per_cu) per_cu = st;
     }
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
@@ -1059,7 +1062,9 @@ hipError_t launch_conv_ms_kernel(const LaunchArgs& a, const ConvDesc& d, bool fu
     if (!d.ms_ok || a.n_frames > (uint32_t)kConvsFrames || (fused && a.mode != MODE_CHAIN)) return hipErrorInvalidValue;
     const bool full = a.n_frames == (uint32_t)kConvsFrames;
     if (fused && full && d.st_ok) {
-        hipLaunchKernelGGL(k_conv_st, dim3(a.n_streams), dim3(kStThreads), convst_lds_floats() * sizeof(float), stream, a, d);
+        bool all_tanh = true;
+        for (int l = 0; l < d.n_layers; ++l) all_tanh = all_tanh && d.L[l].activation == 1;
+        hipLaunchKernelGGL(all_tanh ? k_conv_st<true> : k_conv_st<false>, dim3(a.n_streams), dim3(kStThreads), convst_lds_floats() * sizeof(float), stream, a, d);
         return hipGetLastError();
     }
     typedef void (*Fn)(LaunchArgs, ConvDesc);

@@ -547,23 +547,25 @@ __global__ __launch_bounds__(kCsThreads, 4) void k_conv_ms(LaunchArgs a, ConvDes
 // Serves: exactly eight layers of three taps, dilation 2^l (BASELINE cfg4's stack; conv_st_shape_ok), blocks of exactly 256 frames, the fused form.
 constexpr int kStThreads = 256;
 // tiles of the ring in front of layer l: history / 16 + 1, + 1 where producer and consumer are different waves
-__host__ __device__ constexpr int st_nt(int l) { return l == 1 || l == 2 || l == 7 ? 2 : l == 3 || l == 4 ? 3 : l == 5 ? 6 : l == 6 ? 5 : 0; }
+__host__ __device__ constexpr int st_nt(int l) { return l == 1 || l == 2 ? 2 : l == 3 || l == 4 ? 3 : l == 5 ? 5 : l == 6 ? 6 : l == 7 ? 1 : 0; }
 __host__ __device__ constexpr int st_len(int l) { return 16 * st_nt(l); }
 __host__ __device__ constexpr int st_off(int l) { int o = 0; for (int i = 1; i < l; ++i) o += 6 * st_len(i); return o; }      // in 16-byte vectors
 constexpr int kStRingVecs = st_off(8);
-constexpr int kStStageVecs = 3 * 2 * 16;                      // [term][channel half][frame]
+constexpr int kStTapVecs = 3 * 2 * 16;                        // one tap of one tile: [term][channel half][frame]
+constexpr int kStStageVecs = 3 * kStTapVecs;                  // the three taps that come from HBM: layer 6's oldest, layer 7's oldest and middle
+constexpr int kStX0 = 4;                                      // frames of layer 0's input history in front of the audio row (conv_st_shape_ok: two)
 // The chain moves in blocks of EIGHT frames, two steps per tick (a six-stage cascade then trails the tiles by two and a half ticks, not five:
 // the launch ends with the post pass's last stage, alone). d1 = ticks between a tile entering the pre pass and layer 0 reading it.
 constexpr int kStChainBlock = 8;
 __device__ __forceinline__ int st_d1(int Kp) { return Kp / 2 + 1; }
-__device__ __forceinline__ int st_ticks(int Kp, int Kq) { return (31 + (Kq - 1) + 2 * (st_d1(Kp) + 4)) / 2 + 1; }
-constexpr int kStHandLanes = 12;                           // pre pass: lanes 0 .. 5, post pass: lanes 6 .. 11
+__device__ __forceinline__ int st_ticks(int Kp, int Kq) { return (31 + (Kq - 1) + 2 * (st_d1(Kp) + 3)) / 2 + 1; }
+constexpr int kStHandLanes = 11;                           // pre pass: lanes 0 .. 5, post pass: lanes 6 .. 11 (a pass's last stage writes the row: lane 11 has no slot)
 constexpr int kStHandFloats = 2 * kStHandLanes * kStChainBlock;                   
 __host__ __device__ constexpr size_t convst_lds_floats()
 {
-    return (size_t)kStRingVecs * 4 + kConvsX0 + kConvsFrames /* the audio row, layer 0's input history in front */
+    return (size_t)kStRingVecs * 4 + kStX0 + kConvsFrames /* the audio row, layer 0's input history in front */
          + 20 /* Dense */ + 64 /* layer 0: [3 taps][16] + bias */ + 7 * 16 /* biases of layers 1 .. 7 */ + kStHandFloats
-         + kStStageVecs * 4 /* layer 6's oldest tap of the tile to come, straight from HBM (global_load_lds) */;
+         + kStStageVecs * 4 /* the far taps of the tile to come, straight from HBM (global_load_lds) */;
 }
 static_assert(convst_lds_floats() * 4 <= 40 * 1024, "four workgroups per CU");
 
@@ -622,9 +624,9 @@ template <int LR> __device__ __forceinline__ void st_emit(cs_u32x4* pl, int q, i
 // One tile of layer L on the matrix cores: tile t of its input ring (+ g0 / g1: the taps that come from HBM) -> the activated outputs.
 // k-step 0 = [oldest tap | padding: the lane's own frame], k-step 1 = [middle tap | newest tap] (conv_ms_tap, three taps).
 // The new history leaves from the newest tap's registers; hist = this layer's history in HBM, scratch = layer 6's first half block.
-template <int L>
+template <int L, bool kEarlyReads = true>
 __device__ __forceinline__ f32x4 st_tile(cs_u32x4* pl, const float* biasl, int t, const cs_u32x4 (&afr)[2][3], int q, int nl, int activation, StRead& rd,
-                                         cs_u32x4* hist, cs_u32x4* scratch, const cs_u32x4* g0, const cs_u32x4* g1, int stage_vec = 0)
+                                         cs_u32x4* hist, cs_u32x4* scratch, int stage_vec)
 {
     constexpr int D = 1 << L, H = 2 * D, LEN = st_len(L);
     const cs_u32x4* ring = pl + st_off(L) + (q & 1) * LEN;
@@ -638,24 +640,28 @@ __device__ __forceinline__ f32x4 st_tile(cs_u32x4* pl, const float* biasl, int t
     if constexpr (L <= 5) {
         const int o1 = lo ? 0 : 2 * LEN;
         b0[0] = ring[i0]; b0[1] = ring[o1 + i0]; b0[2] = ring[2 * LEN + o1 + i0];
-    } else if constexpr (L == 6) {
-        // ... out of the staging area ([term][half][frame], where the wave's LDS-DMA put it a tick ago)
-        const cs_u32x4* stg = pl + stage_vec + (q & 1) * 16 + nl;
+    } else {
+        // ... out of the staging area ([tap][term][half][frame], where the wave's LDS-DMA put it a tick ago: layer 6's oldest tap first, then layer 7's)
+        const cs_u32x4* stg = pl + stage_vec + (L == 6 ? 0 : kStTapVecs) + (q & 1) * 16 + nl;
         const int o1 = lo ? 0 : 32;
         b0[0] = stg[0]; b0[1] = stg[o1]; b0[2] = stg[32 + o1];
-    } else {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) b0[i] = g0[i];             // ... as they came from HBM (fetch_g asks by the same rule)
     }
+    if constexpr (L <= 6) {
 #pragma unroll
-    for (int term = 0; term < 3; ++term) {
-        b1[term] = ring[term * 2 * LEN + i1];
-        if constexpr (L == 7) b1[term] = lo ? g1[term] : b1[term];
+        for (int term = 0; term < 3; ++term) b1[term] = ring[term * 2 * LEN + i1];
+    } else {
+        // layer 7, k-step 1: the middle tap (first half) out of the staging area, the newest (second half) out of the one-tile ring — both 32
+        // vectors from term to term: a per-lane base
+        const int a1 = lo ? stage_vec + 2 * kStTapVecs + (q & 1) * 16 + nl : st_off(L) + (q & 1) * LEN + i1;
+        static_assert(L != 7 || 2 * LEN == 32, "the ring in front of layer 7 is one tile");
+#pragma unroll
+        for (int term = 0; term < 3; ++term) b1[term] = pl[a1 + term * 32];
     }
     f32x4 acc = *reinterpret_cast<const f32x4*>(biasl + (L - 1) * 16 + 4 * q);
     // (all seven reads are on their way before the first product: left alone the compiler asks for a fragment right where it is used, and a
-    // tile pays the LDS round trip four times in a row — the wave that sets the tick has two or three tiles per tick)
-    __builtin_amdgcn_sched_barrier(0);
+    // tile pays the LDS round trip four times in a row — the wave that sets the tick has two or three tiles per tick. Not on the wave that
+    // carries three layers' A fragments: the twelve registers this costs are twelve it does not have.)
+    if constexpr (kEarlyReads) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 3; ++i)
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cs_bf16x8, afr[0][i]), __builtin_bit_cast(cs_bf16x8, b0[i]), acc, 0, 0, 0);
@@ -665,7 +671,8 @@ __device__ __forceinline__ f32x4 st_tile(cs_u32x4* pl, const float* biasl, int t
         for (int tw = 0; tw < 3 - th; ++tw)
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cs_bf16x8, afr[1][tw]), __builtin_bit_cast(cs_bf16x8, b1[th]), acc, 0, 0, 0);
     // the history: the last H frames of the block, as the vectors they are (lanes q >= 2 of k-step 1: term, half q & 1, frame 16 t + nl)
-    const int f = 16 * t + nl;
+    int f = 16 * t + nl;
+    asm volatile("" : "+v"(f));                               // (opaque: otherwise every layer's store address becomes a 64-bit pointer that is carried, and stepped, through every tick)
     if constexpr (L <= 5) {
         if (16 * t + 15 >= kConvsFrames - H && !lo && f >= kConvsFrames - H) {
 #pragma unroll
@@ -704,7 +711,7 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
     const size_t rstride = a.row_stride ? a.row_stride : (size_t)n;
     cs_u32x4* pl = reinterpret_cast<cs_u32x4*>(smem);
     float* xbuf = smem + (size_t)kStRingVecs * 4;
-    float* xrow = xbuf + kConvsX0;
+    float* xrow = xbuf + kStX0;
     float* wdl = xrow + kConvsFrames;                         // Dense weights [16] + bias
     float* l0w = wdl + 20;                                    // layer 0: [tap][16] (tanh: times 2 log2 e), then its bias
     float* biasl = l0w + 64;                                  // [layer - 1][16]
@@ -750,7 +757,6 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
         ChainPass c;
         uint32_t pending = 0;
         float pre_mem = 0.f, master_mem = 0.f, pre_tgt = 0.f, master_tgt = 0.f, pre_target = 0.f, master_target = 0.f, ramp_coef = 0.f;
-        cs_u32x4 afrA[2][3];
         rowv = reinterpret_cast<const float4*>(in_row)[lane];
         chain_load(c, ctl, st, slot, false);
         pending = st.pending;
@@ -761,11 +767,13 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
         const float pt0 = ctl.p_target[0], pt1 = ctl.p_target[1], p_den = ctl.p_den;
         float ptg0 = st.p_tgt[0], ptg1 = st.p_tgt[1];
         const float pm0 = st.p_mem[0], pm1 = st.p_mem[1];
-        fetch_afrags(7, afrA);
         const uint32_t flags = ctl.flags;
         if (!(flags & CTL_ENABLED) || !(flags & CTL_NET_ON)) {
             // pre-run / bypass / the model out of circuit: the chain alone, k_conv_ms's own path for such a stream
             if (wave != 0) return;
+#ifdef AIDAX_CONV_TRACE
+            return;                                               // (measurement build: every stream is in circuit, and the chain helpers' stamp area would cost the fourth workgroup per CU)
+#endif
             ChainCtx ctx = chain_prologue<true>(ctl, st, in_row, out_row, xrow, n, lane, hand);
             if (!ctx.live) return;
             chain_epilogue(ctl, st, ctx, out_row, xrow, n, lane, hand);
@@ -781,7 +789,7 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
         c.gain_lane = isQ ? Kq - 1 : 0;
         c.active = stage == 0 ? (flags & (isQ ? CTL_DC_ON : CTL_LPF_ON)) != 0 : ((flags & CTL_EQ_BANDPASS) ? slot == BQ_MID : true);
         c.g.arm(isQ ? master_mem : pre_mem, isQ ? master_tgt : pre_tgt, ramp_coef);
-        const bool run = lane < kStHandLanes && stage < c.K;
+        const bool run = lane < 12 && stage < c.K;
         reinterpret_cast<float4*>(xrow)[lane] = rowv;
         const double z1o = c.z1, z2o = c.z2;
         ExpRamp g = c.g;
@@ -790,29 +798,7 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
         const bool last = stage == c.K - 1;
         const bool fussy = run && (!c.active || g.mem * g.coef + g.tc != g.mem);
         const bool plain = __builtin_amdgcn_ballot_w64(fussy) == 0;
-        const int m0 = isQ ? 2 * (d1 + 4) : 0;
-        // ... and layer 7 (both old taps from its history in HBM, which is the block itself by the end) with the Dense(16, 1) + skip / output gain
-        const int actA = kTanh ? 1 : d.L[7].activation;
-        StRead rdA = st_read0<7>(q, nl);
-        cs_u32x4* h7 = hist_of(7);
-        cs_u32x4 g0[3] = { cs_u32x4{ 0u, 0u, 0u, 0u }, cs_u32x4{ 0u, 0u, 0u, 0u }, cs_u32x4{ 0u, 0u, 0u, 0u } };
-        cs_u32x4 g1[3] = { cs_u32x4{ 0u, 0u, 0u, 0u }, cs_u32x4{ 0u, 0u, 0u, 0u }, cs_u32x4{ 0u, 0u, 0u, 0u } };
-        auto fetch_g = [&](int t) {
-            if (t < 16) {
-                // frame f - 256 (k-step 0, every lane, terms by the packed rule): index f of the old history
-                const cs_u32x4* s0 = h7 + (q & 1) * 256 + 16 * t + nl;
-                const int o1 = q < 2 ? 0 : 2 * 256;
-                g0[0] = s0[0]; g0[1] = s0[o1]; g0[2] = s0[2 * 256 + o1];
-                if (q < 2) {
-                    // frame f - 128 (k-step 1's first half): index f + 128 of the old history, or — the block's second half — f - 128 of the new
-                    const cs_u32x4* s1 = h7 + (q & 1) * 256 + (t < 8 ? 16 * t + 128 : 16 * t - 128) + nl;
-#pragma unroll
-                    for (int term = 0; term < 3; ++term) g1[term] = s1[term * 2 * 256];
-                }
-            }
-        };
-        fetch_g(0);
-        const float* wdq = wdl + 4 * q;
+        const int m0 = isQ ? 2 * (d1 + 3) : 0;
         cs_lds_barrier();                                     // (the other waves' staging)
         for (int tick = 0; tick < T; ++tick) {
             if (!(AIDAX_TUNE(a) & 2048)) st_prio(tick);         // (this wave — the longest of the four — always on top instead: 42.8 against 42.3 us)
@@ -821,24 +807,6 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
             for (int hs = 0; hs < 2; ++hs) {
                 if (plain) chain_macro_step<true, kStChainBlock, kStHandLanes>(c, g, stage, run, last, xrow, hand, 32, 2 * tick + hs - m0, lane);
                 else chain_macro_step<false, kStChainBlock, kStHandLanes>(c, g, stage, run, last, xrow, hand, 32, 2 * tick + hs - m0, lane);
-            }
-            const int t = tick - d1 - 3;
-            if (t >= 0 && t < 16) {
-                const f32x4 v = st_tile<7>(pl, biasl, t, afrA, q, nl, actA, rdA, h7, nullptr, g0, g1);
-                fetch_g(t + 1);
-                float y = wdq[0] * v.x;                       // (:171-181; emit()'s arithmetic in k_conv_ms)
-                y = __builtin_fmaf(wdq[1], v.y, y);
-                y = __builtin_fmaf(wdq[2], v.z, y);
-                y = __builtin_fmaf(wdq[3], v.w, y);
-                const Pair r2 = share_rows(y);
-                y = r2.lo + r2.hi;
-                const Pair r4 = share_halves(y);
-                y = (r4.lo + r4.hi) + wdl[16];
-                const int f = 16 * t + nl;
-                const float x = xrow[f];
-                const float o = (a.input_skip ? x + y : y) * a.out_gain;
-                __builtin_amdgcn_wave_barrier();
-                if (q == 0) xrow[f] = o;
             }
             ST_TICK_END(tick);
             cs_lds_barrier();
@@ -890,7 +858,7 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
         if (u < 112) sm_b = W[d.L[1 + (u >> 4)].bs_off + (u & 15)];
     }
     auto stage_small = [&]() {
-        if (u < d.L[0].hist) xbuf[kConvsX0 - d.L[0].hist + u] = sm_x;
+        if (u < d.L[0].hist) xbuf[kStX0 - d.L[0].hist + u] = sm_x;
         if (u < 17) wdl[u] = sm_wd;
         if (u >= 64 && u < 128) l0w[u - 64] = sm_l0;
         if (u < 112) biasl[u] = sm_b;
@@ -935,103 +903,127 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
                 if (t == 15 && lane >= 14 && lane < 16) st_base[L0.ms_state_off + lane - 14] = xrow[240 + lane];
                 st_emit<1>(pl, q, po1, cs_activate(v, act0));
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                st_emit<2>(pl, q, po2, st_tile<1>(pl, biasl, t, afrA, q, nl, act1, rdA, hist_of(1), nullptr, nullptr, nullptr));
+                st_emit<2>(pl, q, po2, st_tile<1>(pl, biasl, t, afrA, q, nl, act1, rdA, hist_of(1), nullptr, 0));
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                st_emit<3>(pl, q, po3, st_tile<2>(pl, biasl, t, afrB, q, nl, act2, rdB, hist_of(2), nullptr, nullptr, nullptr));
+                st_emit<3>(pl, q, po3, st_tile<2>(pl, biasl, t, afrB, q, nl, act2, rdB, hist_of(2), nullptr, 0));
             }
             ST_TICK_END(tick);
             cs_lds_barrier();
         }
     } else if (wave == 2) {
-        cs_u32x4 hv[5], afrA[2][3], afrB[2][3];
+        // ---- layers 3, 4, 5
+        cs_u32x4 hv[6], afrA[2][3], afrB[2][3], afrC[2][3];
 #pragma unroll
         for (int r = 0; r < 2; ++r) hv[r] = st_ring_fetch<3>(hist_of(3), lane + r * kWave);
 #pragma unroll
         for (int r = 0; r < 3; ++r) hv[2 + r] = st_ring_fetch<4>(hist_of(4), lane + r * kWave);
         fetch_afrags(3, afrA);
-        fetch_afrags(4, afrB);
         const uint32_t flags = ctl.flags;
         if (out_of_circuit(flags)) return;
         const int Kp = (flags & CTL_EQ_PRE) ? 6 : 1, Kq = (flags & CTL_EQ_POST) ? 6 : 1, d1 = st_d1(Kp), T = st_ticks(Kp, Kq);
         stage_small();
-        const int actA = kTanh ? 1 : d.L[3].activation, actB = kTanh ? 1 : d.L[4].activation;
-        StRead rdA = st_read0<3>(q, nl), rdB = st_read0<4>(q, nl);
-        int po4 = nl, po5 = nl;
+        const int actA = kTanh ? 1 : d.L[3].activation, actB = kTanh ? 1 : d.L[4].activation, actC = kTanh ? 1 : d.L[5].activation;
+        StRead rdA = st_read0<3>(q, nl), rdB = st_read0<4>(q, nl), rdC = st_read0<5>(q, nl);
+        int po4 = nl, po5 = nl, po6 = nl;
         cs_lds_barrier();
-        int tick = 0;
-        for (; tick < d1 + 1; ++tick) cs_lds_barrier();            // (nothing to do yet: the pipeline fills)
+        // (the first two rings' histories go in as they arrive; the third's — 6 of this wave's 10.5 KiB — are asked for only now, behind the first
+        // barrier: all at once, the 18 MB the chip reads at a launch's start kept the first tick waiting for 4.5 us)
 #pragma unroll
         for (int r = 0; r < 2; ++r) st_ring_put<3>(pl, lane + r * kWave, hv[r]);
 #pragma unroll
         for (int r = 0; r < 3; ++r) st_ring_put<4>(pl, lane + r * kWave, hv[2 + r]);
+        fetch_afrags(4, afrB);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) hv[r] = st_ring_fetch<5>(hist_of(5), lane + r * kWave);
+        int tick = 0;
+        for (; tick < d1 + 1; ++tick) cs_lds_barrier();            // (nothing to do yet: the pipeline fills)
+#pragma unroll
+        for (int r = 0; r < 6; ++r) st_ring_put<5>(pl, lane + r * kWave, hv[r]);
+        fetch_afrags(5, afrC);                                 // (in the registers the history just left; L2-resident, two tiles of work in front of its first use)
         for (; tick < T; ++tick) {
             const int t = tick - d1 - 1;
             if (!(AIDAX_TUNE(a) & 2048)) st_prio(tick);
             ST_TICK_BEGIN();
             if (t < 16) {
-                st_emit<4>(pl, q, po4, st_tile<3>(pl, biasl, t, afrA, q, nl, actA, rdA, hist_of(3), nullptr, nullptr, nullptr));
+                st_emit<4>(pl, q, po4, st_tile<3, false>(pl, biasl, t, afrA, q, nl, actA, rdA, hist_of(3), nullptr, 0));
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                st_emit<5>(pl, q, po5, st_tile<4>(pl, biasl, t, afrB, q, nl, actB, rdB, hist_of(4), nullptr, nullptr, nullptr));
+                st_emit<5>(pl, q, po5, st_tile<4, false>(pl, biasl, t, afrB, q, nl, actB, rdB, hist_of(4), nullptr, 0));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                st_emit<6>(pl, q, po6, st_tile<5, false>(pl, biasl, t, afrC, q, nl, actC, rdC, hist_of(5), nullptr, 0));
             }
             ST_TICK_END(tick);
             cs_lds_barrier();
         }
     } else if (wave == 3) {
-        cs_u32x4 hv[12], afrA[2][3], afrB[2][3];
-        fetch_afrags(5, afrA);
+        // ---- layers 6, 7, Dense(16, 1) + skip / output gain. The three taps that reach further back than the rings hold — layer 6's oldest (128
+        // frames), layer 7's oldest and middle (256, 128) — go from HBM into the staging area without passing through registers (LDS-DMA: the
+        // low 32 lanes' (half, frame) vectors land at base + 16 lane, a term per instruction), requested when the tile before has been read:
+        // out of a layer's history where the frame belongs to the block before, out of what this launch has written where it belongs to this one
+        // (layer 6: the scratch; layer 7: its history, which is the block itself by the end).
+        cs_u32x4 hv[6], afrA[2][3], afrB[2][3];
+        fetch_afrags(6, afrA);
+        fetch_afrags(7, afrB);
         const uint32_t flags = ctl.flags;
         if (out_of_circuit(flags)) return;
         const int Kp = (flags & CTL_EQ_PRE) ? 6 : 1, Kq = (flags & CTL_EQ_POST) ? 6 : 1, d1 = st_d1(Kp), T = st_ticks(Kp, Kq);
         stage_small();
-        const int actA = kTanh ? 1 : d.L[5].activation, actB = kTanh ? 1 : d.L[6].activation;
-        StRead rdA = st_read0<5>(q, nl), rdB = st_read0<6>(q, nl);
-        int po6 = nl, po7 = nl;
+        const int actA = kTanh ? 1 : d.L[6].activation, actB = kTanh ? 1 : d.L[7].activation;
+        StRead rdA = st_read0<6>(q, nl), rdB = st_read0<7>(q, nl);
+        int po7 = nl;
         cs_u32x4* h6 = hist_of(6);
+        cs_u32x4* h7 = hist_of(7);
         cs_u32x4* scratch = reinterpret_cast<cs_u32x4*>(st_base + d.st_scratch_off);
-        // layer 6's oldest tap (128 frames back) of tile t — out of the old history for the block's first half, out of the scratch for the
-        // second — goes from HBM into the staging area without passing through registers (the wave has none left: two layers' A fragments):
-        // lane (half, frame) of the low 32 lands at base + 16 lane, a term per instruction. Requested when the tile before has been read.
         const int stage_vec = (int)(hand + kStHandFloats - smem) / 4;
         auto fetch_g = [&](int t) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (the reads of the tile before have left the staging area)
             if (q < 2 && t < 16) {
-                const cs_u32x4* src = (t < 8 ? h6 + 16 * t : scratch + 16 * (t - 8)) + (q & 1) * 128 + nl;
+                const cs_u32x4* src[3] = { (t < 8 ? h6 + 16 * t : scratch + 16 * (t - 8)) + (q & 1) * 128 + nl,           // layer 6, frame f - 128
+                                           h7 + (q & 1) * 256 + 16 * t + nl,                                              // layer 7, frame f - 256: index f of the old history
+                                           h7 + (q & 1) * 256 + (t < 8 ? 16 * t + 128 : 16 * t - 128) + nl };             // layer 7, frame f - 128: old index f + 128, or new index f - 128
 #pragma unroll
-                for (int term = 0; term < 3; ++term) {
-                    unsigned keep;
-                    const unsigned dst = (unsigned)(size_t)(pl + stage_vec + term * 32);      // (LDS byte address: the low 32 bits of the pointer)
-                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                                 : "=&s"(keep) : "v"(src + term * 2 * 128), "s"(dst) : "memory");
-                }
+                for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+                    for (int term = 0; term < 3; ++term) {
+                        unsigned keep;
+                        const unsigned dst = (unsigned)(size_t)(pl + stage_vec + tap * kStTapVecs + term * 32);      // (LDS byte address: the low 32 bits of the pointer)
+                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                     : "=&s"(keep) : "v"(src[tap] + term * 2 * (tap == 0 ? 128 : 256)), "s"(dst) : "memory");
+                    }
             }
         };
+        const float* wdq = wdl + 4 * q;
         cs_lds_barrier();
-        // This wave's histories are two thirds of what the launch reads at its start (12 of 18 KiB per stream), and its first tile is three
-        // ticks away: they are requested BEHIND the first barrier, when the chain wave's row and coefficients — which that barrier waits
-        // for — are home (all at once, the chip's 18 MB kept the first tick waiting for 4.5 us).
+        // (this ring's history — the 64 frames layer 6's middle tap reaches — is asked for behind the first barrier, like wave 2's third)
 #pragma unroll
-        for (int r = 0; r < 6; ++r) hv[r] = st_ring_fetch<5>(hist_of(5), lane + r * kWave);
-#pragma unroll
-        for (int r = 0; r < 6; ++r) hv[6 + r] = st_ring_fetch<6>(hist_of(6), lane + r * kWave);
+        for (int r = 0; r < 6; ++r) hv[r] = st_ring_fetch<6>(hist_of(6), lane + r * kWave);
         fetch_g(0);
         int tick = 0;
         for (; tick < d1 + 2; ++tick) cs_lds_barrier();            // (nothing to do yet: the pipeline fills)
 #pragma unroll
-        for (int r = 0; r < 6; ++r) st_ring_put<5>(pl, lane + r * kWave, hv[r]);
-#pragma unroll
-        for (int r = 0; r < 6; ++r) st_ring_put<6>(pl, lane + r * kWave, hv[6 + r]);
-        fetch_afrags(6, afrB);
+        for (int r = 0; r < 6; ++r) st_ring_put<6>(pl, lane + r * kWave, hv[r]);
         for (; tick < T; ++tick) {
             const int t = tick - d1 - 2;
             if (!(AIDAX_TUNE(a) & 2048)) st_prio(tick);
             ST_TICK_BEGIN();
             if (t < 16) {
-                st_emit<6>(pl, q, po6, st_tile<5>(pl, biasl, t, afrA, q, nl, actA, rdA, hist_of(5), nullptr, nullptr, nullptr));
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the staged taps have landed
+                st_emit<7>(pl, q, po7, st_tile<6>(pl, biasl, t, afrA, q, nl, actA, rdA, h6, scratch, stage_vec));
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the staged tap has landed
-                const f32x4 v = st_tile<6>(pl, biasl, t, afrB, q, nl, actB, rdB, h6, scratch, nullptr, nullptr, stage_vec);
+                const f32x4 v = st_tile<7>(pl, biasl, t, afrB, q, nl, actB, rdB, h7, nullptr, stage_vec);
                 fetch_g(t + 1);
-                st_emit<7>(pl, q, po7, v);
+                float y = wdq[0] * v.x;                       // (:171-181; emit()'s arithmetic in k_conv_ms)
+                y = __builtin_fmaf(wdq[1], v.y, y);
+                y = __builtin_fmaf(wdq[2], v.z, y);
+                y = __builtin_fmaf(wdq[3], v.w, y);
+                const Pair r2 = share_rows(y);
+                y = r2.lo + r2.hi;
+                const Pair r4 = share_halves(y);
+                y = (r4.lo + r4.hi) + wdl[16];
+                const int f = 16 * t + nl;
+                const float x = xrow[f];
+                const float o = (a.input_skip ? x + y : y) * a.out_gain;
+                __builtin_amdgcn_wave_barrier();
+                if (q == 0) xrow[f] = o;
             }
             ST_TICK_END(tick);
             cs_lds_barrier();

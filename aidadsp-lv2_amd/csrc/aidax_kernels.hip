@@ -57,6 +57,10 @@ struct LstmCell {
     static constexpr int KW = lstm_row_weights(H, ROT4);   // recurrent weights per gate row in this instantiation's record
 
     float w[NU][GPL][KW];
+    // ROT (H = 32): the two gate rows' weights for the sixteen units that come through LDS, SIDE BY SIDE — operand pairs of v_pk_fma_f32:
+    // one instruction advances both rows' accumulators by one unit (see step)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 wl2[16];
     float wx[NU][GPL][kMaxInputs];
     float bias[NU][GPL];
     float wd[NU], bd;
@@ -92,6 +96,12 @@ struct LstmCell {
 #pragma unroll
         for (int m = 0; m < NU; ++m) wd[m] = wp[(r++) * kWave + lane];
         bd = wp[(r++) * kWave + lane];
+        if constexpr (ROTP && lstm_rot2(H)) {
+            // (read once more from the record rather than copied out of w[][]: rows 0 and 1 of unit slot 0, KW + inputs + bias registers apart)
+            constexpr int kRow = KW + kMaxInputs + 1;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) wl2[k] = f32x2{ wp[(16 + k) * kWave + lane], wp[(kRow + 16 + k) * kWave + lane] };
+        }
 #pragma unroll
         for (int e = 0; e < GPL; ++e) {
             // row positions whose gate type differs between lanes are evaluated in the common
@@ -178,17 +188,25 @@ struct LstmCell {
             a1 = __builtin_fmaf(w[0][1][0], hr, a1);
             fmac_row_ror_1_15(a0, hr, w[0][0]);               // rotations 1..15 of each row: one asm statement per row
             fmac_row_ror_1_15(a1, hr, w[0][1]);
+            // (the rows' rotations as four chains — row x even / odd rotation, round robin — measured no better: 64.6 against 64.25 us)
             // (the four reads were issued ~35 instructions ago: ONE wait for all of them instead of one in front of each quad of FMAs)
             __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0)
-            const float4 qs[4] = { q0, q1, q2, q3 };
+            // The sixteen units that came through LDS, both gate ROWS per instruction — {a0, a1} += {w0[k], w1[k]} * {h[k], h[k]}: v_pk_fma_f32 with
+            // one half of the h pair selected for both results — on FOUR accumulator pairs in turn: a lone wave issues a packed FMA in the interval
+            // of a plain one, but a DEPENDENT instruction only ~8.7 cycles after the one it waits for, an independent one after ~5.8
+            // (scratch/ub/upk.hip). One pair chain of sixteen: 67.3 us (slower than the 32 plain FMAs on two chains, 66.2); four chains of four: 64.25.
+            f32x2 pA = { a0, a1 }, pB = { 0.f, 0.f }, pC = { 0.f, 0.f }, pD = { 0.f, 0.f };
+            const f32x2 hq[8] = { f32x2{ q0.x, q0.y }, f32x2{ q0.z, q0.w }, f32x2{ q1.x, q1.y }, f32x2{ q1.z, q1.w },
+                                  f32x2{ q2.x, q2.y }, f32x2{ q2.z, q2.w }, f32x2{ q3.x, q3.y }, f32x2{ q3.z, q3.w } };
 #pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) {
-                a0 = __builtin_fmaf(w[0][0][16 + 4 * k4 + 0], qs[k4].x, a0); a1 = __builtin_fmaf(w[0][1][16 + 4 * k4 + 0], qs[k4].x, a1);
-                a0 = __builtin_fmaf(w[0][0][16 + 4 * k4 + 1], qs[k4].y, a0); a1 = __builtin_fmaf(w[0][1][16 + 4 * k4 + 1], qs[k4].y, a1);
-                a0 = __builtin_fmaf(w[0][0][16 + 4 * k4 + 2], qs[k4].z, a0); a1 = __builtin_fmaf(w[0][1][16 + 4 * k4 + 2], qs[k4].z, a1);
-                a0 = __builtin_fmaf(w[0][0][16 + 4 * k4 + 3], qs[k4].w, a0); a1 = __builtin_fmaf(w[0][1][16 + 4 * k4 + 3], qs[k4].w, a1);
+            for (int k2 = 0; k2 < 8; k2 += 2) {
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(pA) : "v"(wl2[2 * k2]), "v"(hq[k2]));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(pB) : "v"(wl2[2 * k2 + 1]), "v"(hq[k2]));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(pC) : "v"(wl2[2 * k2 + 2]), "v"(hq[k2 + 1]));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(pD) : "v"(wl2[2 * k2 + 3]), "v"(hq[k2 + 1]));
             }
-            acc[0][0] = a0; acc[0][1] = a1;
+            const f32x2 a01 = (pA + pB) + (pC + pD);
+            acc[0][0] = a01.x; acc[0][1] = a01.y;
         } else {
         const float4* hv = reinterpret_cast<const float4*>(hprev);
 #pragma unroll

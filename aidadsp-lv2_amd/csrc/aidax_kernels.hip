@@ -748,7 +748,7 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
     // ---------------------------------------------------------------- pipeline
     for (int p = 0; p < n_sub + 2; ++p) {
         if (wave == 0) {
-            if (p < n_sub) {
+            if (p < n_sub && !(AIDAX_TUNE(a) & 262144)) {       // (bit 262144, test build: wave P idle — what the helper waves cost the recurrent one; wrong output)
                 const int base = p * kSB;
                 const int cnt = n - base < kSB ? n - base : kSB;
                 float* stage = xq + (p % 3) * kStage;
@@ -815,7 +815,7 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
                 }
             }
         } else {
-            if (p >= 2) {
+            if (p >= 2 && !(AIDAX_TUNE(a) & 524288)) {          // (bit 524288: wave Q idle)
                 const int base = (p - 2) * kSB;
                 const int cnt = n - base < kSB ? n - base : kSB;
                 const int tl = lane < cnt ? lane : cnt - 1;

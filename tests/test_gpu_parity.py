@@ -761,6 +761,7 @@ def test_random_conv_architectures(seed, tmp_path, monkeypatch):
 _MS_STACKS = [
     # (layer 0: taps, dilation), then (taps, dilation, activation) per sixteen-channel layer — what k_conv_ms admits (conv_ms_shape_ok), corners first
     ("cfg4-like", (3, 1), [(3, 2, "tanh"), (3, 4, "tanh"), (3, 8, "tanh"), (3, 16, "tanh"), (3, 32, "tanh"), (3, 64, "tanh"), (3, 128, "tanh")]),   # last layer: 256 frames back, beyond the plane
+    ("cfg4 shape, mixed activations", (3, 1), [(3, 2, "relu"), (3, 4, "tanh"), (3, 8, "sigmoid"), (3, 16, ""), (3, 32, "tanh"), (3, 64, "relu"), (3, 128, "sigmoid")]),   # k_conv_st<false>: the activation switch left in
     ("two taps, one deep", (2, 3), [(2, 200, "relu"), (2, 1, "tanh")]),                                   # 200 frames back: tiles 0 .. 4 read the history in HBM
     ("four taps, two deep taps in one k-step", (4, 5), [(4, 85, "tanh"), (4, 1, "sigmoid"), (4, 7, "")]),      # shifts 255 / 170 share k-step 0: per-lane sources
     ("four taps, 64 apart", (1, 1), [(4, 64, "tanh"), (4, 42, "relu")]),                                 # shift 192: tiles 0 .. 3 deep; layer 0 with ONE tap
@@ -793,7 +794,7 @@ def test_conv_stacks_on_the_split_kernel_corners(name, l0, rest, tmp_path, monke
     scale = max(1.0, float(np.abs(want).max()))
     outs = {}
     # (the first stack is the one k_conv_st serves: its full blocks run there — tile-major, the same bits — unless AIDAX_CONV_ST=0)
-    streamed = name == "cfg4-like"
+    streamed = name in ("cfg4-like", "cfg4 shape, mixed activations")
     for env, kname in (({}, "k_conv_ms"), ({"AIDAX_CONV_FUSED": "0"}, "k_chain+k_conv_ms"), ({"AIDAX_CONV_MS": "0"}, "k_conv_mfma"), ({"AIDAX_CONV_ST": "0"}, "k_conv_ms/all")):
         for k_ in ("AIDAX_CONV_FUSED", "AIDAX_CONV_MS", "AIDAX_CONV_ST"):
             monkeypatch.delenv(k_, raising=False)

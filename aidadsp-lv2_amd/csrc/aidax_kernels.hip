@@ -67,6 +67,13 @@ struct LstmCell {
     float aka[GPL], akb[GPL];
     float c[NU], h[NU];
     int part, slot;
+#ifdef AIDAX_PIPE_TRACE
+    unsigned long long ts6 = 0;
+    unsigned long long ts[6];             // measurement build: s_memtime at five points of ONE frame of the unrolled stage (scratch/pipe_frame.py)
+#define PT_STAMP(k) do { if constexpr (TR) { __builtin_amdgcn_sched_barrier(0); ts[k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define PT_STAMP(k) do { } while (0)
+#endif
     static constexpr int kStatePart = S == 2 ? 1 : 0;      // the lanes whose c / h are the cell's
     // H = 32 (two full 16-lane rows of units): half of a row's recurrent FMAs take h(t-1) straight out of the
     // neighbours' registers — the lane's own unit plus 15 rotations within its row (v_fmac_f32_dpp) — while the reads of the
@@ -156,9 +163,10 @@ struct LstmCell {
     // NI = inputs that can be non-zero (the packer zero-fills the weights of absent inputs).
     // WINDOW > 0 fences the scheduler every WINDOW float4 loads of h, bounding the registers held by
     // in-flight LDS reads (the many-streams kernels trade that latency for occupancy); 0 = all at once.
-    template <int NI = kMaxInputs, int WINDOW = 0>
+    template <int NI = kMaxInputs, int WINDOW = 0, bool TR = false>
     __device__ __forceinline__ void step(float x0, float x1, float x2, const float* hprev, float* hout)
     {
+        PT_STAMP(0);                                        // frame starts
         float acc[NU][GPL];
 #pragma unroll
         for (int m = 0; m < NU; ++m)
@@ -191,6 +199,7 @@ struct LstmCell {
             // (the rows' rotations as four chains — row x even / odd rotation, round robin — measured no better: 64.6 against 64.25 us)
             // (the four reads were issued ~35 instructions ago: ONE wait for all of them instead of one in front of each quad of FMAs)
             __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0)
+            PT_STAMP(1);                                    // rotations issued, the other row's h has arrived
             // The sixteen units that came through LDS, both gate ROWS per instruction — {a0, a1} += {w0[k], w1[k]} * {h[k], h[k]}: v_pk_fma_f32 with
             // one half of the h pair selected for both results — on FOUR accumulator pairs in turn: a lone wave issues a packed FMA in the interval
             // of a plain one, but a DEPENDENT instruction only ~8.7 cycles after the one it waits for, an independent one after ~5.8
@@ -207,6 +216,7 @@ struct LstmCell {
             }
             const f32x2 a01 = (pA + pB) + (pC + pD);
             acc[0][0] = a01.x; acc[0][1] = a01.y;
+            PT_STAMP(2);                                    // products done
         } else {
         const float4* hv = reinterpret_cast<const float4*>(hprev);
 #pragma unroll
@@ -240,6 +250,7 @@ struct LstmCell {
                     act[e] = __builtin_fmaf(tanh_rat(acc[m][e]), aka[e], akb[e]);
                 }
             }
+            PT_STAMP(3);                                    // gate activations issued
             // c' = f*c + i*g, h = o*tanh(c') — where the four gates of a unit come together:
             float gi_gg, gf, go;
             if constexpr (S == 1) {                         // one lane holds all four
@@ -267,8 +278,10 @@ struct LstmCell {
             if constexpr (ROT) h[m] = share_halves(hn).hi;  // the (f, o) half's h into both halves: the rotations read it
             else h[m] = hn;
         }
+        PT_STAMP(4);                                        // h(t) in registers
         publish_h(hout);
         __builtin_amdgcn_wave_barrier();
+        PT_STAMP(5);                                        // ... and on its way to LDS
     }
 };
 
@@ -285,6 +298,9 @@ struct GruCell {
     static constexpr int KS = H / S;          // recurrent columns per lane (K-split across the S lanes of a unit)
     static constexpr int PACK = gru_pack_regs(H);
     static constexpr int STATE = H;
+#ifdef AIDAX_PIPE_TRACE
+    unsigned long long ts6 = 0, ts[6] = { 0, 0, 0, 0, 0, 0 };      // (LstmCell's frame stamps: not taken here)
+#endif
     static_assert(KS % 4 == 0, "K slice must stay float4 aligned");
 
     float w[NU][3][KS];
@@ -358,7 +374,7 @@ struct GruCell {
         else { const Pair p = share_halves(v); const float t = p.lo + p.hi; const Pair q = share_rows(t); return q.lo + q.hi; }
     }
 
-    template <int NI = kMaxInputs, int WINDOW = 0>
+    template <int NI = kMaxInputs, int WINDOW = 0, bool TR = false>
     __device__ __forceinline__ void step(float x0, float x1, float x2, const float* hprev, float* hout)
     {
         float ax[NU][3], ar[NU][3];
@@ -599,7 +615,11 @@ constexpr int kStage = 4 * kSB;         // floats of one hand-over stage of the 
 __host__ __device__ constexpr int pipe_row_stride(int H) { return H + 4; }   // floats; keeps rows 16-B aligned
 __host__ __device__ constexpr size_t pipe_lds_floats(int H, int n_frames)
 {
-    return (size_t)((n_frames + 3) & ~3) + 3 * kSB * 4 + (size_t)kRing * pipe_row_stride(H) + kSB + (size_t)(H + 4);
+    return (size_t)((n_frames + 3) & ~3) + 3 * kSB * 4 + (size_t)kRing * pipe_row_stride(H) + kSB + (size_t)(H + 4)
+#ifdef AIDAX_PIPE_TRACE
+         + 80                                               // the recurrent wave's stage stamps (scratch/pipe_frame.py)
+#endif
+        ;
 }
 
 // Wave P, a whole stage of a ONE-stage pre pass (no EQ in front of the model — the default): the stage's sixteen frames as one
@@ -655,6 +675,9 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
     float*  hh    = xq + 3 * kStage;                                        // h history, kRing rows
     float*  qb    = hh + kRing * HS;                                        // Q private
     float*  wdl   = qb + kSB;                                               // Q private: Dense weights, natural order
+#ifdef AIDAX_PIPE_TRACE
+    uint32_t* stg_tr = reinterpret_cast<uint32_t*>(wdl + H + 4);            // [2 x 18 stages + 4]: wave N's clock at the begin / end of its work per pipeline step
+#endif
 
     const StreamCtl& ctl = a.ctl[s];
     StreamState& st = a.st[s];
@@ -772,6 +795,9 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
                 }
             }
         } else if (wave == 1) {
+#ifdef AIDAX_PIPE_TRACE
+            if (lane == 0 && p < 18) stg_tr[2 * p] = (uint32_t)(clock64() - tr_c0);
+#endif
             if (net_on && p >= 1 && p <= n_sub) {
                 const int base = (p - 1) * kSB;
                 const int cnt = n - base < kSB ? n - base : kSB;
@@ -797,9 +823,18 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
                         xr[4 * q] = v.x * in_gain; xr[4 * q + 1] = v.y * in_gain;       // out[i] *= input_gain
                         xr[4 * q + 2] = v.z * in_gain; xr[4 * q + 3] = v.w * in_gain;
                     }
+#ifdef AIDAX_PIPE_TRACE
+#pragma unroll
+                    for (int t = 0; t < kSB; ++t) {
+                        if (t == 8) cell.template step<1, 0, true>(xr[t], 0.f, 0.f, hcur + (t - 1) * HS, hcur + t * HS);
+                        else cell.template step<1>(xr[t], 0.f, 0.f, t == 0 ? hprev : hcur + (t - 1) * HS, hcur + t * HS);
+                        if (t == 9) cell.ts6 = __builtin_amdgcn_s_memtime();      // the frame after the traced one has been issued
+                    }
+#else
 #pragma unroll
                     for (int t = 0; t < kSB; ++t)
                         cell.template step<1>(xr[t], 0.f, 0.f, t == 0 ? hprev : hcur + (t - 1) * HS, hcur + t * HS);
+#endif
                 } else if (I == 1) {                            // ragged last stage
                     for (int t = 0; t < cnt; ++t) {
                         cell.template step<1>(stage[t] * in_gain, 0.f, 0.f, hprev, hcur);
@@ -873,8 +908,14 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
                 if (hi > q_done) q_done = hi;
             }
         }
+#ifdef AIDAX_PIPE_TRACE
+        if (wave == 1 && lane == 0 && p < 18) stg_tr[2 * p + 1] = (uint32_t)(clock64() - tr_c0);
+#endif
         __syncthreads();
     }
+#ifdef AIDAX_PIPE_TRACE
+    if (wave == 1 && lane == 0) stg_tr[36] = (uint32_t)(clock64() - tr_c0);
+#endif
 
     // ---------------------------------------------------------------- state write-back
     if (wave == 0) {
@@ -891,6 +932,17 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
         }
     } else if (wave == 1) {
         if (net_on) cell.store(nnst);
+#ifdef AIDAX_PIPE_TRACE
+        if constexpr (H == 32) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) out_row[8 + k] = __builtin_bit_cast(float, (uint32_t)(cell.ts[k] - cell.ts[0]));
+                out_row[14] = __builtin_bit_cast(float, (uint32_t)(cell.ts6 - cell.ts[0]));
+            }
+            if (lane < 37) out_row[16 + lane] = __builtin_bit_cast(float, stg_tr[lane]);
+        }
+#endif
     } else {
         if (lane >= cp.K || !cp.active) { cp.z1 = q_z1o; cp.z2 = q_z2o; }      // a bypassed biquad keeps its state (:646)
         if (lane < cp.K) { st.z[slot][0] = cp.z1; st.z[slot][1] = cp.z2; }

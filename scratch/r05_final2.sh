@@ -7,3 +7,5 @@ cat gpurun_out/r05_gpu_suite.txt
 bash scratch/r05_final_prof.sh r05 2>&1 | tail -30
 AIDAX_LIB=$PWD/build/lib_cv/libaidax_hip.so python scratch/st_trace.py > gpurun_out/r05_st_trace.txt 2>&1
 tail -8 gpurun_out/r05_st_trace.txt
+AIDAX_LIB=$PWD/build/lib_pt/libaidax_hip.so python scratch/pipe_frame.py > gpurun_out/r05_pipe_frame.txt 2>&1
+tail -30 gpurun_out/r05_pipe_frame.txt

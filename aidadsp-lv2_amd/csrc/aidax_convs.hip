@@ -531,19 +531,21 @@ __global__ __launch_bounds__(kCsThreads, 4) void k_conv_ms(LaunchArgs a, ConvDes
 // tick:
 //     wave 0   both chain passes AT ONCE: the pre pass on lanes 0 .. 5, the post pass on lanes 6 .. 11 of the same instructions
 //              (chain_macro_step: a stage per lane, eight frames per hand-over, two steps per tick) — tile j of the input at tick j, tile j
-//              of the output d1 + 4 ticks later; then layer 7, Dense + skip / gain of the tile between them;
-//     wave 1   layer 0 (fp32 FMAs), layers 1, 2         wave 2   layers 3, 4         wave 3   layers 5, 6,
+//              of the output d1 + 3 ticks later;
+//     wave 1   layer 0 (fp32 FMAs), layers 1, 2         wave 2   layers 3, 4, 5         wave 3   layers 6, 7, Dense + skip / gain,
 // each a tick behind the one in front of it (FOUR waves: a fifth would put two of a workgroup's waves on one SIMD, and the CU does not then
 // take four workgroups — measured: 768 of cfg4's 1024 resident), a wave's layers back to back on the same tile (LDS runs a wave's accesses in order). A
 // layer's input lives in a RING of its own in LDS — its history plus the tiles in flight, in k_conv_ms's [term][channel half][frame]
 // vectors — so nothing is copied between layers, no history goes out and in through HBM per layer pass, and a wave keeps the A fragments
-// of its two layers in registers for the whole launch. 23 tiles of rings = 34.5 KiB: four workgroups per CU as before. What does not
-// fit comes from HBM as B fragments, requested a tick ahead: layer 6's oldest tap (128 frames back) and both old taps of layer 7
-// (256, 128) — out of the layer's history where the frame belongs to the block before (k_conv_ms's layout: the two kernels share the
-// state, ragged blocks and the split form go through k_conv_ms), out of what this launch has written where it belongs to this one
-// (layer 7's history IS the block; layer 6's takes the block's second half, the first goes to 12 KiB of scratch per stream). The new
-// histories leave as the tiles pass: the wave that reads a tile's newest tap has the very vectors the history consists of in registers.
-// Same fragments, same MFMA order, same epilogue arithmetic as k_conv_ms: the outputs are bit-identical to it.
+// of its layers in registers for the whole launch. 22 tiles of rings = 33 KiB: four workgroups per CU as before (40 928 of a quarter CU's
+// 40 960 bytes with the row, the small tables and the staging area). What no ring holds comes from HBM as B fragments WITHOUT passing through
+// registers (global_load_lds_dwordx4 into a 4.5 KiB staging area, requested when the tile before has been read): layer 6's oldest tap (128
+// frames back) and both old taps of layer 7 (256, 128) — out of the layer's history where the frame belongs to the block before (k_conv_ms's
+// layout: the two kernels share the state, ragged blocks and the split form go through k_conv_ms), out of what this launch has written
+// where it belongs to this one (layer 7's history IS the block; layer 6's takes the block's second half, the first goes to 12 KiB of
+// scratch per stream). The new histories leave as the tiles pass: the wave that reads a tile's newest tap has the very vectors the history
+// consists of in registers. Same fragments, same MFMA order, same epilogue arithmetic as k_conv_ms: the outputs are bit-identical to it.
+// How it got here, step by step with every measurement: profiles/r05_cfg4_stream_steps.txt; its timeline: profiles/r05_cfg4_stream_trace.txt.
 // Serves: exactly eight layers of three taps, dilation 2^l (BASELINE cfg4's stack; conv_st_shape_ok), blocks of exactly 256 frames, the fused form.
 constexpr int kStThreads = 256;
 // tiles of the ring in front of layer l: history / 16 + 1, + 1 where producer and consumer are different waves
@@ -740,7 +742,8 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
     // Everything the launch reads from memory before its first tick is requested HERE, in front of the control word the first branch depends
     // on — reads only, whatever that branch decides: one trip to HBM instead of two or three in a row (the prologue was 5 us of a 45 us
     // workgroup: scratch/st_trace.py). Wave 0: the audio row, the smoothers, both passes' coefficients and state by lane (a lane beyond
-    // its cascade holds some stage's numbers and does not run), layer 7's fragments; waves 1 .. 3: the rings' histories, two layers' fragments.
+    // its cascade holds some stage's numbers and does not run); waves 1 .. 3: the histories of their first rings, their layers' fragments (what a wave
+    // needs only at its first tile — a tick or more away — is asked for behind the first barrier: see the roles).
     auto hist_of = [&](int l) { return reinterpret_cast<cs_u32x4*>(st_base + d.L[l].ms_state_off); };
     auto fetch_afrags = [&](int l, cs_u32x4 (&afr)[2][3]) {
         const cs_u32x4* rec = reinterpret_cast<const cs_u32x4*>(W + d.L[l].ms_w_off) + lane;

@@ -125,6 +125,22 @@ __device__ __forceinline__ float tanh_rat(float v)
 {
     const float x = tanh_rat_clamp(v);
     const float u = x * x;
+#ifndef AIDAX_TANH_PLAIN
+    // The first three Horner steps of P and all three of Q side by side in v_pk_fma_f32 ({p, q} <- {p, q} * {u, u} + {cP, cQ}: the same FMAs on the same
+    // operands, so the same bits), the last three of P alone: six instructions for nine. A lone wave issues a packed FMA in a plain one's interval
+    // (profiles/r05_lone_wave_issue.txt), and the recurrent wave's frame is its instruction count (profiles/r05_cfg2_frame_trace.txt): two rationals per frame.
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t uu = { u, u };
+    f32x2_t pq = { kTanhP[6], kTanhQ[3] };
+    pq = __builtin_elementwise_fma(pq, uu, f32x2_t{ kTanhP[5], kTanhQ[2] });
+    pq = __builtin_elementwise_fma(pq, uu, f32x2_t{ kTanhP[4], kTanhQ[1] });
+    pq = __builtin_elementwise_fma(pq, uu, f32x2_t{ kTanhP[3], kTanhQ[0] });
+    float pp = pq.x;
+    pp = __builtin_fmaf(pp, u, kTanhP[2]);
+    pp = __builtin_fmaf(pp, u, kTanhP[1]);
+    pp = __builtin_fmaf(pp, u, kTanhP[0]);
+    return (pp * x) * __builtin_amdgcn_rcpf(pq.y);
+#endif
     float p = kTanhP[6];
     p = __builtin_fmaf(p, u, kTanhP[5]);
     p = __builtin_fmaf(p, u, kTanhP[4]);

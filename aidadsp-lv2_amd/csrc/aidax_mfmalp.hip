@@ -1147,8 +1147,25 @@ __device__ __forceinline__ unsigned gs_pack_bf16(float a, float b)
     return u;
 }
 // four fp32 values -> three terms of four bf16 each (term t: two dwords), v = t0 + t1 + t2 exactly
+typedef float gs_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void gs_split4(const float (&v)[4], u32x2 (&t)[3])
 {
+#ifndef AIDAX_GS_NOPK
+    // The residuals' subtractions two values per instruction (v_pk_add_f32: the same IEEE subtraction per value). The main waves of the
+    // tick kernels share their SIMD with one helper wave: they issue like a lone wave, for which a packed instruction costs what a plain
+    // one does (profiles/r05_lone_wave_issue.txt) — and this split sits between a tick's last MFMA and its barrier.
+    gs_f32x2 r01 = { v[0], v[1] }, r23 = { v[2], v[3] };
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const unsigned p01 = gs_pack_bf16(r01.x, r01.y), p23 = gs_pack_bf16(r23.x, r23.y);
+        t[k] = u32x2{ p01, p23 };
+        if (k < 2) {
+            r01 = r01 - gs_f32x2{ __builtin_bit_cast(float, p01 << 16), __builtin_bit_cast(float, p01 & 0xffff0000u) };
+            r23 = r23 - gs_f32x2{ __builtin_bit_cast(float, p23 << 16), __builtin_bit_cast(float, p23 & 0xffff0000u) };
+        }
+    }
+    return;
+#endif
     float r[4] = { v[0], v[1], v[2], v[3] };
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -1333,12 +1350,28 @@ __global__ __launch_bounds__((UT + NHELP) * kWave) void k_gru_gs(LaunchArgs a, M
 #ifdef AIDAX_GS_PRIO                                             // (measurement: the main wave's tail — cell update, split, publish — ahead of the helpers)
                 __builtin_amdgcn_s_setprio(3);
 #endif
+#ifndef AIDAX_GS_NOPK
+                // the cell update two units per instruction (v_pk_fma_f32 / v_pk_add_f32 around the two exponentials and reciprocals: the
+                // same operations per unit, the same bits): 18 instructions for 28 between the last MFMA and the publish
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    const gs_f32x2 gz = { sg8[e], sg8[e + 1] }, gr = { sg8[4 + e], sg8[5 + e] };
+                    const gs_f32x2 pre = __builtin_elementwise_fma(gr, gs_f32x2{ acc[2][e], acc[2][e + 1] }, gs_f32x2{ ax[e], ax[e + 1] });      // (the record's candidate rows carry 2 log2 e)
+                    const gs_f32x2 ex = { __builtin_amdgcn_exp2f(pre.x), __builtin_amdgcn_exp2f(pre.y) };
+                    const gs_f32x2 sm = ex + gs_f32x2{ 1.0f, 1.0f };
+                    const gs_f32x2 rc = { __builtin_amdgcn_rcpf(sm.x), __builtin_amdgcn_rcpf(sm.y) };
+                    const gs_f32x2 nn = __builtin_elementwise_fma(gs_f32x2{ -2.0f, -2.0f }, rc, gs_f32x2{ 1.0f, 1.0f });     // tanh_exp_pre
+                    const gs_f32x2 hh = __builtin_elementwise_fma(gz, gs_f32x2{ hreg[e], hreg[e + 1] } - nn, nn);
+                    hreg[e] = hh.x; hreg[e + 1] = hh.y;
+                }
+#else
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float gz = sg8[e], gr = sg8[4 + e];
                     const float nn = tanh_exp_pre(__builtin_fmaf(gr, acc[2][e], ax[e]));      // (the record's candidate rows carry 2 log2 e)
                     hreg[e] = __builtin_fmaf(gz, hreg[e] - nn, nn);
                 }
+#endif
                 LP_STAMP(3);
                 par ^= 1;
                 publish(par);

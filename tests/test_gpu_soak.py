@@ -17,6 +17,8 @@ def test_random_host_behaviour(form):
     env = dict(os.environ)
     env.pop("AIDAX_KERNEL", None)
     if form:
+        from tests.conftest import needs_hook
+        needs_hook("AIDAX_KERNEL")
         env["AIDAX_KERNEL"] = form                      # read at pool creation: one process per form
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "soak.py"), "250"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=600)

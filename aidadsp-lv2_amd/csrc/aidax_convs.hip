@@ -130,6 +130,12 @@ __global__ __launch_bounds__(kCsThreads, 4) void k_conv_ms(LaunchArgs a, ConvDes
     const float* W = a.wpack;
     float* st_base = a.nn + (size_t)sg * a.nn_stride;
     const ConvLayer& L0 = d.L[0];
+    // A layer's history in HBM is a RING (round 6): the frame at absolute time tau of the stream sits at index tau mod hist of every strip, `pos` = the
+    // time of this block's first frame modulo the stack's common period (ConvDesc::ms_pos_mod). A block then costs its own frames and nothing else —
+    // no history is moved up when a block is shorter than it — and k_conv_st can take blocks of any tile count on the same state.
+    uint32_t* pos_slot = reinterpret_cast<uint32_t*>(st_base + d.ms_pos_off);
+    const uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)*pos_slot);
+    auto head_of = [&](const ConvLayer& L) { return (int)(pos % (uint32_t)L.hist); };       // where frame 0 of this block goes
 
     // ---- register prefetches: a layer's A fragments, the in-plane part of its input history, its deep B fragments
     cs_u32x4 afr[2][3];                                       // [k-step][term]
@@ -153,12 +159,15 @@ __global__ __launch_bounds__(kCsThreads, 4) void k_conv_ms(LaunchArgs a, ConvDes
         const int hp = L.hist < Hh ? L.hist : Hh;
         const float inv_hp = __builtin_amdgcn_rcpf((float)hp);
         const cs_u32x4* src = reinterpret_cast<const cs_u32x4*>(st_base + L.ms_state_off);
+        const int head = head_of(L);
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int v = tid + r * kCsThreads;
             int strip, k;
             prefix_index(v < 6 * hp ? v : 0, hp, inv_hp, strip, k);
-            hpv[r] = v < 6 * hp ? src[strip * L.hist + (L.hist - hp + k)] : cs_u32x4{ 0u, 0u, 0u, 0u };
+            int i = head - hp + k;                                  // frame k - hp of the block's time
+            i = i < 0 ? i + L.hist : i;
+            hpv[r] = v < 6 * hp ? src[strip * L.hist + i] : cs_u32x4{ 0u, 0u, 0u, 0u };
         }
     };
     auto store_prefix = [&](int l) {
@@ -201,12 +210,14 @@ __global__ __launch_bounds__(kCsThreads, 4) void k_conv_ms(LaunchArgs a, ConvDes
         const cs_u32x4* src = reinterpret_cast<const cs_u32x4*>(st_base + L.ms_state_off) + (q & 1) * L.hist;
         const int sh = lane_shift(L, 0);
         const bool pad = lane_pad(L, 0);
+        const int head = head_of(L);
 #pragma unroll
         for (int j = 0; j < kCsMaxDeep; ++j) {
             const int t = wave + 4 * j;
             if (t >= ntiles || !pair_deep(L, 0, t)) continue;
             const int f = 16 * t + nl - sh;                                // this lane's source frame
-            const int hi = (f < -Hh && !pad) ? L.hist + f : 0;             // frame f of the history = index hist + f
+            int hi = (f < -Hh && !pad) ? head + f : 0;                     // frame f < 0 of the history: index (head + f) mod hist
+            hi = hi < 0 ? hi + L.hist : hi;
 #pragma unroll
             for (int term = 0; term < 3; ++term) {
                 const cs_u32x4 v = src[b_term_off(L, 0, term, 2 * L.hist) + hi];
@@ -378,39 +389,24 @@ __global__ __launch_bounds__(kCsThreads, 4) void k_conv_ms(LaunchArgs a, ConvDes
             {
                 cs_u32x4* hbm = reinterpret_cast<cs_u32x4*>(st_base + L.ms_state_off);
                 if (deep_layer) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); cs_lds_barrier(); }
-                const bool from_old = L.hist > Hh + n;        // a short block on a deep layer: part of the new history is old history, moved up
-                if (!from_old) {
-                    cs_u32x4 hv[6];
-                    const int i = tid < L.hist ? tid : 0;
-                    const int f = n - L.hist + i;
+                // the ring takes the block's last c = min(n, hist) frames, frame n - c + i at index (start + i) mod hist: a block shorter than the
+                // history leaves the rest of it where it is
+                const int c = n < L.hist ? n : L.hist;
+                const int start = (int)((pos + (uint32_t)(n - c)) % (uint32_t)L.hist);
+                cs_u32x4 hv[6];
+                const int i = tid < c ? tid : 0;
 #pragma unroll
-                    for (int strip = 0; strip < 6; ++strip) hv[strip] = pl[strip * kCsStrip + f + Hh];
-                    if (tid < L.hist) {
+                for (int strip = 0; strip < 6; ++strip) hv[strip] = pl[strip * kCsStrip + (n - c + i) + Hh];
+                if (tid < c) {
+                    int j = start + i;
+                    j = j >= L.hist ? j - L.hist : j;
 #pragma unroll
-                        for (int strip = 0; strip < 6; ++strip) hbm[strip * L.hist + i] = hv[strip];
-                    }
-                    for (int i2 = tid + kCsThreads; i2 < L.hist; i2 += kCsThreads)      // histories of more than 256 frames
-                        for (int strip = 0; strip < 6; ++strip) hbm[strip * L.hist + i2] = pl[strip * kCsStrip + n - L.hist + i2 + Hh];
-                } else {
-                    for (int strip = 0; strip < 6; ++strip) {
-                        cs_u32x4 hv[2];
-#pragma unroll
-                        for (int r = 0; r < 2; ++r) {
-                            const int i = tid + r * kCsThreads;
-                            if (r * kCsThreads >= L.hist) break;
-                            const int f = n - L.hist + (i < L.hist ? i : 0);
-                            hv[r] = pl[strip * kCsStrip + (f >= -Hh ? f + Hh : 0)];
-                            if (f < -Hh) hv[r] = hbm[strip * L.hist + (i < L.hist ? i + n : 0)];      // (separate statements: an LDS and a global address in one select make a flat pointer)
-                        }
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        cs_lds_barrier();                     // everybody has read this strip's old frames
-#pragma unroll
-                        for (int r = 0; r < 2; ++r) {
-                            const int i = tid + r * kCsThreads;
-                            if (r * kCsThreads >= L.hist) break;
-                            if (i < L.hist) hbm[strip * L.hist + i] = hv[r];
-                        }
-                    }
+                    for (int strip = 0; strip < 6; ++strip) hbm[strip * L.hist + j] = hv[strip];
+                }
+                for (int i2 = tid + kCsThreads; i2 < c; i2 += kCsThreads) {      // histories of more than 256 frames
+                    int j = start + i2;
+                    j = j >= L.hist ? j - L.hist : j;
+                    for (int strip = 0; strip < 6; ++strip) hbm[strip * L.hist + j] = pl[strip * kCsStrip + (n - c + i2) + Hh];
                 }
             }
             f32x4 acc[kCsTiles];
@@ -499,6 +495,7 @@ __global__ __launch_bounds__(kCsThreads, 4) void k_conv_ms(LaunchArgs a, ConvDes
         // not the sixteen cycles' worth: an epilogue's ~220 barely fit under the other pair's 96 MFMAs, and a layer costs close to the sum.)
         for (int l = 1; l + 1 < NL; ++l) layer(l, std::false_type{});
         if (NL > 1) layer(NL - 1, std::true_type{});
+        if (tid == 0) *pos_slot = (pos + (uint32_t)n) % d.ms_pos_mod;      // the stream's time moves on by the block (every layer's ring with it)
         if (NL == 1) {                                        // (conv_ms_shape_ok asks for two layers; kept for completeness)
             if constexpr (FUSED) { if (wave == chain_wave) post_begin(); }
         }
@@ -546,36 +543,75 @@ __global__ __launch_bounds__(kCsThreads, 4) void k_conv_ms(LaunchArgs a, ConvDes
 // scratch per stream). The new histories leave as the tiles pass: the wave that reads a tile's newest tap has the very vectors the history
 // consists of in registers. Same fragments, same MFMA order, same epilogue arithmetic as k_conv_ms: the outputs are bit-identical to it.
 // How it got here, step by step with every measurement: profiles/r05_cfg4_stream_steps.txt; its timeline: profiles/r05_cfg4_stream_trace.txt.
-// Serves: exactly eight layers of three taps, dilation 2^l (BASELINE cfg4's stack; conv_st_shape_ok), blocks of exactly 256 frames, the fused form.
+// Serves (round 6): the stacks whose GEOMETRY is compiled (aidax_layout.h: StGeoA .. — layer count, two or three taps, power-of-two dilations
+// incl. repeated cycles; conv_st_shape), blocks of 64 / 128 / 256 frames (a host's period), the fused form. The ring geometry, which taps come
+// from HBM, the staging slots and the layers of each wave follow from the geometry at compile time (StG<G>).
 constexpr int kStThreads = 256;
-// tiles of the ring in front of layer l: history / 16 + 1, + 1 where producer and consumer are different waves
-__host__ __device__ constexpr int st_nt(int l) { return l == 1 || l == 2 ? 2 : l == 3 || l == 4 ? 3 : l == 5 ? 5 : l == 6 ? 6 : l == 7 ? 1 : 0; }
-__host__ __device__ constexpr int st_len(int l) { return 16 * st_nt(l); }
-__host__ __device__ constexpr int st_off(int l) { int o = 0; for (int i = 1; i < l; ++i) o += 6 * st_len(i); return o; }      // in 16-byte vectors
-constexpr int kStRingVecs = st_off(8);
-constexpr int kStTapVecs = 3 * 2 * 16;                        // one tap of one tile: [term][channel half][frame]
-constexpr int kStStageVecs = 3 * kStTapVecs;                  // the three taps that come from HBM: layer 6's oldest, layer 7's oldest and middle
-constexpr int kStX0 = 4;                                      // frames of layer 0's input history in front of the audio row (conv_st_shape_ok: two)
+constexpr int kStRingReach = 64;                              // a tap up to this many frames back lives in the LDS ring in front of its layer; a further one comes from HBM
+constexpr int kStTapVecs = 3 * 2 * 16;                        // one tap of one tile in the staging area: [term][channel half][frame]
+constexpr int kStX0 = 4;                                      // frames of layer 0's input history in front of the audio row
 // The chain moves in blocks of EIGHT frames, two steps per tick (a six-stage cascade then trails the tiles by two and a half ticks, not five:
 // the launch ends with the post pass's last stage, alone). d1 = ticks between a tile entering the pre pass and layer 0 reading it.
 constexpr int kStChainBlock = 8;
 __device__ __forceinline__ int st_d1(int Kp) { return Kp / 2 + 1; }
-__device__ __forceinline__ int st_ticks(int Kp, int Kq) { return (31 + (Kq - 1) + 2 * (st_d1(Kp) + 3)) / 2 + 1; }
+template <int NF> __device__ __forceinline__ int st_ticks(int Kp, int Kq) { return (NF / kStChainBlock - 1 + (Kq - 1) + 2 * (st_d1(Kp) + 3)) / 2 + 1; }
 constexpr int kStHandLanes = 11;                           // pre pass: lanes 0 .. 5, post pass: lanes 6 .. 11 (a pass's last stage writes the row: lane 11 has no slot)
-constexpr int kStHandFloats = 2 * kStHandLanes * kStChainBlock;                   
-__host__ __device__ constexpr size_t convst_lds_floats()
+constexpr int kStHandFloats = 2 * kStHandLanes * kStChainBlock;
+
+// Everything a geometry G (aidax_layout.h) implies, at compile time.
+template <class G> struct StG {
+    static constexpr int NL = G::NL, K = G::K, KS = (G::K + 1) / 2;
+    static_assert(K == 2 || K == 3, "two or three taps");
+    static constexpr int shift(int l, int tap) { return (K - 1 - tap) * G::dil[l]; }       // frames back of tap `tap` (0 = the oldest)
+    static constexpr int H(int l) { return (K - 1) * G::dil[l]; }                           // the layer's history: a power of two
+    static constexpr bool far(int l, int tap) { return shift(l, tap) > kStRingReach; }
+    static constexpr bool has_far(int l) { return far(l, 0); }
+    static constexpr int ring_hist(int l)                                                   // frames of history the ring in front of layer l holds
+    {
+        int r = 0;
+        for (int tap = 0; tap < K; ++tap) if (!far(l, tap) && shift(l, tap) > r) r = shift(l, tap);
+        return r;
+    }
+    static constexpr int wave_of(int l) { return l < G::wbeg[1] ? 1 : l < G::wbeg[2] ? 2 : 3; }
+    // tiles of the ring in front of layer l: its history, the tile in flight, one more where producer and consumer are different waves
+    static constexpr int nt(int l) { return l == 0 ? 0 : (ring_hist(l) + 15) / 16 + 1 + (wave_of(l - 1) != wave_of(l) ? 1 : 0); }
+    static constexpr int len(int l) { return 16 * nt(l); }
+    static constexpr int off(int l) { int o = 0; for (int i = 1; i < l; ++i) o += 6 * len(i); return o; }      // in 16-byte vectors
+    static constexpr int ring_vecs = off(NL);
+    static constexpr int far_slot(int l, int tap)                                           // the staging slot of a far tap (layers ascending, the oldest tap first)
+    {
+        int n = 0;
+        for (int i = 1; i < NL; ++i) for (int t = 0; t < K; ++t) { if (i == l && t == tap) return n; if (far(i, t)) ++n; }
+        return n;
+    }
+    static constexpr int n_far = far_slot(NL, 0);
+    static constexpr int stage_vecs = n_far * kStTapVecs;
+    static constexpr int fetch_vecs(int l) { return (6 * ring_hist(l) + kWave - 1) / kWave; }   // per lane, a ring's history at the launch's start
+    // the rings a wave asks for before the control word (at most five vectors per lane in flight) / behind the first barrier
+    static constexpr int cum_fetch(int l) { int c = 0; for (int i = G::wbeg[wave_of(l) - 1]; i <= l; ++i) c += fetch_vecs(i); return c; }
+    static constexpr bool early(int l) { return fetch_vecs(l) > 0 && cum_fetch(l) <= 5; }
+    static constexpr bool late(int l) { return fetch_vecs(l) > 0 && cum_fetch(l) > 5; }
+    static constexpr int early_slot(int l) { return cum_fetch(l) - fetch_vecs(l); }
+    static constexpr bool valid()
+    {
+        if (G::wbeg[0] != 1 || G::wbeg[3] != NL || NL > kMaxConvLayers) return false;
+        for (int l = 0; l < NL; ++l) if (G::dil[l] < 1 || (G::dil[l] & (G::dil[l] - 1))) return false;
+        return (K - 1) * G::dil[0] <= kStX0;
+    }
+    static_assert(valid(), "geometry");
+};
+template <class G, int NF> __host__ __device__ constexpr size_t convst_lds_floats()
 {
-    return (size_t)kStRingVecs * 4 + kStX0 + kConvsFrames /* the audio row, layer 0's input history in front */
-         + 20 /* Dense */ + 64 /* layer 0: [3 taps][16] + bias */ + 7 * 16 /* biases of layers 1 .. 7 */ + kStHandFloats
-         + kStStageVecs * 4 /* the far taps of the tile to come, straight from HBM (global_load_lds) */;
+    return (size_t)StG<G>::ring_vecs * 4 + kStX0 + NF /* the audio row, layer 0's input history in front */
+         + 20 /* Dense */ + 64 /* layer 0: [3 taps][16] + bias */ + (StG<G>::NL - 1) * 16 /* biases of the other layers */ + kStHandFloats
+         + StG<G>::stage_vecs * 4 /* the far taps of the tile to come, straight from HBM (global_load_lds) */;
 }
-static_assert(convst_lds_floats() * 4 <= 40 * 1024, "four workgroups per CU");
 
 // A lane's place in a ring WALKS: frame f sits at f mod LEN, a tile later the lane reads / writes sixteen frames on — one add and a wrap
 // per tile and place (computed from the tile number every time — two taps, the writer — the ring arithmetic was ~75 scalar instructions
 // per tile and layer: a third of what a wave issued).
-template <int L> __device__ __forceinline__ int st_place0(int nl, int shift) { return (nl - shift + 16 * st_len(L)) % st_len(L); }
-template <int L> __device__ __forceinline__ void st_walk(int& p) { p += 16; p = p >= st_len(L) ? p - st_len(L) : p; }
+template <int LEN> __device__ __forceinline__ int st_place0(int nl, int shift) { return (nl - shift + 16 * LEN) % LEN; }
+template <int LEN> __device__ __forceinline__ void st_walk(int& p) { p += 16; p = p >= LEN ? p - LEN : p; }
 // Issue priority by progress (k_conv_ms's, for the same reason): a CU's four workgroups compete for its SIMDs, the arbiter favours the oldest
 // wave, and the workgroup dispatched last trails the first by microseconds — the launch ends with it, the CU three quarters idle. A wave's
 // priority steps down with every tick, cyclically over the four levels: of a CU's workgroups the ones behind go first.
@@ -588,118 +624,143 @@ __device__ __forceinline__ void st_prio(int tick)
     default: __builtin_amdgcn_s_setprio(0); break;
     }
 }
-// the places a lane reads layer L's two k-steps from (tile 0): k-step 0 = the oldest tap in both halves (the packed form: ConvLayer::ms_packed0),
-// k-step 1 = [middle tap | newest tap]. (Layers 6, 7: what comes from HBM has no place in the ring — the lane's own frame stands in.)
+// the places a lane reads layer L's k-steps from (tile 0). Three taps: k-step 0 = the oldest tap in both halves (the packed form:
+// ConvLayer::ms_packed0), k-step 1 = [middle tap | newest tap]; two taps: one k-step, [oldest | newest] (p0 unused). A tap that comes from HBM
+// has no place in the ring — the lane's own frame stands in.
 struct StRead { int p0, p1; };
-template <int L> __device__ __forceinline__ StRead st_read0(int q, int nl)
+template <class G, int L> __device__ __forceinline__ StRead st_read0(int q, int nl)
 {
-    constexpr int D = 1 << L;
+    using S = StG<G>;
+    constexpr int LEN = S::len(L);
+    constexpr int s0 = (S::K == 3 && !S::far(L, 0)) ? S::shift(L, 0) : 0;
+    constexpr int tl = S::K == 3 ? 1 : 0;                     // the tap in the low half of the plain k-step
+    constexpr int s1 = !S::far(L, tl) ? S::shift(L, tl) : 0;
     const bool lo = q < 2;
-    return StRead{ st_place0<L>(nl, L <= 5 ? 2 * D : 0), st_place0<L>(nl, lo && L <= 6 ? D : 0) };
+    return StRead{ st_place0<LEN>(nl, s0), st_place0<LEN>(nl, lo ? s1 : 0) };
 }
-// one vector of layer L's history -> its place in the ring (v-th of the 6 hl the ring takes: strip v / hl, frame v % hl - hl)
-template <int L> __device__ __forceinline__ cs_u32x4 st_ring_fetch(const cs_u32x4* h, int v)
+// one vector of layer L's history (a ring in HBM: the frame at time tau at index tau mod H, `pos` = the time of this block's first frame) ->
+// its place in the LDS ring (v-th of the 6 hl the ring takes: strip v / hl, frame v % hl - hl)
+template <class G, int L> __device__ __forceinline__ cs_u32x4 st_ring_fetch(const cs_u32x4* h, uint32_t pos, int v)
 {
-    constexpr int hl = L == 6 ? 64 : 2 << L, H = 2 << L;
-    if (v >= 6 * hl) return cs_u32x4{ 0u, 0u, 0u, 0u };
-    const int strip = v / hl, kf = v % hl;
-    return h[strip * H + H - hl + kf];
+    constexpr int hl = StG<G>::ring_hist(L), H = StG<G>::H(L);
+    if constexpr (hl == 0) return cs_u32x4{ 0u, 0u, 0u, 0u };
+    else {
+        if (v >= 6 * hl) return cs_u32x4{ 0u, 0u, 0u, 0u };
+        const int strip = v / hl, kf = v % hl;
+        return h[strip * H + (int)((pos + (uint32_t)(H - hl + kf)) & (uint32_t)(H - 1))];
+    }
 }
-template <int L> __device__ __forceinline__ void st_ring_put(cs_u32x4* pl, int v, const cs_u32x4& hv)
+template <class G, int L> __device__ __forceinline__ void st_ring_put(cs_u32x4* pl, int v, const cs_u32x4& hv)
 {
-    constexpr int hl = L == 6 ? 64 : 2 << L, LEN = st_len(L);
-    if (v >= 6 * hl) return;
-    const int strip = v / hl, f = v % hl - hl;
-    pl[st_off(L) + strip * LEN + (f + 16 * LEN) % LEN] = hv;
+    constexpr int hl = StG<G>::ring_hist(L), LEN = StG<G>::len(L);
+    if constexpr (hl != 0) {
+        if (v >= 6 * hl) return;
+        const int strip = v / hl, f = v % hl - hl;
+        pl[StG<G>::off(L) + strip * LEN + (f + 16 * LEN) % LEN] = hv;
+    }
 }
 // the activated outputs of layer LR - 1 (a lane: channels 4q .. 4q+3 of frame 16 t + nl) -> the ring in front of layer LR, at the lane's place po
-template <int LR> __device__ __forceinline__ void st_emit(cs_u32x4* pl, int q, int& po, const f32x4& v)
+template <class G, int LR> __device__ __forceinline__ void st_emit(cs_u32x4* pl, int q, int& po, const f32x4& v)
 {
-    constexpr int LEN = st_len(LR);
+    constexpr int LEN = StG<G>::len(LR);
     cs_u32x2 tm[3];
     cs_split4(v, tm);
-    cs_u32x2* dst = reinterpret_cast<cs_u32x2*>(pl + st_off(LR) + (q >> 1) * LEN + po) + (q & 1);
+    cs_u32x2* dst = reinterpret_cast<cs_u32x2*>(pl + StG<G>::off(LR) + (q >> 1) * LEN + po) + (q & 1);
 #pragma unroll
     for (int term = 0; term < 3; ++term) dst[term * 4 * LEN] = tm[term];
-    st_walk<LR>(po);
+    st_walk<LEN>(po);
 }
-// One tile of layer L on the matrix cores: tile t of its input ring (+ g0 / g1: the taps that come from HBM) -> the activated outputs.
-// k-step 0 = [oldest tap | padding: the lane's own frame], k-step 1 = [middle tap | newest tap] (conv_ms_tap, three taps).
-// The new history leaves from the newest tap's registers; hist = this layer's history in HBM, scratch = layer 6's first half block.
-template <int L, bool kEarlyReads = true>
-__device__ __forceinline__ f32x4 st_tile(cs_u32x4* pl, const float* biasl, int t, const cs_u32x4 (&afr)[2][3], int q, int nl, int activation, StRead& rd,
-                                         cs_u32x4* hist, cs_u32x4* scratch, int stage_vec)
+// One tile of layer L on the matrix cores: tile t of its input ring (+ the taps that come from HBM, out of the staging area) -> the activated
+// outputs. Three taps: k-step 0 = [oldest tap | the same, packed], k-step 1 = [middle tap | newest tap] (conv_ms_tap); two taps: one plain k-step
+// [oldest | newest]. The new history leaves from the newest tap's registers into the layer's ring in HBM (hist).
+template <class G, int L, int NF, bool kEarlyReads>
+__device__ __forceinline__ f32x4 st_tile(cs_u32x4* pl, const float* biasl, int t, const cs_u32x4 (&afr)[StG<G>::KS][3], int q, int nl, int activation, StRead& rd,
+                                         cs_u32x4* hist, uint32_t pos, int stage_vec)
 {
-    constexpr int D = 1 << L, H = 2 * D, LEN = st_len(L);
-    const cs_u32x4* ring = pl + st_off(L) + (q & 1) * LEN;
+    using S = StG<G>;
+    constexpr int K = S::K, H = S::H(L), LEN = S::len(L);
+    const cs_u32x4* ring = pl + S::off(L) + (q & 1) * LEN;
     const bool lo = q < 2;
     const int i0 = rd.p0, i1 = rd.p1;
-    st_walk<L>(rd.p0);
-    st_walk<L>(rd.p1);
-    // k-step 0, packed: instruction i multiplies [w0 | w1], [w2 | w0], [w1 | w0] (the packer's fragments) by terms {0, 0, 1}[i] of the oldest tap in
-    // the k-step's first half and {0, 1, 2}[i] in its second: a lane's three reads are term 0, then one and two terms on from where its half starts
+    if constexpr (K == 3) st_walk<LEN>(rd.p0);
+    st_walk<LEN>(rd.p1);
     cs_u32x4 b0[3], b1[3];
-    if constexpr (L <= 5) {
-        const int o1 = lo ? 0 : 2 * LEN;
-        b0[0] = ring[i0]; b0[1] = ring[o1 + i0]; b0[2] = ring[2 * LEN + o1 + i0];
-    } else {
-        // ... out of the staging area ([tap][term][half][frame], where the wave's LDS-DMA put it a tick ago: layer 6's oldest tap first, then layer 7's)
-        const cs_u32x4* stg = pl + stage_vec + (L == 6 ? 0 : kStTapVecs) + (q & 1) * 16 + nl;
-        const int o1 = lo ? 0 : 32;
-        b0[0] = stg[0]; b0[1] = stg[o1]; b0[2] = stg[32 + o1];
+    if constexpr (K == 3) {
+        // k-step 0, packed: instruction i multiplies [w0 | w1], [w2 | w0], [w1 | w0] (the packer's fragments) by terms {0, 0, 1}[i] of the oldest tap in
+        // the k-step's first half and {0, 1, 2}[i] in its second: a lane's three reads are term 0, then one and two terms on from where its half starts
+        if constexpr (!S::far(L, 0)) {
+            const int o1 = lo ? 0 : 2 * LEN;
+            b0[0] = ring[i0]; b0[1] = ring[o1 + i0]; b0[2] = ring[2 * LEN + o1 + i0];
+        } else {
+            // ... out of the staging area ([slot][term][half][frame], where the wave's LDS-DMA put it a tick ago)
+            const cs_u32x4* stg = pl + stage_vec + S::far_slot(L, 0) * kStTapVecs + (q & 1) * 16 + nl;
+            const int o1 = lo ? 0 : 32;
+            b0[0] = stg[0]; b0[1] = stg[o1]; b0[2] = stg[32 + o1];
+        }
     }
-    if constexpr (L <= 6) {
+    {
+        // the plain k-step: [middle (three taps) or oldest (two) | newest]
+        constexpr int tl = K == 3 ? 1 : 0;
+        if constexpr (!S::far(L, tl)) {
 #pragma unroll
-        for (int term = 0; term < 3; ++term) b1[term] = ring[term * 2 * LEN + i1];
-    } else {
-        // layer 7, k-step 1: the middle tap (first half) out of the staging area, the newest (second half) out of the one-tile ring — both 32
-        // vectors from term to term: a per-lane base
-        const int a1 = lo ? stage_vec + 2 * kStTapVecs + (q & 1) * 16 + nl : st_off(L) + (q & 1) * LEN + i1;
-        static_assert(L != 7 || 2 * LEN == 32, "the ring in front of layer 7 is one tile");
+            for (int term = 0; term < 3; ++term) b1[term] = ring[term * 2 * LEN + i1];
+        } else {
+            // the low half out of the staging area, the newest tap (second half) out of the ring: a per-lane base (and, unless the ring is one
+            // tile long like a staging strip, a per-lane distance from term to term)
+            const int a1 = lo ? stage_vec + S::far_slot(L, tl) * kStTapVecs + (q & 1) * 16 + nl : S::off(L) + (q & 1) * LEN + i1;
+            if constexpr (2 * LEN == 32) {
 #pragma unroll
-        for (int term = 0; term < 3; ++term) b1[term] = pl[a1 + term * 32];
+                for (int term = 0; term < 3; ++term) b1[term] = pl[a1 + term * 32];
+            } else {
+                const int ts = lo ? 32 : 2 * LEN;
+#pragma unroll
+                for (int term = 0; term < 3; ++term) b1[term] = pl[a1 + term * ts];
+            }
+        }
     }
     f32x4 acc = *reinterpret_cast<const f32x4*>(biasl + (L - 1) * 16 + 4 * q);
-    // (all seven reads are on their way before the first product: left alone the compiler asks for a fragment right where it is used, and a
-    // tile pays the LDS round trip four times in a row — the wave that sets the tick has two or three tiles per tick. Not on the wave that
+    // (all the reads are on their way before the first product: left alone the compiler asks for a fragment right where it is used, and a
+    // tile pays the LDS round trip four times in a row — the wave that sets the tick has two or three tiles per tick. Not on a wave that
     // carries three layers' A fragments: the twelve registers this costs are twelve it does not have.)
     if constexpr (kEarlyReads) __builtin_amdgcn_sched_barrier(0);
+    if constexpr (K == 3) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cs_bf16x8, afr[0][i]), __builtin_bit_cast(cs_bf16x8, b0[i]), acc, 0, 0, 0);
+        for (int i = 0; i < 3; ++i)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cs_bf16x8, afr[0][i]), __builtin_bit_cast(cs_bf16x8, b0[i]), acc, 0, 0, 0);
+    }
 #pragma unroll
     for (int th = 0; th < 3; ++th)
 #pragma unroll
         for (int tw = 0; tw < 3 - th; ++tw)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cs_bf16x8, afr[1][tw]), __builtin_bit_cast(cs_bf16x8, b1[th]), acc, 0, 0, 0);
-    // the history: the last H frames of the block, as the vectors they are (lanes q >= 2 of k-step 1: term, half q & 1, frame 16 t + nl)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cs_bf16x8, afr[S::KS - 1][tw]), __builtin_bit_cast(cs_bf16x8, b1[th]), acc, 0, 0, 0);
+    // the history: the block's last H frames (every frame where a far tap of this very launch reads the block back), as the vectors they are
+    // (lanes q >= 2 of the plain k-step: term, half q & 1, frame 16 t + nl), frame f at index (pos + f) mod H of the layer's ring in HBM
     int f = 16 * t + nl;
     asm volatile("" : "+v"(f));                               // (opaque: otherwise every layer's store address becomes a 64-bit pointer that is carried, and stepped, through every tick)
-    if constexpr (L <= 5) {
-        if (16 * t + 15 >= kConvsFrames - H && !lo && f >= kConvsFrames - H) {
+    constexpr bool all = S::has_far(L) || H >= NF;
+    if ((all || 16 * t + 15 >= NF - H) && !lo && (all || f >= NF - H)) {
+        const int j = (int)((pos + (uint32_t)f) & (uint32_t)(H - 1));
 #pragma unroll
-            for (int term = 0; term < 3; ++term) hist[(term * 2 + (q & 1)) * H + f - (kConvsFrames - H)] = b1[term];
-        }
-    } else if constexpr (L == 6) {
-        if (!lo) {
-            cs_u32x4* dst = t < 8 ? scratch + f : hist + (f - 128);
-#pragma unroll
-            for (int term = 0; term < 3; ++term) dst[(term * 2 + (q & 1)) * 128] = b1[term];
-        }
-    } else {
-        if (!lo) {
-#pragma unroll
-            for (int term = 0; term < 3; ++term) hist[(term * 2 + (q & 1)) * 256 + f] = b1[term];
-        }
+        for (int term = 0; term < 3; ++term) hist[(term * 2 + (q & 1)) * H + j] = b1[term];
     }
     return cs_activate(acc, activation);
 }
 
+template <int I, int N, class F> __device__ __forceinline__ void st_for(F&& f)
+{
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); st_for<I + 1, N>(f); }
+}
+
+// G: the stack's geometry; NF: the block, 64 / 128 / 256 frames (a host's period: the reference's run() gets the host's block, rt-neural-generic.cpp:484);
 // kTanh: every layer's activation is tanh (what a WaveNet-like stack has): the epilogue's switch on the layer's activation — a dozen scalar
 // instructions and branches per tile and layer — is compiled out.
-template <bool kTanh>
+template <class G, int NF, bool kTanh>
 __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDesc d)
 {
+    using S = StG<G>;
+    constexpr int NL = S::NL, K = S::K, KS = S::KS, NT = NF / 16;
+    static_assert(NF % 64 == 0 && NF <= kConvsFrames, "whole tiles, whole float4 rows");
+    static_assert(convst_lds_floats<G, NF>() * 4 <= 40 * 1024, "four workgroups per CU");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -709,15 +770,15 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
     // 51.8 us, scratch/st_trace.py.)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, nl = lane & 15;
-    constexpr int n = kConvsFrames;
+    constexpr int n = NF;
     const size_t rstride = a.row_stride ? a.row_stride : (size_t)n;
     cs_u32x4* pl = reinterpret_cast<cs_u32x4*>(smem);
-    float* xbuf = smem + (size_t)kStRingVecs * 4;
+    float* xbuf = smem + (size_t)S::ring_vecs * 4;
     float* xrow = xbuf + kStX0;
-    float* wdl = xrow + kConvsFrames;                         // Dense weights [16] + bias
-    float* l0w = wdl + 20;                                    // layer 0: [tap][16] (tanh: times 2 log2 e), then its bias
+    float* wdl = xrow + NF;                                   // Dense weights [16] + bias
+    float* l0w = wdl + 20;                                    // layer 0: [tap][16] (tanh: times 2 log2 e), then its bias at [48]
     float* biasl = l0w + 64;                                  // [layer - 1][16]
-    float* hand = biasl + 7 * 16;
+    float* hand = biasl + (NL - 1) * 16;
     const float* W = a.wpack;
     float* st_base = a.nn + (size_t)sg * a.nn_stride;
     const StreamCtl& ctl = a.ctl[sg];
@@ -727,8 +788,8 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
 
 #ifdef AIDAX_CONV_TRACE
     // measurement build (scratch/st_trace.py): per wave and tick, (cycles from the kernel's start to the tick's work) / 16 << 16 | cycles of work,
-    // in 256 words behind the scratch; the chain wave copies them into the output row at the end
-    uint32_t* trace = reinterpret_cast<uint32_t*>(st_base + d.st_scratch_off + 6 * 128 * 4);
+    // in 256 words behind the histories; the chain wave copies them into the output row at the end
+    uint32_t* trace = reinterpret_cast<uint32_t*>(st_base + d.st_trace_off);
     const unsigned long long t_start = clock64();
     const unsigned long long w_start = wall_clock64();
     unsigned long long t_tick = t_start;
@@ -740,15 +801,15 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
 #define ST_TICK_END(tick) do { } while (0)
 #endif
     // Everything the launch reads from memory before its first tick is requested HERE, in front of the control word the first branch depends
-    // on — reads only, whatever that branch decides: one trip to HBM instead of two or three in a row (the prologue was 5 us of a 45 us
-    // workgroup: scratch/st_trace.py). Wave 0: the audio row, the smoothers, both passes' coefficients and state by lane (a lane beyond
-    // its cascade holds some stage's numbers and does not run); waves 1 .. 3: the histories of their first rings, their layers' fragments (what a wave
-    // needs only at its first tile — a tick or more away — is asked for behind the first barrier: see the roles).
+    // on — reads only, whatever that branch decides. Wave 0: the audio row, the smoothers, both passes' coefficients and state by lane (a lane
+    // beyond its cascade holds some stage's numbers and does not run); waves 1 .. 3: the time the histories' rings stand at, then the histories
+    // of their first rings, their layers' fragments (what a wave needs only at its first tile — a tick or more away — is asked for behind the
+    // first barrier: see the roles).
     auto hist_of = [&](int l) { return reinterpret_cast<cs_u32x4*>(st_base + d.L[l].ms_state_off); };
-    auto fetch_afrags = [&](int l, cs_u32x4 (&afr)[2][3]) {
+    auto fetch_afrags = [&](int l, cs_u32x4 (&afr)[KS][3]) {
         const cs_u32x4* rec = reinterpret_cast<const cs_u32x4*>(W + d.L[l].ms_w_off) + lane;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int t = 0; t < 3; ++t) afr[ks][t] = rec[(ks * 3 + t) * kWave];
     };
@@ -760,7 +821,7 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
         ChainPass c;
         uint32_t pending = 0;
         float pre_mem = 0.f, master_mem = 0.f, pre_tgt = 0.f, master_tgt = 0.f, pre_target = 0.f, master_target = 0.f, ramp_coef = 0.f;
-        rowv = reinterpret_cast<const float4*>(in_row)[lane];
+        if (NF == 256 || lane < NF / 4) rowv = reinterpret_cast<const float4*>(in_row)[lane];
         chain_load(c, ctl, st, slot, false);
         pending = st.pending;
         pre_mem = st.pre_mem; master_mem = st.master_mem; pre_tgt = st.pre_tgt; master_tgt = st.master_tgt;
@@ -773,17 +834,19 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
         const uint32_t flags = ctl.flags;
         if (!(flags & CTL_ENABLED) || !(flags & CTL_NET_ON)) {
             // pre-run / bypass / the model out of circuit: the chain alone, k_conv_ms's own path for such a stream
-            if (wave != 0) return;
 #ifdef AIDAX_CONV_TRACE
             return;                                               // (measurement build: every stream is in circuit, and the chain helpers' stamp area would cost the fourth workgroup per CU)
 #endif
-            ChainCtx ctx = chain_prologue<true>(ctl, st, in_row, out_row, xrow, n, lane, hand);
+            // (the blocked passes' hand-over slots — kChainHandFloats, more than this kernel's own — in the ring area: no ring is in use here)
+            static_assert((size_t)S::ring_vecs * 4 >= (size_t)kChainHandFloats, "the chain-only path borrows the rings");
+            float* wide_hand = smem;
+            ChainCtx ctx = chain_prologue<true>(ctl, st, in_row, out_row, xrow, n, lane, wide_hand);
             if (!ctx.live) return;
-            chain_epilogue(ctl, st, ctx, out_row, xrow, n, lane, hand);
+            chain_epilogue(ctl, st, ctx, out_row, xrow, n, lane, wide_hand);
             return;
         }
         const int Kp = (flags & CTL_EQ_PRE) ? 6 : 1, Kq = (flags & CTL_EQ_POST) ? 6 : 1;
-        const int d1 = st_d1(Kp), T = st_ticks(Kp, Kq);
+        const int d1 = st_d1(Kp), T = st_ticks<NF>(Kp, Kq);
         // ---- the chain wave: lanes 0 .. 5 the pre pass's stages, lanes 6 .. 11 the post pass's (chain_prologue / chain_epilogue, side by side)
         if (pending & PEND_ACTIVATE) { pre_mem = pre_tgt; master_mem = master_tgt; pending &= ~PEND_ACTIVATE; }
         pre_tgt = pre_target;
@@ -793,7 +856,7 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
         c.active = stage == 0 ? (flags & (isQ ? CTL_DC_ON : CTL_LPF_ON)) != 0 : ((flags & CTL_EQ_BANDPASS) ? slot == BQ_MID : true);
         c.g.arm(isQ ? master_mem : pre_mem, isQ ? master_tgt : pre_tgt, ramp_coef);
         const bool run = lane < 12 && stage < c.K;
-        reinterpret_cast<float4*>(xrow)[lane] = rowv;
+        if (NF == 256 || lane < NF / 4) reinterpret_cast<float4*>(xrow)[lane] = rowv;
         const double z1o = c.z1, z2o = c.z2;
         ExpRamp g = c.g;
         const bool is_gain = stage == c.gain_lane;
@@ -808,8 +871,8 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
             ST_TICK_BEGIN();
 #pragma unroll
             for (int hs = 0; hs < 2; ++hs) {
-                if (plain) chain_macro_step<true, kStChainBlock, kStHandLanes>(c, g, stage, run, last, xrow, hand, 32, 2 * tick + hs - m0, lane);
-                else chain_macro_step<false, kStChainBlock, kStHandLanes>(c, g, stage, run, last, xrow, hand, 32, 2 * tick + hs - m0, lane);
+                if (plain) chain_macro_step<true, kStChainBlock, kStHandLanes>(c, g, stage, run, last, xrow, hand, NF / kStChainBlock, 2 * tick + hs - m0, lane);
+                else chain_macro_step<false, kStChainBlock, kStHandLanes>(c, g, stage, run, last, xrow, hand, NF / kStChainBlock, 2 * tick + hs - m0, lane);
             }
             ST_TICK_END(tick);
             cs_lds_barrier();
@@ -819,14 +882,16 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
         if (run) { st.z[slot][0] = c.z1; st.z[slot][1] = c.z2; }
         pre_mem = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c.g.mem), 0));
         master_mem = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c.g.mem), 6 + Kq - 1));
-        reinterpret_cast<float4*>(out_row)[lane] = reinterpret_cast<const float4*>(xrow)[lane];
+        if (NF == 256 || lane < NF / 4) reinterpret_cast<float4*>(out_row)[lane] = reinterpret_cast<const float4*>(xrow)[lane];
 #ifdef AIDAX_CONV_TRACE
+        if constexpr (NF == 256) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         for (int i = lane; i < 132; i += kWave) out_row[i] = __builtin_bit_cast(float, trace[i]);
         if (lane == 0) { out_row[160] = __builtin_bit_cast(float, (uint32_t)(clock64() - t_start)); out_row[166] = __builtin_bit_cast(float, (uint32_t)blockIdx.x); out_row[161] = __builtin_bit_cast(float, (uint32_t)T);
                          out_row[162] = __builtin_bit_cast(float, (uint32_t)(w_start & 0xffffffffu)); out_row[163] = __builtin_bit_cast(float, (uint32_t)(wall_clock64() & 0xffffffffu));
                          unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
                          out_row[164] = __builtin_bit_cast(float, hw); out_row[165] = __builtin_bit_cast(float, xcc); }
+        }
 #endif
         if (lane == 0) {
             // run() :634-640 for a model without PARAM inputs (param_targets, aidax_device.h): the smoothers' targets follow the controls,
@@ -841,11 +906,14 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
         return;
     }
 
-    // A layer wave loads the histories of ITS two rings — layer l's last hl frames (all of them; layer 6: the 64 its middle tap reaches), 6 hl
-    // vectors — and puts them into the rings right in front of its first tile, one to three ticks into the launch: the first tick waits for
-    // nobody's history (all of it behind the first barrier, the 18 MB the chip loads at once made a 5 us prologue).
-    // ---- waves 1 .. 3. Each is self-contained from here (no value of one role alive in another's code): its early reads, the control word,
-    // its share of the small staging — layer 0's input history and weights, the biases, the Dense: L2-resident weights —, its ticks.
+    // ---- waves 1 .. 3: the layers. Each is self-contained from here (no value of one role alive in another's code): its early reads, the
+    // control word, its share of the small staging — layer 0's input history and weights, the biases, the Dense: L2-resident weights —, its
+    // ticks. A layer wave loads the histories of ITS rings — layer l's last ring_hist(l) frames out of the layer's ring in HBM — and puts them
+    // into the LDS rings in front of its first tile, one to three ticks into the launch: the first rings' (up to five vectors per lane) are
+    // asked for with everything else, the rest behind the first barrier (all at once, the 18 MB cfg4's launch reads at its start kept the first
+    // tick waiting for 4.5 us).
+    uint32_t* pos_slot = reinterpret_cast<uint32_t*>(st_base + d.ms_pos_off);
+    const uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)*pos_slot);
     auto out_of_circuit = [&](uint32_t flags) { return !(flags & CTL_ENABLED) || !(flags & CTL_NET_ON); };      // (wave 0 runs such a stream alone)
     const int u = (wave - 1) * kWave + lane;                  // 0 .. 191
     float sm_x = 0.f, sm_wd = 0.f, sm_l0 = 0.f, sm_b = 0.f;
@@ -856,195 +924,214 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
         if (u >= 64 && u < 128) {
             const int j = u - 64;
             const float scale = L0.activation == 1 ? kTwoLog2e : 1.0f;
-            sm_l0 = j < 48 ? scale * W[L0.w_off + j] : W[L0.bs_off + j - 48];
+            sm_l0 = j < 16 * K ? scale * W[L0.w_off + j] : j >= 48 ? W[L0.bs_off + j - 48] : 0.f;
         }
-        if (u < 112) sm_b = W[d.L[1 + (u >> 4)].bs_off + (u & 15)];
+        if (u < (NL - 1) * 16) sm_b = W[d.L[1 + (u >> 4)].bs_off + (u & 15)];
     }
     auto stage_small = [&]() {
         if (u < d.L[0].hist) xbuf[kStX0 - d.L[0].hist + u] = sm_x;
         if (u < 17) wdl[u] = sm_wd;
         if (u >= 64 && u < 128) l0w[u - 64] = sm_l0;
-        if (u < 112) biasl[u] = sm_b;
+        if (u < (NL - 1) * 16) biasl[u] = sm_b;
     };
-    if (wave == 1) {
-        // ---- layer 0 (one scalar input, three taps, fp32 FMAs), layers 1, 2
-        cs_u32x4 hv[2], afrA[2][3], afrB[2][3];
-        hv[0] = st_ring_fetch<1>(hist_of(1), lane);
-        hv[1] = st_ring_fetch<2>(hist_of(2), lane);
-        fetch_afrags(1, afrA);
-        fetch_afrags(2, afrB);
+    constexpr int stage_vec = (int)((convst_lds_floats<G, NF>() - (size_t)S::stage_vecs * 4) / 4);
+    static_assert((convst_lds_floats<G, NF>() - (size_t)S::stage_vecs * 4) % 4 == 0, "the staging area starts on a vector");
+
+    auto role = [&](auto Wc) {
+        constexpr int Wv = decltype(Wc)::value;               // 1 .. 3
+        constexpr int LB = G::wbeg[Wv - 1], LE = G::wbeg[Wv], NW = LE - LB;
+        static_assert(NW >= 1 && NW <= 4, "layers per wave");
+        constexpr bool kEarlyReads = NW * KS <= 4;            // (a wave with three layers of two k-steps has no registers for it)
+        constexpr bool first = Wv == 1, lastw = Wv == 3;
+        cs_u32x4 hv[6], afr[NW][KS][3];
+        // early reads
+        st_for<0, NW>([&](auto ic) {
+            constexpr int i = decltype(ic)::value, L = LB + i;
+            if constexpr (S::early(L)) {
+#pragma unroll
+                for (int r = 0; r < S::fetch_vecs(L); ++r) hv[S::early_slot(L) + r] = st_ring_fetch<G, L>(hist_of(L), pos, lane + r * kWave);
+            }
+        });
+        st_for<0, NW>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (i == 0 || NW <= 2) fetch_afrags(LB + i, afr[i]);
+        });
         const uint32_t flags = ctl.flags;
         if (out_of_circuit(flags)) return;
-        const int Kp = (flags & CTL_EQ_PRE) ? 6 : 1, Kq = (flags & CTL_EQ_POST) ? 6 : 1, d1 = st_d1(Kp), T = st_ticks(Kp, Kq);
+        const int Kp = (flags & CTL_EQ_PRE) ? 6 : 1, Kq = (flags & CTL_EQ_POST) ? 6 : 1, d1 = st_d1(Kp), T = st_ticks<NF>(Kp, Kq);
         stage_small();
         const ConvLayer& L0 = d.L[0];
-        const int act0 = kTanh ? 1 : L0.activation, act1 = kTanh ? 1 : d.L[1].activation, act2 = kTanh ? 1 : d.L[2].activation;
-        StRead rdA = st_read0<1>(q, nl), rdB = st_read0<2>(q, nl);
-        int po1 = nl, po2 = nl, po3 = nl;
-        cs_lds_barrier();
-        int tick = 0;
-        for (; tick < d1; ++tick) cs_lds_barrier();            // (nothing to do yet: the pipeline fills)
-        st_ring_put<1>(pl, lane, hv[0]);
-        st_ring_put<2>(pl, lane, hv[1]);
-        for (; tick < T; ++tick) {
-            const int t = tick - d1;
-            if (!(AIDAX_TUNE(a) & 2048)) st_prio(tick);
-            ST_TICK_BEGIN();
-            if (t < 16) {
-                // the tile of the model's input: x * in_gain, in place (the Dense's skip path and layer 0's history read it scaled)
-                if (lane < 16) xrow[16 * t + lane] = xrow[16 * t + lane] * a.in_gain;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                f32x4 v = *reinterpret_cast<const f32x4*>(l0w + 48 + 4 * q);
-#pragma unroll
-                for (int tap = 0; tap < 3; ++tap) {
-                    const float x = xrow[16 * t + nl - (2 - tap)];
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(l0w + tap * 16 + 4 * q);
-                    v.x = __builtin_fmaf(w.x, x, v.x); v.y = __builtin_fmaf(w.y, x, v.y);
-                    v.z = __builtin_fmaf(w.z, x, v.z); v.w = __builtin_fmaf(w.w, x, v.w);
-                }
-                if (t == 15 && lane >= 14 && lane < 16) st_base[L0.ms_state_off + lane - 14] = xrow[240 + lane];
-                st_emit<1>(pl, q, po1, cs_activate(v, act0));
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                st_emit<2>(pl, q, po2, st_tile<1>(pl, biasl, t, afrA, q, nl, act1, rdA, hist_of(1), nullptr, 0));
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                st_emit<3>(pl, q, po3, st_tile<2>(pl, biasl, t, afrB, q, nl, act2, rdB, hist_of(2), nullptr, 0));
-            }
-            ST_TICK_END(tick);
-            cs_lds_barrier();
-        }
-    } else if (wave == 2) {
-        // ---- layers 3, 4, 5
-        cs_u32x4 hv[6], afrA[2][3], afrB[2][3], afrC[2][3];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) hv[r] = st_ring_fetch<3>(hist_of(3), lane + r * kWave);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) hv[2 + r] = st_ring_fetch<4>(hist_of(4), lane + r * kWave);
-        fetch_afrags(3, afrA);
-        const uint32_t flags = ctl.flags;
-        if (out_of_circuit(flags)) return;
-        const int Kp = (flags & CTL_EQ_PRE) ? 6 : 1, Kq = (flags & CTL_EQ_POST) ? 6 : 1, d1 = st_d1(Kp), T = st_ticks(Kp, Kq);
-        stage_small();
-        const int actA = kTanh ? 1 : d.L[3].activation, actB = kTanh ? 1 : d.L[4].activation, actC = kTanh ? 1 : d.L[5].activation;
-        StRead rdA = st_read0<3>(q, nl), rdB = st_read0<4>(q, nl), rdC = st_read0<5>(q, nl);
-        int po4 = nl, po5 = nl, po6 = nl;
-        cs_lds_barrier();
-        // (the first two rings' histories go in as they arrive; the third's — 6 of this wave's 10.5 KiB — are asked for only now, behind the first
-        // barrier: all at once, the 18 MB the chip reads at a launch's start kept the first tick waiting for 4.5 us)
-#pragma unroll
-        for (int r = 0; r < 2; ++r) st_ring_put<3>(pl, lane + r * kWave, hv[r]);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) st_ring_put<4>(pl, lane + r * kWave, hv[2 + r]);
-        fetch_afrags(4, afrB);
-#pragma unroll
-        for (int r = 0; r < 6; ++r) hv[r] = st_ring_fetch<5>(hist_of(5), lane + r * kWave);
-        int tick = 0;
-        for (; tick < d1 + 1; ++tick) cs_lds_barrier();            // (nothing to do yet: the pipeline fills)
-#pragma unroll
-        for (int r = 0; r < 6; ++r) st_ring_put<5>(pl, lane + r * kWave, hv[r]);
-        fetch_afrags(5, afrC);                                 // (in the registers the history just left; L2-resident, two tiles of work in front of its first use)
-        for (; tick < T; ++tick) {
-            const int t = tick - d1 - 1;
-            if (!(AIDAX_TUNE(a) & 2048)) st_prio(tick);
-            ST_TICK_BEGIN();
-            if (t < 16) {
-                st_emit<4>(pl, q, po4, st_tile<3, false>(pl, biasl, t, afrA, q, nl, actA, rdA, hist_of(3), nullptr, 0));
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                st_emit<5>(pl, q, po5, st_tile<4, false>(pl, biasl, t, afrB, q, nl, actB, rdB, hist_of(4), nullptr, 0));
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                st_emit<6>(pl, q, po6, st_tile<5, false>(pl, biasl, t, afrC, q, nl, actC, rdC, hist_of(5), nullptr, 0));
-            }
-            ST_TICK_END(tick);
-            cs_lds_barrier();
-        }
-    } else if (wave == 3) {
-        // ---- layers 6, 7, Dense(16, 1) + skip / output gain. The three taps that reach further back than the rings hold — layer 6's oldest (128
-        // frames), layer 7's oldest and middle (256, 128) — go from HBM into the staging area without passing through registers (LDS-DMA: the
-        // low 32 lanes' (half, frame) vectors land at base + 16 lane, a term per instruction), requested when the tile before has been read:
-        // out of a layer's history where the frame belongs to the block before, out of what this launch has written where it belongs to this one
-        // (layer 6: the scratch; layer 7: its history, which is the block itself by the end).
-        cs_u32x4 hv[6], afrA[2][3], afrB[2][3];
-        fetch_afrags(6, afrA);
-        fetch_afrags(7, afrB);
-        const uint32_t flags = ctl.flags;
-        if (out_of_circuit(flags)) return;
-        const int Kp = (flags & CTL_EQ_PRE) ? 6 : 1, Kq = (flags & CTL_EQ_POST) ? 6 : 1, d1 = st_d1(Kp), T = st_ticks(Kp, Kq);
-        stage_small();
-        const int actA = kTanh ? 1 : d.L[6].activation, actB = kTanh ? 1 : d.L[7].activation;
-        StRead rdA = st_read0<6>(q, nl), rdB = st_read0<7>(q, nl);
-        int po7 = nl;
-        cs_u32x4* h6 = hist_of(6);
-        cs_u32x4* h7 = hist_of(7);
-        cs_u32x4* scratch = reinterpret_cast<cs_u32x4*>(st_base + d.st_scratch_off);
-        const int stage_vec = (int)(hand + kStHandFloats - smem) / 4;
+        int act[NW];
+        StRead rd[NW];
+        int po[NW];                                           // this lane's place in the ring BEHIND layer LB + i (the last wave's last: unused, the Dense takes it)
+        st_for<0, NW>([&](auto ic) {
+            constexpr int i = decltype(ic)::value, L = LB + i;
+            act[i] = kTanh ? 1 : d.L[L].activation;
+            rd[i] = st_read0<G, L>(q, nl);
+            po[i] = nl;
+        });
+        const int act0 = kTanh ? 1 : L0.activation;
+        int po1 = nl;                                         // (wave 1: layer 0's place in the ring in front of layer 1)
+        // the far taps of this wave's layers, from HBM into the staging area without passing through registers (LDS-DMA: the low 32 lanes'
+        // (half, frame) vectors land at base + 16 lane, a term per instruction), requested when the tile before has been read: frame f - s of
+        // a layer's ring in HBM — written by the block before where it is older than this block, by this very launch (st_tile) where it is not
         auto fetch_g = [&](int t) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (the reads of the tile before have left the staging area)
-            if (q < 2 && t < 16) {
-                const cs_u32x4* src[3] = { (t < 8 ? h6 + 16 * t : scratch + 16 * (t - 8)) + (q & 1) * 128 + nl,           // layer 6, frame f - 128
-                                           h7 + (q & 1) * 256 + 16 * t + nl,                                              // layer 7, frame f - 256: index f of the old history
-                                           h7 + (q & 1) * 256 + (t < 8 ? 16 * t + 128 : 16 * t - 128) + nl };             // layer 7, frame f - 128: old index f + 128, or new index f - 128
+            if (q < 2 && t < NT) {
+                st_for<0, NW>([&](auto ic) {
+                    constexpr int L = LB + decltype(ic)::value, H = S::H(L);
+                    st_for<0, K>([&](auto tc) {
+                        constexpr int tap = decltype(tc)::value;
+                        if constexpr (S::far(L, tap)) {
+                            const int j = (int)((pos + (uint32_t)(16 * t + nl) - (uint32_t)S::shift(L, tap)) & (uint32_t)(H - 1));
+                            const cs_u32x4* src = hist_of(L) + (q & 1) * H + j;
 #pragma unroll
-                for (int tap = 0; tap < 3; ++tap)
-#pragma unroll
-                    for (int term = 0; term < 3; ++term) {
-                        unsigned keep;
-                        const unsigned dst = (unsigned)(size_t)(pl + stage_vec + tap * kStTapVecs + term * 32);      // (LDS byte address: the low 32 bits of the pointer)
-                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                                     : "=&s"(keep) : "v"(src[tap] + term * 2 * (tap == 0 ? 128 : 256)), "s"(dst) : "memory");
-                    }
+                            for (int term = 0; term < 3; ++term) {
+                                unsigned keep;
+                                const unsigned dst = (unsigned)(size_t)(pl + stage_vec + S::far_slot(L, tap) * kStTapVecs + term * 32);      // (LDS byte address: the low 32 bits of the pointer)
+                                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                             : "=&s"(keep) : "v"(src + term * 2 * H), "s"(dst) : "memory");
+                            }
+                        }
+                    });
+                });
             }
         };
+        constexpr bool wave_far = [] { bool f = false; for (int l = LB; l < LE; ++l) f = f || S::has_far(l); return f; }();
         const float* wdq = wdl + 4 * q;
         cs_lds_barrier();
-        // (this ring's history — the 64 frames layer 6's middle tap reaches — is asked for behind the first barrier, like wave 2's third)
+        // the first rings' histories go in as they arrive
+        st_for<0, NW>([&](auto ic) {
+            constexpr int L = LB + decltype(ic)::value;
+            if constexpr (S::early(L)) {
 #pragma unroll
-        for (int r = 0; r < 6; ++r) hv[r] = st_ring_fetch<6>(hist_of(6), lane + r * kWave);
-        fetch_g(0);
+                for (int r = 0; r < S::fetch_vecs(L); ++r) st_ring_put<G, L>(pl, lane + r * kWave, hv[S::early_slot(L) + r]);
+            }
+        });
+        if constexpr (NW >= 3) fetch_afrags(LB + 1, afr[1]);
+        // ... the first of the others is asked for now, behind the first barrier, and goes in right in front of the wave's first tile
+        constexpr int first_late = [] { for (int l = LB; l < LE; ++l) if (S::late(l)) return l; return -1; }();
+        if constexpr (first_late >= 0) {
+#pragma unroll
+            for (int r = 0; r < S::fetch_vecs(first_late); ++r) hv[r] = st_ring_fetch<G, first_late>(hist_of(first_late), pos, lane + r * kWave);
+        }
+        if constexpr (wave_far) fetch_g(0);
         int tick = 0;
-        for (; tick < d1 + 2; ++tick) cs_lds_barrier();            // (nothing to do yet: the pipeline fills)
+        for (; tick < d1 + (Wv - 1); ++tick) cs_lds_barrier();     // (nothing to do yet: the pipeline fills)
+        if constexpr (first_late >= 0) {
 #pragma unroll
-        for (int r = 0; r < 6; ++r) st_ring_put<6>(pl, lane + r * kWave, hv[r]);
+            for (int r = 0; r < S::fetch_vecs(first_late); ++r) st_ring_put<G, first_late>(pl, lane + r * kWave, hv[r]);
+        }
+        st_for<0, NW>([&](auto ic) {                          // (a geometry with more late rings per wave than one: one after the other, the wave waits)
+            constexpr int L = LB + decltype(ic)::value;
+            if constexpr (S::late(L) && L != first_late) {
+#pragma unroll
+                for (int r = 0; r < S::fetch_vecs(L); ++r) hv[r] = st_ring_fetch<G, L>(hist_of(L), pos, lane + r * kWave);
+#pragma unroll
+                for (int r = 0; r < S::fetch_vecs(L); ++r) st_ring_put<G, L>(pl, lane + r * kWave, hv[r]);
+            }
+        });
+        st_for<2, NW>([&](auto ic) {                          // (in the registers the history just left; L2-resident, two tiles of work in front of its first use)
+            constexpr int i = decltype(ic)::value;
+            if constexpr (NW >= 3) fetch_afrags(LB + i, afr[i]);
+        });
+#pragma nounroll
         for (; tick < T; ++tick) {
-            const int t = tick - d1 - 2;
+            const int t = tick - d1 - (Wv - 1);
             if (!(AIDAX_TUNE(a) & 2048)) st_prio(tick);
             ST_TICK_BEGIN();
-            if (t < 16) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the staged taps have landed
-                st_emit<7>(pl, q, po7, st_tile<6>(pl, biasl, t, afrA, q, nl, actA, rdA, h6, scratch, stage_vec));
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                const f32x4 v = st_tile<7>(pl, biasl, t, afrB, q, nl, actB, rdB, h7, nullptr, stage_vec);
-                fetch_g(t + 1);
-                float y = wdq[0] * v.x;                       // (:171-181; emit()'s arithmetic in k_conv_ms)
-                y = __builtin_fmaf(wdq[1], v.y, y);
-                y = __builtin_fmaf(wdq[2], v.z, y);
-                y = __builtin_fmaf(wdq[3], v.w, y);
-                const Pair r2 = share_rows(y);
-                y = r2.lo + r2.hi;
-                const Pair r4 = share_halves(y);
-                y = (r4.lo + r4.hi) + wdl[16];
-                const int f = 16 * t + nl;
-                const float x = xrow[f];
-                const float o = (a.input_skip ? x + y : y) * a.out_gain;
-                __builtin_amdgcn_wave_barrier();
-                if (q == 0) xrow[f] = o;
+            if (t < NT) {
+                if constexpr (wave_far) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the staged taps have landed
+                if constexpr (first) {
+                    // ---- layer 0 (one scalar input, fp32 FMAs). The tile of the model's input: x * in_gain, in place (the Dense's skip path and
+                    // layer 0's history read it scaled)
+                    if (lane < 16) xrow[16 * t + lane] = xrow[16 * t + lane] * a.in_gain;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    f32x4 v = *reinterpret_cast<const f32x4*>(l0w + 48 + 4 * q);
+#pragma unroll
+                    for (int tap = 0; tap < K; ++tap) {
+                        const float x = xrow[16 * t + nl - (K - 1 - tap) * G::dil[0]];
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(l0w + tap * 16 + 4 * q);
+                        v.x = __builtin_fmaf(w.x, x, v.x); v.y = __builtin_fmaf(w.y, x, v.y);
+                        v.z = __builtin_fmaf(w.z, x, v.z); v.w = __builtin_fmaf(w.w, x, v.w);
+                    }
+                    constexpr int h0 = (K - 1) * G::dil[0];
+                    if (t == NT - 1 && lane >= 16 - h0 && lane < 16) st_base[L0.ms_state_off + lane - (16 - h0)] = xrow[NF - 16 + lane];
+                    st_emit<G, 1>(pl, q, po1, cs_activate(v, act0));
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                }
+                st_for<0, NW>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value, L = LB + i;
+                    const f32x4 v = st_tile<G, L, NF, kEarlyReads>(pl, biasl, t, afr[i], q, nl, act[i], rd[i], hist_of(L), pos, stage_vec);
+                    if constexpr (L + 1 < NL) {
+                        st_emit<G, L + 1>(pl, q, po[i], v);
+                        if constexpr (i + 1 < NW) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    } else {
+                        // ---- Dense(16, 1) + skip / output gain (:171-181; emit()'s arithmetic in k_conv_ms)
+                        if constexpr (wave_far) fetch_g(t + 1);
+                        float y = wdq[0] * v.x;
+                        y = __builtin_fmaf(wdq[1], v.y, y);
+                        y = __builtin_fmaf(wdq[2], v.z, y);
+                        y = __builtin_fmaf(wdq[3], v.w, y);
+                        const Pair r2 = share_rows(y);
+                        y = r2.lo + r2.hi;
+                        const Pair r4 = share_halves(y);
+                        y = (r4.lo + r4.hi) + wdl[16];
+                        const int f = 16 * t + nl;
+                        const float x = xrow[f];
+                        const float o = (a.input_skip ? x + y : y) * a.out_gain;
+                        __builtin_amdgcn_wave_barrier();
+                        if (q == 0) xrow[f] = o;
+                    }
+                });
+                if constexpr (wave_far && !lastw) fetch_g(t + 1);
             }
             ST_TICK_END(tick);
             cs_lds_barrier();
         }
-    }
+        if constexpr (lastw) {
+            if (lane == 0) *pos_slot = (pos + (uint32_t)NF) % d.ms_pos_mod;      // the stream's time moves on by the block
+        }
+    };
+    if (wave == 1) role(std::integral_constant<int, 1>{});
+    else if (wave == 2) role(std::integral_constant<int, 2>{});
+    else role(std::integral_constant<int, 3>{});
 }
 
 size_t convs_lds_bytes() { return convs_lds_floats() * sizeof(float); }
 
+// ---- k_conv_st's instantiations: geometry x block length x (every layer tanh?)
+typedef void (*StKernel)(LaunchArgs, ConvDesc);
+struct StEntry { StKernel fn; size_t lds; };
+template <class G, int NF> static StEntry st_entry_nf(bool all_tanh)
+{
+    return StEntry{ all_tanh ? k_conv_st<G, NF, true> : k_conv_st<G, NF, false>, convst_lds_floats<G, NF>() * sizeof(float) };
+}
+// the streaming kernel of geometry `geo` for blocks of n_frames, {nullptr, 0} where there is none (a block that is not 64, 128 or 256 frames)
+static StEntry st_entry(int geo, uint32_t n_frames, bool all_tanh)
+{
+    return st_geo_dispatch(geo, [&](auto g) {
+        using G = decltype(g);
+        switch (n_frames) {
+        case 64: return st_entry_nf<G, 64>(all_tanh);
+        case 128: return st_entry_nf<G, 128>(all_tanh);
+        case 256: return st_entry_nf<G, 256>(all_tanh);
+        default: return StEntry{ nullptr, 0 };
+        }
+    });
+}
+bool conv_st_block_ok(uint32_t n_frames) { return n_frames == 64 || n_frames == 128 || n_frames == 256; }
 
-int convs_resident_streams(int device, bool streaming_form)
+int convs_resident_streams(int device, int st_geo)
 {
     int per_cu = 0, cus = 0;
     const void* fn = reinterpret_cast<const void*>(k_conv_ms<true, false>);      // (both instantiations have the same footprint)
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kCsThreads, convs_lds_bytes()) != hipSuccess) return 0;
-    if (streaming_form) {                                     // full blocks go through k_conv_st: both must be resident at the pool's size
+    if (st_geo >= 0) {                                        // whole-tile blocks go through k_conv_st: both must be resident at the pool's size
+        const StEntry e = st_entry(st_geo, 256, false);
         int st = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&st, reinterpret_cast<const void*>(k_conv_st<false>), kStThreads, convst_lds_floats() * sizeof(float)) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&st, reinterpret_cast<const void*>(e.fn), kStThreads, e.lds) != hipSuccess) return 0;
         if (st < per_cu) per_cu = st;
     }
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
@@ -1056,10 +1143,13 @@ hipError_t launch_conv_ms_kernel(const LaunchArgs& a, const ConvDesc& d, bool fu
 {
     if (!d.ms_ok || a.n_frames > (uint32_t)kConvsFrames || (fused && a.mode != MODE_CHAIN)) return hipErrorInvalidValue;
     const bool full = a.n_frames == (uint32_t)kConvsFrames;
-    if (fused && full && d.st_ok) {
+    // the streaming form: a stack with a compiled geometry, a block of 64 / 128 / 256 frames, rows the kernel's 16-byte accesses can take
+    // (a time slice of a longer block keeps the block's pitch: any multiple of four frames)
+    if (fused && d.st_ok && conv_st_block_ok(a.n_frames) && (a.row_stride & 3u) == 0) {
         bool all_tanh = true;
         for (int l = 0; l < d.n_layers; ++l) all_tanh = all_tanh && d.L[l].activation == 1;
-        hipLaunchKernelGGL(all_tanh ? k_conv_st<true> : k_conv_st<false>, dim3(a.n_streams), dim3(kStThreads), convst_lds_floats() * sizeof(float), stream, a, d);
+        const StEntry e = st_entry(d.st_ok - 1, a.n_frames, all_tanh);
+        hipLaunchKernelGGL(e.fn, dim3(a.n_streams), dim3(kStThreads), e.lds, stream, a, d);
         return hipGetLastError();
     }
     typedef void (*Fn)(LaunchArgs, ConvDesc);

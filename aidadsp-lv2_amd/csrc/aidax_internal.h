@@ -80,6 +80,7 @@ std::vector<float> pack_q4(const aidax_model& m);       // LSTM-32, one input: t
 std::vector<float> pack_conv(const aidax_model& m, ConvDesc* d, uint32_t* state_floats);
 int  conv_ms_tap(int ksize, int pos);
 bool conv_ms_shape_ok(const ConvDesc& d);
-bool conv_st_shape_ok(const ConvDesc& d);
+int conv_st_shape(const ConvDesc& d);          // 1 + the index of the stack's k_conv_st geometry (aidax_layout.h), 0 = none
+uint32_t conv_ms_period(const ConvDesc& d);
 
 }  // namespace aidax

@@ -75,7 +75,8 @@ hipError_t launch_conv_mfma_kernel(const LaunchArgs& a, const ConvDesc& d, bool 
 hipError_t launch_conv_kernel(const LaunchArgs& a, const ConvDesc& d, hipStream_t stream);
 // k_conv_ms (aidax_convs.hip): the conv stacks conv_ms_shape_ok admits, as bf16 term products; its own history layout (ConvDesc::ms_*)
 size_t convs_lds_bytes();
-int convs_resident_streams(int device, bool streaming_form);
+int convs_resident_streams(int device, int st_geo);      // st_geo: the stack's k_conv_st geometry (ConvDesc::st_ok - 1), -1 = none
+bool conv_st_block_ok(uint32_t n_frames);                // a block length k_conv_st is compiled for (64 / 128 / 256 frames)
 hipError_t launch_conv_ms_kernel(const LaunchArgs& a, const ConvDesc& d, bool fused, hipStream_t stream);   // n_frames <= 256; fused: whole run()
 hipError_t launch_set_pending(StreamState* st, uint32_t n_streams, int32_t stream, uint32_t bits, hipStream_t q);
 hipError_t launch_init_streams(StreamState* st, uint32_t n, hipStream_t q);

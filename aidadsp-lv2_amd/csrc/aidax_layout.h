@@ -235,7 +235,8 @@ struct ConvLayer {
     // k-step of 32 = two taps x sixteen input channels (quarter q: tap ms_tap[ks][q >> 1], channels 8 (q & 1) ..); every weight
     // (times 2 log2 e on tanh layers, like the records above) split exactly into three bf16 terms. ms_shift[ks][h]: frames back
     // of the tap in half h of k-step ks, -1 = padding (zero weights). ms_state_off: this layer's input history in the stream's nn
-    // state in the layout of the kernel's activation plane ([3 terms][2 channel halves][hist frames][8 bf16]; layer 0: fp32 [hist]).
+    // state in the layout of the kernel's activation plane ([3 terms][2 channel halves][hist frames][8 bf16]; layer 0: fp32 [hist]) — every
+    // strip a RING over time: the frame at time tau of the stream at index tau mod hist (ConvDesc::ms_pos_off holds the time).
     uint32_t ms_w_off;
     int32_t  ms_ksteps;
     int16_t  ms_shift[2][2];
@@ -270,9 +271,33 @@ struct ConvDesc {
     uint32_t wd_off, bd_off;
     int32_t  ms_ok;             // k_conv_ms serves this stack (pack_conv: conv_ms_shape_ok)
     uint32_t ms_state_floats;   // ... with this much state per stream (its history layout differs from k_conv's / k_conv_mfma's)
-    int32_t  st_ok;             // k_conv_st (the streaming form of full fused blocks) serves this stack (conv_st_shape_ok)
-    uint32_t st_scratch_off;    // ... with 6 x 128 vectors of scratch per stream behind the histories (layer 6's input, first half block)
+    uint32_t ms_pos_off;        // ... in it one uint32: the time of the next block's first frame, modulo ms_pos_mod — where the histories' rings stand
+    uint32_t ms_pos_mod;        // the least common multiple of the layers' history lengths (conv_ms_shape_ok bounds it)
+    int32_t  st_ok;             // k_conv_st (the streaming form of whole-tile fused blocks) serves this stack: 1 + the index of its geometry (conv_st_shape)
+    uint32_t st_trace_off;      // (measurement build: k_conv_st's stamps behind the histories)
 };
+
+// k_conv_st's GEOMETRIES (aidax_convs.hip): the stacks whose streaming form is compiled — layer count, taps per layer, the layers' dilations
+// (powers of two: a history length is then one too, and a ring index a mask) and which of the three layer waves runs which layers
+// (wave w = 1 .. 3: layers [wbeg[w - 1], wbeg[w]); layer 0, the scalar input layer, rides on wave 1). Everything else — which taps live in
+// the LDS ring in front of a layer and which come from HBM, ring lengths and offsets, the staging slots — follows from these at compile time
+// (StG<G> in aidax_convs.hip); conv_st_shape() (aidax_pack.cpp) matches a model against this list.
+struct StGeoA { static constexpr int NL = 8,  K = 3; static constexpr int dil[kMaxConvLayers] = { 1, 2, 4, 8, 16, 32, 64, 128 };      static constexpr int wbeg[4] = { 1, 3, 6, 8 }; };   // BASELINE cfg4
+struct StGeoB { static constexpr int NL = 10, K = 2; static constexpr int dil[kMaxConvLayers] = { 1, 2, 4, 8, 16, 1, 2, 4, 8, 16 };    static constexpr int wbeg[4] = { 1, 4, 7, 10 }; };  // two cycles 1 .. 16, two taps
+struct StGeoC { static constexpr int NL = 6,  K = 3; static constexpr int dil[kMaxConvLayers] = { 1, 2, 4, 8, 16, 32 };                static constexpr int wbeg[4] = { 1, 2, 4, 6 }; };   // a shallow stack
+struct StGeoD { static constexpr int NL = 8,  K = 3; static constexpr int dil[kMaxConvLayers] = { 1, 2, 4, 8, 1, 2, 4, 8 };            static constexpr int wbeg[4] = { 1, 3, 6, 8 }; };   // two cycles 1 .. 8, three taps
+struct StGeoE { static constexpr int NL = 8,  K = 2; static constexpr int dil[kMaxConvLayers] = { 1, 2, 4, 8, 16, 32, 64, 128 };      static constexpr int wbeg[4] = { 1, 3, 6, 8 }; };   // cfg4's dilations, two taps
+constexpr int kStGeos = 5;
+template <class F> constexpr auto st_geo_dispatch(int g, F&& f)     // f(G{}) for geometry index g
+{
+    switch (g) {
+    case 0: return f(StGeoA{});
+    case 1: return f(StGeoB{});
+    case 2: return f(StGeoC{});
+    case 3: return f(StGeoD{});
+    default: return f(StGeoE{});
+    }
+}
 
 struct LaunchArgs {
     const StreamCtl* ctl;

@@ -528,9 +528,25 @@ int conv_ms_tap(int ksize, int pos)
 // frames; every other layer is sixteen channels into sixteen with two to four taps; a history reaches at most kConvsFrames frames
 // beyond the plane's kConvsHist (a source frame is then either in the plane or in the layer's history in HBM), and of a wave's
 // four frame tiles at most two (tile, k-step) pairs read from beyond the plane (they travel in registers).
+// The histories of layers 1 .. are rings over time (the frame at time tau at index tau mod hist); the stream's time is kept modulo the
+// least common multiple of the history lengths, so that it never wraps out of step with any ring. 0: no common period below 2^24
+// (such a stack — long, mutually prime dilations — stays on k_conv_mfma).
+uint32_t conv_ms_period(const ConvDesc& d)
+{
+    uint64_t m = 1;
+    for (int l = 1; l < d.n_layers; ++l) {
+        const uint64_t h = static_cast<uint64_t>(d.L[l].hist > 0 ? d.L[l].hist : 1);
+        uint64_t a = m, b = h;
+        while (b) { const uint64_t t = a % b; a = b; b = t; }
+        m = m / a * h;
+        if (m > (1u << 24)) return 0;
+    }
+    return static_cast<uint32_t>(m);
+}
 bool conv_ms_shape_ok(const ConvDesc& d)
 {
     if (d.channels != 16 || d.n_layers < 2) return false;
+    if (conv_ms_period(d) == 0) return false;
     for (int l = 0; l < d.n_layers; ++l) {
         const ConvLayer& C = d.L[l];
         if (C.out_ch != 16 || C.in_ch != (l == 0 ? 1 : 16) || C.ksize < 1 || C.dilation < 1 || C.activation < 0 || C.activation > 3) return false;
@@ -548,14 +564,22 @@ bool conv_ms_shape_ok(const ConvDesc& d)
     return true;
 }
 
-// Which of them k_conv_st serves as well (full fused blocks as a stream of tiles; its ring geometry is compiled in): eight layers of
-// three taps, layer l dilated by 2^l — BASELINE cfg4's stack.
-bool conv_st_shape_ok(const ConvDesc& d)
+// Which of them k_conv_st serves as well (whole-tile fused blocks as a stream of tiles): the stacks whose geometry is compiled
+// (aidax_layout.h: StGeoA ..). 1 + the geometry's index, 0 = none.
+int conv_st_shape(const ConvDesc& d)
 {
-    if (!conv_ms_shape_ok(d) || d.n_layers != 8) return false;
-    for (int l = 0; l < 8; ++l)
-        if (d.L[l].ksize != 3 || d.L[l].dilation != (1 << l)) return false;
-    return true;
+    if (!conv_ms_shape_ok(d)) return 0;
+    for (int g = 0; g < kStGeos; ++g) {
+        const bool match = st_geo_dispatch(g, [&](auto geo) {
+            using G = decltype(geo);
+            if (d.n_layers != G::NL) return false;
+            for (int l = 0; l < G::NL; ++l)
+                if (d.L[l].ksize != G::K || d.L[l].dilation != G::dil[l]) return false;
+            return true;
+        });
+        if (match) return g + 1;
+    }
+    return 0;
 }
 
 std::vector<float> pack_conv(const aidax_model& m, ConvDesc* d, uint32_t* state_floats)
@@ -673,10 +697,12 @@ std::vector<float> pack_conv(const aidax_model& m, ConvDesc* d, uint32_t* state_
                         }
                     }
         }
-        d->st_ok = conv_st_shape_ok(*d) ? 1 : 0;
-        if (d->st_ok) { d->st_scratch_off = mst; mst += 6u * 128u * 4u; }
+        d->ms_pos_off = mst;                                        // the stream's time (uint32), one 16-byte slot
+        mst += 4u;
+        d->ms_pos_mod = conv_ms_period(*d);
+        d->st_ok = conv_st_shape(*d);
 #ifdef AIDAX_CONV_TRACE
-        if (d->st_ok) mst += 256u;                                  // the measurement build's stamps (k_conv_st)
+        if (d->st_ok) { d->st_trace_off = mst; mst += 256u; }       // the measurement build's stamps (k_conv_st)
 #endif
         d->ms_state_floats = mst;
     }

@@ -651,8 +651,8 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
         const char* cms = AIDAX_HOOK_ENV("AIDAX_CONV_MS");
         ms.conv_ms = ms.conv_mfma && ms.cdesc.ms_ok && !(cms && cms[0] == '0');
         if (ms.conv_ms) state_floats = ms.cdesc.ms_state_floats;
-        // ... and of those, the eight-layer power-of-two stack (conv_st_shape_ok) takes full fused blocks through k_conv_st, the streaming
-        // form on the same state (AIDAX_CONV_ST=0, test build: k_conv_ms for every block)
+        // ... and of those, the stacks with a compiled geometry (conv_st_shape) take fused blocks of 64 / 128 / 256 frames through k_conv_st,
+        // the streaming form on the same state (AIDAX_CONV_ST=0, test build: k_conv_ms for every block)
         const char* cst = AIDAX_HOOK_ENV("AIDAX_CONV_ST");
         if (!ms.conv_ms || (cst && cst[0] == '0')) ms.cdesc.st_ok = 0;
         // chain passes inside the conv launch while every workgroup of the pool is resident at once (their serial
@@ -660,7 +660,7 @@ int prepare_impl(aidax_pool& p, const aidax_model* m, int start_mode, aidax_stag
         // k_chain launches around the kernel are cheaper). AIDAX_CONV_FUSED=1 / 0 forces the form.
         const char* fused = AIDAX_HOOK_ENV("AIDAX_CONV_FUSED");
         ms.conv_fused = ms.conv_mfma && (fused ? fused[0] != '0'
-                                               : static_cast<int>(p.n_streams) <= (ms.conv_ms ? convs_resident_streams(p.device, ms.cdesc.st_ok != 0) : convm_resident_streams(ms.cdesc, p.ext_chunk(), p.device)));
+                                               : static_cast<int>(p.n_streams) <= (ms.conv_ms ? convs_resident_streams(p.device, ms.cdesc.st_ok - 1) : convm_resident_streams(ms.cdesc, p.ext_chunk(), p.device)));
         if (ms.conv_mfma && p.max_frames > 256) ms.conv_fused = true;      // long blocks go through in time slices: the one-launch form only
         if (!ms.conv_mfma && conv_lds_bytes(ms.cdesc, p.max_frames) > 160 * 1024)
             return fail(AIDAX_ERR_ARG, "conv model: pool max_frames too large for the LDS activation planes");
@@ -1429,7 +1429,7 @@ AIDAX_API const char* aidax_pool_kernel_name(const aidax_pool* p)
     if (m.kind == ModelSlot::MFMA && m.lstm_gs) return "k_lstm_gs";
     if (m.kind == ModelSlot::MFMA) return m.gru_gm ? (m.gru_gs ? "k_gru_gs" : "k_gru_gm") : !p->lp_in_use(m) ? "k_chain+k_mfma" : m.lp_split ? (m.mdesc.n_layers == 1 ? (m.lp_fused ? "k_mfma_ls1" : "k_chain+k_mfma_ls1") : m.lp_fused ? "k_mfma_ls" : "k_chain+k_mfma_ls") : m.lp_fused ? "k_mfma_lp" : "k_chain+k_mfma_lp";
     if (m.kind == ModelSlot::QUAD) return "k_chain+k_quad";
-    if (m.kind == ModelSlot::CONV && m.conv_ms && m.conv_fused && m.cdesc.st_ok && p->max_frames >= 256) return "k_conv_st";      // (what a full block runs; shorter ones: k_conv_ms)
+    if (m.kind == ModelSlot::CONV && m.conv_ms && m.conv_fused && m.cdesc.st_ok && p->max_frames >= 64) return "k_conv_st";      // (what a block of 64 / 128 / 256 frames runs; every other length: k_conv_ms)
     if (m.kind == ModelSlot::CONV) return m.conv_ms ? (m.conv_fused ? "k_conv_ms" : "k_chain+k_conv_ms") : m.conv_fused ? "k_conv_mfma" : m.conv_mfma ? "k_chain+k_conv_mfma" : "k_conv";
     const int form = p->chain_form(m);
     return form == 3 ? "k_lstm_q4<32>" : form == 1 ? m.kernel->name_pipe : form == 2 ? m.kernel->name_split : m.kernel->name;

@@ -60,8 +60,9 @@ def conv_layer(rs, in_size: int, out: int, ksize: int, dilation: int, activation
 def make_model(kind: str, hidden: int, input_size: int = 1, seed: int = 0, n_rnn: int = 1,
                in_skip: Optional[int] = None, in_gain: Optional[float] = None,
                out_gain: Optional[float] = None, samplerate=None,
-               conv_layers: int = 8, conv_k: int = 3) -> Dict:
-    """kind in {'lstm','gru','conv'}; returns the json dict."""
+               conv_layers: int = 8, conv_k: int = 3, conv_dilations=None) -> Dict:
+    """kind in {'lstm','gru','conv'}; returns the json dict. conv: conv_layers layers of conv_k taps, layer l dilated by 2^l — or by
+    conv_dilations[l] (then as many layers as it has entries)."""
     rs = np.random.RandomState(seed)
     layers = []
     if kind in ("lstm", "gru"):
@@ -72,8 +73,9 @@ def make_model(kind: str, hidden: int, input_size: int = 1, seed: int = 0, n_rnn
         layers.append(dense_layer(rs, hidden))
     elif kind == "conv":
         cur = input_size
-        for l in range(conv_layers):
-            layers.append(conv_layer(rs, cur, hidden, conv_k, 2 ** l))
+        dil = list(conv_dilations) if conv_dilations is not None else [2 ** l for l in range(conv_layers)]
+        for l in range(len(dil)):
+            layers.append(conv_layer(rs, cur, hidden, conv_k, dil[l]))
             cur = hidden
         layers.append(dense_layer(rs, hidden))
     else:

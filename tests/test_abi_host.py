@@ -145,18 +145,24 @@ def test_control_defaults_match_ttl():
 
 
 def test_conv_stack_form_rule_by_shape(tmp_path):
-    """aidax_model_conv_form — which kernel family a conv1d stack runs on is a pure function of its shape (the packer's rules): BASELINE
-    cfg4's stack — eight layers of three taps, dilation 2^l, sixteen channels — is the one whose full blocks stream through k_conv_st (4);
-    other sixteen-channel stacks of two to four taps stay layer-major on k_conv_ms (3); narrower or wider-tap stacks on the fp32 matrix
-    kernel (2); recurrent models are not conv stacks (0)."""
+    """aidax_model_conv_form — which kernel family a conv1d stack runs on is a pure function of its shape (the packer's rules): the
+    sixteen-channel stacks whose geometry is compiled (aidax_layout.h StGeoA ..: BASELINE cfg4's eight layers of three taps with dilation
+    2^l; ten layers of two taps in two cycles 1 .. 16; six layers of three taps; two cycles 1 .. 8 of three taps; cfg4's dilations with two
+    taps) stream their blocks of 64 / 128 / 256 frames through k_conv_st (4); other sixteen-channel stacks of two to four taps stay
+    layer-major on k_conv_ms (3); narrower or wider-tap stacks on the fp32 matrix kernel (2); recurrent models are not conv stacks (0)."""
     from tests import modelgen
     ax = importlib.import_module("aidadsp-lv2_amd")
 
     def form(**kw):
         return ax.Model(modelgen.write_model(modelgen.make_model(**kw), str(tmp_path / "m.json"))).conv_form
     assert form(kind="conv", hidden=16, input_size=1, seed=1608) == 4                       # cfg4
-    assert form(kind="conv", hidden=16, input_size=1, seed=3, conv_layers=5) == 3           # the same taps and dilations, five layers
-    assert form(kind="conv", hidden=16, input_size=1, seed=3, conv_layers=8, conv_k=2) == 3 # eight layers of two taps
+    assert form(kind="conv", hidden=16, input_size=1, seed=3, conv_k=2, conv_dilations=[1, 2, 4, 8, 16] * 2) == 4
+    assert form(kind="conv", hidden=16, input_size=1, seed=3, conv_layers=6) == 4
+    assert form(kind="conv", hidden=16, input_size=1, seed=3, conv_dilations=[1, 2, 4, 8] * 2) == 4
+    assert form(kind="conv", hidden=16, input_size=1, seed=3, conv_layers=8, conv_k=2) == 4
+    assert form(kind="conv", hidden=16, input_size=1, seed=3, conv_layers=5) == 3           # cfg4's taps and dilations, five layers: no geometry
+    assert form(kind="conv", hidden=16, input_size=1, seed=3, conv_layers=7, conv_k=4) == 3 # seven layers of four taps
+    assert form(kind="conv", hidden=16, input_size=1, seed=3, conv_k=2, conv_dilations=[1, 2, 4, 8, 16, 1, 2, 4, 8, 32]) == 3
     assert form(kind="conv", hidden=8, input_size=1, seed=85, conv_layers=4, conv_k=5) == 2 # eight channels, five taps
     assert form(kind="lstm", hidden=32, input_size=1, seed=32) == 0
     # dilations that are not 2^l: an eight-layer stack of three taps that k_conv_st does not take

@@ -767,15 +767,18 @@ _MS_STACKS = [
     ("four taps, 64 apart", (1, 1), [(4, 64, "tanh"), (4, 42, "relu")]),                                 # shift 192: tiles 0 .. 3 deep; layer 0 with ONE tap
     ("odd dilations", (3, 8), [(3, 3, "tanh"), (3, 9, "tanh"), (3, 27, ""), (3, 81, "tanh"), (2, 127, "sigmoid")]),   # shifts that are no multiples of 16: unaligned reads
     ("history = the plane's", (2, 16), [(3, 64, "tanh"), (2, 128, "tanh"), (4, 42, "tanh")]),            # 128 frames back: the last in-plane frame
+    # the other geometries k_conv_st is compiled for (aidax_layout.h StGeoB .. E): blocks of 64 / 128 / 256 frames stream, the rest runs k_conv_ms on the same state
+    ("two cycles 1..16, two taps", (2, 1), [(2, d, "tanh") for d in (2, 4, 8, 16, 1, 2, 4, 8, 16)]),
+    ("six layers, three taps", (3, 1), [(3, d, "tanh") for d in (2, 4, 8, 16, 32)]),
+    ("two cycles 1..8, three taps, mixed activations", (3, 1), [(3, d, a) for d, a in zip((2, 4, 8, 1, 2, 4, 8), ("tanh", "relu", "tanh", "sigmoid", "", "tanh", "tanh"))]),
+    ("cfg4's dilations, two taps", (2, 1), [(2, d, "tanh") for d in (2, 4, 8, 16, 32, 64, 128)]),         # one far tap (128 frames back) through the staging area
 ]
+_ST_STACKS = ("cfg4-like", "cfg4 shape, mixed activations", "two cycles 1..16, two taps", "six layers, three taps",
+              "two cycles 1..8, three taps, mixed activations", "cfg4's dilations, two taps")
+_MS_SIZES = [256, 100, 1, 255, 0, 64, 256, 17, 128, 130, 3, 256, 64, 128, 64, 256]
 
 
-@pytest.mark.parametrize("name,l0,rest", _MS_STACKS, ids=[s[0] for s in _MS_STACKS])
-def test_conv_stacks_on_the_split_kernel_corners(name, l0, rest, tmp_path, monkeypatch):
-    """k_conv_ms at the corners of what it admits — two to four taps (one or two bf16 k-steps, the first half empty for odd counts), histories
-    up to and beyond the 128 frames its plane holds (fragments straight from the history in HBM, lanes of one fragment from different
-    sources), dilations that are no multiples of sixteen, every activation — against the oracle and against k_conv_mfma (fp32 MFMAs) on ragged
-    blocks: short blocks on deep layers move old history up in HBM; 0- and 1-frame blocks; the split-launch form too."""
+def _ms_stack_model(name, l0, rest, tmp_path):
     import zlib
     rs = np.random.RandomState(zlib.crc32(name.encode()))
     layers = [modelgen.conv_layer(rs, 1, 16, l0[0], l0[1], "tanh")]
@@ -784,17 +787,53 @@ def test_conv_stacks_on_the_split_kernel_corners(name, l0, rest, tmp_path, monke
     layers.append(modelgen.dense_layer(rs, 16))
     j = {"in_shape": [None, None, 1], "layers": layers, "metadata": {"name": name, "samplerate": "48000"},
          "in_skip": 1, "in_gain": -1.0, "out_gain": 2.0}
-    path = modelgen.write_model(j, str(tmp_path / "ms.json"))
-    spec = O.parse_model(j)
+    return modelgen.write_model(j, str(tmp_path / "ms.json")), O.parse_model(j)
+
+
+@pytest.mark.parametrize("name,l0,rest", _MS_STACKS, ids=[s[0] for s in _MS_STACKS])
+def test_conv_stacks_as_the_pool_runs_them(name, l0, rest, tmp_path):
+    """The same corner stacks with no switch set — the kernels a host gets (and the ship leg's copy of this test the shipped library's):
+    k_conv_st for the blocks of 64 / 128 / 256 frames of the stacks with a compiled geometry, k_conv_ms for every other block and stack,
+    one state under both (every strip of a layer's history a ring over time: ragged blocks in between leave the rings at any phase)."""
+    path, spec = _ms_stack_model(name, l0, rest, tmp_path)
     S = 6
-    sizes = [256, 100, 1, 255, 0, 64, 256, 17, 130, 3, 256, 256]
+    x = modelgen.signal(S, sum(_MS_SIZES), seed=41)
+    cg, co = _ctl_pair(pregain_db=1.0, treble_boost_db=2.0)
+    want = O.run_streams(spec, co, x, 256)
+    scale = max(1.0, float(np.abs(want).max()))
+    m = ax.Model(path)
+    assert m.conv_form == (4 if name in _ST_STACKS else 3)
+    pool = ax.Pool(S, 256)
+    pool.set_model(m)
+    assert pool.kernel_name == ("k_conv_st" if name in _ST_STACKS else "k_conv_ms")
+    pool.set_controls(cg)
+    got = np.empty_like(x)
+    pos = 0
+    for n in _MS_SIZES:
+        got[:, pos:pos + n] = pool.process(np.ascontiguousarray(x[:, pos:pos + n]))
+        pos += n
+    pool.close()
+    assert np.isfinite(got).all()
+    errlog.bound(np.abs(got - want).max() / scale, 3e-6, "gpu_parity:conv_stacks_default")
+
+
+@pytest.mark.parametrize("name,l0,rest", _MS_STACKS, ids=[s[0] for s in _MS_STACKS])
+def test_conv_stacks_on_the_split_kernel_corners(name, l0, rest, tmp_path, monkeypatch):
+    """k_conv_ms at the corners of what it admits — two to four taps (one or two bf16 k-steps, the first half empty for odd counts), histories
+    up to and beyond the 128 frames its plane holds (fragments straight from the history in HBM, lanes of one fragment from different
+    sources), dilations that are no multiples of sixteen, every activation — against the oracle and against k_conv_mfma (fp32 MFMAs) on ragged
+    blocks (a layer's history is a ring over time: a short block on a deep layer writes its own frames and nothing else); 0- and 1-frame blocks; the
+    split-launch form too; and, for the stacks with a compiled k_conv_st geometry, the streaming form against the layer-major one bit for bit."""
+    path, spec = _ms_stack_model(name, l0, rest, tmp_path)
+    S = 6
+    sizes = _MS_SIZES
     x = modelgen.signal(S, sum(sizes), seed=41)
     cg, co = _ctl_pair(pregain_db=1.0, treble_boost_db=2.0)
     want = O.run_streams(spec, co, x, 256)
     scale = max(1.0, float(np.abs(want).max()))
     outs = {}
-    # (the first stack is the one k_conv_st serves: its full blocks run there — tile-major, the same bits — unless AIDAX_CONV_ST=0)
-    streamed = name in ("cfg4-like", "cfg4 shape, mixed activations")
+    # (the stacks k_conv_st serves: their blocks of 64 / 128 / 256 frames run there — tile-major, the same bits — unless AIDAX_CONV_ST=0)
+    streamed = name in _ST_STACKS
     for env, kname in (({}, "k_conv_ms"), ({"AIDAX_CONV_FUSED": "0"}, "k_chain+k_conv_ms"), ({"AIDAX_CONV_MS": "0"}, "k_conv_mfma"), ({"AIDAX_CONV_ST": "0"}, "k_conv_ms/all")):
         for k_ in ("AIDAX_CONV_FUSED", "AIDAX_CONV_MS", "AIDAX_CONV_ST"):
             monkeypatch.delenv(k_, raising=False)
@@ -903,7 +942,7 @@ def test_conv_fused_launch_is_bit_identical_to_split_launches(ms, tmp_path, monk
     to the bit — ragged blocks incl. 0 and 1 frames, per-stream disable / model bypass / EQ position / bandpass."""
     path, _ = _model_file(tmp_path, "c16x8f", kind="conv", hidden=16, input_size=1, seed=78, in_skip=1, in_gain=-1.5, out_gain=2.0)
     S = 37
-    sizes = [256, 1, 0, 37, 200, 16, 255, 129, 3, 256]
+    sizes = [256, 1, 0, 37, 200, 16, 255, 64, 129, 3, 128, 256]
     x = modelgen.signal(S, sum(sizes), seed=22)
     kws = [dict(), dict(enabled=0.0), dict(net_bypass=1.0), dict(eq_position=1.0, bass_boost_db=5.0, mid_type=1.0),
            dict(dc_blocker=0.0, in_lpf_pc=0.0, eq_bypass=1.0), dict(pregain_db=6.0, master_db=-6.0, treble_boost_db=4.0)]

@@ -675,7 +675,7 @@ template <class G, int LR> __device__ __forceinline__ void st_emit(cs_u32x4* pl,
 // [oldest | newest]. The new history leaves from the newest tap's registers into the layer's ring in HBM (hist).
 template <class G, int L, int NF, bool kEarlyReads>
 __device__ __forceinline__ f32x4 st_tile(cs_u32x4* pl, const float* biasl, int t, const cs_u32x4 (&afr)[StG<G>::KS][3], int q, int nl, int activation, StRead& rd,
-                                         cs_u32x4* hist, uint32_t pos, int stage_vec)
+                                         cs_u32x4* hist, uint32_t pos, int stage_vec, int tune)
 {
     using S = StG<G>;
     constexpr int K = S::K, H = S::H(L), LEN = S::len(L);
@@ -738,7 +738,7 @@ __device__ __forceinline__ f32x4 st_tile(cs_u32x4* pl, const float* biasl, int t
     int f = 16 * t + nl;
     asm volatile("" : "+v"(f));                               // (opaque: otherwise every layer's store address becomes a 64-bit pointer that is carried, and stepped, through every tick)
     constexpr bool all = S::has_far(L) || H >= NF;
-    if ((all || 16 * t + 15 >= NF - H) && !lo && (all || f >= NF - H)) {
+    if ((all || 16 * t + 15 >= NF - H) && !lo && (all || f >= NF - H) && !(tune & 32768)) {      // (bit 32768, test build: no history leaves — what the stores cost; wrong state)
         const int j = (int)((pos + (uint32_t)f) & (uint32_t)(H - 1));
 #pragma unroll
         for (int term = 0; term < 3; ++term) hist[(term * 2 + (q & 1)) * H + j] = b1[term];
@@ -983,7 +983,8 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
                     st_for<0, K>([&](auto tc) {
                         constexpr int tap = decltype(tc)::value;
                         if constexpr (S::far(L, tap)) {
-                            const int j = (int)((pos + (uint32_t)(16 * t + nl) - (uint32_t)S::shift(L, tap)) & (uint32_t)(H - 1));
+                            int j = (int)((pos + (uint32_t)(16 * t + nl) - (uint32_t)S::shift(L, tap)) & (uint32_t)(H - 1));
+                            if (AIDAX_TUNE(a) & 65536) j = nl;      // (bit 65536, test build: every far tap reads the same sixteen frames — what their trip to HBM costs; wrong output)
                             const cs_u32x4* src = hist_of(L) + (q & 1) * H + j;
 #pragma unroll
                             for (int term = 0; term < 3; ++term) {
@@ -1063,7 +1064,7 @@ __global__ __launch_bounds__(kStThreads, 4) void k_conv_st(LaunchArgs a, ConvDes
                 }
                 st_for<0, NW>([&](auto ic) {
                     constexpr int i = decltype(ic)::value, L = LB + i;
-                    const f32x4 v = st_tile<G, L, NF, kEarlyReads>(pl, biasl, t, afr[i], q, nl, act[i], rd[i], hist_of(L), pos, stage_vec);
+                    const f32x4 v = st_tile<G, L, NF, kEarlyReads>(pl, biasl, t, afr[i], q, nl, act[i], rd[i], hist_of(L), pos, stage_vec, AIDAX_TUNE(a));
                     if constexpr (L + 1 < NL) {
                         st_emit<G, L + 1>(pl, q, po[i], v);
                         if constexpr (i + 1 < NW) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

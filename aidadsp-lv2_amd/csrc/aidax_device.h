@@ -403,7 +403,7 @@ __device__ __forceinline__ void chain_run_blocked(ChainPass& c, float* buf, floa
 // ------------------------------------------------------------- block I/O
 __device__ __forceinline__ void load_block(float* buf, const float* __restrict__ src, int n, int lane)
 {
-    if ((n & 3) == 0) {
+    if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
         const float4* s4 = reinterpret_cast<const float4*>(src);
         float4* b4 = reinterpret_cast<float4*>(buf);
         for (int i = lane; i < n / 4; i += kWave) b4[i] = s4[i];     // 16 B/lane, 1 KiB per wave instruction
@@ -414,7 +414,7 @@ __device__ __forceinline__ void load_block(float* buf, const float* __restrict__
 
 __device__ __forceinline__ void store_block(float* __restrict__ dst, const float* buf, int n, int lane)
 {
-    if ((n & 3) == 0) {
+    if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
         float4* d4 = reinterpret_cast<float4*>(dst);
         const float4* b4 = reinterpret_cast<const float4*>(buf);
         for (int i = lane; i < n / 4; i += kWave) d4[i] = b4[i];
@@ -463,7 +463,8 @@ __device__ __forceinline__ ChainCtx chain_prologue(const StreamCtl& ctl, StreamS
                                                    float* out_row, float* buf, int n, int lane, float* hand = nullptr)
 {
     ChainCtx c;
-    const bool row_in_regs = EAGER && (n & 3) == 0 && n <= 4 * kWave;
+    // (a time slice of a longer block keeps the block's pitch: rows start 16-byte aligned only if that pitch is a multiple of four frames)
+    const bool row_in_regs = EAGER && (n & 3) == 0 && n <= 4 * kWave && (reinterpret_cast<uintptr_t>(in_row) & 15u) == 0;
     float4 rowv = float4{ 0.f, 0.f, 0.f, 0.f };
     ChainPass p;
     if constexpr (EAGER) {

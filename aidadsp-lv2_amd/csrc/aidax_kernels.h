@@ -16,6 +16,8 @@ struct KernelEntry {
     const char* name;
     const char* name_pipe;
     const char* name_split;
+    void (*fn_pipe4)(LaunchArgs);     // four streams per workgroup, one helper wave (k_*_pipe4; nullptr: the cell has none)
+    const char* name_pipe4;
 };
 
 const KernelEntry* find_kernel(int cell, int hidden);
@@ -25,6 +27,9 @@ bool split_form_pays(const KernelEntry* e, uint32_t n_frames);
 size_t pipe_lds_bytes(int hidden, uint32_t n_frames);
 hipError_t launch_pipe_kernel(const KernelEntry* e, const LaunchArgs& a, hipStream_t stream);
 int pipe_resident_streams(const KernelEntry* e, uint32_t n_frames, int device);
+// k_*_pipe4: a pass of whole 16-frame tiles, whole workgroups of four streams, every stream in circuit, a model without PARAM inputs (the caller checks)
+size_t pipe4_lds_bytes(int hidden, uint32_t n_frames);
+hipError_t launch_pipe4_kernel(const KernelEntry* e, const LaunchArgs& a, hipStream_t stream);
 size_t stack_lds_bytes(const StackDesc& d, uint32_t n_frames);
 size_t conv_lds_bytes(const ConvDesc& d, uint32_t n_frames);
 size_t mfma_lds_bytes(const MfmaDesc& d, uint32_t n_frames);
@@ -85,5 +90,7 @@ hipError_t launch_install_params(StreamState* live, const StreamState* staged, u
 hipError_t launch_set_param_targets(StreamState* st, float t0, float t1, hipStream_t q);
 hipError_t launch_adopt_dsp(StreamState* dst, const StreamState* src, hipStream_t q);
 hipError_t launch_reset_for_model(StreamState* st, float* nn, uint32_t n_streams, uint32_t nn_stride, float p_den, hipStream_t q);
+
+hipError_t launch_keep_warm_kernel(int workgroups, hipStream_t stream);      // an empty grid (AIDAX_KEEP_WARM_US, aidax_pool.cpp)
 
 }  // namespace aidax

@@ -608,6 +608,7 @@ __device__ __forceinline__ void stream_body(const LaunchArgs& a, float* smem)
 //   one workgroup barrier per phase; the N wave keeps weights, c and h in registers throughout.
 // ======================================================================
 constexpr int kSB = 16;                 // frames per pipeline stage
+constexpr int kStChainBlockP4 = 8;      // k_*_pipe4: frames per hand-over of the helper wave's cascades (two steps per stage)
 constexpr int kRing = 2 * kSB;          // rows of the h history ring
 constexpr int kPipeWaves = 3;
 constexpr int kStage = 4 * kSB;         // floats of one hand-over stage of the input ring
@@ -823,6 +824,8 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
                         xr[4 * q] = v.x * in_gain; xr[4 * q + 1] = v.y * in_gain;       // out[i] *= input_gain
                         xr[4 * q + 2] = v.z * in_gain; xr[4 * q + 3] = v.w * in_gain;
                     }
+                    // (round 6, measured and not kept: the sixteen multiplies on wave P — x * in_gain handed over in the stage's fourth quarter,
+                    // read four frames at a time to stay under the register count of three waves per SIMD: 64.2 against 63.9 us)
 #ifdef AIDAX_PIPE_TRACE
 #pragma unroll
                     for (int t = 0; t < kSB; ++t) {
@@ -974,6 +977,258 @@ __global__ __launch_bounds__(kPipeWaves * kWave) void k_gru_pipe(LaunchArgs a)
     stream_body_pipe<GruCell<H>>(a, smem);
 }
 
+
+// ======================================================================
+// The pipeline with ONE helper wave per FOUR streams (round 6, review item 4).
+//
+// k_*_pipe gives every stream two helper waves; a CU's four streams put eight of them on its four SIMDs, and what they issue there
+// — two fp64 cascades and a Dense per stream and stage — costs the recurrent waves 3.3 us of cfg2's 64 (profiles/r05_cfg2_ledger.txt:
+// a recurrent wave alone runs the launch in 61.3). Here a workgroup is a CU's four streams: four recurrent waves, one per SIMD, and
+// ONE helper wave that carries all four streams' chain passes side by side — stream j's pre pass on lanes 12 j .. 12 j + 5, its post
+// pass on lanes 12 j + 6 .. 12 j + 11 of the same fp64 instructions (k_conv_st's chain_macro_step, eight frames per hand-over, two
+// steps per tick) — the four Dense(H, 1) + skip / gain tails on a lane per (stream, frame), the four rows' loads and stores. The
+// helper issues per tick what ONE of the eight did, three SIMDs of four see no helper at all. A tick = a tile of sixteen frames:
+//   tick p:  helper   Dense + skip / gain of tile p - d1 - 1, both passes' two macro-steps, tile p - d1 + 1 times in_gain
+//            wave j   the recurrent cell of stream j over tile p - d1
+// paced by progress words in LDS, not by barriers (see below). The host sends a pass here only when every stream of the pool is in circuit (enabled, model on),
+// the model takes the audio alone (no PARAM inputs), the block is whole tiles and the stream count whole workgroups; k_*_pipe serves
+// every other pass on the same state. Same operations per sample in the same order as k_*_pipe: bit-identical.
+// ======================================================================
+constexpr int kP4Streams = 4;
+constexpr int kP4Helpers = 1;                          // helper waves; more than one take the ticks in turns (4: a recurrent wave meets a helper's burst every fourth tick — measured SLOWER, 65.2 against 64.6 us: profiles/r06_cfg2_pipe4.txt)
+constexpr int kP4Waves = kP4Streams + kP4Helpers;
+constexpr int kP4ChainLanes = 12 * kP4Streams;
+constexpr int kP4HandFloats = 2 * kP4ChainLanes * kStChainBlockP4;
+__host__ __device__ constexpr size_t pipe4_lds_floats(int H, int n_frames)
+{
+    return (size_t)kP4Streams * n_frames + (size_t)kP4Streams * kRing * pipe_row_stride(H) + kP4HandFloats + (size_t)(H + 4) + 8 /* progress words */
+         + 5 * kWave /* the cascades' state on its way from one helper wave to the next: z1, z2 (fp64), the ramp's memory */;
+}
+// a progress word in LDS, written by one wave and polled by others (LDS runs a wave's accesses in order: a word written behind the
+// data it announces is seen behind it)
+__device__ __forceinline__ int p4_peek(const int* w)
+{
+    const int v = *reinterpret_cast<const volatile int*>(w);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ void p4_post(int* w, int v, int lane)
+{
+    asm volatile("" ::: "memory");
+    if (lane == 0) *reinterpret_cast<volatile int*>(w) = v;
+    asm volatile("" ::: "memory");
+}
+
+template <class Cell>
+__device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* smem)
+{
+    constexpr int H = Cell::HID;
+    constexpr int HS = pipe_row_stride(H);
+    constexpr int B = kStChainBlockP4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int s0 = kP4Streams * blockIdx.x;
+    const int n = (int)a.n_frames;                        // a multiple of kSB (the host's promise)
+    const int NT = n / kSB;
+    float* rows = smem;                                   // [4][n]: a stream's block, processed in place by three actors a tile apart
+    float* hh = rows + kP4Streams * n;                    // [4][kRing][HS]: h history
+    float* hand = hh + kP4Streams * kRing * HS;           // the cascades' hand-over slots [2][48][B]
+    float* wdl = hand + kP4HandFloats;                    // Dense weights, natural order, then the bias
+    // Progress words instead of a barrier per tick: the recurrent waves never wait for EACH OTHER — four waves that leave a barrier
+    // together run the same instructions in lockstep for the whole tile, and whether their LDS accesses and instruction fetches then
+    // collide is decided by a few cycles of phase: the same kernel measured 61.4 .. 66.8 us over seven builds that differed by
+    // 4 .. 64 bytes of padding (profiles/r06_cfg2_pipe4.txt). Left to themselves the waves drift apart and stay apart.
+    int* prog = reinterpret_cast<int*>(wdl + H + 4);      // [0] tiles the helpers have made ready (pre pass done, times in_gain)
+                                                          // [1] tiles whose Dense is done (their rows of the h ring are free)
+                                                          // [2 + j] tiles the cell of stream j has finished
+                                                          // [6] helper ticks done (whose turn it is)
+    float* hstate = reinterpret_cast<float*>(prog + 8);   // [5][64]: a cascade lane's z1, z2, ramp memory between two helper waves
+
+    // every wave derives the launch's timing from the four control words (wave-uniform): the longest cascades set it
+    int Kp = 1, Kq = 1;
+#pragma unroll
+    for (int j = 0; j < kP4Streams; ++j) {
+        const uint32_t f = a.ctl[s0 + j].flags;
+        if (f & CTL_EQ_PRE) Kp = 6;
+        if (f & CTL_EQ_POST) Kq = 6;
+    }
+    const int d1 = Kp / 2 + 1;                            // ticks between a tile entering the pre pass and the cell reading it
+    const int T = (n / B - 1 + (Kq - 1) + 2 * (d1 + 1)) / 2 + 1;
+
+    if (wave < kP4Streams) {
+        // ---------------------------------------------------------------- a recurrent wave
+        const int s = s0 + wave;
+        float* nnst = a.nn + (size_t)s * a.nn_stride;
+        float* hj = hh + wave * kRing * HS;
+        const float* row = rows + wave * n;
+        Cell cell;
+        if (!(AIDAX_TUNE(a) & 1)) __builtin_amdgcn_s_setprio(3);
+        cell.load(a.wpack, nnst, lane);
+        cell.publish_h(hj + (kRing - 1) * HS);            // h(-1): the row "before" frame 0
+        __syncthreads();                                  // (the progress words are zero)
+        for (int t = 0; t < NT; ++t) {
+            // the tile's inputs are ready, and the Dense has read the rows this tile overwrites (two tiles back)
+            while (p4_peek(prog) <= t || p4_peek(prog + 1) < t - 1) __builtin_amdgcn_s_sleep(1);
+            {
+                const int base = t * kSB;
+                const float* hprev = hj + ((base + kRing - 1) & (kRing - 1)) * HS;
+                float* hcur = hj + (base & (kRing - 1)) * HS;
+                const float* xs = row + base;             // x * in_gain (the helper's product, in place)
+                float xr[kSB];
+                asm volatile(".p2align 6");
+                auto fetch_x = [&](int q) {
+                    const float4 v = reinterpret_cast<const float4*>(xs)[q];
+                    xr[4 * q] = v.x; xr[4 * q + 1] = v.y;
+                    xr[4 * q + 2] = v.z; xr[4 * q + 3] = v.w;
+                };
+                fetch_x(0);
+#pragma unroll
+                for (int f = 0; f < kSB; ++f) {
+                    if ((f & 3) == 1 && f / 4 + 1 < kSB / 4) fetch_x(f / 4 + 1);
+                    cell.template step<1>(xr[f], 0.f, 0.f, f == 0 ? hprev : hcur + (f - 1) * HS, hcur + f * HS);
+                }
+            }
+            p4_post(prog + 2 + wave, t + 1, lane);
+        }
+        cell.store(nnst);
+        return;
+    }
+
+    // ---------------------------------------------------------------- the helper wave(s)
+    // kP4Helpers of them taking the ticks in turns: helper q runs ticks q, q + kP4Helpers, ... — every one with all the constants (the
+    // cascades' coefficients, the Dense) of its own, the cascades' state (z1, z2, the ramp's memory: five words per lane) handed from
+    // one to the next through LDS. (Four helpers, one per SIMD, so that each recurrent wave meets a burst every fourth tick instead of one
+    // wave meeting all of them, measured no better than one: profiles/r06_cfg2_pipe4.txt.)
+    const int hq = wave - kP4Streams;
+    const int j = lane < kP4ChainLanes ? lane / 12 : kP4Streams - 1;      // this lane's stream as a cascade lane
+    const int r = lane - 12 * (lane / 12);
+    const bool isQ = r >= 6;
+    const int stage = isQ ? r - 6 : r;
+    const int sj = s0 + j;
+    const StreamCtl& ctl = a.ctl[sj];
+    StreamState& st = a.st[sj];
+    const int slot = isQ ? post_slot(stage) : pre_slot(stage);
+    // the four rows, dealt out over the helper waves (one 16-byte read per lane and 256 frames)
+    for (int jj = hq; jj < kP4Streams; jj += kP4Helpers) {
+        const float4* src = reinterpret_cast<const float4*>(a.in + (size_t)(s0 + jj) * n);
+        float4* dst = reinterpret_cast<float4*>(rows + jj * n);
+        for (int i = lane; i < n / 4; i += kWave) dst[i] = src[i];
+    }
+    if (hq == 0) {
+        const float* wd_nat = a.wpack + (size_t)Cell::PACK * kWave;         // [H] Dense weights then bias
+        for (int i = lane; i < H + 1; i += kWave) wdl[i] = wd_nat[i];
+    }
+    ChainPass c;
+    chain_load(c, ctl, st, slot, false);
+    const uint32_t flags = ctl.flags;
+    uint32_t pending = st.pending;
+    float pre_mem = st.pre_mem, master_mem = st.master_mem, pre_tgt = st.pre_tgt, master_tgt = st.master_tgt;
+    if (pending & PEND_ACTIVATE) { pre_mem = pre_tgt; master_mem = master_tgt; pending &= ~PEND_ACTIVATE; }     // activate(): :341-342
+    pre_tgt = ctl.pre_target;
+    master_tgt = ctl.master_target;
+    const int Kpj = (flags & CTL_EQ_PRE) ? 6 : 1, Kqj = (flags & CTL_EQ_POST) ? 6 : 1;
+    c.K = isQ ? Kqj : Kpj;
+    c.gain_lane = isQ ? Kqj - 1 : 0;
+    c.active = stage == 0 ? (flags & (isQ ? CTL_DC_ON : CTL_LPF_ON)) != 0 : ((flags & CTL_EQ_BANDPASS) ? slot == BQ_MID : true);
+    c.g.arm(isQ ? master_mem : pre_mem, isQ ? master_tgt : pre_tgt, isQ ? ctl.master_coef : ctl.pre_coef);
+    const bool run = lane < kP4ChainLanes && stage < c.K;
+    const double z1o = c.z1, z2o = c.z2;
+    ExpRamp g = c.g;
+    const bool is_gain = stage == c.gain_lane;
+    if (!is_gain) { g.mem = 1.f; g.coef = 1.f; g.tc = 0.f; }
+    const bool last = stage == c.K - 1;
+    const bool fussy = run && (!c.active || g.mem * g.coef + g.tc != g.mem);
+    const bool plain = __builtin_amdgcn_ballot_w64(fussy) == 0;
+    const int m0 = isQ ? 2 * (d1 + 1) : 0;
+    float* myrow = rows + j * n;
+    // the Dense's lanes: a lane per (stream, frame of the tile)
+    const int dj = lane >> 4, df = lane & 15;
+    const float* hdj = hh + dj * kRing * HS;
+    float* drow = rows + dj * n;
+    if (hq == 0 && lane < 8) prog[lane] = 0;
+    __syncthreads();
+    for (int tick = hq; tick < T; tick += kP4Helpers) {
+        // my turn: the helper before me has finished tick - 1 and left the cascades' state
+        if (tick != 0) {
+            while (p4_peek(prog + 6) < tick) __builtin_amdgcn_s_sleep(8);
+            const double* zs = reinterpret_cast<const double*>(hstate);
+            c.z1 = zs[lane]; c.z2 = zs[kWave + lane];
+            g.mem = hstate[4 * kWave + lane];
+        }
+        // Dense + skip / output gain of the tile the cells finished a tick ago (applyModel :171-181), into the row: the post pass's input
+        const int td = tick - d1 - 1;
+        if (td >= 0 && td < NT) {
+#pragma unroll
+            for (int jj = 0; jj < kP4Streams; ++jj)
+                while (p4_peek(prog + 2 + jj) <= td) __builtin_amdgcn_s_sleep(4);      // every cell has finished the tile
+        }
+        if (td >= 0 && td < NT && !(AIDAX_TUNE(a) & 524288)) {      // (bit 524288, test build: no Dense — what it costs the recurrent wave it shares a SIMD with; wrong output)
+            const int f = td * kSB + df;
+            asm volatile("" ::: "memory");
+            const float4* hrow = reinterpret_cast<const float4*>(hdj + (f & (kRing - 1)) * HS);
+            const float4* w4 = reinterpret_cast<const float4*>(wdl);
+            float y = wdl[H];
+#pragma unroll 2
+            for (int k4 = 0; k4 < H / 4; ++k4) {
+                const float4 w = w4[k4];
+                const float4 hv = hrow[k4];
+                y = __builtin_fmaf(w.x, hv.x, y);
+                y = __builtin_fmaf(w.y, hv.y, y);
+                y = __builtin_fmaf(w.z, hv.z, y);
+                y = __builtin_fmaf(w.w, hv.w, y);
+            }
+            const float xg = drow[f];
+            float o = a.input_skip ? xg + y : y;
+            o = o * a.out_gain;
+            drow[f] = o;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (td >= 0 && td < NT) p4_post(prog + 1, td + 1, lane);
+        if (!(AIDAX_TUNE(a) & 262144))                          // (bit 262144, test build: no chain passes; wrong output)
+#pragma unroll
+        for (int hs = 0; hs < 2; ++hs) {
+            if (plain) chain_macro_step<true, B, kP4ChainLanes>(c, g, stage, run, last, myrow, hand, n / B, 2 * tick + hs - m0, lane);
+            else chain_macro_step<false, B, kP4ChainLanes>(c, g, stage, run, last, myrow, hand, n / B, 2 * tick + hs - m0, lane);
+        }
+        // the tile the cells read next tick: times in_gain, in place (out[i] *= input_gain, :170; every stream's pre pass has finished it)
+        const int ts = tick - d1 + 1;
+        if (ts >= 0 && ts < NT) {
+            const int f = ts * kSB + df;
+            drow[f] = drow[f] * a.in_gain;
+            __builtin_amdgcn_wave_barrier();
+            p4_post(prog, ts + 1, lane);
+        }
+        if (tick + 1 < T) {
+            // the next tick is another helper's: the state, then the word that says so
+            double* zs = reinterpret_cast<double*>(hstate);
+            zs[lane] = c.z1; zs[kWave + lane] = c.z2;
+            hstate[4 * kWave + lane] = g.mem;
+            __builtin_amdgcn_wave_barrier();
+            p4_post(prog + 6, tick + 1, lane);
+        }
+    }
+    if ((T - 1) % kP4Helpers != hq) return;               // the helper of the last tick holds the final state
+    // ---------------------------------------------------------------- state write-back, the rows' stores
+    if (is_gain) c.g = g;
+    if (!run || !c.active) { c.z1 = z1o; c.z2 = z2o; }                      // a bypassed biquad keeps its state (:622, :646)
+    if (run) { st.z[slot][0] = c.z1; st.z[slot][1] = c.z2; }
+    if (lane < kP4ChainLanes && !isQ && stage == 0) { st.pre_mem = c.g.mem; st.pre_tgt = pre_tgt; }
+    if (lane < kP4ChainLanes && isQ && stage == c.K - 1) { st.master_mem = c.g.mem; st.master_tgt = master_tgt; }
+    if (lane < kP4ChainLanes && r == 0) st.pending = param_targets(ctl, st, pending);      // run() :634-640 for a model without PARAM inputs
+    for (int jj = 0; jj < kP4Streams; ++jj) {
+        float4* dst = reinterpret_cast<float4*>(a.out + (size_t)(s0 + jj) * n);
+        const float4* src = reinterpret_cast<const float4*>(rows + jj * n);
+        for (int i = lane; i < n / 4; i += kWave) dst[i] = src[i];
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(kP4Waves * kWave) void k_lstm_pipe4(LaunchArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    stream_body_pipe4<LstmCell<H>>(a, smem);
+}
 
 // ======================================================================
 // Split form (3 launches) — the many-streams form.
@@ -1155,6 +1410,13 @@ __global__ __launch_bounds__(kWave) void k_nomodel(LaunchArgs a)
 
 // one-shot pokes from the control thread (activate / loading are host-latched in ctl;
 // this sets StreamState.pending bits stream-ordered with the process launches)
+__global__ void k_keep_warm() {}
+hipError_t launch_keep_warm_kernel(int workgroups, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_keep_warm, dim3(workgroups), dim3(kWave), 0, stream);
+    return hipGetLastError();
+}
+
 __global__ void k_set_pending(StreamState* st, uint32_t n_streams, int32_t stream, uint32_t bits)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1244,17 +1506,19 @@ __global__ void k_adopt_dsp(StreamState* dst, const StreamState* src)
 }
 
 // ------------------------------------------------------------ host dispatch
-#define AIDAX_LSTM(H) { 0, H, k_lstm<H>, k_lstm_pipe<H>, k_nn<LstmCell<H, false>>, LstmCell<H>::PACK, LstmCell<H>::STATE, "k_lstm<" #H ">", "k_lstm_pipe<" #H ">", "k_chain+k_nn<lstm" #H ">" }
+#define AIDAX_LSTM(H) { 0, H, k_lstm<H>, k_lstm_pipe<H>, k_nn<LstmCell<H, false>>, LstmCell<H>::PACK, LstmCell<H>::STATE, "k_lstm<" #H ">", "k_lstm_pipe<" #H ">", "k_chain+k_nn<lstm" #H ">", nullptr, "-" }
+// ... with the four-streams-per-workgroup pipeline as well (BASELINE cfg2's cell)
+#define AIDAX_LSTM_P4(H) { 0, H, k_lstm<H>, k_lstm_pipe<H>, k_nn<LstmCell<H, false>>, LstmCell<H>::PACK, LstmCell<H>::STATE, "k_lstm<" #H ">", "k_lstm_pipe<" #H ">", "k_chain+k_nn<lstm" #H ">", k_lstm_pipe4<H>, "k_lstm_pipe4<" #H ">" }
 // LSTM-64 / LSTM-80: the helper waves' share of the register file (pipe) resp. the Dense ring (split, H = 80) push the
 // 4H-row cell past 512 registers — those forms would spill, so they do not exist; the pool serves these cells
 // with k_quad / k_mfma, or the one-wave kernel when neither fits (pools with long blocks).
-#define AIDAX_LSTM_WIDE(H, NN) { 0, H, k_lstm<H>, nullptr, NN, LstmCell<H>::PACK, LstmCell<H>::STATE, "k_lstm<" #H ">", "-", "k_chain+k_nn<lstm" #H ">" }
-#define AIDAX_GRU(H)  { 1, H, k_gru<H>,  k_gru_pipe<H>,  k_nn<GruCell<H>>,  GruCell<H>::PACK,  GruCell<H>::STATE,  "k_gru<" #H ">", "k_gru_pipe<" #H ">", "k_chain+k_nn<gru" #H ">" }
+#define AIDAX_LSTM_WIDE(H, NN) { 0, H, k_lstm<H>, nullptr, NN, LstmCell<H>::PACK, LstmCell<H>::STATE, "k_lstm<" #H ">", "-", "k_chain+k_nn<lstm" #H ">", nullptr, "-" }
+#define AIDAX_GRU(H)  { 1, H, k_gru<H>,  k_gru_pipe<H>,  k_nn<GruCell<H>>,  GruCell<H>::PACK,  GruCell<H>::STATE,  "k_gru<" #H ">", "k_gru_pipe<" #H ">", "k_chain+k_nn<gru" #H ">", nullptr, "-" }
 
 static const KernelEntry kTable[] = {
     // the 18 (cell, hidden) pairs of variant/generate_variant_hpp.py:4-6; input size is a run-time argument
     AIDAX_LSTM(8), AIDAX_LSTM(12), AIDAX_LSTM(16), AIDAX_LSTM(20), AIDAX_LSTM(24),
-    AIDAX_LSTM(32), AIDAX_LSTM(40), AIDAX_LSTM_WIDE(64, k_nn<LstmCell<64>>), AIDAX_LSTM_WIDE(80, nullptr),
+    AIDAX_LSTM_P4(32), AIDAX_LSTM(40), AIDAX_LSTM_WIDE(64, k_nn<LstmCell<64>>), AIDAX_LSTM_WIDE(80, nullptr),
     AIDAX_GRU(8), AIDAX_GRU(12), AIDAX_GRU(16), AIDAX_GRU(20), AIDAX_GRU(24),
     AIDAX_GRU(32), AIDAX_GRU(40), AIDAX_GRU(64), AIDAX_GRU(80),
 };
@@ -1328,6 +1592,27 @@ hipError_t launch_pipe_kernel(const KernelEntry* e, const LaunchArgs& a, hipStre
 {
     if (!e->fn_pipe) return hipErrorInvalidDeviceFunction;
     hipLaunchKernelGGL(e->fn_pipe, dim3(a.n_streams), dim3(kPipeWaves * kWave), pipe_lds_bytes(e->hidden, a.n_frames), stream, a);
+    return hipGetLastError();
+}
+
+// k_*_pipe4's workgroup asks for more than half a CU's LDS whatever its rows need: the dispatcher then cannot put two of them on one CU
+// while another CU stands empty (a CU with two runs both at half speed, and the launch ends with them)
+size_t pipe4_lds_bytes(int hidden, uint32_t n_frames)
+{
+    const size_t need = pipe4_lds_floats(hidden, (int)n_frames) * sizeof(float);
+    return need > 81 * 1024 ? need : (size_t)81 * 1024;
+}
+hipError_t launch_pipe4_kernel(const KernelEntry* e, const LaunchArgs& a, hipStream_t stream)
+{
+    if (!e->fn_pipe4 || a.n_streams % kP4Streams || a.n_frames % kSB || a.n_frames == 0) return hipErrorInvalidValue;
+    const size_t lds = pipe4_lds_bytes(e->hidden, a.n_frames);
+    static bool raised = false;
+    if (!raised) {
+        const hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(e->fn_pipe4), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (err != hipSuccess) return err;
+        raised = true;
+    }
+    hipLaunchKernelGGL(e->fn_pipe4, dim3(a.n_streams / kP4Streams), dim3(kP4Waves * kWave), lds, stream, a);
     return hipGetLastError();
 }
 

@@ -316,6 +316,7 @@ struct LaunchArgs {
     int32_t          tune;        // AIDAX_TUNE bit mask, measurement / test switches of the kernels (0 in production):
                                   // 1 = no issue priority for the recurrent wave of k_*_pipe, 2 = k_mfma_lp with a group's layers on adjacent workgroup ids,
                                   // 16 = k_mfma_lp reports a hand-over give-up that did not happen (tests of the fault path),
+                                  // 32768 / 65536 = k_conv_st without its history stores / with every far tap reading one resident tile (scratch/r06_cfg4_ablate.sh),
                                   // 8192 = the last layer's workgroup of k_mfma_lp's one-launch form starts 100 us late (tests: nothing may lean on the layers' workgroups starting together)
     uint32_t         row_stride;  // k_conv_mfma: frames between two streams' rows in `in` / `out` when a launch carries a
                                   // time slice of a longer block (0: rows are n_frames apart)

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <sstream>
 
 #include "aidax_internal.h"
@@ -121,22 +122,39 @@ ManyForm many_streams_form(int cell, int hidden, uint32_t n, int cus, uint32_t m
     // Round 5: GRU-64 is k_gru_gs's at EVERY pool size, the one-stream pool of an LV2 instance included — 49.9 / 93.1 / 179 us per block
     // of 64 / 128 / 256 frames at one stream against 55.4 / 99.1 / 187 on k_quad, 54 / 99 / 188 against 64 / 108 / 197 at 16 .. 192 streams
     // (the 256-stream threshold of round 4 was measured at 256 frames only, where the gap is 4 %; at a 64-frame period it is 19 %).
-    if (!lstm && cus > 0 && !gm_f32 && (hidden == 64 || (hidden == 40 && groups * 2 > static_cast<uint32_t>(cus))))
+    // Round 6 (advisor): that evidence is blocks of 64 frames and more; a pool created for shorter blocks than any measured (hub mode's
+    // four-frame placeholder pool) keeps round 4's threshold — a sixteenth of a round of stream groups (256 streams on 256 CUs).
+    if (!lstm && cus > 0 && !gm_f32 && ((hidden == 64 && (max_frames >= 64 || groups * 16 >= static_cast<uint32_t>(cus))) || (hidden == 40 && groups * 2 > static_cast<uint32_t>(cus))))
         return MANY_MFMA;
     if (!lstm && cus > 0 && ((hidden == 64 && groups * 8 >= static_cast<uint32_t>(cus) * 5) || (hidden == 40 && groups * 8 >= static_cast<uint32_t>(cus) * 7)))
         return MANY_MFMA;
-    if (hidden <= 32) return n >= 4096 ? MANY_QUAD : MANY_NONE;
-    if (hidden == 40) return n >= 8192 ? MANY_MFMA : n >= (lstm ? 512u : 4096u) ? MANY_QUAD : MANY_NONE;
-    if (hidden == 64 && !lstm) return n >= 16384 ? MANY_MFMA : n <= 1024 ? MANY_QUAD : MANY_NONE;
+    // What is left of the table, in ROUNDS of stream groups like the rules above (round 6: these were stream counts measured on 256 CUs —
+    // 4096 streams = one round of sixteen-stream workgroups there; a partition with 32 or 64 CUs reaches its round at 512 or 1024
+    // streams). A device whose CU count is unknown (cus <= 0) is taken for the one the table was measured on.
+    const uint32_t round = static_cast<uint32_t>(kMfmaStreams) * (cus > 0 ? static_cast<uint32_t>(cus) : 256u);      // streams of one round of workgroups
+    if (hidden <= 32) return n >= round ? MANY_QUAD : MANY_NONE;
+    if (hidden == 40) return n >= 2 * round ? MANY_MFMA : n >= (lstm ? round / 8 : round) ? MANY_QUAD : MANY_NONE;
+    if (hidden == 64 && !lstm) return n >= 4 * round ? MANY_MFMA : n <= round / 4 ? MANY_QUAD : MANY_NONE;
     // LSTM-64, LSTM-80, GRU-80: their one-wave kernels hold 250-500 weight registers; k_quad is 1.35-1.75x
-    // faster already at 64 streams, k_mfma takes over from 4096
-    return n >= 4096 ? MANY_MFMA : MANY_QUAD;
+    // faster already at 64 streams, k_mfma takes over from a full round of stream groups
+    return n >= round ? MANY_MFMA : MANY_QUAD;
 }
 
 // k_mfma_lp needs every workgroup of its grid resident at once, which the pool can promise only for ONE grid on the
 // device: one pool per device holds the right to use the kernel (a pool's staged model shares its own pool's hold), the
 // others serve their stacked models with k_mfma. Process-wide; another process on the same GPU is beyond its reach
 // and ends in a reported give-up (aidax_mfmalp.hip).
+// a flag written on the launch path and read by other threads (aidax_pool_kernel_name, lp_in_use from the worker): an atomic that
+// a struct assignment of its owner (a model swap is one) may copy
+struct RelaxedFlag {
+    std::atomic<bool> v{false};
+    RelaxedFlag() = default;
+    RelaxedFlag(const RelaxedFlag& o) : v(o.v.load(std::memory_order_relaxed)) {}
+    RelaxedFlag& operator=(const RelaxedFlag& o) { v.store(o.v.load(std::memory_order_relaxed), std::memory_order_relaxed); return *this; }
+    RelaxedFlag& operator=(bool b) { v.store(b, std::memory_order_relaxed); return *this; }
+    operator bool() const { return v.load(std::memory_order_relaxed); }
+};
+
 struct LpGate {
     std::mutex mu;
     // `off`: the owner's "I have stopped using the kernel" flag (a pool whose hand-over gave up serves its model with
@@ -165,6 +183,66 @@ struct LpGate {
     }
 };
 LpGate& lp_gate() { static LpGate g; return g; }
+
+// AIDAX_KEEP_WARM_US=<period in us> (off unless set): a host calls run() once per audio period (rt-neural-generic.cpp:484) — 1.3 to 5.3 ms
+// apart — and a GPU that has idled for that long serves the next launch slower than one that is kept busy (bench.py realtime_paced: the
+// same pass 8 - 13 % longer, the call's tail several times longer). With the variable set, ONE thread per device launches an empty grid
+// (a wave per CU) on a stream of the lowest priority every <period>, while any pool on that device exists. Never on the audio thread;
+// what it buys on a box is measured by bench.py (realtime_paced.keep_warm) and stated in INTEGRATION.md §3.
+struct KeepWarm {
+    std::mutex mu;
+    struct Dev { int refs = 0; std::thread th; std::atomic<bool> stop{false}; } dev[64];
+    ~KeepWarm()
+    {
+        for (Dev& d : dev) { d.stop.store(true); if (d.th.joinable()) d.th.detach(); }      // (a pool that outlived main(): no join at exit)
+    }
+    static long period_us()
+    {
+        const char* e = std::getenv("AIDAX_KEEP_WARM_US");
+        const long v = e ? std::strtol(e, nullptr, 10) : 0;
+        return v >= 50 && v <= 1000000 ? v : 0;
+    }
+    bool acquire(int device)
+    {
+        const long us = period_us();
+        if (us == 0 || device < 0 || device >= 64) return false;
+        std::lock_guard<std::mutex> g(mu);
+        Dev& d = dev[device];
+        if (d.refs++ == 0) {
+            d.stop.store(false);
+            d.th = std::thread([device, us, &d] {
+                if (hipSetDevice(device) != hipSuccess) return;
+                int least = 0, greatest = 0, cus = 0;
+                hipStream_t q = nullptr;
+                (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+                if (hipStreamCreateWithPriority(&q, hipStreamNonBlocking, least) != hipSuccess) return;
+                (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+                auto next = std::chrono::steady_clock::now();
+                while (!d.stop.load(std::memory_order_relaxed)) {
+                    (void)launch_keep_warm_kernel(cus > 0 ? cus : 1, q);
+                    next += std::chrono::microseconds(us);
+                    const auto now = std::chrono::steady_clock::now();
+                    if (next < now) next = now;
+                    std::this_thread::sleep_until(next);
+                }
+                (void)hipStreamSynchronize(q);
+                (void)hipStreamDestroy(q);
+            });
+        }
+        return true;
+    }
+    void release(int device)
+    {
+        std::thread done;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            Dev& d = dev[device];
+            if (d.refs > 0 && --d.refs == 0) { d.stop.store(true); done = std::move(d.th); }
+        }
+        if (done.joinable()) done.join();
+    }
+};
+KeepWarm& keep_warm() { static KeepWarm k; return k; }
 
 struct HipFail : std::runtime_error { using std::runtime_error::runtime_error; };
 
@@ -216,10 +294,10 @@ struct ModelSlot {
     float* d_nn = nullptr;           // recurrent state [n_streams][nn_stride]
     float* d_ring = nullptr;         // k_mfma_lp: h of layer l-1 on its way to layer l, per stream group
     uint32_t* d_counters = nullptr;  // k_mfma_lp: frames produced / consumed per (group, layer boundary)
-    const void* lp_owner = nullptr;  // the pool whose hold on the device's LpGate this slot shares (d_ring != nullptr)
+    mutable const void* lp_owner = nullptr;  // the pool whose hold on the device's LpGate this slot shares (d_ring != nullptr); given up on the launch path when the grid is refused
     bool lp_fused = false;           // k_mfma_lp runs the DSP chain too (one-layer models, helper waves): one launch per block
     uint32_t lp_round_streams = 0;   // k_mfma_ls on a pool larger than one resident grid: streams per launch (a pass is several launches over stream ranges); 0: one launch
-    mutable bool lp_refused = false; // the runtime refused this model's chained grid (cooperative launch: not co-resident on this device): k_mfma serves it — this
+    mutable RelaxedFlag lp_refused;  // the runtime refused this model's chained grid (cooperative launch: not co-resident on this device): k_mfma serves it — this
                                      // model only; another model of the pool, with a smaller grid, may still fit (set on the launch path, hence mutable)
     int lp_split = 0;                // stacked models: k_mfma_ls serves the passes (contractions as bf16 term products of split operands): 6 or 9 products; 0: k_mfma_lp (fp32 MFMAs)
     bool gru_gm = false;             // one-layer GRU: k_gru_gm (gate-major tiles, the whole run() in one launch) serves the passes
@@ -273,6 +351,8 @@ struct aidax_pool {
     uint32_t* hd_done = nullptr;
     uint32_t done_seq = 0;
     bool spin_wait = false;
+    bool spin_collect = true;        // aidax_pool_collect polls the download's event instead of sleeping on it (AIDAX_SPIN_WAIT=0: off)
+    bool keep_warm = false;          // this pool holds a reference on its device's keep-warm thread (AIDAX_KEEP_WARM_US)
     // k_mfma_lp: a word in pinned host memory that a workgroup bumps when a layer hand-over timed out. The pass that did
     // so is wrong; whoever notices reports it, and the pool serves the model with k_mfma from then on (lp_off).
     uint32_t* h_lp_fault = nullptr;
@@ -292,15 +372,20 @@ struct aidax_pool {
         return true;
     }
 
-    // aidax_pool_submit / aidax_pool_collect: two staging sets and two copy streams, so that the upload of block k+1
-    // and the download of block k-1 run under the pass of block k (allocated by the first submit)
+    // aidax_pool_submit / aidax_pool_collect: kPipeSets staging sets and two copy streams, so that the upload of the blocks behind
+    // block k and the download of the blocks in front of it run under the pass of block k (allocated by the first submit).
+    // THREE sets since round 6: with two, submit(k) has to wait for collect(k - 2), which returns a cross-stream hop and a download
+    // after pass k - 2 has ended; the upload of k and its own hop then end ~110 us after that — later than pass k - 1 (65 us for a
+    // cfg2 block) does, and the GPU idles for the difference every block (88 us per block predicted, 83.8 measured in round 3).
+    // A third set takes the host's round trip off the GPU's critical path: the pass is what is left.
+    static constexpr int kPipeSets = 3;
     struct Pipeline {
         bool ready = false;
-        float* h_in[2] = {}; float* h_out[2] = {}; float* d_in[2] = {}; float* d_out[2] = {};
-        hipEvent_t ev_up[2] = {}, ev_pass[2] = {}, ev_down[2] = {};
+        float* h_in[kPipeSets] = {}; float* h_out[kPipeSets] = {}; float* d_in[kPipeSets] = {}; float* d_out[kPipeSets] = {};
+        hipEvent_t ev_up[kPipeSets] = {}, ev_pass[kPipeSets] = {}, ev_down[kPipeSets] = {};
         hipStream_t q_up = nullptr, q_down = nullptr;
-        uint32_t frames[2] = {};
-        float* direct_out[2] = {};      // the block's download went straight to this caller buffer (registered): collect() only waits
+        uint32_t frames[kPipeSets] = {};
+        float* direct_out[kPipeSets] = {};      // the block's download went straight to this caller buffer (registered): collect() only waits
         uint64_t submitted = 0, collected = 0;
     } pipe;
     // aidax_pool_register_host: page-locked ranges of the caller's memory (copies to and from them need no staging)
@@ -381,8 +466,32 @@ struct aidax_pool {
         return (static_cast<size_t>((n_frames + 3) & ~3u) + static_cast<size_t>(m.hidden > 0 ? m.hidden + 4 : 4)) * sizeof(float);   // block + h row + spare slot
     }
 
+    // k_*_pipe4 takes a pass only when every stream is in circuit (enabled, the model on): a summary of the control records, rebuilt after they changed
+    mutable bool circuit_dirty = true, circuit_all = false;
+    bool all_in_circuit() const
+    {
+        if (circuit_dirty) {
+            circuit_all = true;
+            const uint32_t want = CTL_ENABLED | CTL_NET_ON;
+            for (uint32_t s = 0; s < n_streams && circuit_all; ++s) circuit_all = (h_ctl[s].flags & want) == want;
+            circuit_dirty = false;
+        }
+        return circuit_all;
+    }
+    // Does a MODE_CHAIN pass of n frames go through the four-streams-per-workgroup pipeline? Only where asked for (AIDAX_PIPE4=1, test
+    // build): built for the round-5 review's item 4 and measured — 64.6 us per cfg2 block against k_lstm_pipe's 63.9 in its robust form,
+    // 61.4 .. 66.8 in the form whose waves run in lockstep, by nothing but where the code happens to lie (profiles/r06_cfg2_pipe4.txt).
+    // It stays as the A/B partner of that measurement; bit-identical to k_*_pipe (tests/test_gpu_parity.py).
+    bool pipe4_serves(const ModelSlot& m, uint32_t n, int input_size) const
+    {
+        const bool off = [] { const char* e = AIDAX_HOOK_ENV("AIDAX_PIPE4"); return !(e && e[0] == '1'); }();      // (read per call: tests switch forms within one process)
+        if (off || !m.kernel || !m.kernel->fn_pipe4 || input_size != 1 || n == 0 || n % 16u || n_streams % 4u) return false;
+        if (cus <= 0 || n_streams > 4u * static_cast<uint32_t>(cus) || pipe4_lds_bytes(m.hidden, n) > 160 * 1024) return false;
+        return all_in_circuit();
+    }
     void mark_dirty(uint32_t lo, uint32_t hi)
     {
+        circuit_dirty = true;
         if (dirty_lo > dirty_hi) { dirty_lo = lo; dirty_hi = hi; }
         else { dirty_lo = std::min(dirty_lo, lo); dirty_hi = std::max(dirty_hi, hi); }
     }
@@ -472,6 +581,9 @@ struct aidax_pool {
                 if (e != hipErrorCooperativeLaunchTooLarge) return false;
                 (void)hipGetLastError();
                 m.lp_refused = true;                          // this model's grid; a pool-wide lp_off is for give-ups (co-tenants)
+                // ... and this slot's share of the pool's hold on the device's gate goes back: a pool that cannot use the chained kernels
+                // must not keep every other pool of the device off them (advisor, round 5)
+                if (m.lp_owner) { lp_gate().release(device, m.lp_owner); m.lp_owner = nullptr; }
                 lp_refusals.fetch_add(1, std::memory_order_relaxed);
                 set_error("a chained grid cannot be co-resident on this device (cooperative launch refused): the model is served by k_mfma");
                 return true;
@@ -550,7 +662,7 @@ struct aidax_pool {
             b.wpack = m.d_wq4;
             return launch_q4_kernel(m.hidden, b, s);
         }
-        if (form == 1) return launch_pipe_kernel(m.kernel, a, s);
+        if (form == 1) return pipe4_serves(m, a.n_frames, a.input_size) ? launch_pipe4_kernel(m.kernel, a, s) : launch_pipe_kernel(m.kernel, a, s);
         if (form == 2) return launch_split_kernels(m.has_model ? m.kernel : nullptr, a, s);
         return launch_stream_kernel(m.has_model ? m.kernel : nullptr, a, lds_bytes(m, a.mode == MODE_CHAIN ? a.n_frames : 0), s);
     }
@@ -572,7 +684,7 @@ struct aidax_pool {
         h_lp_fault = nullptr;
         for (const HostRange& r : host_ranges) (void)hipHostUnregister(r.base);
         host_ranges.clear();
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < kPipeSets; ++k) {
             if (pipe.h_in[k]) (void)hipHostFree(pipe.h_in[k]);
             if (pipe.h_out[k]) (void)hipHostFree(pipe.h_out[k]);
             if (pipe.d_in[k]) (void)hipFree(pipe.d_in[k]);
@@ -900,6 +1012,8 @@ AIDAX_API int aidax_pool_create(uint32_t n_streams, uint32_t max_frames, double 
             HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
             HIP_TRY(hipStreamCreateWithPriority(&p->q, hipStreamNonBlocking, prio_greatest));
             HIP_TRY(hipStreamCreateWithPriority(&p->wq, hipStreamNonBlocking, prio_least));
+            { const char* sp = std::getenv("AIDAX_SPIN_WAIT"); p->spin_collect = !(sp && sp[0] == '0'); }
+            p->keep_warm = keep_warm().acquire(device_id);
             HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_lp_fault), 8192, hipHostMallocDefault));     // the fault word + the time stamps of scratch/lp_trace.py, r05_modes.py
             HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->hd_lp_fault), p->h_lp_fault, 0));
             *p->h_lp_fault = 0;
@@ -963,6 +1077,7 @@ AIDAX_API void aidax_pool_destroy(aidax_pool* p)
     if (p->pipe.q_up) (void)hipStreamSynchronize(p->pipe.q_up);
     if (p->pipe.q_down) (void)hipStreamSynchronize(p->pipe.q_down);
     p->release();
+    if (p->keep_warm) keep_warm().release(p->device);
     delete p;
 }
 
@@ -1261,7 +1376,7 @@ static int pool_submit_impl(aidax_pool* p, const float* in, float* out, uint32_t
             const size_t cap = sizeof(float) * p->n_streams * static_cast<size_t>(p->max_frames);
             HIP_TRY(hipStreamCreateWithFlags(&pl.q_up, hipStreamNonBlocking));
             HIP_TRY(hipStreamCreateWithFlags(&pl.q_down, hipStreamNonBlocking));
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < aidax_pool::kPipeSets; ++k) {
                 HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&pl.h_in[k]), cap, hipHostMallocDefault));
                 HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&pl.h_out[k]), cap, hipHostMallocDefault));
                 HIP_TRY(hipMalloc(&pl.d_in[k], cap));
@@ -1272,10 +1387,10 @@ static int pool_submit_impl(aidax_pool* p, const float* in, float* out, uint32_t
             }
             pl.ready = true;
         }
-        if (pl.submitted - pl.collected >= 2) return fail(AIDAX_ERR_STATE, "two blocks are in flight: collect one first");
-        const int s = static_cast<int>(pl.submitted & 1);
+        if (pl.submitted - pl.collected >= static_cast<uint64_t>(aidax_pool::kPipeSets)) return fail(AIDAX_ERR_STATE, "three blocks are in flight: collect one first");
+        const int s = static_cast<int>(pl.submitted % aidax_pool::kPipeSets);
         const size_t bytes = sizeof(float) * p->n_streams * static_cast<size_t>(n_frames);
-        // set s was last used by block k-2, which has been collected: its pass and both its copies are complete
+        // set s was last used by block k-3, which has been collected: its pass and both its copies are complete
         const float* up_from = in;                          // a registered caller buffer is uploaded as it lies
         if (!p->host_registered(in, bytes)) {
             std::memcpy(pl.h_in[s], in, bytes);
@@ -1343,11 +1458,26 @@ AIDAX_API int aidax_pool_collect(aidax_pool* p, float* out, uint32_t n_frames)
     return guarded([&]() -> int {
         auto& pl = p->pipe;
         if (!pl.ready || pl.collected == pl.submitted) return fail(AIDAX_ERR_STATE, "nothing was submitted");
-        const int s = static_cast<int>(pl.collected & 1);
+        const int s = static_cast<int>(pl.collected % aidax_pool::kPipeSets);
         if (pl.frames[s] != n_frames) return fail(AIDAX_ERR_ARG, "n_frames differs from the submitted block's");
         if (pl.direct_out[s] && pl.direct_out[s] != out) return fail(AIDAX_ERR_ARG, "collect: the block was submitted with another destination");
         HIP_TRY(hipSetDevice(p->device));
-        if (hipEventQuery(pl.ev_down[s]) != hipSuccess) HIP_TRY(hipEventSynchronize(pl.ev_down[s]));
+        if (hipEventQuery(pl.ev_down[s]) != hipSuccess) {
+            // like aidax_pool_process: poll (no interrupt, no wake-up on the way back) for up to ~2 ms, then wait the usual way
+            bool done = false;
+            if (p->spin_collect) {
+                const auto t0 = std::chrono::steady_clock::now();
+                uint32_t polls = 0;
+                while (!(done = hipEventQuery(pl.ev_down[s]) == hipSuccess)) {
+                    if ((++polls & 63u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+#if defined(__x86_64__)
+                    __builtin_ia32_pause();
+#endif
+                }
+                (void)hipGetLastError();                        // (hipErrorNotReady of the polls)
+            }
+            if (!done) HIP_TRY(hipEventSynchronize(pl.ev_down[s]));
+        }
         ++pl.collected;
         const size_t bytes = sizeof(float) * p->n_streams * static_cast<size_t>(n_frames);
         if (p->take_lp_fault()) {
@@ -1432,6 +1562,8 @@ AIDAX_API const char* aidax_pool_kernel_name(const aidax_pool* p)
     if (m.kind == ModelSlot::CONV && m.conv_ms && m.conv_fused && m.cdesc.st_ok && p->max_frames >= 64) return "k_conv_st";      // (what a block of 64 / 128 / 256 frames runs; every other length: k_conv_ms)
     if (m.kind == ModelSlot::CONV) return m.conv_ms ? (m.conv_fused ? "k_conv_ms" : "k_chain+k_conv_ms") : m.conv_fused ? "k_conv_mfma" : m.conv_mfma ? "k_chain+k_conv_mfma" : "k_conv";
     const int form = p->chain_form(m);
+    // (form 1: what a block of the pool's full length runs with the controls as they stand — k_*_pipe4 where it serves, k_*_pipe otherwise)
+    if (form == 1 && p->pipe4_serves(m, p->max_frames, m.input_size)) return m.kernel->name_pipe4;
     return form == 3 ? "k_lstm_q4<32>" : form == 1 ? m.kernel->name_pipe : form == 2 ? m.kernel->name_split : m.kernel->name;
 }
 

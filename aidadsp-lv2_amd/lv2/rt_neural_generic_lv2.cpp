@@ -47,11 +47,12 @@ enum PortIndex {   // ports_t, rt-neural-generic.h:84-112 (generic build)
     DCBLOCKER, MASTER, INPUT_SIZE, PLUGIN_ENABLED, LATENCY, PLUGIN_PORT_COUNT
 };
 
-enum WorkerMessageType { kWorkerLoad, kWorkerApply, kWorkerFree };          // rt-neural-generic.h:132-136
+enum WorkerMessageType { kWorkerLoad, kWorkerApply, kWorkerFree, kWorkerNote };   // rt-neural-generic.h:132-136 (+ kWorkerNote: a log line the audio thread wants said)
 struct WorkerMessage { WorkerMessageType type; };
 struct WorkerLoadMessage { WorkerMessageType type; char path[1024]; };      // :144-151
 // :154-157 with the C-ABI handles: the model, what aidax_pool_prepare_model staged for it (after the swap: what the
 // swap retired), and in hub mode the seat (hub, slot) the worker attached for this instance
+struct WorkerNoteMessage { WorkerMessageType type; uint32_t n_samples, slices, slice_len, cap; };
 struct WorkerApplyMessage { WorkerMessageType type; aidax_model* model; aidax_staged* staged; aidax_hub* hub; int32_t slot; };
 
 struct PluginURIs {   // uris.h:33-48
@@ -490,9 +491,12 @@ void run(LV2_Handle instance, uint32_t n_samples)
                 self->slice_len = n_samples / k;
                 // (said once per block length, not per call: a length with no divisor between 32 frames and the hub's block costs a
                 // pass per few frames — correct, one slice late, and far from real time)
-                if (self->slice_len < 32u)
-                    plog(self, uris->log_Note, "aidax: hub mode: a host block of %u frames goes through in %u slices of %u (no larger divisor fits the hub's %u-frame blocks): "
-                         "use a block length with a divisor in [32, %u] or raise AIDAX_HUB_FRAMES\n", n_samples, k, self->slice_len, cap, cap);
+                // run() formats and logs nothing itself (the reference's never does; log:log is not real-time safe): the note travels to
+                // the worker thread like a load request does (schedule_work is the one call a run() may make, :576)
+                if (self->slice_len < 32u) {
+                    const WorkerNoteMessage note = { kWorkerNote, n_samples, k, self->slice_len, cap };
+                    self->schedule->schedule_work(self->schedule->handle, sizeof(note), &note);
+                }
             }
             const uint32_t slice = self->slice_len;
             for (uint32_t done = 0; done < n_samples && rc == AIDAX_OK; done += slice)
@@ -606,6 +610,12 @@ LV2_Worker_Status work(LV2_Handle instance, LV2_Worker_Respond_Function respond,
         self->last_input_size = info.input_size;                 // cached for the ModelInSize port (:1082)
         plog(self, self->uris.log_Note, "Successfully loaded json file: %s\n", path);
         respond(handle, sizeof(reply), &reply);
+        return LV2_WORKER_SUCCESS;
+    }
+    case kWorkerNote: {
+        const WorkerNoteMessage* nt = static_cast<const WorkerNoteMessage*>(data);
+        plog(self, self->uris.log_Note, "aidax: hub mode: a host block of %u frames goes through in %u slices of %u (no larger divisor fits the hub's %u-frame blocks): "
+             "use a block length with a divisor in [32, %u] or raise AIDAX_HUB_FRAMES\n", nt->n_samples, nt->slices, nt->slice_len, nt->cap, nt->cap);
         return LV2_WORKER_SUCCESS;
     }
     case kWorkerFree: {

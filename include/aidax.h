@@ -254,9 +254,10 @@ AIDAX_API int  aidax_pool_process(aidax_pool* p, const float* in, float* out, ui
 /* The same pass for a host that streams blocks: submit() stages block k (pinned copy, upload on a copy stream, the
  * pass, download on another copy stream) and returns; collect() waits for the OLDEST submitted block and copies it
  * out. With one block kept in flight — submit(k+1) before collect(k) — the upload of k+1 and the download of k-1 run
- * under the pass of k. At most two blocks between submit and collect (AIDAX_ERR_STATE beyond); collect's n_frames is
- * the submitted block's. One caller thread. The first submit allocates the second staging set: make it before going
- * real-time. */
+ * under the pass of k; with two — submit(k+2) before collect(k) — the host's own round trip (a download, the caller's
+ * turn-around, an upload) is off the GPU's critical path as well and the pass is what bounds the rate. At most three
+ * blocks between submit and collect (AIDAX_ERR_STATE beyond); collect's n_frames is the submitted block's. One caller
+ * thread. The first submit allocates the staging sets: make it before going real-time. */
 AIDAX_API int  aidax_pool_submit(aidax_pool* p, const float* in, uint32_t n_frames);
 AIDAX_API int  aidax_pool_collect(aidax_pool* p, float* out, uint32_t n_frames);
 

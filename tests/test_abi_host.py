@@ -200,6 +200,18 @@ def test_launch_form_rule_for_one_layer_table_models(monkeypatch):
     assert [f(GRU, 64, n, 256, 64) for n in (1, 64, 4096)] == [2, 2, 2] and [f(LSTM, 64, n, 256, 64) for n in (1024, 1025)] == [1, 2]
     # half the CUs (a partitioned device): the stream counts of the crossovers halve
     assert [f(LSTM, 64, n, 128) for n in (512, 513)] == [1, 2] and [f(GRU, 80, n, 128) for n in (512, 513)] == [1, 2]
+    # round 6: EVERY threshold is counted in rounds of sixteen-stream groups — a 64-CU and a 32-CU partition (CPX mode) see the whole table
+    # at a quarter / an eighth of the stream counts it was measured at (256 CUs: 4096 streams = one round)
+    for cus in (64, 32):
+        k = 256 // cus
+        assert [f(LSTM, 16, n, cus) for n in (1, 4095 // k, 4096 // k, 16384 // k)] == [0, 0, 1, 1], cus
+        assert [f(GRU, 32, n, cus) for n in (2048 // k, 4096 // k, 6144 // k, 6144 // k + 1, 16384 // k)] == [0, 2, 1, 2, 2], cus
+        assert [f(LSTM, 64, n, cus) for n in (64 // k, 1024 // k, 1024 // k + 1, 4096 // k)] == [1, 1, 2, 2], cus
+        assert [f(LSTM, 40, n, cus) for n in (256 // k, 512 // k, 2048 // k, 2048 // k + 1, 8192 // k)] == [0, 1, 1, 2, 2], cus
+        assert [f(GRU, 40, n, cus) for n in (2048 // k, 2048 // k + 1)] == [0, 2], cus
+        assert [f(LSTM, 32, n, cus) for n in (4096 // k, 4096 // k + 1, 5120 // k, 6144 // k, 6144 // k + 1)] == [2, 0, 0, 2, 2], cus
+    # a pool for blocks shorter than any measured (hub mode's four-frame placeholder pool): GRU-64 keeps round 4's threshold there
+    assert [f(GRU, 64, n, 256, 4) for n in (1, 240, 241, 4096)] == [1, 1, 2, 2] and [f(GRU, 64, n, 256, 64) for n in (1, 240)] == [2, 2]
     # switches: read per call
     monkeypatch.setenv("AIDAX_LSTM_GS", "0")
     assert f(LSTM, 64, 2048) == 1 and f(LSTM, 64, 2049) == 2          # k_mfma_ls1's rule takes over (beyond 2048 streams)
@@ -310,7 +322,7 @@ def test_the_shipped_library_has_no_test_or_measurement_switch():
         out = subprocess.run(["strings", "-a", path], capture_output=True, text=True, check=True).stdout
         return set(re.findall(r"AIDAX_[A-Z0-9_]+", out))
     ship, hooks = names(SHIP_LIB), names(HOOKS_LIB)
-    assert ship == {"AIDAX_SPIN_WAIT", "AIDAX_ZEROCOPY", "AIDAX_STRICT_REFERENCE_SET"}, ship
+    assert ship == {"AIDAX_SPIN_WAIT", "AIDAX_ZEROCOPY", "AIDAX_STRICT_REFERENCE_SET", "AIDAX_KEEP_WARM_US"}, ship      # configuration, INTEGRATION.md §3
     assert {"AIDAX_TUNE", "AIDAX_KERNEL", "AIDAX_LP_COOP", "AIDAX_MFMA_LP", "AIDAX_LP_SPLIT"} <= hooks
     shell = names(os.path.join(ROOT, "aidadsp-lv2_amd", "lv2", "rt-neural-generic.so"))
     assert shell == {"AIDAX_DEVICE", "AIDAX_HUB", "AIDAX_HUB_FRAMES", "AIDAX_HUB_DEADLINE_US", "AIDAX_STRICT_REFERENCE_SET"}, shell

@@ -289,11 +289,23 @@ def test_pipelined_host_buffer_path_is_the_blocking_path_bit_for_bit(tmp_path):
     for k in range(1, len(blocks)):
         b.set_controls(ctl(k))                                   # applies to the block submitted next, not to the one in flight
         b.submit(blocks[k])
-        if k == 3:
-            assert L.aidax_pool_submit(b.h, blocks[k].ctypes.data_as(C.POINTER(C.c_float)), sizes[k]) == -6   # two in flight already
         got = b.collect(sizes[k - 1])
         assert np.array_equal(got, want[k - 1]), k
     assert np.array_equal(b.collect(sizes[-1]), want[-1])
+    a.close(); b.close()
+    # the depth of the pipeline: three blocks between submit and collect (three staging sets, round 6), AIDAX_ERR_STATE for a fourth;
+    # collected oldest first, the same bits as the blocking path
+    a, b = ax.Pool(S, 256), ax.Pool(S, 256)
+    a.set_model(m); b.set_model(m)
+    want = [a.process(blk) for blk in blocks[:5]]
+    for k in range(3):
+        b.submit(blocks[k])
+    assert L.aidax_pool_submit(b.h, blocks[3].ctypes.data_as(C.POINTER(C.c_float)), sizes[3]) == -6
+    for k in range(3, 5):
+        assert np.array_equal(b.collect(sizes[k - 3]), want[k - 3]), k
+        b.submit(blocks[k])
+    for k in range(2, 5):
+        assert np.array_equal(b.collect(sizes[k]), want[k]), k
     a.close(); b.close()
 
 

@@ -1590,3 +1590,86 @@ def test_layer_pipelined_kernel_keeps_the_state_of_the_one_workgroup_kernel_bit_
         want = O.run_streams(spec, co, x[s_:s_ + 1], 4096)       # block partition does not matter to the oracle
         errlog.bound(np.abs(outs["1"][s_] - want[0]).max(), 2e-6, "gpu_parity:lp_vs_oracle")
         errlog.bound(np.abs(outs["s"][s_] - want[0]).max(), 2e-6, "gpu_parity:ls_vs_oracle")
+
+
+# ------------------------------------------------- k_lstm_pipe4: four streams per workgroup, one helper wave (round 6)
+
+def _pipe4_run(path, S, sizes, x, schedule):
+    """one pool through the block sequence; schedule[block index] = list of (stream or None, controls kwargs) applied before that block"""
+    pool = ax.Pool(S, 256)
+    pool.set_model(ax.Model(path))
+    names = [pool.kernel_name]
+    got = np.empty_like(x)
+    pos = 0
+    for bi, n in enumerate(sizes):
+        for s_, kw in schedule.get(bi, []):
+            if s_ == "activate":
+                pool.activate()
+            elif s_ is None:
+                pool.set_controls(ax.default_controls(**kw))
+            else:
+                pool.set_controls(ax.default_controls(**kw), stream=s_)
+        names.append(pool.kernel_name)
+        got[:, pos:pos + n] = pool.process(np.ascontiguousarray(x[:, pos:pos + n]))
+        pos += n
+    pool.close()
+    return got, names
+
+
+def test_four_streams_per_workgroup_pipeline_matches_the_oracle(tmp_path, monkeypatch):
+    """k_lstm_pipe4<32> (BASELINE cfg2's cell: a CU's four streams in one workgroup, four recurrent waves and ONE helper wave that carries
+    all four streams' chain passes side by side; opt-in, AIDAX_PIPE4=1 — the A/B partner of profiles/r06_cfg2_pipe4.txt, measured no faster
+    than k_lstm_pipe): whole-tile blocks of a pool whose streams are all in circuit run there,
+    every other pass — a ragged block, a pass with a stream disabled or its model bypassed — runs k_lstm_pipe<32> on the same state. Per-stream
+    controls: EQ in front of and behind the model on some streams (six-stage cascades next to one-stage ones in the same wave), gain ramps
+    that move, activate(); against the oracle's plugin mirror per stream."""
+    monkeypatch.setenv("AIDAX_PIPE4", "1")
+    path, spec = _model_file(tmp_path, "l32p4", kind="lstm", hidden=32, input_size=1, seed=32, in_skip=1, in_gain=-2.0, out_gain=1.5)
+    S = 8
+    sizes = [256, 64, 16, 128, 100, 256, 0, 1, 48, 256, 256, 32]
+    x = modelgen.signal(S, sum(sizes), seed=77)
+    per = [dict(), dict(eq_position=1.0, bass_boost_db=5.0, mid_boost_db=-2.0), dict(treble_boost_db=3.0, depth_boost_db=2.0),
+           dict(eq_position=1.0, mid_type=1.0, mid_boost_db=4.0), dict(dc_blocker=0.0, in_lpf_pc=0.0), dict(eq_bypass=1.0, pregain_db=3.0),
+           dict(pregain_db=-6.0, master_db=-3.0), dict(eq_position=1.0, presence_boost_db=4.0, in_lpf_pc=30.0)]
+    schedule = {0: [(s_, per[s_]) for s_ in range(S)],
+                3: [(2, dict(per[2], pregain_db=6.0, master_db=-6.0))],                      # ramps move on one stream: the general macro-step
+                5: [("activate", None)],
+                8: [(5, dict(per[5], enabled=0.0))],                                         # a stream out of circuit: k_lstm_pipe serves the pass
+                9: [(5, per[5])],
+                10: [(1, dict(per[1], net_bypass=1.0))]}
+    got, names = _pipe4_run(path, S, sizes, x, schedule)
+    assert names[1] == "k_lstm_pipe4<32>" and names[9] == "k_lstm_pipe<32>" and names[10] == "k_lstm_pipe4<32>" and names[11] == "k_lstm_pipe<32>", names
+    plugs = [O.OraclePlugin() for _ in range(S)]
+    for p_ in plugs:
+        p_.set_model(O.OracleModel(spec))
+    cur = [dict() for _ in range(S)]
+    worst, pos = 0.0, 0
+    for bi, n in enumerate(sizes):
+        for s_, kw in schedule.get(bi, []):
+            if s_ == "activate":
+                for p_ in plugs:
+                    p_.activate()
+            else:
+                cur[s_] = kw
+        for s_ in range(S):
+            want = plugs[s_].run(O.default_controls(**cur[s_]), x[s_, pos:pos + n])
+            if n:
+                worst = max(worst, float(np.abs(got[s_, pos:pos + n] - want).max()))
+        pos += n
+    errlog.bound(worst, 2e-6, "gpu_parity:pipe4")
+
+
+def test_four_streams_per_workgroup_pipeline_is_bit_identical_to_the_three_wave_pipeline(tmp_path, monkeypatch):
+    """... and against k_lstm_pipe<32> serving every pass (the default): same operations per sample in the same order, the same bits."""
+    path, _ = _model_file(tmp_path, "l32p4b", kind="lstm", hidden=32, input_size=1, seed=33, in_skip=0, in_gain=1.0, out_gain=-1.0)
+    S = 12
+    sizes = [256, 64, 16, 128, 100, 256, 48, 256]
+    x = modelgen.signal(S, sum(sizes), seed=78)
+    per = [dict(), dict(eq_position=1.0, bass_boost_db=5.0), dict(treble_boost_db=3.0), dict(eq_position=1.0, mid_type=1.0, mid_boost_db=4.0)]
+    schedule = {0: [(s_, per[s_ % 4]) for s_ in range(S)], 2: [(3, dict(per[3], pregain_db=4.0))], 4: [("activate", None)]}
+    monkeypatch.setenv("AIDAX_PIPE4", "1")
+    a, na = _pipe4_run(path, S, sizes, x, schedule)
+    monkeypatch.delenv("AIDAX_PIPE4")
+    b, nb = _pipe4_run(path, S, sizes, x, schedule)
+    assert na[1] == "k_lstm_pipe4<32>" and set(nb) == {"k_lstm_pipe<32>"}, (na, nb)
+    assert np.array_equal(a, b)

@@ -26,6 +26,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NOT_REPRODUCIBLE = (
     "test_two_full_size_stacked_pools_driven_at_once",      # two threads race for the device's chained-kernel gate: the number of blocks each serves differs from run to run
     "test_pools_of_one_process_on_several_threads",          # threads pick up work as they come: arrays per test differ from run to run
+    "test_full_size_pool_processes_while_stacked_models_are_prepared_and_swapped_in",      # a model swap lands at whatever block the worker thread reaches it
+    "test_worker_thread_prepares_while_the_audio_thread_processes",                         # the same
+    "test_deadline_",                                        # the hub's deadline tests: which pass a block joins depends on the wall clock
 )
 
 
@@ -63,7 +66,7 @@ def test_hook_free_suite_on_the_shipped_library(tmp_path):
 
     # bit identity of the two builds on everything both legs ran
     mine = {k: [hex(v[0]), v[1]] for k, v in conftest.DIGESTS.items()}
-    common = sorted(k for k in ship["digests"] if k in mine and not any(t in k for t in NOT_REPRODUCIBLE))
+    common = sorted(k for k in ship["digests"] if k in mine and k not in second_attempt and not any(t in k for t in NOT_REPRODUCIBLE))
     differ = [k for k in common if ship["digests"][k] != mine[k]]
     report = {"ship_passed": passed, "ship_skipped_need_a_hook": skipped, "tests_compared": len(common),
               "arrays_compared": sum(mine[k][1] for k in common), "differ": differ, "passed_on_second_attempt": second_attempt}

@@ -607,6 +607,8 @@ __device__ __forceinline__ void stream_body(const LaunchArgs& a, float* smem)
 //             wave Q  Dense + skip/out gain + post pass of p-2    -> global out
 //   one workgroup barrier per phase; the N wave keeps weights, c and h in registers throughout.
 // ======================================================================
+#define AIDAX_STR2(x) #x
+#define AIDAX_STR(x) AIDAX_STR2(x)
 constexpr int kSB = 16;                 // frames per pipeline stage
 constexpr int kStChainBlockP4 = 8;      // k_*_pipe4: frames per hand-over of the helper wave's cascades (two steps per stage)
 constexpr int kRing = 2 * kSB;          // rows of the h history ring
@@ -886,6 +888,9 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
                 // (it runs two stages ahead) — and what a stage completes leaves for HBM at its end.
                 const bool first_stage = p == 2, last_stage = p == n_sub + 1;
                 const bool q_run = lane < cp.K, q_writer = lane == cp.K - 1;
+                // (round 6, measured and not kept: a ONE-stage post pass as lane-0 macro-steps like wave P's — twelve instructions per sample
+                // instead of the systolic step's ~27, the same bits: 0.4 us SLOWER per cfg2 block at every placement tried, and sixteen values in
+                // flight put the kernel over the register count of three waves per SIMD: profiles/r06_cfg2_pipe4.txt)
                 if (first_stage) {                          // lanes k > 0 start k steps late: range tests
                     for (int t = 0; t < cnt; ++t) {
                         chain_step<1, true>(cp, lane, q_run, q_writer, qb[t], q_carry, inbuf, base + t, n);

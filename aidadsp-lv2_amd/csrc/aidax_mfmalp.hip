@@ -1255,6 +1255,13 @@ __global__ __launch_bounds__((UT + NHELP) * kWave) void k_gru_gs(LaunchArgs a, M
     const int my_slot = (wave >> 1) * 64 + (2 * (wave & 1) + (q >> 1)) * 16 + c;
     const int my_half = q & 1;
     auto publish = [&](int parity) {
+        if (AIDAX_TUNE(a) & 1048576) {
+            // (bit 1048576, test build: term 0 of h only — an upper bound on what taking terms 1 and 2 of the split off the tick's critical
+            // path could buy, the round-5 review's item 8; wrong output)
+            u32x2 t0 = { gs_pack_bf16(hreg[0], hreg[1]), gs_pack_bf16(hreg[2], hreg[3]) };
+            reinterpret_cast<u32x2*>(hB + parity * kFrag + my_slot)[my_half] = t0;
+            return;
+        }
         u32x2 t[3];
         gs_split4(hreg, t);
 #pragma unroll

@@ -1669,8 +1669,18 @@ __host__ __device__ constexpr size_t ls_ring_floats(int hidden, int waves, int m
 // VALU work that issues in the MFMAs' shadow.
 template <int KS2> struct LsFrags { bf16x8 v[3][KS2]; };       // one h buffer's B fragments in registers: [term][k-step]
 template <int KS2>
-__device__ __forceinline__ void ls_load_frags(LsFrags<KS2>& hb, const u32x4* frags, int lane)
+__device__ __forceinline__ void ls_load_frags(LsFrags<KS2>& hb, const u32x4* frags, int lane, int tune = 0)
 {
+    if (tune & 2097152) {
+        // (bit 2097152, test build: ONE 16-byte read instead of 3 KS2 — an upper bound on what fewer LDS bytes per tick could buy
+        // (the round-5 review's item 6 a: the eight waves of a CU each read all nine h fragments, 72 KiB per tick); wrong output)
+        const bf16x8 v = __builtin_bit_cast(bf16x8, frags[lane]);
+#pragma unroll
+        for (int th = 0; th < 3; ++th)
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) hb.v[th][ks] = v;
+        return;
+    }
 #pragma unroll
     for (int th = 0; th < 3; ++th)                          // (term 0 first: it meets the most weight terms and is multiplied first)
 #pragma unroll
@@ -2055,7 +2065,7 @@ __device__ __forceinline__ void ls_body(const LaunchArgs& a, const MfmaDesc& d, 
 #pragma unroll
             for (int tl = MW; tl < TPW; ++tl) z[tl] = bias_of(tl, false);
             LsFrags<KS2> hbn;
-            ls_load_frags(hbn, below + parity * kFrag, lane);
+            ls_load_frags(hbn, below + parity * kFrag, lane, AIDAX_TUNE(a));
             ls_gates<KS2, NPROD, MW, TPW, TPW>(z, hbn, below_w, valu);
 #pragma unroll
             for (int tl = MW; tl < TPW; ++tl) nacc[tl - MW] = z[tl];
@@ -2114,7 +2124,7 @@ __device__ __forceinline__ void ls_body(const LaunchArgs& a, const MfmaDesc& d, 
             // 48 KiB for the eight waves of LSTM-64, 384 cycles of the LDS port; the stacked roles have no registers to spare for that)
             constexpr bool early_frags = first && last;
             LsFrags<KS2> hb;                                // own h(t-1)
-            if constexpr (early_frags) { if (body) ls_load_frags(hb, hT + rd * kFrag, lane); }
+            if constexpr (early_frags) { if (body) ls_load_frags(hb, hT + rd * kFrag, lane, AIDAX_TUNE(a)); }
             // ---- Dense(H,1) of frame tick-1 from the lanes' own h(tick-1): this wave's units, summed in a fixed order
             if (last && tick >= 1 && tick <= cnt) {
                 float y = wdu[0] * hv[0];
@@ -2142,7 +2152,7 @@ __device__ __forceinline__ void ls_body(const LaunchArgs& a, const MfmaDesc& d, 
             if (body) {
                 const u32x4* h_rd = hT + rd * kFrag;
                 u32x4* h_wr = hT + wr * kFrag;
-                if constexpr (!early_frags) ls_load_frags(hb, h_rd, lane);      // requested first, on its way while the frame before goes up the ring
+                if constexpr (!early_frags) ls_load_frags(hb, h_rd, lane, AIDAX_TUNE(a));      // requested first, on its way while the frame before goes up the ring
                 if (!last && F >= 1) ship_h(h_rd, F - 1);              // h_rd = h(F-1)
                 if constexpr (first) {
                     if (MW > 0 && F >= 2) ship_started(held, F - 2);

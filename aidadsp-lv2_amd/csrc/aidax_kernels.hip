@@ -1071,10 +1071,23 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
         cell.load(a.wpack, nnst, lane);
         cell.publish_h(hj + (kRing - 1) * HS);            // h(-1): the row "before" frame 0
         __syncthreads();                                  // (the progress words are zero)
+#ifdef AIDAX_P4_BARRIER
+        // (measurement build, scratch/r06_p4_phase.sh: the first form — one workgroup barrier per tick, the waves in lockstep — with the
+        // phase between the waves as a RUN-TIME parameter: bits 20 .. 23 of AIDAX_TUNE = sixteen-cycle steps the helper waits behind every
+        // barrier, bits 24 .. 25 = steps recurrent wave j waits, times j. Same code for every setting: what changes is phase alone.)
+        for (int tick = 0; tick < T; ++tick) {
+            const int t = tick - d1;
+            for (int i = 0; i < wave * ((AIDAX_TUNE(a) >> 24) & 3); ++i) asm volatile("s_nop 15");
+            if (t >= 0 && t < NT) {
+#else
+        // (test build: bits 24 .. 27 of AIDAX_TUNE = sixteen-cycle steps recurrent wave j waits ONCE, times j, before its first tile — nothing
+        // brings free-running waves back into step)
+        for (int i = 0; i < wave * ((AIDAX_TUNE(a) >> 24) & 15); ++i) asm volatile("s_nop 15");
         for (int t = 0; t < NT; ++t) {
             // the tile's inputs are ready, and the Dense has read the rows this tile overwrites (two tiles back)
             while (p4_peek(prog) <= t || p4_peek(prog + 1) < t - 1) __builtin_amdgcn_s_sleep(1);
             {
+#endif
                 const int base = t * kSB;
                 const float* hprev = hj + ((base + kRing - 1) & (kRing - 1)) * HS;
                 float* hcur = hj + (base & (kRing - 1)) * HS;
@@ -1093,7 +1106,11 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
                     cell.template step<1>(xr[f], 0.f, 0.f, f == 0 ? hprev : hcur + (f - 1) * HS, hcur + f * HS);
                 }
             }
+#ifdef AIDAX_P4_BARRIER
+            __syncthreads();
+#else
             p4_post(prog + 2 + wave, t + 1, lane);
+#endif
         }
         cell.store(nnst);
         return;
@@ -1154,7 +1171,10 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
     __syncthreads();
     for (int tick = hq; tick < T; tick += kP4Helpers) {
         // my turn: the helper before me has finished tick - 1 and left the cascades' state
-        if (tick != 0) {
+#ifdef AIDAX_P4_BARRIER
+        for (int i = 0; i < ((AIDAX_TUNE(a) >> 20) & 15); ++i) asm volatile("s_nop 15");
+#endif
+        if (kP4Helpers > 1 && tick != 0) {
             while (p4_peek(prog + 6) < tick) __builtin_amdgcn_s_sleep(8);
             const double* zs = reinterpret_cast<const double*>(hstate);
             c.z1 = zs[lane]; c.z2 = zs[kWave + lane];
@@ -1163,9 +1183,11 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
         // Dense + skip / output gain of the tile the cells finished a tick ago (applyModel :171-181), into the row: the post pass's input
         const int td = tick - d1 - 1;
         if (td >= 0 && td < NT) {
+#ifndef AIDAX_P4_BARRIER
 #pragma unroll
             for (int jj = 0; jj < kP4Streams; ++jj)
                 while (p4_peek(prog + 2 + jj) <= td) __builtin_amdgcn_s_sleep(4);      // every cell has finished the tile
+#endif
         }
         if (td >= 0 && td < NT && !(AIDAX_TUNE(a) & 524288)) {      // (bit 524288, test build: no Dense — what it costs the recurrent wave it shares a SIMD with; wrong output)
             const int f = td * kSB + df;
@@ -1204,7 +1226,10 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
             __builtin_amdgcn_wave_barrier();
             p4_post(prog, ts + 1, lane);
         }
-        if (tick + 1 < T) {
+#ifdef AIDAX_P4_BARRIER
+        __syncthreads();
+#endif
+        if (kP4Helpers > 1 && tick + 1 < T) {
             // the next tick is another helper's: the state, then the word that says so
             double* zs = reinterpret_cast<double*>(hstate);
             zs[lane] = c.z1; zs[kWave + lane] = c.z2;

@@ -298,3 +298,34 @@ def test_instances_are_placed_over_the_devices_the_process_sees(bundle, monkeypa
     monkeypatch.setenv("AIDAX_DEVICE", str(n_dev + 3))
     h = lv2host.Host(bundle_dir=bundle)
     assert not h.handle                                  # instantiate() returns NULL, with the reason on stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geo,kw", [("cfg4's stack", dict(seed=1608)), ("two cycles 1..16, two taps", dict(seed=3, conv_k=2, conv_dilations=[1, 2, 4, 8, 16] * 2))])
+def test_conv_stack_through_the_plugin_at_a_hosts_block_lengths(bundle, geo, kw):
+    """An extension model (the reference's loader would refuse it) through the plugin's own boundary, at the block lengths a host
+    really sends — run() gets the host's period (rt-neural-generic.cpp:484): blocks of 64 / 128 / 256 frames of a stack with a compiled geometry
+    stream through k_conv_st, a 100-frame block and a pre-run in between go through k_conv_ms on the same state; against the oracle's plugin mirror."""
+    path = os.path.join(bundle, "models", "conv.json")
+    modelgen.write_model(modelgen.make_model(kind="conv", hidden=16, input_size=1, in_skip=1, out_gain=-3.0, **kw), path)
+    h = lv2host.Host(bundle_dir=bundle)
+    plug = O.OraclePlugin()
+    h.send_patch_set(path)
+    h.run(np.zeros(64, np.float32)); plug.set_loading(True); plug.run(_oracle_controls(h), np.zeros(64, np.float32))
+    assert h.pump_worker() == 1 and h.deliver_responses() == 1
+    plug.set_model(O.OracleModel(O.load_model(path), 0.0, 0.0))
+    h.pump_worker()
+    sizes = [64, 64, 128, 256, 100, 0, 64, 128, 256, 256, 64]
+    x = modelgen.signal(1, sum(sizes), seed=52)[0]
+    pos, worst = 0, 0.0
+    for i, n in enumerate(sizes):
+        if i == 3:
+            h.controls(EQPOS=1.0, BASS=3.0, TREBLE=-2.0, PREGAIN=2.0)
+        blk = x[pos:pos + n]
+        got = h.run(blk)
+        want = plug.run(_oracle_controls(h), blk)
+        if n:
+            worst = max(worst, float(np.abs(got - want).max()))
+        pos += n
+    assert worst < THR, (geo, worst)
+    h.close()

@@ -188,7 +188,7 @@ def test_deadline_one_stalled_instance_does_not_hold_the_others(tmp_path):
     hub.flush()
     # (a period whose three submissions straddle the 2 ms deadline — a python host that was descheduled in between — goes out as two
     # passes and loses nothing: test_deadline_that_splits_a_period_loses_nothing; the audio above is the contract)
-    assert periods <= hub.launches <= periods + 1, hub.launches
+    assert periods <= hub.launches <= 2 * periods, hub.launches
     # on an idle box every period after the stall is closed by the deadline (periods - 3 or so); on a saturated one the
     # launcher thread may come late and a re-entering instance closes the period instead — the audio above is the contract
     assert hub.deadline_launches >= 1

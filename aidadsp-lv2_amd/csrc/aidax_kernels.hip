@@ -835,6 +835,25 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
                         else cell.template step<1>(xr[t], 0.f, 0.f, t == 0 ? hprev : hcur + (t - 1) * HS, hcur + t * HS);
                         if (t == 9) cell.ts6 = __builtin_amdgcn_s_memtime();      // the frame after the traced one has been issued
                     }
+#elif defined(AIDAX_PIPE_ROLL)
+                    // (measurement build, scratch/r06_pipe_roll.sh: the stage as a LOOP of AIDAX_PIPE_ROLL frames per iteration instead of
+                    // sixteen unrolled — 11 KB of straight-line code per stage against 0.7 KB per frame: does instruction fetch bound a lone wave?)
+                    {
+                        const float* hp = hprev;
+                        float* hc = hcur;
+#pragma unroll 1
+                        for (int t0 = 0; t0 < kSB; t0 += AIDAX_PIPE_ROLL) {
+                            float xs[AIDAX_PIPE_ROLL];
+#pragma unroll
+                            for (int i = 0; i < AIDAX_PIPE_ROLL; ++i) xs[i] = stage[t0 + i] * in_gain;
+#pragma unroll
+                            for (int i = 0; i < AIDAX_PIPE_ROLL; ++i) {
+                                cell.template step<1>(xs[i], 0.f, 0.f, hp, hc);
+                                hp = hc;
+                                hc += HS;
+                            }
+                        }
+                    }
 #else
 #pragma unroll
                     for (int t = 0; t < kSB; ++t)

@@ -478,14 +478,13 @@ struct aidax_pool {
         }
         return circuit_all;
     }
-    // Does a MODE_CHAIN pass of n frames go through the four-streams-per-workgroup pipeline? Only where asked for (AIDAX_PIPE4=1, test
-    // build): built for the round-5 review's item 4 and measured — 64.6 us per cfg2 block against k_lstm_pipe's 63.9 in its robust form,
-    // 61.4 .. 66.8 in the form whose waves run in lockstep, by nothing but where the code happens to lie (profiles/r06_cfg2_pipe4.txt).
-    // It stays as the A/B partner of that measurement; bit-identical to k_*_pipe (tests/test_gpu_parity.py).
+    // Does a MODE_CHAIN pass of n frames go through the four-streams-per-workgroup pipeline (k_*_pipe4: 61.5 us per cfg2 block against
+    // k_lstm_pipe's 63.9, profiles/r06_cfg2_pipe4.txt)? Whole 16-frame tiles, whole workgroups of four streams, every workgroup on a CU of its
+    // own, every stream in circuit, a model without PARAM inputs; k_*_pipe serves every other pass on the same state (AIDAX_PIPE4=0, test build: all).
     bool pipe4_serves(const ModelSlot& m, uint32_t n, int input_size) const
     {
-        const bool off = [] { const char* e = AIDAX_HOOK_ENV("AIDAX_PIPE4"); return !(e && e[0] == '1'); }();      // (read per call: tests switch forms within one process)
-        if (off || !m.kernel || !m.kernel->fn_pipe4 || input_size != 1 || n == 0 || n % 16u || n_streams % 4u) return false;
+        const bool off = [] { const char* e = AIDAX_HOOK_ENV("AIDAX_PIPE4"); return e && e[0] == '0'; }();      // (read per call: tests switch forms within one process)
+        if (off || force_form != 0 || !m.kernel || !m.kernel->fn_pipe4 || input_size != 1 || n == 0 || n % 16u || n_streams % 4u) return false;
         if (cus <= 0 || n_streams > 4u * static_cast<uint32_t>(cus) || pipe4_lds_bytes(m.hidden, n) > 160 * 1024) return false;
         return all_in_circuit();
     }

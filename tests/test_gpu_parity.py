@@ -593,7 +593,7 @@ def test_long_run_drift_small_gru_on_the_pipeline_kernel(tmp_path):
 
 
 @pytest.mark.parametrize("name,kw,S,ckw,kernel", [
-    ("cfg2", dict(kind="lstm", hidden=32, input_size=1, seed=32), 1024, {}, "k_lstm_pipe<32>"),
+    ("cfg2", dict(kind="lstm", hidden=32, input_size=1, seed=32), 1024, {}, "k_lstm_pipe4<32>"),
     ("cfg3", dict(kind="gru", hidden=64, input_size=3, seed=64), 4096, _EQ_POST, "k_gru_gs"),                     # one launch: gate-major tiles, the chain on the helper waves
     ("cfg4", dict(kind="conv", hidden=16, input_size=1, seed=1608), 1024, {}, "k_conv_st"),
     ("cfg5", dict(kind="lstm", hidden=96, input_size=1, seed=96, n_rnn=2), 2048, {}, "k_mfma_ls"),
@@ -1616,14 +1616,13 @@ def _pipe4_run(path, S, sizes, x, schedule):
     return got, names
 
 
-def test_four_streams_per_workgroup_pipeline_matches_the_oracle(tmp_path, monkeypatch):
-    """k_lstm_pipe4<32> (BASELINE cfg2's cell: a CU's four streams in one workgroup, four recurrent waves and ONE helper wave that carries
-    all four streams' chain passes side by side; opt-in, AIDAX_PIPE4=1 — the A/B partner of profiles/r06_cfg2_pipe4.txt, measured no faster
-    than k_lstm_pipe): whole-tile blocks of a pool whose streams are all in circuit run there,
+def test_four_streams_per_workgroup_pipeline_matches_the_oracle(tmp_path):
+    """k_lstm_pipe4<32> (BASELINE cfg2's cell: a CU's four streams in one workgroup, four free-running recurrent waves and ONE helper wave that
+    carries all four streams' chain passes side by side, paced by progress words in LDS: profiles/r06_cfg2_pipe4.txt) with no switch set —
+    whole-tile blocks of a pool whose streams are all in circuit run there,
     every other pass — a ragged block, a pass with a stream disabled or its model bypassed — runs k_lstm_pipe<32> on the same state. Per-stream
     controls: EQ in front of and behind the model on some streams (six-stage cascades next to one-stage ones in the same wave), gain ramps
     that move, activate(); against the oracle's plugin mirror per stream."""
-    monkeypatch.setenv("AIDAX_PIPE4", "1")
     path, spec = _model_file(tmp_path, "l32p4", kind="lstm", hidden=32, input_size=1, seed=32, in_skip=1, in_gain=-2.0, out_gain=1.5)
     S = 8
     sizes = [256, 64, 16, 128, 100, 256, 0, 1, 48, 256, 256, 32]
@@ -1660,16 +1659,15 @@ def test_four_streams_per_workgroup_pipeline_matches_the_oracle(tmp_path, monkey
 
 
 def test_four_streams_per_workgroup_pipeline_is_bit_identical_to_the_three_wave_pipeline(tmp_path, monkeypatch):
-    """... and against k_lstm_pipe<32> serving every pass (the default): same operations per sample in the same order, the same bits."""
+    """... and against k_lstm_pipe<32> serving every pass (AIDAX_PIPE4=0, test build): same operations per sample in the same order, the same bits."""
     path, _ = _model_file(tmp_path, "l32p4b", kind="lstm", hidden=32, input_size=1, seed=33, in_skip=0, in_gain=1.0, out_gain=-1.0)
     S = 12
     sizes = [256, 64, 16, 128, 100, 256, 48, 256]
     x = modelgen.signal(S, sum(sizes), seed=78)
     per = [dict(), dict(eq_position=1.0, bass_boost_db=5.0), dict(treble_boost_db=3.0), dict(eq_position=1.0, mid_type=1.0, mid_boost_db=4.0)]
     schedule = {0: [(s_, per[s_ % 4]) for s_ in range(S)], 2: [(3, dict(per[3], pregain_db=4.0))], 4: [("activate", None)]}
-    monkeypatch.setenv("AIDAX_PIPE4", "1")
     a, na = _pipe4_run(path, S, sizes, x, schedule)
-    monkeypatch.delenv("AIDAX_PIPE4")
+    monkeypatch.setenv("AIDAX_PIPE4", "0")
     b, nb = _pipe4_run(path, S, sizes, x, schedule)
     assert na[1] == "k_lstm_pipe4<32>" and set(nb) == {"k_lstm_pipe<32>"}, (na, nb)
     assert np.array_equal(a, b)

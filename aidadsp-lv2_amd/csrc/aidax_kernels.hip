@@ -33,6 +33,7 @@
 
 #include <cfloat>
 
+#include <mutex>
 #include "aidax_device.h"
 #include "aidax_kernels.h"
 #include "aidax_layout.h"
@@ -1289,6 +1290,13 @@ __global__ __launch_bounds__(kP4Waves * kWave) void k_lstm_pipe4(LaunchArgs a)
     stream_body_pipe4<LstmCell<H>>(a, smem);
 }
 
+template <int H>
+__global__ __launch_bounds__(kP4Waves * kWave) void k_gru_pipe4(LaunchArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    stream_body_pipe4<GruCell<H>>(a, smem);
+}
+
 // ======================================================================
 // Split form (3 launches) — the many-streams form.
 //
@@ -1573,12 +1581,15 @@ __global__ void k_adopt_dsp(StreamState* dst, const StreamState* src)
 // with k_quad / k_mfma, or the one-wave kernel when neither fits (pools with long blocks).
 #define AIDAX_LSTM_WIDE(H, NN) { 0, H, k_lstm<H>, nullptr, NN, LstmCell<H>::PACK, LstmCell<H>::STATE, "k_lstm<" #H ">", "-", "k_chain+k_nn<lstm" #H ">", nullptr, "-" }
 #define AIDAX_GRU(H)  { 1, H, k_gru<H>,  k_gru_pipe<H>,  k_nn<GruCell<H>>,  GruCell<H>::PACK,  GruCell<H>::STATE,  "k_gru<" #H ">", "k_gru_pipe<" #H ">", "k_chain+k_nn<gru" #H ">", nullptr, "-" }
+#define AIDAX_GRU_P4(H)  { 1, H, k_gru<H>,  k_gru_pipe<H>,  k_nn<GruCell<H>>,  GruCell<H>::PACK,  GruCell<H>::STATE,  "k_gru<" #H ">", "k_gru_pipe<" #H ">", "k_chain+k_nn<gru" #H ">", k_gru_pipe4<H>, "k_gru_pipe4<" #H ">" }
 
 static const KernelEntry kTable[] = {
     // the 18 (cell, hidden) pairs of variant/generate_variant_hpp.py:4-6; input size is a run-time argument
-    AIDAX_LSTM(8), AIDAX_LSTM(12), AIDAX_LSTM(16), AIDAX_LSTM(20), AIDAX_LSTM(24),
+    // (k_*_pipe4 where it measured ahead of k_*_pipe at a full pool of 1024 streams, profiles/r06_pipe4_cells.txt: LSTM-8 / 12 / 16 by 14 - 19 %,
+    // GRU-8 / 12 / 16 by 9 - 14 %, LSTM-32 by 3 %; LSTM-20 / 24 and GRU-20 / 24 / 32 measured 1 - 13 % behind and keep the three-wave pipeline)
+    AIDAX_LSTM_P4(8), AIDAX_LSTM_P4(12), AIDAX_LSTM_P4(16), AIDAX_LSTM(20), AIDAX_LSTM(24),
     AIDAX_LSTM_P4(32), AIDAX_LSTM(40), AIDAX_LSTM_WIDE(64, k_nn<LstmCell<64>>), AIDAX_LSTM_WIDE(80, nullptr),
-    AIDAX_GRU(8), AIDAX_GRU(12), AIDAX_GRU(16), AIDAX_GRU(20), AIDAX_GRU(24),
+    AIDAX_GRU_P4(8), AIDAX_GRU_P4(12), AIDAX_GRU_P4(16), AIDAX_GRU(20), AIDAX_GRU(24),
     AIDAX_GRU(32), AIDAX_GRU(40), AIDAX_GRU(64), AIDAX_GRU(80),
 };
 
@@ -1665,11 +1676,20 @@ hipError_t launch_pipe4_kernel(const KernelEntry* e, const LaunchArgs& a, hipStr
 {
     if (!e->fn_pipe4 || a.n_streams % kP4Streams || a.n_frames % kSB || a.n_frames == 0) return hipErrorInvalidValue;
     const size_t lds = pipe4_lds_bytes(e->hidden, a.n_frames);
-    static bool raised = false;
-    if (!raised) {
-        const hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(e->fn_pipe4), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (err != hipSuccess) return err;
-        raised = true;
+    {
+        // (per kernel, once: more than 64 KiB of dynamic LDS has to be asked for)
+        static std::mutex mu;
+        static const void* raised[64];
+        static int n_raised = 0;
+        std::lock_guard<std::mutex> g(mu);
+        const void* fn = reinterpret_cast<const void*>(e->fn_pipe4);
+        bool done = false;
+        for (int i = 0; i < n_raised; ++i) done = done || raised[i] == fn;
+        if (!done) {
+            const hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (err != hipSuccess) return err;
+            if (n_raised < 64) raised[n_raised++] = fn;
+        }
     }
     hipLaunchKernelGGL(e->fn_pipe4, dim3(a.n_streams / kP4Streams), dim3(kP4Waves * kWave), lds, stream, a);
     return hipGetLastError();

@@ -1671,3 +1671,39 @@ def test_four_streams_per_workgroup_pipeline_is_bit_identical_to_the_three_wave_
     b, nb = _pipe4_run(path, S, sizes, x, schedule)
     assert na[1] == "k_lstm_pipe4<32>" and set(nb) == {"k_lstm_pipe<32>"}, (na, nb)
     assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("kind,hidden", [("lstm", 8), ("lstm", 12), ("lstm", 16), ("gru", 8), ("gru", 12), ("gru", 16)])
+def test_four_streams_per_workgroup_pipeline_small_cells(kind, hidden, tmp_path, monkeypatch):
+    """The other cells of the reference's table that run k_*_pipe4 (where it measured ahead of the three-wave pipeline at a full pool:
+    profiles/r06_pipe4_cells.txt — the sizes the reference's own models have, LSTM-12 / 16): against the oracle's plugin mirror per stream
+    with per-stream EQ placement and moving ramps, and bit-identical to k_*_pipe serving every pass (AIDAX_PIPE4=0, test build)."""
+    path, spec = _model_file(tmp_path, f"{kind}{hidden}p4", kind=kind, hidden=hidden, input_size=1, seed=100 + hidden, in_skip=hidden % 16 == 0, in_gain=1.5, out_gain=-2.0)
+    S = 8
+    sizes = [256, 64, 100, 32, 256, 128]
+    x = modelgen.signal(S, sum(sizes), seed=79 + hidden)
+    per = [dict(), dict(eq_position=1.0, bass_boost_db=5.0), dict(treble_boost_db=3.0, dc_blocker=0.0), dict(eq_position=1.0, mid_type=1.0, mid_boost_db=4.0)]
+    schedule = {0: [(s_, per[s_ % 4]) for s_ in range(S)], 2: [(5, dict(per[1], pregain_db=4.0, master_db=-5.0))], 4: [("activate", None)]}
+    got, names = _pipe4_run(path, S, sizes, x, schedule)
+    assert names[1] == f"k_{kind}_pipe4<{hidden}>", names
+    plugs = [O.OraclePlugin() for _ in range(S)]
+    for p_ in plugs:
+        p_.set_model(O.OracleModel(spec))
+    cur = [dict() for _ in range(S)]
+    worst, pos = 0.0, 0
+    for bi, n in enumerate(sizes):
+        for s_, kw in schedule.get(bi, []):
+            if s_ == "activate":
+                for p_ in plugs:
+                    p_.activate()
+            else:
+                cur[s_] = kw
+        for s_ in range(S):
+            want = plugs[s_].run(O.default_controls(**cur[s_]), x[s_, pos:pos + n])
+            worst = max(worst, float(np.abs(got[s_, pos:pos + n] - want).max()))
+        pos += n
+    errlog.bound(worst, 2e-6, "gpu_parity:pipe4_small")
+    monkeypatch.setenv("AIDAX_PIPE4", "0")
+    ref, names0 = _pipe4_run(path, S, sizes, x, schedule)
+    assert set(names0) == {f"k_{kind}_pipe<{hidden}>"}, names0
+    assert np.array_equal(got, ref)

@@ -1015,9 +1015,10 @@ __global__ __launch_bounds__(kPipeWaves * kWave) void k_gru_pipe(LaunchArgs a)
 // helper issues per tick what ONE of the eight did, three SIMDs of four see no helper at all. A tick = a tile of sixteen frames:
 //   tick p:  helper   Dense + skip / gain of tile p - d1 - 1, both passes' two macro-steps, tile p - d1 + 1 times in_gain
 //            wave j   the recurrent cell of stream j over tile p - d1
-// paced by progress words in LDS, not by barriers (see below). The host sends a pass here only when every stream of the pool is in circuit (enabled, model on),
-// the model takes the audio alone (no PARAM inputs), the block is whole tiles and the stream count whole workgroups; k_*_pipe serves
-// every other pass on the same state. Same operations per sample in the same order as k_*_pipe: bit-identical.
+// paced by progress words in LDS, not by barriers (see below). The host sends a pass here when the model takes the audio alone (no PARAM inputs),
+// the block is whole tiles and every workgroup gets a CU of its own; streams that are disabled or have their model out of circuit ride along (their
+// recurrent wave leaves at once, the helper copies or filters the row), the last workgroup may have fewer than four streams. k_*_pipe serves every
+// other pass on the same state. Same operations per sample in the same order as k_*_pipe: bit-identical.
 // ======================================================================
 constexpr int kP4Streams = 4;
 constexpr int kP4Helpers = 1;                          // helper waves; more than one take the ticks in turns (4: a recurrent wave meets a helper's burst every fourth tick — measured SLOWER, 65.2 against 64.6 us: profiles/r06_cfg2_pipe4.txt)
@@ -1071,11 +1072,17 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
 
     // every wave derives the launch's timing from the four control words (wave-uniform): the longest cascades set it
     int Kp = 1, Kq = 1;
+    uint32_t fw[kP4Streams];                              // the four control words' flags (scalar loads: registers of the scalar file)
 #pragma unroll
     for (int j = 0; j < kP4Streams; ++j) {
-        const uint32_t f = a.ctl[s0 + j].flags;
-        if (f & CTL_EQ_PRE) Kp = 6;
-        if (f & CTL_EQ_POST) Kq = 6;
+        // (the pool's last workgroup may have fewer than four streams: a missing one reads the last stream's word — an unconditional load of a
+        // uniform address stays a scalar load, all four in flight together; behind a condition each became a loop of its own, one trip to memory
+        // after the other in front of every wave's first instruction: 2 us of the launch)
+        const int jc = s0 + j < (int)a.n_streams ? s0 + j : (int)a.n_streams - 1;
+        const uint32_t f = a.ctl[jc].flags;
+        fw[j] = s0 + j < (int)a.n_streams ? f : 0u;
+        if ((f & CTL_EQ_PRE) && s0 + j < (int)a.n_streams) Kp = 6;
+        if ((f & CTL_EQ_POST) && s0 + j < (int)a.n_streams) Kq = 6;
     }
     const int d1 = Kp / 2 + 1;                            // ticks between a tile entering the pre pass and the cell reading it
     const int T = (n / B - 1 + (Kq - 1) + 2 * (d1 + 1)) / 2 + 1;
@@ -1083,14 +1090,27 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
     if (wave < kP4Streams) {
         // ---------------------------------------------------------------- a recurrent wave
         const int s = s0 + wave;
-        float* nnst = a.nn + (size_t)s * a.nn_stride;
+        // a stream that is not there, is disabled (:612-619) or has its model out of circuit (:631-632) has no cell to run: its wave says
+        // "all tiles finished" and leaves (the helper copies or filters the row on its own)
+        // (the weights and the state are requested FIRST, the control word behind them — one trip to memory, not two in a row: asked for in
+        // front of the loads the word cost the launch 2 us; a stream out of circuit has read them for nothing)
+        const int sc = s < (int)a.n_streams ? s : (int)a.n_streams - 1;
+        float* nnst = a.nn + (size_t)sc * a.nn_stride;
         float* hj = hh + wave * kRing * HS;
         const float* row = rows + wave * n;
         Cell cell;
         if (!(AIDAX_TUNE(a) & 1)) __builtin_amdgcn_s_setprio(3);
         cell.load(a.wpack, nnst, lane);
-        cell.publish_h(hj + (kRing - 1) * HS);            // h(-1): the row "before" frame 0
+        // (the word is one of the four every wave read with scalar loads above; and NOTHING in front of the first tile may depend on it but the
+        // way out: with h(-1) published under the condition every vector load of the prologue was waited for there, and the first frames no
+        // longer ran while the last weights were still arriving — 1.6 us of the launch)
+        const uint32_t fl = wave == 0 ? fw[0] : wave == 1 ? fw[1] : wave == 2 ? fw[2] : fw[3];
+        const bool net = (fl & (CTL_ENABLED | CTL_NET_ON)) == (CTL_ENABLED | CTL_NET_ON);
+        cell.publish_h(hj + (kRing - 1) * HS);            // h(-1): the row "before" frame 0 (unconditionally: a stream out of circuit publishes into its own ring for nothing)
         __syncthreads();                                  // (the progress words are zero)
+#ifndef AIDAX_P4_BARRIER
+        if (!net) { p4_post(prog + 2 + wave, NT, lane); return; }
+#endif
 #ifdef AIDAX_P4_BARRIER
         // (measurement build, scratch/r06_p4_phase.sh: the first form — one workgroup barrier per tick, the waves in lockstep — with the
         // phase between the waves as a RUN-TIME parameter: bits 20 .. 23 of AIDAX_TUNE = sixteen-cycle steps the helper waits behind every
@@ -1156,15 +1176,31 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
     const int r = lane - 12 * (lane / 12);
     const bool isQ = r >= 6;
     const int stage = isQ ? r - 6 : r;
-    const int sj = s0 + j;
+    const bool there = s0 + j < (int)a.n_streams;             // (the pool's last workgroup may have fewer than four streams: nothing of a missing one is read or written)
+    const int sj = there ? s0 + j : (int)a.n_streams - 1;
     const StreamCtl& ctl = a.ctl[sj];
     StreamState& st = a.st[sj];
     const int slot = isQ ? post_slot(stage) : pre_slot(stage);
     // the four rows, dealt out over the helper waves (one 16-byte read per lane and 256 frames)
-    for (int jj = hq; jj < kP4Streams; jj += kP4Helpers) {
-        const float4* src = reinterpret_cast<const float4*>(a.in + (size_t)(s0 + jj) * n);
-        float4* dst = reinterpret_cast<float4*>(rows + jj * n);
-        for (int i = lane; i < n / 4; i += kWave) dst[i] = src[i];
+    // (all four requested before the first is waited for — the loop stays unrolled, a missing stream is a predicate, not a way out of the
+    // loop: one after the other the four reads kept the recurrent waves waiting 2 us for their first tile)
+    if (kP4Helpers == 1 && n == 256) {
+        const bool t1 = s0 + 1 < (int)a.n_streams, t2 = s0 + 2 < (int)a.n_streams, t3 = s0 + 3 < (int)a.n_streams;      // (stream s0 is always there)
+        const float4 r0 = reinterpret_cast<const float4*>(a.in + (size_t)s0 * n)[lane];
+        const float4 r1 = reinterpret_cast<const float4*>(a.in + (size_t)(t1 ? s0 + 1 : s0) * n)[lane];
+        const float4 r2 = reinterpret_cast<const float4*>(a.in + (size_t)(t2 ? s0 + 2 : s0) * n)[lane];
+        const float4 r3 = reinterpret_cast<const float4*>(a.in + (size_t)(t3 ? s0 + 3 : s0) * n)[lane];
+        reinterpret_cast<float4*>(rows)[lane] = r0;
+        reinterpret_cast<float4*>(rows + n)[lane] = r1;
+        reinterpret_cast<float4*>(rows + 2 * n)[lane] = r2;
+        reinterpret_cast<float4*>(rows + 3 * n)[lane] = r3;
+    } else {
+        for (int jj = hq; jj < kP4Streams; jj += kP4Helpers) {
+            if (s0 + jj >= (int)a.n_streams) break;
+            const float4* src = reinterpret_cast<const float4*>(a.in + (size_t)(s0 + jj) * n);
+            float4* dst = reinterpret_cast<float4*>(rows + jj * n);
+            for (int i = lane; i < n / 4; i += kWave) dst[i] = src[i];
+        }
     }
     if (hq == 0) {
         const float* wd_nat = a.wpack + (size_t)Cell::PACK * kWave;         // [H] Dense weights then bias
@@ -1173,17 +1209,20 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
     ChainPass c;
     chain_load(c, ctl, st, slot, false);
     const uint32_t flags = ctl.flags;
+    // this lane's stream: disabled = a raw copy, nothing advances but the latches (:612-619); model out of circuit = the chain alone (:631-632)
+    const bool live = there && (flags & CTL_ENABLED) != 0;
+    const bool netj = live && (flags & CTL_NET_ON) != 0;
     uint32_t pending = st.pending;
     float pre_mem = st.pre_mem, master_mem = st.master_mem, pre_tgt = st.pre_tgt, master_tgt = st.master_tgt;
     if (pending & PEND_ACTIVATE) { pre_mem = pre_tgt; master_mem = master_tgt; pending &= ~PEND_ACTIVATE; }     // activate(): :341-342
     pre_tgt = ctl.pre_target;
-    master_tgt = ctl.master_target;
+    if (live) master_tgt = ctl.master_target;
     const int Kpj = (flags & CTL_EQ_PRE) ? 6 : 1, Kqj = (flags & CTL_EQ_POST) ? 6 : 1;
     c.K = isQ ? Kqj : Kpj;
     c.gain_lane = isQ ? Kqj - 1 : 0;
     c.active = stage == 0 ? (flags & (isQ ? CTL_DC_ON : CTL_LPF_ON)) != 0 : ((flags & CTL_EQ_BANDPASS) ? slot == BQ_MID : true);
     c.g.arm(isQ ? master_mem : pre_mem, isQ ? master_tgt : pre_tgt, isQ ? ctl.master_coef : ctl.pre_coef);
-    const bool run = lane < kP4ChainLanes && stage < c.K;
+    const bool run = lane < kP4ChainLanes && stage < c.K && live;
     const double z1o = c.z1, z2o = c.z2;
     ExpRamp g = c.g;
     const bool is_gain = stage == c.gain_lane;
@@ -1197,6 +1236,7 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
     const int dj = lane >> 4, df = lane & 15;
     const float* hdj = hh + dj * kRing * HS;
     float* drow = rows + dj * n;
+    const bool netd = s0 + dj < (int)a.n_streams && (a.ctl[s0 + dj < (int)a.n_streams ? s0 + dj : (int)a.n_streams - 1].flags & (CTL_ENABLED | CTL_NET_ON)) == (CTL_ENABLED | CTL_NET_ON);
     if (hq == 0 && lane < 8) prog[lane] = 0;
     __syncthreads();
     for (int tick = hq; tick < T; tick += kP4Helpers) {
@@ -1219,7 +1259,7 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
                 while (p4_peek(prog + 2 + jj) <= td) __builtin_amdgcn_s_sleep(4);      // every cell has finished the tile
 #endif
         }
-        if (td >= 0 && td < NT && !(AIDAX_TUNE(a) & 524288)) {      // (bit 524288, test build: no Dense — what it costs the recurrent wave it shares a SIMD with; wrong output)
+        if (td >= 0 && td < NT && netd && !(AIDAX_TUNE(a) & 524288)) {      // (bit 524288, test build: no Dense — what it costs the recurrent wave it shares a SIMD with; wrong output)
             const int f = td * kSB + df;
             asm volatile("" ::: "memory");
             const float4* hrow = reinterpret_cast<const float4*>(hdj + (f & (kRing - 1)) * HS);
@@ -1252,7 +1292,7 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
         const int ts = tick - d1 + 1;
         if (ts >= 0 && ts < NT) {
             const int f = ts * kSB + df;
-            drow[f] = drow[f] * a.in_gain;
+            if (netd) drow[f] = drow[f] * a.in_gain;
             __builtin_amdgcn_wave_barrier();
             p4_post(prog, ts + 1, lane);
         }
@@ -1273,13 +1313,24 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
     if (is_gain) c.g = g;
     if (!run || !c.active) { c.z1 = z1o; c.z2 = z2o; }                      // a bypassed biquad keeps its state (:622, :646)
     if (run) { st.z[slot][0] = c.z1; st.z[slot][1] = c.z2; }
-    if (lane < kP4ChainLanes && !isQ && stage == 0) { st.pre_mem = c.g.mem; st.pre_tgt = pre_tgt; }
-    if (lane < kP4ChainLanes && isQ && stage == c.K - 1) { st.master_mem = c.g.mem; st.master_tgt = master_tgt; }
-    if (lane < kP4ChainLanes && r == 0) st.pending = param_targets(ctl, st, pending);      // run() :634-640 for a model without PARAM inputs
-    for (int jj = 0; jj < kP4Streams; ++jj) {
-        float4* dst = reinterpret_cast<float4*>(a.out + (size_t)(s0 + jj) * n);
-        const float4* src = reinterpret_cast<const float4*>(rows + jj * n);
-        for (int i = lane; i < n / 4; i += kWave) dst[i] = src[i];
+    // (a disabled stream: the gain memories as activate() left them, the pre-gain target latched, nothing else — :612-619 and k_*_pipe's early-out)
+    if (there && lane < kP4ChainLanes && !isQ && stage == 0) { st.pre_mem = c.g.mem; st.pre_tgt = pre_tgt; }
+    if (there && lane < kP4ChainLanes && isQ && stage == c.K - 1) { st.master_mem = c.g.mem; st.master_tgt = master_tgt; }
+    if (there && lane < kP4ChainLanes && r == 0) st.pending = netj ? param_targets(ctl, st, pending) : pending;      // run() :634-640 for a model without PARAM inputs
+    if (n == 256) {
+        const float4 r0 = reinterpret_cast<const float4*>(rows)[lane], r1 = reinterpret_cast<const float4*>(rows + n)[lane];
+        const float4 r2 = reinterpret_cast<const float4*>(rows + 2 * n)[lane], r3 = reinterpret_cast<const float4*>(rows + 3 * n)[lane];
+        reinterpret_cast<float4*>(a.out + (size_t)s0 * n)[lane] = r0;
+        if (s0 + 1 < (int)a.n_streams) reinterpret_cast<float4*>(a.out + (size_t)(s0 + 1) * n)[lane] = r1;
+        if (s0 + 2 < (int)a.n_streams) reinterpret_cast<float4*>(a.out + (size_t)(s0 + 2) * n)[lane] = r2;
+        if (s0 + 3 < (int)a.n_streams) reinterpret_cast<float4*>(a.out + (size_t)(s0 + 3) * n)[lane] = r3;
+    } else {
+        for (int jj = 0; jj < kP4Streams; ++jj) {
+            if (s0 + jj >= (int)a.n_streams) break;
+            float4* dst = reinterpret_cast<float4*>(a.out + (size_t)(s0 + jj) * n);
+            const float4* src = reinterpret_cast<const float4*>(rows + jj * n);
+            for (int i = lane; i < n / 4; i += kWave) dst[i] = src[i];
+        }
     }
 }
 
@@ -1674,7 +1725,7 @@ size_t pipe4_lds_bytes(int hidden, uint32_t n_frames)
 }
 hipError_t launch_pipe4_kernel(const KernelEntry* e, const LaunchArgs& a, hipStream_t stream)
 {
-    if (!e->fn_pipe4 || a.n_streams % kP4Streams || a.n_frames % kSB || a.n_frames == 0) return hipErrorInvalidValue;
+    if (!e->fn_pipe4 || a.n_frames % kSB || a.n_frames == 0) return hipErrorInvalidValue;
     const size_t lds = pipe4_lds_bytes(e->hidden, a.n_frames);
     {
         // (per kernel, once: more than 64 KiB of dynamic LDS has to be asked for)
@@ -1691,7 +1742,7 @@ hipError_t launch_pipe4_kernel(const KernelEntry* e, const LaunchArgs& a, hipStr
             if (n_raised < 64) raised[n_raised++] = fn;
         }
     }
-    hipLaunchKernelGGL(e->fn_pipe4, dim3(a.n_streams / kP4Streams), dim3(kP4Waves * kWave), lds, stream, a);
+    hipLaunchKernelGGL(e->fn_pipe4, dim3((a.n_streams + kP4Streams - 1) / kP4Streams), dim3(kP4Waves * kWave), lds, stream, a);
     return hipGetLastError();
 }
 

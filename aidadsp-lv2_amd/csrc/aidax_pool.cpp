@@ -466,31 +466,18 @@ struct aidax_pool {
         return (static_cast<size_t>((n_frames + 3) & ~3u) + static_cast<size_t>(m.hidden > 0 ? m.hidden + 4 : 4)) * sizeof(float);   // block + h row + spare slot
     }
 
-    // k_*_pipe4 takes a pass only when every stream is in circuit (enabled, the model on): a summary of the control records, rebuilt after they changed
-    mutable bool circuit_dirty = true, circuit_all = false;
-    bool all_in_circuit() const
-    {
-        if (circuit_dirty) {
-            circuit_all = true;
-            const uint32_t want = CTL_ENABLED | CTL_NET_ON;
-            for (uint32_t s = 0; s < n_streams && circuit_all; ++s) circuit_all = (h_ctl[s].flags & want) == want;
-            circuit_dirty = false;
-        }
-        return circuit_all;
-    }
-    // Does a MODE_CHAIN pass of n frames go through the four-streams-per-workgroup pipeline (k_*_pipe4: 61.5 us per cfg2 block against
-    // k_lstm_pipe's 63.9, profiles/r06_cfg2_pipe4.txt)? Whole 16-frame tiles, whole workgroups of four streams, every workgroup on a CU of its
-    // own, every stream in circuit, a model without PARAM inputs; k_*_pipe serves every other pass on the same state (AIDAX_PIPE4=0, test build: all).
+    // Does a MODE_CHAIN pass of n frames go through the four-streams-per-workgroup pipeline (k_*_pipe4: 61.9 us per cfg2 block against
+    // k_lstm_pipe's 63.8, the small cells 9 - 19 % ahead: profiles/r06_cfg2_pipe4.txt, r06_pipe4_cells.txt)? Whole 16-frame tiles, at least one full
+    // workgroup of four streams, every workgroup on a CU of its own, a model without PARAM inputs; k_*_pipe serves every other pass on the same
+    // state (AIDAX_PIPE4=0, test build: all of them).
     bool pipe4_serves(const ModelSlot& m, uint32_t n, int input_size) const
     {
         const bool off = [] { const char* e = AIDAX_HOOK_ENV("AIDAX_PIPE4"); return e && e[0] == '0'; }();      // (read per call: tests switch forms within one process)
-        if (off || force_form != 0 || !m.kernel || !m.kernel->fn_pipe4 || input_size != 1 || n == 0 || n % 16u || n_streams % 4u) return false;
-        if (cus <= 0 || n_streams > 4u * static_cast<uint32_t>(cus) || pipe4_lds_bytes(m.hidden, n) > 160 * 1024) return false;
-        return all_in_circuit();
+        if (off || force_form != 0 || !m.kernel || !m.kernel->fn_pipe4 || input_size != 1 || n == 0 || n % 16u || n_streams < 4u) return false;
+        return cus > 0 && (n_streams + 3u) / 4u <= static_cast<uint32_t>(cus) && pipe4_lds_bytes(m.hidden, n) <= 160 * 1024;
     }
     void mark_dirty(uint32_t lo, uint32_t hi)
     {
-        circuit_dirty = true;
         if (dirty_lo > dirty_hi) { dirty_lo = lo; dirty_hi = hi; }
         else { dirty_lo = std::min(dirty_lo, lo); dirty_hi = std::max(dirty_hi, hi); }
     }

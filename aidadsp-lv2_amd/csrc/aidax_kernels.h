@@ -18,6 +18,7 @@ struct KernelEntry {
     const char* name_split;
     void (*fn_pipe4)(LaunchArgs);     // four streams per workgroup, one helper wave (k_*_pipe4; nullptr: the cell has none)
     const char* name_pipe4;
+    void (*fn_pipe4c)(LaunchArgs);    // the same for a conditioned model (PARAM1 / PARAM2 as inputs): the helper wave also runs the PARAM smoothers
 };
 
 const KernelEntry* find_kernel(int cell, int hidden);
@@ -27,8 +28,8 @@ bool split_form_pays(const KernelEntry* e, uint32_t n_frames);
 size_t pipe_lds_bytes(int hidden, uint32_t n_frames);
 hipError_t launch_pipe_kernel(const KernelEntry* e, const LaunchArgs& a, hipStream_t stream);
 int pipe_resident_streams(const KernelEntry* e, uint32_t n_frames, int device);
-// k_*_pipe4: a pass of whole 16-frame tiles, whole workgroups of four streams, every stream in circuit, a model without PARAM inputs (the caller checks)
-size_t pipe4_lds_bytes(int hidden, uint32_t n_frames);
+// k_*_pipe4: a pass of whole 16-frame tiles, whole workgroups of four streams, (the caller checks)
+size_t pipe4_lds_bytes(int hidden, uint32_t n_frames, int input_size);
 hipError_t launch_pipe4_kernel(const KernelEntry* e, const LaunchArgs& a, hipStream_t stream);
 size_t stack_lds_bytes(const StackDesc& d, uint32_t n_frames);
 size_t conv_lds_bytes(const ConvDesc& d, uint32_t n_frames);

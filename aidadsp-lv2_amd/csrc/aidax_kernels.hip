@@ -1025,10 +1025,11 @@ constexpr int kP4Helpers = 1;                          // helper waves; more tha
 constexpr int kP4Waves = kP4Streams + kP4Helpers;
 constexpr int kP4ChainLanes = 12 * kP4Streams;
 constexpr int kP4HandFloats = 2 * kP4ChainLanes * kStChainBlockP4;
-__host__ __device__ constexpr size_t pipe4_lds_floats(int H, int n_frames)
+__host__ __device__ constexpr size_t pipe4_lds_floats(int H, int n_frames, bool conditioned)
 {
     return (size_t)kP4Streams * n_frames + (size_t)kP4Streams * kRing * pipe_row_stride(H) + kP4HandFloats + (size_t)(H + 4) + 8 /* progress words */
-         + 5 * kWave /* the cascades' state on its way from one helper wave to the next: z1, z2 (fp64), the ramp's memory */;
+         + 5 * kWave /* the cascades' state on its way from one helper wave to the next: z1, z2 (fp64), the ramp's memory */
+         + (conditioned ? (size_t)2 * kP4Streams * n_frames : 0) /* PARAM1 / PARAM2 per frame (models with two or three inputs) */;
 }
 // a progress word in LDS, written by one wave and polled by others (LDS runs a wave's accesses in order: a word written behind the
 // data it announces is seen behind it)
@@ -1045,7 +1046,9 @@ __device__ __forceinline__ void p4_post(int* w, int v, int lane)
     asm volatile("" ::: "memory");
 }
 
-template <class Cell>
+// kCond: the model takes PARAM1 (and PARAM2) as inputs — a kernel of its own, so that the plain model's keeps its registers and its schedule
+// (one body with the input count read at run time cost cfg2 2.5 us of 61.8: profiles/r06_pipe4_cells.txt)
+template <class Cell, bool kCond>
 __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* smem)
 {
     constexpr int H = Cell::HID;
@@ -1069,6 +1072,8 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
                                                           // [2 + j] tiles the cell of stream j has finished
                                                           // [6] helper ticks done (whose turn it is)
     float* hstate = reinterpret_cast<float*>(prog + 8);   // [5][64]: a cascade lane's z1, z2, ramp memory between two helper waves
+    float* prow = hstate + 5 * kWave;                     // [4 streams][2 params][n]: the smoothed PARAM inputs of every frame (kCond)
+    const int I = kCond ? (int)a.input_size : 1;
 
     // every wave derives the launch's timing from the four control words (wave-uniform): the longest cascades set it
     int Kp = 1, Kq = 1;
@@ -1147,13 +1152,35 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
                     xr[4 * q + 2] = v.z; xr[4 * q + 3] = v.w;
                 };
                 fetch_x(0);
+                if constexpr (!kCond) {
 #pragma unroll
-                for (int f = 0; f < kSB; ++f) {
-                    if ((f & 3) == 1 && f / 4 + 1 < kSB / 4) fetch_x(f / 4 + 1);
+                    for (int f = 0; f < kSB; ++f) {
+                        if ((f & 3) == 1 && f / 4 + 1 < kSB / 4) fetch_x(f / 4 + 1);
 #ifndef AIDAX_P4_BARRIER
-                    if (f == kSB - 4) ahead = *reinterpret_cast<const volatile p4_i2*>(prog);
+                        if (f == kSB - 4) ahead = *reinterpret_cast<const volatile p4_i2*>(prog);
 #endif
-                    cell.template step<1>(xr[f], 0.f, 0.f, f == 0 ? hprev : hcur + (f - 1) * HS, hcur + f * HS);
+                        cell.template step<1>(xr[f], 0.f, 0.f, f == 0 ? hprev : hcur + (f - 1) * HS, hcur + f * HS);
+                    }
+                } else {
+                    // conditioned models (input_size 2 / 3, :186-233): PARAM1 / PARAM2 of every frame are the helper's (LinearValueSmoother per sample)
+                    const float* p1s = prow + (wave * 2 + 0) * n + base;
+                    const float* p2s = prow + (wave * 2 + 1) * n + base;
+                    float p1r[kSB], p2r[kSB];
+                    auto fetch_p = [&](int q) {
+                        const float4 u = reinterpret_cast<const float4*>(p1s)[q];
+                        const float4 w = reinterpret_cast<const float4*>(p2s)[q];
+                        p1r[4 * q] = u.x; p1r[4 * q + 1] = u.y; p1r[4 * q + 2] = u.z; p1r[4 * q + 3] = u.w;
+                        p2r[4 * q] = w.x; p2r[4 * q + 1] = w.y; p2r[4 * q + 2] = w.z; p2r[4 * q + 3] = w.w;
+                    };
+                    fetch_p(0);
+#pragma unroll
+                    for (int f = 0; f < kSB; ++f) {
+                        if ((f & 3) == 1 && f / 4 + 1 < kSB / 4) { fetch_x(f / 4 + 1); fetch_p(f / 4 + 1); }
+#ifndef AIDAX_P4_BARRIER
+                        if (f == kSB - 4) ahead = *reinterpret_cast<const volatile p4_i2*>(prog);
+#endif
+                        cell.template step<3>(xr[f], p1r[f], I >= 3 ? p2r[f] : 0.f, f == 0 ? hprev : hcur + (f - 1) * HS, hcur + f * HS);
+                    }
                 }
             }
 #ifdef AIDAX_P4_BARRIER
@@ -1236,6 +1263,23 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
     const int dj = lane >> 4, df = lane & 15;
     const float* hdj = hh + dj * kRing * HS;
     float* drow = rows + dj * n;
+    // the PARAM smoothers (LinearValueSmoother, ValueSmoother.hpp:166-241; run() :634-640) of a conditioned model: lane 48 + 2 j + i owns
+    // PARAM(i + 1) of stream j — target changes and the first-run snap here (param_targets()' arithmetic), then a value per frame
+    static_assert(kP4Helpers == 1, "the PARAM lanes' state is not handed from helper to helper");
+    const bool plane = kCond && lane >= kP4ChainLanes && lane < kP4ChainLanes + 2 * kP4Streams;
+    const int jp = plane ? (lane - kP4ChainLanes) >> 1 : 0, ip = lane & 1;
+    const bool there_p = s0 + jp < (int)a.n_streams;
+    const int sp = there_p ? s0 + jp : (int)a.n_streams - 1;
+    const bool net_p = plane && there_p && (a.ctl[sp].flags & (CTL_ENABLED | CTL_NET_ON)) == (CTL_ENABLED | CTL_NET_ON);
+    float pm = 0.f, pt = 0.f, ps = 0.f;
+    if constexpr (kCond) {
+        pm = a.st[sp].p_mem[ip]; pt = a.st[sp].p_tgt[ip]; ps = a.st[sp].p_step[ip];
+        const float nt = a.ctl[sp].p_target[ip];
+        if (__builtin_fabsf(pt - nt) >= FLT_EPSILON) { pt = nt; ps = (pt - pm) / a.ctl[sp].p_den; }      // setTargetValue (:209-216)
+        if (a.st[sp].pending & PEND_PARAM_FIRST) pm = pt;                                                // paramFirstRun (:636-640)
+    }
+    const bool pstep = net_p && ip < I - 1;                   // this PARAM is a model input: a smoothed value per frame
+    float* pdst = prow + (jp * 2 + ip) * n;
     const bool netd = s0 + dj < (int)a.n_streams && (a.ctl[s0 + dj < (int)a.n_streams ? s0 + dj : (int)a.n_streams - 1].flags & (CTL_ENABLED | CTL_NET_ON)) == (CTL_ENABLED | CTL_NET_ON);
     if (hq == 0 && lane < 8) prog[lane] = 0;
     __syncthreads();
@@ -1290,6 +1334,12 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
         }
         // the tile the cells read next tick: times in_gain, in place (out[i] *= input_gain, :170; every stream's pre pass has finished it)
         const int ts = tick - d1 + 1;
+        if (kCond && ts >= 0 && ts < NT) {
+            if (pstep) {
+#pragma unroll 4
+                for (int f = 0; f < kSB; ++f) pdst[ts * kSB + f] = lin_next(pm, pt, ps);
+            }
+        }
         if (ts >= 0 && ts < NT) {
             const int f = ts * kSB + df;
             if (netd) drow[f] = drow[f] * a.in_gain;
@@ -1316,7 +1366,12 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
     // (a disabled stream: the gain memories as activate() left them, the pre-gain target latched, nothing else — :612-619 and k_*_pipe's early-out)
     if (there && lane < kP4ChainLanes && !isQ && stage == 0) { st.pre_mem = c.g.mem; st.pre_tgt = pre_tgt; }
     if (there && lane < kP4ChainLanes && isQ && stage == c.K - 1) { st.master_mem = c.g.mem; st.master_tgt = master_tgt; }
-    if (there && lane < kP4ChainLanes && r == 0) st.pending = netj ? param_targets(ctl, st, pending) : pending;      // run() :634-640 for a model without PARAM inputs
+    if constexpr (kCond) {
+        if (there && lane < kP4ChainLanes && r == 0) st.pending = netj ? (pending & ~PEND_PARAM_FIRST) : pending;      // (the first-run snap is the PARAM lanes')
+        if (net_p) { a.st[sp].p_mem[ip] = pm; a.st[sp].p_tgt[ip] = pt; a.st[sp].p_step[ip] = ps; }
+    } else {
+        if (there && lane < kP4ChainLanes && r == 0) st.pending = netj ? param_targets(ctl, st, pending) : pending;      // run() :634-640 for a model without PARAM inputs
+    }
     if (n == 256) {
         const float4 r0 = reinterpret_cast<const float4*>(rows)[lane], r1 = reinterpret_cast<const float4*>(rows + n)[lane];
         const float4 r2 = reinterpret_cast<const float4*>(rows + 2 * n)[lane], r3 = reinterpret_cast<const float4*>(rows + 3 * n)[lane];
@@ -1334,18 +1389,18 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
     }
 }
 
-template <int H>
+template <int H, bool kCond = false>
 __global__ __launch_bounds__(kP4Waves * kWave) void k_lstm_pipe4(LaunchArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    stream_body_pipe4<LstmCell<H>>(a, smem);
+    stream_body_pipe4<LstmCell<H>, kCond>(a, smem);
 }
 
-template <int H>
+template <int H, bool kCond = false>
 __global__ __launch_bounds__(kP4Waves * kWave) void k_gru_pipe4(LaunchArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    stream_body_pipe4<GruCell<H>>(a, smem);
+    stream_body_pipe4<GruCell<H>, kCond>(a, smem);
 }
 
 // ======================================================================
@@ -1624,24 +1679,27 @@ __global__ void k_adopt_dsp(StreamState* dst, const StreamState* src)
 }
 
 // ------------------------------------------------------------ host dispatch
-#define AIDAX_LSTM(H) { 0, H, k_lstm<H>, k_lstm_pipe<H>, k_nn<LstmCell<H, false>>, LstmCell<H>::PACK, LstmCell<H>::STATE, "k_lstm<" #H ">", "k_lstm_pipe<" #H ">", "k_chain+k_nn<lstm" #H ">", nullptr, "-" }
+#define AIDAX_LSTM(H) { 0, H, k_lstm<H>, k_lstm_pipe<H>, k_nn<LstmCell<H, false>>, LstmCell<H>::PACK, LstmCell<H>::STATE, "k_lstm<" #H ">", "k_lstm_pipe<" #H ">", "k_chain+k_nn<lstm" #H ">", nullptr, "-", nullptr }
 // ... with the four-streams-per-workgroup pipeline as well (BASELINE cfg2's cell)
-#define AIDAX_LSTM_P4(H) { 0, H, k_lstm<H>, k_lstm_pipe<H>, k_nn<LstmCell<H, false>>, LstmCell<H>::PACK, LstmCell<H>::STATE, "k_lstm<" #H ">", "k_lstm_pipe<" #H ">", "k_chain+k_nn<lstm" #H ">", k_lstm_pipe4<H>, "k_lstm_pipe4<" #H ">" }
+#define AIDAX_LSTM_P4(H) { 0, H, k_lstm<H>, k_lstm_pipe<H>, k_nn<LstmCell<H, false>>, LstmCell<H>::PACK, LstmCell<H>::STATE, "k_lstm<" #H ">", "k_lstm_pipe<" #H ">", "k_chain+k_nn<lstm" #H ">", k_lstm_pipe4<H>, "k_lstm_pipe4<" #H ">", k_lstm_pipe4<H, true> }
 // LSTM-64 / LSTM-80: the helper waves' share of the register file (pipe) resp. the Dense ring (split, H = 80) push the
 // 4H-row cell past 512 registers — those forms would spill, so they do not exist; the pool serves these cells
 // with k_quad / k_mfma, or the one-wave kernel when neither fits (pools with long blocks).
-#define AIDAX_LSTM_WIDE(H, NN) { 0, H, k_lstm<H>, nullptr, NN, LstmCell<H>::PACK, LstmCell<H>::STATE, "k_lstm<" #H ">", "-", "k_chain+k_nn<lstm" #H ">", nullptr, "-" }
-#define AIDAX_GRU(H)  { 1, H, k_gru<H>,  k_gru_pipe<H>,  k_nn<GruCell<H>>,  GruCell<H>::PACK,  GruCell<H>::STATE,  "k_gru<" #H ">", "k_gru_pipe<" #H ">", "k_chain+k_nn<gru" #H ">", nullptr, "-" }
-#define AIDAX_GRU_P4(H)  { 1, H, k_gru<H>,  k_gru_pipe<H>,  k_nn<GruCell<H>>,  GruCell<H>::PACK,  GruCell<H>::STATE,  "k_gru<" #H ">", "k_gru_pipe<" #H ">", "k_chain+k_nn<gru" #H ">", k_gru_pipe4<H>, "k_gru_pipe4<" #H ">" }
+#define AIDAX_LSTM_WIDE(H, NN) { 0, H, k_lstm<H>, nullptr, NN, LstmCell<H>::PACK, LstmCell<H>::STATE, "k_lstm<" #H ">", "-", "k_chain+k_nn<lstm" #H ">", nullptr, "-", nullptr }
+#define AIDAX_GRU(H)  { 1, H, k_gru<H>,  k_gru_pipe<H>,  k_nn<GruCell<H>>,  GruCell<H>::PACK,  GruCell<H>::STATE,  "k_gru<" #H ">", "k_gru_pipe<" #H ">", "k_chain+k_nn<gru" #H ">", nullptr, "-", nullptr }
+#define AIDAX_LSTM_P4C(H) { 0, H, k_lstm<H>, k_lstm_pipe<H>, k_nn<LstmCell<H, false>>, LstmCell<H>::PACK, LstmCell<H>::STATE, "k_lstm<" #H ">", "k_lstm_pipe<" #H ">", "k_chain+k_nn<lstm" #H ">", nullptr, "k_lstm_pipe4<" #H ">", k_lstm_pipe4<H, true> }
+#define AIDAX_GRU_P4C(H)  { 1, H, k_gru<H>,  k_gru_pipe<H>,  k_nn<GruCell<H>>,  GruCell<H>::PACK,  GruCell<H>::STATE,  "k_gru<" #H ">", "k_gru_pipe<" #H ">", "k_chain+k_nn<gru" #H ">", nullptr, "k_gru_pipe4<" #H ">", k_gru_pipe4<H, true> }
+#define AIDAX_GRU_P4(H)  { 1, H, k_gru<H>,  k_gru_pipe<H>,  k_nn<GruCell<H>>,  GruCell<H>::PACK,  GruCell<H>::STATE,  "k_gru<" #H ">", "k_gru_pipe<" #H ">", "k_chain+k_nn<gru" #H ">", k_gru_pipe4<H>, "k_gru_pipe4<" #H ">", k_gru_pipe4<H, true> }
 
 static const KernelEntry kTable[] = {
     // the 18 (cell, hidden) pairs of variant/generate_variant_hpp.py:4-6; input size is a run-time argument
     // (k_*_pipe4 where it measured ahead of k_*_pipe at a full pool of 1024 streams, profiles/r06_pipe4_cells.txt: LSTM-8 / 12 / 16 by 14 - 19 %,
-    // GRU-8 / 12 / 16 by 9 - 14 %, LSTM-32 by 3 %; LSTM-20 / 24 and GRU-20 / 24 / 32 measured 1 - 13 % behind and keep the three-wave pipeline)
-    AIDAX_LSTM_P4(8), AIDAX_LSTM_P4(12), AIDAX_LSTM_P4(16), AIDAX_LSTM(20), AIDAX_LSTM(24),
+    // GRU-8 / 12 / 16 by 9 - 14 %, LSTM-32 by 3 %; LSTM-20 / 24 and GRU-20 / 24 / 32 measured 1 - 13 % behind and keep the three-wave pipeline.
+    // A CONDITIONED model — PARAM1 / PARAM2 as inputs — runs k_*_pipe4<H, true> at every cell up to 32: 9 - 25 % ahead, same file)
+    AIDAX_LSTM_P4(8), AIDAX_LSTM_P4(12), AIDAX_LSTM_P4(16), AIDAX_LSTM_P4C(20), AIDAX_LSTM_P4C(24),
     AIDAX_LSTM_P4(32), AIDAX_LSTM(40), AIDAX_LSTM_WIDE(64, k_nn<LstmCell<64>>), AIDAX_LSTM_WIDE(80, nullptr),
-    AIDAX_GRU_P4(8), AIDAX_GRU_P4(12), AIDAX_GRU_P4(16), AIDAX_GRU(20), AIDAX_GRU(24),
-    AIDAX_GRU(32), AIDAX_GRU(40), AIDAX_GRU(64), AIDAX_GRU(80),
+    AIDAX_GRU_P4(8), AIDAX_GRU_P4(12), AIDAX_GRU_P4(16), AIDAX_GRU_P4C(20), AIDAX_GRU_P4C(24),
+    AIDAX_GRU_P4C(32), AIDAX_GRU(40), AIDAX_GRU(64), AIDAX_GRU(80),
 };
 
 const KernelEntry* find_kernel(int cell, int hidden)
@@ -1718,22 +1776,23 @@ hipError_t launch_pipe_kernel(const KernelEntry* e, const LaunchArgs& a, hipStre
 
 // k_*_pipe4's workgroup asks for more than half a CU's LDS whatever its rows need: the dispatcher then cannot put two of them on one CU
 // while another CU stands empty (a CU with two runs both at half speed, and the launch ends with them)
-size_t pipe4_lds_bytes(int hidden, uint32_t n_frames)
+size_t pipe4_lds_bytes(int hidden, uint32_t n_frames, int input_size)
 {
-    const size_t need = pipe4_lds_floats(hidden, (int)n_frames) * sizeof(float);
+    const size_t need = pipe4_lds_floats(hidden, (int)n_frames, input_size > 1) * sizeof(float);
     return need > 81 * 1024 ? need : (size_t)81 * 1024;
 }
 hipError_t launch_pipe4_kernel(const KernelEntry* e, const LaunchArgs& a, hipStream_t stream)
 {
-    if (!e->fn_pipe4 || a.n_frames % kSB || a.n_frames == 0) return hipErrorInvalidValue;
-    const size_t lds = pipe4_lds_bytes(e->hidden, a.n_frames);
+    void (*const kernel)(LaunchArgs) = a.input_size > 1 ? e->fn_pipe4c : e->fn_pipe4;      // (the conditioned model's kernel: PARAM rows beside the audio)
+    if (!kernel || a.n_frames % kSB || a.n_frames == 0) return hipErrorInvalidValue;
+    const size_t lds = pipe4_lds_bytes(e->hidden, a.n_frames, (int)a.input_size);
     {
         // (per kernel, once: more than 64 KiB of dynamic LDS has to be asked for)
         static std::mutex mu;
         static const void* raised[64];
         static int n_raised = 0;
         std::lock_guard<std::mutex> g(mu);
-        const void* fn = reinterpret_cast<const void*>(e->fn_pipe4);
+        const void* fn = reinterpret_cast<const void*>(kernel);
         bool done = false;
         for (int i = 0; i < n_raised; ++i) done = done || raised[i] == fn;
         if (!done) {
@@ -1742,7 +1801,7 @@ hipError_t launch_pipe4_kernel(const KernelEntry* e, const LaunchArgs& a, hipStr
             if (n_raised < 64) raised[n_raised++] = fn;
         }
     }
-    hipLaunchKernelGGL(e->fn_pipe4, dim3((a.n_streams + kP4Streams - 1) / kP4Streams), dim3(kP4Waves * kWave), lds, stream, a);
+    hipLaunchKernelGGL(kernel, dim3((a.n_streams + kP4Streams - 1) / kP4Streams), dim3(kP4Waves * kWave), lds, stream, a);
     return hipGetLastError();
 }
 

@@ -1708,3 +1708,47 @@ def test_four_streams_per_workgroup_pipeline_small_cells(kind, hidden, tmp_path,
     ref, names0 = _pipe4_run(path, S, sizes, x, schedule)
     assert set(names0) == {f"k_{kind}_pipe<{hidden}>"}, names0
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("kind,hidden,inputs", [("lstm", 12, 2), ("lstm", 16, 3), ("gru", 8, 3), ("gru", 12, 2), ("lstm", 32, 2), ("lstm", 32, 3),
+                                                ("lstm", 20, 3), ("lstm", 24, 2), ("gru", 20, 2), ("gru", 24, 3), ("gru", 32, 3)])
+def test_four_streams_per_workgroup_pipeline_conditioned_models(kind, hidden, inputs, tmp_path, monkeypatch):
+    """Conditioned models (PARAM1 / PARAM2 as model inputs, rt-neural-generic.cpp:175-189) in k_*_pipe4: the helper wave's PARAM lanes run the
+    linear smoothers a value per frame into LDS rows beside the audio tile. Per-stream PARAM targets that move between blocks (ramps still
+    under way when the next target arrives), a first run that snaps, activate(), a stream whose model is out of circuit while its PARAMs
+    change; against the oracle's plugin mirror, and bit-identical to k_*_pipe serving every pass (AIDAX_PIPE4=0, test build). Conditioned, every
+    cell of the table up to 32 runs here (profiles/r06_pipe4_cells.txt) — also LSTM-20 / 24 and GRU-20 / 24 / 32, whose plain models keep k_*_pipe."""
+    path, spec = _model_file(tmp_path, f"{kind}{hidden}i{inputs}p4", kind=kind, hidden=hidden, input_size=inputs, seed=300 + hidden + inputs,
+                             in_skip=1, in_gain=1.25, out_gain=-1.5)
+    S = 7
+    sizes = [256, 64, 128, 32, 256, 16, 128]
+    x = modelgen.signal(S, sum(sizes), seed=91 + hidden)
+    per = [dict(param1=0.2 + 0.1 * s_, param2=0.9 - 0.1 * s_, **(dict(eq_position=1.0, bass_boost_db=4.0) if s_ % 3 == 1 else {})) for s_ in range(S)]
+    schedule = {0: [(s_, per[s_]) for s_ in range(S)],
+                1: [(2, dict(per[2], param1=0.95)), (4, dict(per[4], param2=0.05, net_bypass=1.0))],
+                2: [(2, dict(per[2], param1=0.5, param2=0.5)), (6, dict(per[6], param1=0.0))],
+                4: [("activate", None), (4, dict(per[4], param1=0.7, param2=0.3))],
+                5: [(0, dict(per[0], param1=1.0, param2=0.0, pregain_db=3.0))]}
+    got, names = _pipe4_run(path, S, sizes, x, schedule)
+    assert set(names[1:]) == {f"k_{kind}_pipe4<{hidden}>"}, names
+    plugs = [O.OraclePlugin() for _ in range(S)]
+    for p_ in plugs:
+        p_.set_model(O.OracleModel(spec))
+    cur = [dict() for _ in range(S)]
+    worst, pos = 0.0, 0
+    for bi, n in enumerate(sizes):
+        for s_, kw in schedule.get(bi, []):
+            if s_ == "activate":
+                for p_ in plugs:
+                    p_.activate()
+            else:
+                cur[s_] = kw
+        for s_ in range(S):
+            want = plugs[s_].run(O.default_controls(**cur[s_]), x[s_, pos:pos + n])
+            worst = max(worst, float(np.abs(got[s_, pos:pos + n] - want).max()))
+        pos += n
+    errlog.bound(worst, 2e-6, "gpu_parity:pipe4_conditioned")
+    monkeypatch.setenv("AIDAX_PIPE4", "0")
+    ref, names0 = _pipe4_run(path, S, sizes, x, schedule)
+    assert set(names0) == {f"k_{kind}_pipe<{hidden}>"}, names0
+    assert np.array_equal(got, ref)

@@ -468,12 +468,15 @@ struct aidax_pool {
 
     // Does a MODE_CHAIN pass of n frames go through the four-streams-per-workgroup pipeline (k_*_pipe4: 61.9 us per cfg2 block against
     // k_lstm_pipe's 63.8, the small cells 9 - 19 % ahead, conditioned models 9 - 25 % at every cell up to 32: profiles/r06_cfg2_pipe4.txt, r06_pipe4_cells.txt)? Whole 16-frame tiles, at least one full
-    // workgroup of four streams, every workgroup on a CU of its own; k_*_pipe serves every other pass on the same
+    // workgroup of four streams (a conditioned model: any pool), every workgroup on a CU of its own; k_*_pipe serves every other pass on the same
     // state (AIDAX_PIPE4=0, test build: all of them).
+    // (a plain model below one full workgroup: level at 256 frames, 0.6 - 1.0 us behind at 64 — the helper wave's longer prologue; a conditioned
+    // model is 11 - 20 % ahead also as a pool of ONE stream, the LV2 instance's: profiles/r06_pipe4_cells.txt. AIDAX_PIPE4_MIN, test build: the measurement's switch)
+    static uint32_t p4_min_streams(int input_size) { const char* e = AIDAX_HOOK_ENV("AIDAX_PIPE4_MIN"); return e ? (uint32_t)atoi(e) : input_size > 1 ? 1u : 4u; }
     bool pipe4_serves(const ModelSlot& m, uint32_t n, int input_size) const
     {
         const bool off = [] { const char* e = AIDAX_HOOK_ENV("AIDAX_PIPE4"); return e && e[0] == '0'; }();      // (read per call: tests switch forms within one process)
-        if (off || force_form != 0 || !m.kernel || !(input_size > 1 ? m.kernel->fn_pipe4c : m.kernel->fn_pipe4) || input_size < 1 || input_size > 3 || n == 0 || n % 16u || n_streams < 4u) return false;
+        if (off || force_form != 0 || !m.kernel || !(input_size > 1 ? m.kernel->fn_pipe4c : m.kernel->fn_pipe4) || input_size < 1 || input_size > 3 || n == 0 || n % 16u || n_streams < p4_min_streams(input_size)) return false;
         return cus > 0 && (n_streams + 3u) / 4u <= static_cast<uint32_t>(cus) && pipe4_lds_bytes(m.hidden, n, input_size) <= 160 * 1024;
     }
     void mark_dirty(uint32_t lo, uint32_t hi)

@@ -1674,63 +1674,35 @@ def test_four_streams_per_workgroup_pipeline_is_bit_identical_to_the_three_wave_
     assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("kind,hidden", [("lstm", 8), ("lstm", 12), ("lstm", 16), ("gru", 8), ("gru", 12), ("gru", 16)])
-def test_four_streams_per_workgroup_pipeline_small_cells(kind, hidden, tmp_path, monkeypatch):
-    """The other cells of the reference's table that run k_*_pipe4 (where it measured ahead of the three-wave pipeline at a full pool:
-    profiles/r06_pipe4_cells.txt — the sizes the reference's own models have, LSTM-12 / 16): against the oracle's plugin mirror per stream
-    with per-stream EQ placement and moving ramps, and bit-identical to k_*_pipe serving every pass (AIDAX_PIPE4=0, test build)."""
-    path, spec = _model_file(tmp_path, f"{kind}{hidden}p4", kind=kind, hidden=hidden, input_size=1, seed=100 + hidden, in_skip=hidden % 16 == 0, in_gain=1.5, out_gain=-2.0)
-    S = 8
-    sizes = [256, 64, 100, 32, 256, 128]
-    x = modelgen.signal(S, sum(sizes), seed=79 + hidden)
-    per = [dict(), dict(eq_position=1.0, bass_boost_db=5.0), dict(treble_boost_db=3.0, dc_blocker=0.0), dict(eq_position=1.0, mid_type=1.0, mid_boost_db=4.0)]
-    schedule = {0: [(s_, per[s_ % 4]) for s_ in range(S)], 2: [(5, dict(per[1], pregain_db=4.0, master_db=-5.0))], 4: [("activate", None)]}
-    got, names = _pipe4_run(path, S, sizes, x, schedule)
-    assert names[1] == f"k_{kind}_pipe4<{hidden}>", names
-    plugs = [O.OraclePlugin() for _ in range(S)]
-    for p_ in plugs:
-        p_.set_model(O.OracleModel(spec))
-    cur = [dict() for _ in range(S)]
-    worst, pos = 0.0, 0
-    for bi, n in enumerate(sizes):
-        for s_, kw in schedule.get(bi, []):
-            if s_ == "activate":
-                for p_ in plugs:
-                    p_.activate()
-            else:
-                cur[s_] = kw
-        for s_ in range(S):
-            want = plugs[s_].run(O.default_controls(**cur[s_]), x[s_, pos:pos + n])
-            worst = max(worst, float(np.abs(got[s_, pos:pos + n] - want).max()))
-        pos += n
-    errlog.bound(worst, 2e-6, "gpu_parity:pipe4_small")
-    monkeypatch.setenv("AIDAX_PIPE4", "0")
-    ref, names0 = _pipe4_run(path, S, sizes, x, schedule)
-    assert set(names0) == {f"k_{kind}_pipe<{hidden}>"}, names0
-    assert np.array_equal(got, ref)
+_P4_PLAIN = [("lstm", 8), ("lstm", 12), ("lstm", 16), ("gru", 8), ("gru", 12), ("gru", 16)]
+_P4_CONDITIONED = [("lstm", 12, 2), ("lstm", 16, 3), ("gru", 8, 3), ("gru", 12, 2), ("lstm", 32, 2), ("lstm", 32, 3),
+                   ("lstm", 20, 3), ("lstm", 24, 2), ("gru", 20, 2), ("gru", 24, 3), ("gru", 32, 3)]
 
 
-@pytest.mark.parametrize("kind,hidden,inputs", [("lstm", 12, 2), ("lstm", 16, 3), ("gru", 8, 3), ("gru", 12, 2), ("lstm", 32, 2), ("lstm", 32, 3),
-                                                ("lstm", 20, 3), ("lstm", 24, 2), ("gru", 20, 2), ("gru", 24, 3), ("gru", 32, 3)])
-def test_four_streams_per_workgroup_pipeline_conditioned_models(kind, hidden, inputs, tmp_path, monkeypatch):
-    """Conditioned models (PARAM1 / PARAM2 as model inputs, rt-neural-generic.cpp:175-189) in k_*_pipe4: the helper wave's PARAM lanes run the
-    linear smoothers a value per frame into LDS rows beside the audio tile. Per-stream PARAM targets that move between blocks (ramps still
-    under way when the next target arrives), a first run that snaps, activate(), a stream whose model is out of circuit while its PARAMs
-    change; against the oracle's plugin mirror, and bit-identical to k_*_pipe serving every pass (AIDAX_PIPE4=0, test build). Conditioned, every
-    cell of the table up to 32 runs here (profiles/r06_pipe4_cells.txt) — also LSTM-20 / 24 and GRU-20 / 24 / 32, whose plain models keep k_*_pipe."""
+def _p4_case(tmp_path, kind, hidden, inputs, streams=7):
+    """a pool's worth of streams, a block sequence of whole tiles (k_*_pipe4) with ragged blocks between (k_*_pipe on the same state), per-stream
+    controls that move: (model path, spec, S, sizes, x, schedule)"""
+    if inputs == 1:
+        path, spec = _model_file(tmp_path, f"{kind}{hidden}p4", kind=kind, hidden=hidden, input_size=1, seed=100 + hidden, in_skip=hidden % 16 == 0, in_gain=1.5, out_gain=-2.0)
+        S, sizes = 8, [256, 64, 100, 32, 256, 128]
+        per = [dict(), dict(eq_position=1.0, bass_boost_db=5.0), dict(treble_boost_db=3.0, dc_blocker=0.0), dict(eq_position=1.0, mid_type=1.0, mid_boost_db=4.0)]
+        schedule = {0: [(s_, per[s_ % 4]) for s_ in range(S)], 2: [(5, dict(per[1], pregain_db=4.0, master_db=-5.0))], 4: [("activate", None)]}
+        return path, spec, S, sizes, modelgen.signal(S, sum(sizes), seed=79 + hidden), schedule
     path, spec = _model_file(tmp_path, f"{kind}{hidden}i{inputs}p4", kind=kind, hidden=hidden, input_size=inputs, seed=300 + hidden + inputs,
                              in_skip=1, in_gain=1.25, out_gain=-1.5)
-    S = 7
-    sizes = [256, 64, 128, 32, 256, 16, 128]
-    x = modelgen.signal(S, sum(sizes), seed=91 + hidden)
-    per = [dict(param1=0.2 + 0.1 * s_, param2=0.9 - 0.1 * s_, **(dict(eq_position=1.0, bass_boost_db=4.0) if s_ % 3 == 1 else {})) for s_ in range(S)]
-    schedule = {0: [(s_, per[s_]) for s_ in range(S)],
-                1: [(2, dict(per[2], param1=0.95)), (4, dict(per[4], param2=0.05, net_bypass=1.0))],
-                2: [(2, dict(per[2], param1=0.5, param2=0.5)), (6, dict(per[6], param1=0.0))],
-                4: [("activate", None), (4, dict(per[4], param1=0.7, param2=0.3))],
-                5: [(0, dict(per[0], param1=1.0, param2=0.0, pregain_db=3.0))]}
-    got, names = _pipe4_run(path, S, sizes, x, schedule)
-    assert set(names[1:]) == {f"k_{kind}_pipe4<{hidden}>"}, names
+    S, sizes = streams, [256, 64, 128, 32, 256, 16, 100, 128]
+    per = [dict(param1=0.2 + 0.1 * s_, param2=0.9 - 0.1 * s_, **(dict(eq_position=1.0, bass_boost_db=4.0) if s_ % 3 == 1 else {})) for s_ in range(7)]
+    schedule = {0: [(s_, per[s_]) for s_ in range(7)],
+                1: [(2, dict(per[2], param1=0.95)), (4, dict(per[4], param2=0.05, net_bypass=1.0))],      # a ramp starts; a model out of circuit whose PARAMs move
+                2: [(2, dict(per[2], param1=0.5, param2=0.5)), (6, dict(per[6], param1=0.0))],             # a new target while the ramp is under way
+                4: [("activate", None), (4, dict(per[4], param1=0.7, param2=0.3))],                          # the model back in circuit
+                5: [(0, dict(per[0], param1=1.0, param2=0.0, pregain_db=3.0))],
+                6: [(3, dict(per[3], param1=0.1))]}                                                         # (block 6 is ragged: k_*_pipe takes the ramp over, block 7 hands it back)
+    schedule = {b: [(s_, kw) for s_, kw in ev if s_ == "activate" or s_ < S] for b, ev in schedule.items()}
+    return path, spec, S, sizes, modelgen.signal(S, sum(sizes), seed=91 + hidden), schedule
+
+
+def _p4_oracle_worst(spec, S, sizes, x, schedule, got):
     plugs = [O.OraclePlugin() for _ in range(S)]
     for p_ in plugs:
         p_.set_model(O.OracleModel(spec))
@@ -1747,7 +1719,55 @@ def test_four_streams_per_workgroup_pipeline_conditioned_models(kind, hidden, in
             want = plugs[s_].run(O.default_controls(**cur[s_]), x[s_, pos:pos + n])
             worst = max(worst, float(np.abs(got[s_, pos:pos + n] - want).max()))
         pos += n
-    errlog.bound(worst, 2e-6, "gpu_parity:pipe4_conditioned")
+    return worst
+
+
+@pytest.mark.parametrize("kind,hidden", _P4_PLAIN)
+def test_four_streams_per_workgroup_pipeline_small_cells(kind, hidden, tmp_path):
+    """The other cells of the reference's table that run k_*_pipe4 (where it measured ahead of the three-wave pipeline at a full pool:
+    profiles/r06_pipe4_cells.txt — the sizes the reference's own models have, LSTM-12 / 16): against the oracle's plugin mirror per stream
+    with per-stream EQ placement and moving ramps. (No switch set: both builds run this, and their outputs are compared bit for bit.)"""
+    path, spec, S, sizes, x, schedule = _p4_case(tmp_path, kind, hidden, 1)
+    got, names = _pipe4_run(path, S, sizes, x, schedule)
+    assert names[1] == f"k_{kind}_pipe4<{hidden}>", names
+    errlog.bound(_p4_oracle_worst(spec, S, sizes, x, schedule, got), 2e-6, "gpu_parity:pipe4_small")
+
+
+@pytest.mark.parametrize("kind,hidden,inputs", _P4_CONDITIONED)
+def test_four_streams_per_workgroup_pipeline_conditioned_models(kind, hidden, inputs, tmp_path):
+    """Conditioned models (PARAM1 / PARAM2 as model inputs, rt-neural-generic.cpp:175-189) in k_*_pipe4<H, conditioned>: the helper wave's
+    PARAM lanes run the linear smoothers a value per frame into LDS rows beside the audio tile. Per-stream PARAM targets that move between
+    blocks (ramps still under way when the next target arrives, and handed to k_*_pipe and back at a ragged block), a first run that snaps,
+    activate(), a stream whose model is out of circuit while its PARAMs change; against the oracle's plugin mirror. Conditioned, every cell
+    of the table up to 32 runs here (profiles/r06_pipe4_cells.txt) — also LSTM-20 / 24 and GRU-20 / 24 / 32, whose plain models keep k_*_pipe."""
+    path, spec, S, sizes, x, schedule = _p4_case(tmp_path, kind, hidden, inputs)
+    got, names = _pipe4_run(path, S, sizes, x, schedule)
+    assert set(names[1:]) == {f"k_{kind}_pipe4<{hidden}>"}, names
+    errlog.bound(_p4_oracle_worst(spec, S, sizes, x, schedule, got), 2e-6, "gpu_parity:pipe4_conditioned")
+
+
+@pytest.mark.parametrize("streams", [1, 3])
+@pytest.mark.parametrize("kind,hidden,inputs", [("lstm", 16, 2), ("gru", 8, 3), ("lstm", 32, 3)])
+def test_four_streams_per_workgroup_pipeline_conditioned_small_pools(kind, hidden, inputs, streams, tmp_path):
+    """a conditioned model runs k_*_pipe4 also below one full workgroup — the LV2 instance's pool of one stream (11 - 20 % ahead of the
+    three-wave pipeline there: profiles/r06_pipe4_cells.txt); a plain model's small pool keeps k_*_pipe"""
+    path, spec, S, sizes, x, schedule = _p4_case(tmp_path, kind, hidden, inputs, streams=streams)
+    got, names = _pipe4_run(path, S, sizes, x, schedule)
+    assert set(names[1:]) == {f"k_{kind}_pipe4<{hidden}>"}, names
+    errlog.bound(_p4_oracle_worst(spec, S, sizes, x, schedule, got), 2e-6, "gpu_parity:pipe4_conditioned")
+    path1, _, S1, sizes1, x1, schedule1 = _p4_case(tmp_path, kind, hidden, 1)
+    pool = ax.Pool(streams, 256)
+    pool.set_model(ax.Model(path1))
+    assert pool.kernel_name == f"k_{kind}_pipe<{hidden}>"
+    pool.close()
+
+
+@pytest.mark.parametrize("kind,hidden,inputs", [(k, h, 1) for k, h in _P4_PLAIN] + _P4_CONDITIONED)
+def test_four_streams_per_workgroup_pipeline_equals_the_three_wave_pipeline(kind, hidden, inputs, tmp_path, monkeypatch):
+    """the same runs, bit for bit, with k_*_pipe serving every pass (AIDAX_PIPE4=0, test build)"""
+    path, spec, S, sizes, x, schedule = _p4_case(tmp_path, kind, hidden, inputs)
+    got, names = _pipe4_run(path, S, sizes, x, schedule)
+    assert f"k_{kind}_pipe4<{hidden}>" in names, names
     monkeypatch.setenv("AIDAX_PIPE4", "0")
     ref, names0 = _pipe4_run(path, S, sizes, x, schedule)
     assert set(names0) == {f"k_{kind}_pipe<{hidden}>"}, names0

@@ -30,7 +30,7 @@ hipError_t launch_pipe_kernel(const KernelEntry* e, const LaunchArgs& a, hipStre
 int pipe_resident_streams(const KernelEntry* e, uint32_t n_frames, int device);
 // k_*_pipe4: a pass of whole 16-frame tiles, whole workgroups of four streams, (the caller checks)
 size_t pipe4_lds_bytes(int hidden, uint32_t n_frames, int input_size);
-hipError_t launch_pipe4_kernel(const KernelEntry* e, const LaunchArgs& a, hipStream_t stream);
+hipError_t launch_pipe4_kernel(const KernelEntry* e, const LaunchArgs& a, hipStream_t stream, hipEvent_t done = nullptr);
 size_t stack_lds_bytes(const StackDesc& d, uint32_t n_frames);
 size_t conv_lds_bytes(const ConvDesc& d, uint32_t n_frames);
 size_t mfma_lds_bytes(const MfmaDesc& d, uint32_t n_frames);

@@ -30,6 +30,7 @@
 // fp32 with explicit fmaf chains; sigmoid/tanh use v_exp_f32 + v_rcp_f32
 // (abs error ~1e-7), compared to tolerance 1e-5 (rt-neural-generic.h:182).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cfloat>
 
@@ -1033,16 +1034,21 @@ __host__ __device__ constexpr size_t pipe4_lds_floats(int H, int n_frames, bool 
 }
 // a progress word in LDS, written by one wave and polled by others (LDS runs a wave's accesses in order: a word written behind the
 // data it announces is seen behind it)
+// (the words are named as LDS words — address space 3 — by hand: a volatile access through a generic pointer stays a FLAT instruction, which
+// takes the long way to the LDS and is waited for with vmcnt(0), behind every global access the wave has in flight: 0.5 us of a cfg2 block)
+typedef __attribute__((address_space(3))) int p4_lds_int;
+typedef int p4_i2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) p4_i2 p4_lds_i2;
 __device__ __forceinline__ int p4_peek(const int* w)
 {
-    const int v = *reinterpret_cast<const volatile int*>(w);
+    const int v = *(const volatile p4_lds_int*)(const p4_lds_int*)(w);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     return __builtin_amdgcn_readfirstlane(v);
 }
 __device__ __forceinline__ void p4_post(int* w, int v, int lane)
 {
     asm volatile("" ::: "memory");
-    if (lane == 0) *reinterpret_cast<volatile int*>(w) = v;
+    if (lane == 0) *(volatile p4_lds_int*)(p4_lds_int*)(w) = v;
     asm volatile("" ::: "memory");
 }
 
@@ -1132,7 +1138,6 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
         // helper is a tile ahead as a rule, the words only ever grow, and a stale look that already says "go" is as good as a fresh one. (Two
         // fresh looks per tile were two LDS round trips on the recurrent wave's critical path: 62.3 us for the recurrent waves alone against
         // 59.1 in the barrier form.)
-        typedef int p4_i2 __attribute__((ext_vector_type(2)));
         p4_i2 ahead = p4_i2{ 0, 0 };
         for (int t = 0; t < NT; ++t) {
             // the tile's inputs are ready, and the Dense has read the rows this tile overwrites (two tiles back)
@@ -1157,7 +1162,7 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
                     for (int f = 0; f < kSB; ++f) {
                         if ((f & 3) == 1 && f / 4 + 1 < kSB / 4) fetch_x(f / 4 + 1);
 #ifndef AIDAX_P4_BARRIER
-                        if (f == kSB - 4) ahead = *reinterpret_cast<const volatile p4_i2*>(prog);
+                        if (f == kSB - 4) ahead = *(const volatile p4_lds_i2*)(const p4_lds_i2*)(prog);
 #endif
                         cell.template step<1>(xr[f], 0.f, 0.f, f == 0 ? hprev : hcur + (f - 1) * HS, hcur + f * HS);
                     }
@@ -1177,7 +1182,7 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
                     for (int f = 0; f < kSB; ++f) {
                         if ((f & 3) == 1 && f / 4 + 1 < kSB / 4) { fetch_x(f / 4 + 1); fetch_p(f / 4 + 1); }
 #ifndef AIDAX_P4_BARRIER
-                        if (f == kSB - 4) ahead = *reinterpret_cast<const volatile p4_i2*>(prog);
+                        if (f == kSB - 4) ahead = *(const volatile p4_lds_i2*)(const p4_lds_i2*)(prog);
 #endif
                         cell.template step<3>(xr[f], p1r[f], I >= 3 ? p2r[f] : 0.f, f == 0 ? hprev : hcur + (f - 1) * HS, hcur + f * HS);
                     }
@@ -1781,7 +1786,7 @@ size_t pipe4_lds_bytes(int hidden, uint32_t n_frames, int input_size)
     const size_t need = pipe4_lds_floats(hidden, (int)n_frames, input_size > 1) * sizeof(float);
     return need > 81 * 1024 ? need : (size_t)81 * 1024;
 }
-hipError_t launch_pipe4_kernel(const KernelEntry* e, const LaunchArgs& a, hipStream_t stream)
+hipError_t launch_pipe4_kernel(const KernelEntry* e, const LaunchArgs& a, hipStream_t stream, hipEvent_t done)
 {
     void (*const kernel)(LaunchArgs) = a.input_size > 1 ? e->fn_pipe4c : e->fn_pipe4;      // (the conditioned model's kernel: PARAM rows beside the audio)
     if (!kernel || a.n_frames % kSB || a.n_frames == 0) return hipErrorInvalidValue;
@@ -1800,6 +1805,11 @@ hipError_t launch_pipe4_kernel(const KernelEntry* e, const LaunchArgs& a, hipStr
             if (err != hipSuccess) return err;
             if (n_raised < 64) raised[n_raised++] = fn;
         }
+    }
+    if (done) {
+        // the dispatch packet's own completion signal is the event: no marker packet behind the pass (profiles/r06_host_pipeline.txt)
+        hipExtLaunchKernelGGL(kernel, dim3((a.n_streams + kP4Streams - 1) / kP4Streams), dim3(kP4Waves * kWave), lds, stream, nullptr, done, 0, a);
+        return hipGetLastError();
     }
     hipLaunchKernelGGL(kernel, dim3((a.n_streams + kP4Streams - 1) / kP4Streams), dim3(kP4Waves * kWave), lds, stream, a);
     return hipGetLastError();

@@ -26,7 +26,7 @@ hipError_t launch_stream_kernel(const KernelEntry* e, const LaunchArgs& a, size_
 hipError_t launch_split_kernels(const KernelEntry* e, const LaunchArgs& a, hipStream_t stream);
 bool split_form_pays(const KernelEntry* e, uint32_t n_frames);
 size_t pipe_lds_bytes(int hidden, uint32_t n_frames);
-hipError_t launch_pipe_kernel(const KernelEntry* e, const LaunchArgs& a, hipStream_t stream);
+hipError_t launch_pipe_kernel(const KernelEntry* e, const LaunchArgs& a, hipStream_t stream, hipEvent_t done = nullptr);
 int pipe_resident_streams(const KernelEntry* e, uint32_t n_frames, int device);
 // k_*_pipe4: a pass of whole 16-frame tiles, whole workgroups of four streams, (the caller checks)
 size_t pipe4_lds_bytes(int hidden, uint32_t n_frames, int input_size);

@@ -662,6 +662,17 @@ __device__ __forceinline__ void pre_stage_solo(ChainPass& c, const float* src, f
         reinterpret_cast<float4*>(dst)[q] = float4{ v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3] };
 }
 
+// The blocking host path of a ONE-stream pool (the LV2 instance's: aidax_pool_process on the pool's own page-locked block): the wave that
+// has stored the block writes the sequence number the caller polls for — behind a system-scope fence, so the block is in the host's memory
+// before the word is — and no packet has to follow the pass on its queue.
+__device__ __forceinline__ void post_done_word(const LaunchArgs& a, int lane)
+{
+    if (a.done_word) {
+        __threadfence_system();
+        if (lane == 0) __hip_atomic_store(a.done_word, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 template <class Cell>
 __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* smem)
 {
@@ -698,6 +709,11 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
             if (pending0 & PEND_ACTIVATE) { st.pre_mem = st.pre_tgt; st.master_mem = st.master_tgt; }
             st.pre_tgt = ctl.pre_target;
             st.pending = pending0 & ~PEND_ACTIVATE;
+        }
+        if (a.done_word) {                                  // (every wave has copied a part)
+            __threadfence_system();
+            __syncthreads();
+            post_done_word(a, (int)threadIdx.x);
         }
         return;
     }
@@ -976,6 +992,7 @@ __device__ __forceinline__ void stream_body_pipe(const LaunchArgs& a, float* sme
         if (lane >= cp.K || !cp.active) { cp.z1 = q_z1o; cp.z2 = q_z2o; }      // a bypassed biquad keeps its state (:646)
         if (lane < cp.K) { st.z[slot][0] = cp.z1; st.z[slot][1] = cp.z2; }
         if (lane == cp.K - 1) { st.master_mem = cp.g.mem; st.master_tgt = master_tgt; }
+        post_done_word(a, lane);                            // (this wave has stored the block)
 #ifdef AIDAX_PIPE_TRACE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) {
@@ -1392,6 +1409,7 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
             for (int i = lane; i < n / 4; i += kWave) dst[i] = src[i];
         }
     }
+    post_done_word(a, lane);                                // (this wave has stored the block)
 }
 
 template <int H, bool kCond = false>
@@ -1772,9 +1790,13 @@ bool split_form_pays(const KernelEntry* e, uint32_t n_frames)
 
 size_t pipe_lds_bytes(int hidden, uint32_t n_frames) { return pipe_lds_floats(hidden, (int)n_frames) * sizeof(float); }
 
-hipError_t launch_pipe_kernel(const KernelEntry* e, const LaunchArgs& a, hipStream_t stream)
+hipError_t launch_pipe_kernel(const KernelEntry* e, const LaunchArgs& a, hipStream_t stream, hipEvent_t done)
 {
     if (!e->fn_pipe) return hipErrorInvalidDeviceFunction;
+    if (done) {                                             // (the dispatch packet's completion signal is the event: see launch_pipe4_kernel)
+        hipExtLaunchKernelGGL(e->fn_pipe, dim3(a.n_streams), dim3(kPipeWaves * kWave), pipe_lds_bytes(e->hidden, a.n_frames), stream, nullptr, done, 0, a);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(e->fn_pipe, dim3(a.n_streams), dim3(kPipeWaves * kWave), pipe_lds_bytes(e->hidden, a.n_frames), stream, a);
     return hipGetLastError();
 }

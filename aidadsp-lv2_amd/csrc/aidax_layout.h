@@ -320,6 +320,9 @@ struct LaunchArgs {
                                   // 8192 = the last layer's workgroup of k_mfma_lp's one-launch form starts 100 us late (tests: nothing may lean on the layers' workgroups starting together)
     uint32_t         row_stride;  // k_conv_mfma: frames between two streams' rows in `in` / `out` when a launch carries a
                                   // time slice of a longer block (0: rows are n_frames apart)
+    uint32_t         done_seq;    // k_*_pipe / k_*_pipe4 of a ONE-stream pool whose `out` is the host's memory: the wave that has stored the block
+    uint32_t*        done_word;   // writes done_seq here behind it (host memory; nullptr: nobody waits this way) — the blocking path's completion
+                                  // word without a packet behind the pass (aidax_pool_process, profiles/r06_host_pipeline.txt)
 };
 
 }  // namespace aidax

@@ -351,6 +351,9 @@ struct aidax_pool {
     uint32_t* hd_done = nullptr;
     uint32_t done_seq = 0;
     bool spin_wait = false;
+    bool kernel_word = true;         // a one-workgroup pass (k_*_pipe / k_*_pipe4 of a one-stream pool) writes the completion word itself, behind its block:
+                                     // no packet follows the pass on its queue — 1.7 us of the LV2 instance's 23 us round trip at 64 frames
+                                     // (profiles/r06_host_pipeline.txt). AIDAX_KERNEL_WORD=0: the queue writes it (hipStreamWriteValue32), as in round 5
     bool spin_collect = true;        // aidax_pool_collect polls the download's event instead of sleeping on it (AIDAX_SPIN_WAIT=0: off)
     bool keep_warm = false;          // this pool holds a reference on its device's keep-warm thread (AIDAX_KEEP_WARM_US)
     // k_mfma_lp: a word in pinned host memory that a workgroup bumps when a layer hand-over timed out. The pass that did
@@ -481,6 +484,9 @@ struct aidax_pool {
     }
     mutable hipEvent_t pass_done = nullptr;  // pool_submit_impl -> launch(): the event that marks this pass's end, for a launch that can carry it
     mutable bool pass_done_taken = false;
+    mutable uint32_t* pass_word = nullptr;   // aidax_pool_process -> launch(): the completion word and the number to write, for a pass of one workgroup
+    mutable uint32_t pass_seq = 0;
+    mutable bool pass_word_taken = false;
     void mark_dirty(uint32_t lo, uint32_t hi)
     {
         if (dirty_lo > dirty_hi) { dirty_lo = lo; dirty_hi = hi; }
@@ -654,12 +660,18 @@ struct aidax_pool {
             return launch_q4_kernel(m.hidden, b, s);
         }
         if (form == 1) {
-            if (!pipe4_serves(m, a.n_frames, a.input_size)) return launch_pipe_kernel(m.kernel, a, s);
             // (the pipelined host path hands the pass its "pass done" event: riding on the dispatch it saves the marker packet behind the kernel)
             hipEvent_t done = pass_done;
             pass_done = nullptr;
             pass_done_taken = done != nullptr;
-            return launch_pipe4_kernel(m.kernel, a, s, done);
+            LaunchArgs b = a;
+            if (pass_word && a.n_streams == 1 && a.n_frames != 0) {      // ... or the blocking path's completion word, written by the one workgroup itself
+                b.done_word = pass_word; b.done_seq = pass_seq;
+                pass_word = nullptr;
+                pass_word_taken = true;
+            }
+            if (!pipe4_serves(m, a.n_frames, a.input_size)) return launch_pipe_kernel(m.kernel, b, s, done);
+            return launch_pipe4_kernel(m.kernel, b, s, done);
         }
         if (form == 2) return launch_split_kernels(m.has_model ? m.kernel : nullptr, a, s);
         return launch_stream_kernel(m.has_model ? m.kernel : nullptr, a, lds_bytes(m, a.mode == MODE_CHAIN ? a.n_frames : 0), s);
@@ -1011,6 +1023,7 @@ AIDAX_API int aidax_pool_create(uint32_t n_streams, uint32_t max_frames, double 
             HIP_TRY(hipStreamCreateWithPriority(&p->q, hipStreamNonBlocking, prio_greatest));
             HIP_TRY(hipStreamCreateWithPriority(&p->wq, hipStreamNonBlocking, prio_least));
             { const char* sp = std::getenv("AIDAX_SPIN_WAIT"); p->spin_collect = !(sp && sp[0] == '0'); }
+            { const char* kw = std::getenv("AIDAX_KERNEL_WORD"); p->kernel_word = !(kw && kw[0] == '0'); }
             p->keep_warm = keep_warm().acquire(device_id);
             HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_lp_fault), 8192, hipHostMallocDefault));     // the fault word + the time stamps of scratch/lp_trace.py, r05_modes.py
             HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->hd_lp_fault), p->h_lp_fault, 0));
@@ -1317,7 +1330,10 @@ AIDAX_API int aidax_pool_process(aidax_pool* p, const float* in, float* out, uin
             // small blocks (the one-instance plugin): the pass reads its input straight from pinned host memory;
             // a one-launch pass also writes its output there, a multi-launch pass works in place on d_out
             const bool direct = p->single_launch(p->cur);
+            p->pass_word_taken = false;
+            if (direct && p->spin_wait && p->kernel_word) { p->pass_word = p->hd_done; p->pass_seq = p->done_seq + 1; }
             rc = aidax_pool_process_device(p, p->hd_in, direct ? p->hd_out : p->d_out, n_frames, p->q);
+            p->pass_word = nullptr;
             if (rc != AIDAX_OK) return rc;
             if (!direct && bytes) HIP_TRY(hipMemcpyAsync(p->h_out, p->d_out, bytes, hipMemcpyDeviceToHost, p->q));
         } else {
@@ -1327,7 +1343,10 @@ AIDAX_API int aidax_pool_process(aidax_pool* p, const float* in, float* out, uin
             if (bytes) HIP_TRY(hipMemcpyAsync(p->h_out, p->d_out, bytes, hipMemcpyDeviceToHost, p->q));
         }
         uint32_t seq = 0;
-        if (p->spin_wait) {
+        if (p->spin_wait && p->pass_word_taken) {
+            seq = ++p->done_seq;                            // (the pass writes it itself)
+            p->pass_word_taken = false;
+        } else if (p->spin_wait) {
             seq = ++p->done_seq;
             if (hipStreamWriteValue32(p->q, p->hd_done, seq, 0) != hipSuccess) {      // a runtime without stream memory operations
                 (void)hipGetLastError();

@@ -322,7 +322,7 @@ def test_the_shipped_library_has_no_test_or_measurement_switch():
         out = subprocess.run(["strings", "-a", path], capture_output=True, text=True, check=True).stdout
         return set(re.findall(r"AIDAX_[A-Z0-9_]+", out))
     ship, hooks = names(SHIP_LIB), names(HOOKS_LIB)
-    assert ship == {"AIDAX_SPIN_WAIT", "AIDAX_ZEROCOPY", "AIDAX_STRICT_REFERENCE_SET", "AIDAX_KEEP_WARM_US"}, ship      # configuration, INTEGRATION.md §3
+    assert ship == {"AIDAX_SPIN_WAIT", "AIDAX_ZEROCOPY", "AIDAX_STRICT_REFERENCE_SET", "AIDAX_KEEP_WARM_US", "AIDAX_KERNEL_WORD"}, ship      # configuration, INTEGRATION.md §3
     assert {"AIDAX_TUNE", "AIDAX_KERNEL", "AIDAX_LP_COOP", "AIDAX_MFMA_LP", "AIDAX_LP_SPLIT"} <= hooks
     shell = names(os.path.join(ROOT, "aidadsp-lv2_amd", "lv2", "rt-neural-generic.so"))
     assert shell == {"AIDAX_DEVICE", "AIDAX_HUB", "AIDAX_HUB_FRAMES", "AIDAX_HUB_DEADLINE_US", "AIDAX_STRICT_REFERENCE_SET"}, shell

@@ -347,3 +347,33 @@ def test_registered_host_buffers_take_the_copies_out_of_the_pipelined_path_same_
     assert L.aidax_pool_unregister_host(b.h, C.c_void_p(outs[1].ctypes.data)) == -1               # not registered any more
     b.submit_to(ins[0], outs[1]); b.collect(n, outs[1])              # ... and still served, staged
     a.close(); b.close()                                             # (the pool's end releases the remaining ranges)
+
+
+@pytest.mark.parametrize("kind,hidden,inputs", [("lstm", 16, 1), ("gru", 8, 2)])
+def test_one_stream_pools_pass_writes_its_own_completion_word_behind_its_block(kind, hidden, inputs, tmp_path, monkeypatch):
+    """The LV2 instance's pool (one stream, the block in the pool's page-locked memory): the pass of k_*_pipe / k_*_pipe4 writes the word
+    aidax_pool_process polls for itself, behind a system-scope fence behind its last store — no packet follows the pass. The caller must
+    never see the word before the block: 4000 blocks of fresh noise, an enabled stream bit for bit against a pool whose queue writes the word
+    (AIDAX_KERNEL_WORD=0, round 5's way), then a disabled one (a raw copy, :612-619 — every sample of every block must be the one just sent),
+    block lengths mixed so that consecutive blocks differ in every frame."""
+    path = str(tmp_path / "w.json")
+    modelgen.write_model(modelgen.make_model(kind=kind, hidden=hidden, input_size=inputs, seed=3 * hidden, in_skip=1), path)
+    m = ax.Model(path)
+    monkeypatch.setenv("AIDAX_KERNEL_WORD", "0")
+    a = ax.Pool(1, 256)
+    monkeypatch.delenv("AIDAX_KERNEL_WORD")
+    b = ax.Pool(1, 256)
+    a.set_model(m); b.set_model(m)
+    rng = np.random.default_rng(hidden)
+    sizes = [64, 256, 16, 128, 100, 32, 1, 256]
+    for k in range(2000):
+        n = sizes[k % len(sizes)]
+        x = (rng.random((1, n), dtype=np.float32) - 0.5)
+        ya, yb = a.process(x), b.process(x)
+        assert np.array_equal(ya, yb), (k, n)
+    b.set_controls(ax.default_controls(enabled=0.0))
+    for k in range(2000):
+        n = sizes[k % len(sizes)]
+        x = (rng.random((1, n), dtype=np.float32) - 0.5)
+        assert np.array_equal(b.process(x), x), (k, n)
+    a.close(); b.close()

@@ -185,8 +185,10 @@ def _kernel_matches(kernel_name: str, text: str) -> bool:
     """`k_lstm_pipe<32>` against a (possibly namespaced, templated) kernel name of a profile"""
     if "<" not in kernel_name:
         return kernel_name in text
+    import re
     base, arg = kernel_name.split("<", 1)
-    return base + "<" in text and arg in text
+    # (the instantiation may carry further template arguments behind the ones the name quotes: k_lstm_pipe4<32> is k_lstm_pipe4<32, false> there)
+    return re.search(re.escape(base) + r"<\s*" + re.escape(arg.rstrip(">").strip()) + r"\s*[,>]", text) is not None
 
 
 def measure_traffic_live(workload: str, kernel_name: str, wide_read_bytes: float, timeout_s: float = 100.0):

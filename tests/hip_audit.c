@@ -72,6 +72,13 @@ int hipLaunchKernel(const void* f, dim3_t g, dim3_t b, void** args, size_t shmem
     COUNT(A_LAUNCH);
     return fn(f, g, b, args, shmem, q);
 }
+int hipExtLaunchKernel(const void* f, dim3_t g, dim3_t b, void** args, size_t shmem, void* q, void* start, void* stop, int flags)
+{
+    /* (the pipelined host path: the pass's "done" event rides on its dispatch) */
+    REAL("hipExtLaunchKernel", const void*, dim3_t, dim3_t, void**, size_t, void*, void*, void*, int);
+    COUNT(A_LAUNCH);
+    return fn(f, g, b, args, shmem, q, start, stop, flags);
+}
 int hipEventRecord(void* e, void* q) { REAL("hipEventRecord", void*, void*); COUNT(A_EVENT_RECORD); return fn(e, q); }
 int hipStreamWaitEvent(void* q, void* e, unsigned f) { REAL("hipStreamWaitEvent", void*, void*, unsigned); COUNT(A_STREAM_WAIT_EVENT); return fn(q, e, f); }
 int hipStreamWriteValue32(void* q, void* p, uint32_t v, unsigned f) { REAL("hipStreamWriteValue32", void*, void*, uint32_t, unsigned); COUNT(A_STREAM_WRITE_VALUE); return fn(q, p, v, f); }

@@ -74,10 +74,16 @@ def test_audio_thread_entry_points_do_not_allocate_or_wait_for_the_device(tmp_pa
     for phase in ("work_response", "abi_commit", "activate", "abi_set_controls"):
         assert rep[phase]["hipStreamSynchronize"] == 0 and rep[phase]["hipEventSynchronize"] == 0, (phase, rep[phase])
         assert rep[phase]["launch"] <= 2 * rep[phase]["calls"], (phase, rep[phase])
-    # run(): exactly one completion per call, for the stream that carries its block — a word in pinned host memory that
-    # the stream writes behind the pass and the caller polls (small pools), or one hipStreamSynchronize
-    for phase in ("run_no_model", "run_model", "run_controls_changed", "run_patch_set", "abi_process"):
+    # run(): exactly one completion per call, for the stream that carries its block — a word in pinned host memory that the caller
+    # polls (small pools), or one hipStreamSynchronize. With a model playing, the pass of a one-stream pool writes that word ITSELF behind
+    # its block (k_*_pipe / k_*_pipe4: nothing follows the pass on its queue, round 6); without one, and for the pre-run call of no
+    # frames, the stream writes it behind the pass.
+    for phase in ("run_model", "run_controls_changed", "run_patch_set"):
+        assert rep[phase]["hipStreamSynchronize"] == 0 and rep[phase]["hipStreamWriteValue32"] == 0, (phase, rep[phase])
+        assert rep[phase]["launch"] == rep[phase]["calls"], (phase, rep[phase])
+    for phase in ("run_no_model", "run_pre_run", "abi_process"):
         assert rep[phase]["hipStreamSynchronize"] + rep[phase]["hipStreamWriteValue32"] == rep[phase]["calls"], (phase, rep[phase])
+    for phase in ("run_no_model", "run_model", "run_controls_changed", "run_patch_set", "abi_process", "run_pre_run"):
         assert rep[phase]["hipEventSynchronize"] == 0, (phase, rep[phase])
     # hub mode: run() of an instance launches nothing and copies nothing through the runtime (the launcher thread does)
     assert rep["hub_run"]["launch"] == 0 and rep["hub_run"]["hipMemcpyAsync"] == 0 and rep["hub_run"]["hipStreamSynchronize"] == 0

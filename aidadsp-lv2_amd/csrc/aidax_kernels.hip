@@ -1082,6 +1082,14 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
     const int s0 = kP4Streams * blockIdx.x;
     const int n = (int)a.n_frames;                        // a multiple of kSB (the host's promise)
     const int NT = n / kSB;
+#ifdef AIDAX_P4_TRACE
+    // measurement build (scratch/r06_p4_trace.sh): s_memrealtime (100 MHz) at the stations of one launch, written over the head of stream s0's output row
+#define P4_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); tr[k] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    P4_STAMP(0);
+#else
+#define P4_STAMP(k) do { } while (0)
+#endif
     float* rows = smem;                                   // [4][n]: a stream's block, processed in place by three actors a tile apart
     float* hh = rows + kP4Streams * n;                    // [4][kRing][HS]: h history
     float* hand = hh + kP4Streams * kRing * HS;           // the cascades' hand-over slots [2][48][B]
@@ -1129,6 +1137,7 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
         Cell cell;
         if (!(AIDAX_TUNE(a) & 1)) __builtin_amdgcn_s_setprio(3);
         cell.load(a.wpack, nnst, lane);
+        P4_STAMP(1);                                          // (the loads are issued)
         // (the word is one of the four every wave read with scalar loads above; and NOTHING in front of the first tile may depend on it but the
         // way out: with h(-1) published under the condition every vector load of the prologue was waited for there, and the first frames no
         // longer ran while the last weights were still arriving — 1.6 us of the launch)
@@ -1136,6 +1145,7 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
         const bool net = (fl & (CTL_ENABLED | CTL_NET_ON)) == (CTL_ENABLED | CTL_NET_ON);
         cell.publish_h(hj + (kRing - 1) * HS);            // h(-1): the row "before" frame 0 (unconditionally: a stream out of circuit publishes into its own ring for nothing)
         __syncthreads();                                  // (the progress words are zero)
+        P4_STAMP(2);
 #ifndef AIDAX_P4_BARRIER
         if (!net) { p4_post(prog + 2 + wave, NT, lane); return; }
 #endif
@@ -1160,6 +1170,11 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
             // the tile's inputs are ready, and the Dense has read the rows this tile overwrites (two tiles back)
             if (ahead.x <= t || ahead.y < t - 1)
                 while (p4_peek(prog) <= t || p4_peek(prog + 1) < t - 1) __builtin_amdgcn_s_sleep(1);
+#ifdef AIDAX_P4_TRACE
+            if (t == 0) P4_STAMP(3);                          // (tile 0 is ready)
+            if (t == 1) P4_STAMP(4);                          // (tile 0 is done and tile 1 ready)
+            if (t == NT - 1) P4_STAMP(5);                     // (the last tile begins)
+#endif
             {
 #endif
                 const int base = t * kSB;
@@ -1211,7 +1226,17 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
             p4_post(prog + 2 + wave, t + 1, lane);
 #endif
         }
+        P4_STAMP(6);                                          // (the last tile is done)
         cell.store(nnst);
+#ifdef AIDAX_P4_TRACE
+        P4_STAMP(7);
+        {
+            unsigned long long mine = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (lane == k) mine = tr[k];
+            if (wave == 0 && lane < 8) reinterpret_cast<unsigned long long*>(hstate)[lane] = mine;      // (the helper takes them out)
+        }
+#endif
         return;
     }
 
@@ -1304,8 +1329,14 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
     float* pdst = prow + (jp * 2 + ip) * n;
     const bool netd = s0 + dj < (int)a.n_streams && (a.ctl[s0 + dj < (int)a.n_streams ? s0 + dj : (int)a.n_streams - 1].flags & (CTL_ENABLED | CTL_NET_ON)) == (CTL_ENABLED | CTL_NET_ON);
     if (hq == 0 && lane < 8) prog[lane] = 0;
+    P4_STAMP(1);                                              // (the helper's loads are issued)
     __syncthreads();
+    P4_STAMP(2);
     for (int tick = hq; tick < T; tick += kP4Helpers) {
+#ifdef AIDAX_P4_TRACE
+        if (tick == 1) P4_STAMP(3);                           // (tick 0 done: tile 0 handed to the cells)
+        if (tick == T - 1) P4_STAMP(4);                       // (the last tick begins)
+#endif
         // my turn: the helper before me has finished tick - 1 and left the cascades' state
 #ifdef AIDAX_P4_BARRIER
         for (int i = 0; i < ((AIDAX_TUNE(a) >> 20) & 15); ++i) asm volatile("s_nop 15");
@@ -1380,6 +1411,7 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
             p4_post(prog + 6, tick + 1, lane);
         }
     }
+    P4_STAMP(5);                                              // (the last tick is done)
     if ((T - 1) % kP4Helpers != hq) return;               // the helper of the last tick holds the final state
     // ---------------------------------------------------------------- state write-back, the rows' stores
     if (is_gain) c.g = g;
@@ -1410,6 +1442,19 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
         }
     }
     post_done_word(a, lane);                                // (this wave has stored the block)
+#ifdef AIDAX_P4_TRACE
+    P4_STAMP(6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    P4_STAMP(7);
+    if (n >= 64) {
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.out + (size_t)s0 * n);
+        if (lane < 8) dst[lane] = reinterpret_cast<const unsigned long long*>(hstate)[lane];      // recurrent wave 0's
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (lane == k) mine = tr[k];
+        if (lane < 8) dst[8 + lane] = mine;                                                       // the helper's
+    }
+#endif
 }
 
 template <int H, bool kCond = false>

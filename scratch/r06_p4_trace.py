@@ -8,7 +8,7 @@ ax = importlib.import_module("aidadsp-lv2_amd"); W = ax.workloads
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 S = 1024
 p = W.write_model(W.make_model("lstm", 32, 1, seed=32), os.path.join(tempfile.mkdtemp(), "m.json"))
-pool = ax.Pool(S, 256); pool.set_model(ax.Model(p)); pool.set_controls(ax.default_controls())
+pool = ax.Pool(S, 256); pool.set_model(ax.Model(p)); pool.set_controls(ax.default_controls(eq_bypass=1.0) if os.environ.get("EQ") == "0" else ax.default_controls())
 x = torch.rand(S, n, device="cuda") - 0.5; y = torch.empty_like(x)
 st = torch.cuda.Stream(); torch.cuda.set_stream(st)
 for _ in range(200): pool.process_device(x.data_ptr(), y.data_ptr(), n, st.cuda_stream)

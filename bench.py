@@ -427,63 +427,65 @@ def realtime_paced(ax, W, torch, local, launch_stream):
     S = WORKLOADS["cfg2"]["streams"]
 
     def lv2_cases(frames_list, cases):
-      # (1) the pool an LV2 instance owns: one stream, the bundled LSTM-12
-      pool = ax.Pool(1, 8192, 48000.0, device=local)
-      pool.set_model(ax.Model(bundled))
-      for frames in frames_list:
-          x = W.signal(1, frames, seed=5)
-          period = frames / 48000.0
-          for _ in range(200):
-              pool.process(x)
-          b2b = np.array([0.0] * 1500)
-          for i in range(b2b.size):
-              t0 = time.perf_counter()
-              pool.process(x)
-              b2b[i] = (time.perf_counter() - t0) * 1e6
-          n_calls = int(min(1500, max(300, 2.0 / period)))
-          holder = {}
-          state = _sclk_while(lambda: holder.__setitem__("t", _paced(lambda: pool.process(x), period, n_calls)))
-          cases.append({"case": "one LV2 instance (one-stream pool, bundled LSTM-12), aidax_pool_process", "frames": frames,
-                               "period_us": period * 1e6, "kernel": pool.kernel_name, "paced_us": _pct(holder["t"]), "back_to_back_us": _pct(b2b),
-                               "gpu_while_paced": state})
-      pool.close()
-    def cfg2_cases(frames_list, cases):
-      # (2) cfg2's pool, device-resident blocks, one launch per period: the kernel's duration when it arrives after the idle gap
-      pool = ax.Pool(S, N_FRAMES, 48000.0, device=local)
-      pool.set_model(ax.Model(path))
-      pool.set_controls(ax.default_controls())
-      for frames in frames_list:
-          d_in = torch.from_numpy(W.signal(S, frames, seed=77)).cuda()
-          d_out = torch.empty_like(d_in)
-          period = frames / 48000.0
-          n_calls = int(min(1000, max(300, 2.0 / period)))
-          evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_calls)]
-          idx = [0]
+        # (1) the pool an LV2 instance owns: one stream, the bundled LSTM-12
+        pool = ax.Pool(1, 8192, 48000.0, device=local)
+        pool.set_model(ax.Model(bundled))
+        for frames in frames_list:
+            x = W.signal(1, frames, seed=5)
+            period = frames / 48000.0
+            for _ in range(200):
+                pool.process(x)
+            b2b = np.array([0.0] * 1500)
+            for i in range(b2b.size):
+                t0 = time.perf_counter()
+                pool.process(x)
+                b2b[i] = (time.perf_counter() - t0) * 1e6
+            n_calls = int(min(1500, max(300, 2.0 / period)))
+            holder = {}
+            state = _sclk_while(lambda: holder.__setitem__("t", _paced(lambda: pool.process(x), period, n_calls)))
+            cases.append({"case": "one LV2 instance (one-stream pool, bundled LSTM-12), aidax_pool_process", "frames": frames,
+                          "period_us": period * 1e6, "kernel": pool.kernel_name, "paced_us": _pct(holder["t"]), "back_to_back_us": _pct(b2b),
+                          "gpu_while_paced": state})
+        pool.close()
 
-          def call():
-              e0, e1 = evs[idx[0] % n_calls]
-              e0.record(launch_stream)
-              pool.process_device(d_in.data_ptr(), d_out.data_ptr(), frames, launch_stream.cuda_stream)
-              e1.record(launch_stream)
-              launch_stream.synchronize()
-              idx[0] += 1
-          for _ in range(50):
-              call()
-          idx[0] = 0
-          b2b_wall = np.empty(n_calls)
-          for i in range(n_calls):
-              t0 = time.perf_counter()
-              call()
-              b2b_wall[i] = (time.perf_counter() - t0) * 1e6
-          b2b_kern = np.array([a_.elapsed_time(b_) * 1e3 for a_, b_ in evs])
-          idx[0] = 0
-          holder = {}
-          state = _sclk_while(lambda: holder.__setitem__("t", _paced(call, period, n_calls)))
-          paced_kern = np.array([a_.elapsed_time(b_) * 1e3 for a_, b_ in evs])
-          cases.append({"case": f"cfg2 pool ({S} streams, LSTM-32), aidax_pool_process_device + stream sync, blocks resident in HBM", "frames": frames,
-                               "period_us": period * 1e6, "kernel": pool.kernel_name, "paced_us": _pct(holder["t"]), "back_to_back_us": _pct(b2b_wall),
-                               "kernel_us_paced": _pct(paced_kern), "kernel_us_back_to_back": _pct(b2b_kern), "gpu_while_paced": state})
-      pool.close()
+    def cfg2_cases(frames_list, cases):
+        # (2) cfg2's pool, device-resident blocks, one launch per period: the kernel's duration when it arrives after the idle gap
+        pool = ax.Pool(S, N_FRAMES, 48000.0, device=local)
+        pool.set_model(ax.Model(path))
+        pool.set_controls(ax.default_controls())
+        for frames in frames_list:
+            d_in = torch.from_numpy(W.signal(S, frames, seed=77)).cuda()
+            d_out = torch.empty_like(d_in)
+            period = frames / 48000.0
+            n_calls = int(min(1000, max(300, 2.0 / period)))
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_calls)]
+            idx = [0]
+
+            def call():
+                e0, e1 = evs[idx[0] % n_calls]
+                e0.record(launch_stream)
+                pool.process_device(d_in.data_ptr(), d_out.data_ptr(), frames, launch_stream.cuda_stream)
+                e1.record(launch_stream)
+                launch_stream.synchronize()
+                idx[0] += 1
+            for _ in range(50):
+                call()
+            idx[0] = 0
+            b2b_wall = np.empty(n_calls)
+            for i in range(n_calls):
+                t0 = time.perf_counter()
+                call()
+                b2b_wall[i] = (time.perf_counter() - t0) * 1e6
+            b2b_kern = np.array([a_.elapsed_time(b_) * 1e3 for a_, b_ in evs])
+            idx[0] = 0
+            holder = {}
+            state = _sclk_while(lambda: holder.__setitem__("t", _paced(call, period, n_calls)))
+            paced_kern = np.array([a_.elapsed_time(b_) * 1e3 for a_, b_ in evs])
+            cases.append({"case": f"cfg2 pool ({S} streams, LSTM-32), aidax_pool_process_device + stream sync, blocks resident in HBM", "frames": frames,
+                          "period_us": period * 1e6, "kernel": pool.kernel_name, "paced_us": _pct(holder["t"]), "back_to_back_us": _pct(b2b_wall),
+                          "kernel_us_paced": _pct(paced_kern), "kernel_us_back_to_back": _pct(b2b_kern), "gpu_while_paced": state})
+        pool.close()
+
     lv2_cases((64, 128, 256), out["cases"])
     cfg2_cases((64, 128, 256), out["cases"])
     # ... and the same paced calls with the library's keep-warm thread on (AIDAX_KEEP_WARM_US: an empty grid on a lowest-priority stream

@@ -1258,7 +1258,11 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
     // the four rows, dealt out over the helper waves (one 16-byte read per lane and 256 frames)
     // (all four requested before the first is waited for — the loop stays unrolled, a missing stream is a predicate, not a way out of the
     // loop: one after the other the four reads kept the recurrent waves waiting 2 us for their first tile)
+    // (the workgroup's rows are ONE run of 4 n floats in the block and in LDS alike — [stream][n], dense: under 256 frames that is at most three
+    // 16-byte reads per lane, all in flight together, whatever the block's length; a shorter block went stream by stream through the loop at the
+    // end, four trips in a row: 0.6 - 0.7 us of a 64- or 128-frame launch, profiles/r06_cfg2_launch_stations.txt)
     if (kP4Helpers == 1 && n == 256) {
+        // (a row per read: measured 0.15 us ahead of the general form below at this length — cfg2's)
         const bool t1 = s0 + 1 < (int)a.n_streams, t2 = s0 + 2 < (int)a.n_streams, t3 = s0 + 3 < (int)a.n_streams;      // (stream s0 is always there)
         const float4 r0 = reinterpret_cast<const float4*>(a.in + (size_t)s0 * n)[lane];
         const float4 r1 = reinterpret_cast<const float4*>(a.in + (size_t)(t1 ? s0 + 1 : s0) * n)[lane];
@@ -1268,6 +1272,19 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
         reinterpret_cast<float4*>(rows + n)[lane] = r1;
         reinterpret_cast<float4*>(rows + 2 * n)[lane] = r2;
         reinterpret_cast<float4*>(rows + 3 * n)[lane] = r3;
+    } else if (kP4Helpers == 1 && n < 256) {
+        const int have4 = ((int)a.n_streams - s0 < kP4Streams ? (int)a.n_streams - s0 : kP4Streams) * (n / 4);      // the 16-byte words that exist
+        const float4* g4 = reinterpret_cast<const float4*>(a.in + (size_t)s0 * n);
+        float4* l4 = reinterpret_cast<float4*>(rows);
+        const int i0 = lane, i1 = kWave + lane, i2 = 2 * kWave + lane, i3 = 3 * kWave + lane;
+        const float4 r0 = g4[i0 < have4 ? i0 : 0];
+        const float4 r1 = g4[i1 < have4 ? i1 : 0];
+        const float4 r2 = g4[i2 < have4 ? i2 : 0];
+        const float4 r3 = g4[i3 < have4 ? i3 : 0];
+        if (i0 < n) l4[i0] = r0;
+        if (i1 < n) l4[i1] = r1;
+        if (i2 < n) l4[i2] = r2;
+        if (i3 < n) l4[i3] = r3;
     } else {
         for (int jj = hq; jj < kP4Streams; jj += kP4Helpers) {
             if (s0 + jj >= (int)a.n_streams) break;
@@ -1433,6 +1450,15 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
         if (s0 + 1 < (int)a.n_streams) reinterpret_cast<float4*>(a.out + (size_t)(s0 + 1) * n)[lane] = r1;
         if (s0 + 2 < (int)a.n_streams) reinterpret_cast<float4*>(a.out + (size_t)(s0 + 2) * n)[lane] = r2;
         if (s0 + 3 < (int)a.n_streams) reinterpret_cast<float4*>(a.out + (size_t)(s0 + 3) * n)[lane] = r3;
+    } else if (kP4Helpers == 1 && n < 256) {
+        const int have4 = ((int)a.n_streams - s0 < kP4Streams ? (int)a.n_streams - s0 : kP4Streams) * (n / 4);
+        const float4* l4 = reinterpret_cast<const float4*>(rows);
+        float4* o4 = reinterpret_cast<float4*>(a.out + (size_t)s0 * n);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = k * kWave + lane;
+            if (i < have4) o4[i] = l4[i];
+        }
     } else {
         for (int jj = 0; jj < kP4Streams; ++jj) {
             if (s0 + jj >= (int)a.n_streams) break;

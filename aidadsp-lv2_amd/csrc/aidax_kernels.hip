@@ -1174,6 +1174,12 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
             if (t == 0) P4_STAMP(3);                          // (tile 0 is ready)
             if (t == 1) P4_STAMP(4);                          // (tile 0 is done and tile 1 ready)
             if (t == NT - 1) P4_STAMP(5);                     // (the last tile begins)
+            if (wave == 0 && t < 32) {                        // (every tile's beginning, for the per-tile picture)
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                if (lane == 0) reinterpret_cast<unsigned long long*>(hstate)[8 + t] = now;
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #endif
             {
 #endif
@@ -1479,6 +1485,7 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
 #pragma unroll
         for (int k = 0; k < 8; ++k) if (lane == k) mine = tr[k];
         if (lane < 8) dst[8 + lane] = mine;                                                       // the helper's
+        if (lane < 32 && lane < NT && 16 + lane < n / 2) dst[16 + lane] = reinterpret_cast<const unsigned long long*>(hstate)[8 + lane];      // recurrent wave 0's tiles
     }
 #endif
 }

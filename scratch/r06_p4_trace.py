@@ -16,6 +16,7 @@ torch.cuda.synchronize()
 names_n = ["entry", "weights asked for", "past the barrier", "tile 0 ready", "tile 0 done, tile 1 ready", "last tile begins", "last tile done", "state stored"]
 names_h = ["entry", "loads asked for", "past the barrier", "tick 0 done", "last tick begins", "last tick done", "rows stored (issued)", "stores landed"]
 acc = []
+tiles = []
 for rep in range(20):
     for _ in range(3): pool.process_device(x.data_ptr(), y.data_ptr(), n, st.cuda_stream)
     torch.cuda.synchronize()
@@ -24,6 +25,8 @@ for rep in range(20):
     for s0 in (0, 400, 1020):
         t = out[s0, :32].copy().view(np.uint64)
         rows.append(t)
+        if s0 == 0 and n >= 128:
+            tiles.append(out[0, 32:32 + 2 * min(n // 16, 32)].copy().view(np.uint64).astype(np.int64))
     acc.append(np.stack(rows))
 acc = np.stack(acc).astype(np.int64)            # [rep][wg][16]
 base = acc[:, :, [0, 8]].min(axis=(1, 2), keepdims=True)
@@ -32,3 +35,6 @@ med = np.median(rel, axis=0)
 print(pool.kernel_name, n, "frames; us since the earliest entry (median of 20 launches); workgroups of streams 0 / 400 / 1020")
 for k in range(8): print(f"  recurrent wave 0: {names_n[k]:28s} " + "  ".join(f"{med[w, k]:7.2f}" for w in range(3)))
 for k in range(8): print(f"  helper wave:      {names_h[k]:28s} " + "  ".join(f"{med[w, 8 + k]:7.2f}" for w in range(3)))
+if tiles:
+    tl = np.median(np.diff(np.stack(tiles), axis=1), axis=0) / 100.0
+    print("  recurrent wave 0 of stream 0, tile by tile (us from one tile's beginning to the next's):", " ".join(f"{v:.2f}" for v in tl))

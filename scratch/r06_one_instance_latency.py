@@ -8,7 +8,7 @@ kind, H, I = (sys.argv[1], int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) 
 path = W.write_model(W.make_model(kind, H, I, seed=H), os.path.join(tempfile.mkdtemp(), "m.json"))
 L = ax.lib(); fp = C.POINTER(C.c_float)
 out = []
-for n in (64, 128, 256):
+for n in tuple(int(v) for v in os.environ.get("FRAMES", "64,128,256").split(",")):
     pool = ax.Pool(1, n); pool.set_model(ax.Model(path)); pool.set_controls(ax.default_controls(param1=0.4))
     x = (np.random.rand(1, n).astype(np.float32) - 0.5); y = np.empty_like(x)
     px, py = x.ctypes.data_as(fp), y.ctypes.data_as(fp)

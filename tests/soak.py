@@ -25,7 +25,7 @@ if MAXF > 512 and os.environ.get("AIDAX_KERNEL") == "valu":   # the VALU conv ke
     models = [m for m in models if m[1].rnn_type != "conv1d"]      # 70: the resident forms (pipe, lp, fused conv); ~4200: the many-streams forms
 SR = float(os.environ.get("SOAK_SR", "48000"))                    # the host's rate: gain smoothers, filter designs
 pool = ax.Pool(S, MAXF, SR)
-watch = [0, S // 2 - 2, S - 1]
+watch = sorted({0, max(0, S // 2 - 2), S - 1})          # (a pool of one or three streams: fewer watched)
 plugs = {s: O.OraclePlugin(SR) for s in watch}
 cur = 0
 pool.set_model(models[cur][0])
@@ -52,7 +52,7 @@ for b in range(blocks):
         pool.activate()
         for s in watch: plugs[s].activate()
     elif r < 0.35:
-        s = watch[rs.randint(3)] if rs.rand() < 0.7 else rs.randint(S)
+        s = watch[rs.randint(len(watch))] if rs.rand() < 0.7 else rs.randint(S)
         choice = rs.randint(7)
         k = dict(kw[s])
         if choice == 0: k["param1"] = float(rs.rand())

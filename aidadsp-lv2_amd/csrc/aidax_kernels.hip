@@ -1267,26 +1267,62 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
     // (the workgroup's rows are ONE run of 4 n floats in the block and in LDS alike — [stream][n], dense: under 256 frames that is at most three
     // 16-byte reads per lane, all in flight together, whatever the block's length; a shorter block went stream by stream through the loop at the
     // end, four trips in a row: 0.6 - 0.7 us of a 64- or 128-frame launch, profiles/r06_cfg2_launch_stations.txt)
+    // EVERYTHING the helper needs from memory is asked for here, in one go, before the first of it is put anywhere: the rows went into LDS as
+    // they came, and behind a store through a generic pointer the compiler asks for nothing further until the store is done — five trips to
+    // memory in a row (rows; Dense weights; coefficients and state; ramps; the Dense lanes' control word) where one is enough: 1.0 us in front
+    // of EVERY launch's first tile (profiles/r06_cfg2_launch_stations.txt)
+    float4 r0 = float4{0.f, 0.f, 0.f, 0.f}, r1 = r0, r2 = r0, r3 = r0;
     if (kP4Helpers == 1 && n == 256) {
         // (a row per read: measured 0.15 us ahead of the general form below at this length — cfg2's)
         const bool t1 = s0 + 1 < (int)a.n_streams, t2 = s0 + 2 < (int)a.n_streams, t3 = s0 + 3 < (int)a.n_streams;      // (stream s0 is always there)
-        const float4 r0 = reinterpret_cast<const float4*>(a.in + (size_t)s0 * n)[lane];
-        const float4 r1 = reinterpret_cast<const float4*>(a.in + (size_t)(t1 ? s0 + 1 : s0) * n)[lane];
-        const float4 r2 = reinterpret_cast<const float4*>(a.in + (size_t)(t2 ? s0 + 2 : s0) * n)[lane];
-        const float4 r3 = reinterpret_cast<const float4*>(a.in + (size_t)(t3 ? s0 + 3 : s0) * n)[lane];
+        r0 = reinterpret_cast<const float4*>(a.in + (size_t)s0 * n)[lane];
+        r1 = reinterpret_cast<const float4*>(a.in + (size_t)(t1 ? s0 + 1 : s0) * n)[lane];
+        r2 = reinterpret_cast<const float4*>(a.in + (size_t)(t2 ? s0 + 2 : s0) * n)[lane];
+        r3 = reinterpret_cast<const float4*>(a.in + (size_t)(t3 ? s0 + 3 : s0) * n)[lane];
+    } else if (kP4Helpers == 1 && n < 256) {
+        const int have4 = ((int)a.n_streams - s0 < kP4Streams ? (int)a.n_streams - s0 : kP4Streams) * (n / 4);      // the 16-byte words that exist
+        const float4* g4 = reinterpret_cast<const float4*>(a.in + (size_t)s0 * n);
+        const int i0 = lane, i1 = kWave + lane, i2 = 2 * kWave + lane, i3 = 3 * kWave + lane;
+        r0 = g4[i0 < have4 ? i0 : 0];
+        r1 = g4[i1 < have4 ? i1 : 0];
+        r2 = g4[i2 < have4 ? i2 : 0];
+        r3 = g4[i3 < have4 ? i3 : 0];
+    }
+    static_assert(H + 1 <= kWave, "the Dense's weights and bias: a lane each");
+    const float* wd_nat = a.wpack + (size_t)Cell::PACK * kWave;             // [H] Dense weights then bias
+    const float wdv = wd_nat[lane < H + 1 ? lane : 0];
+    ChainPass c;
+    chain_load(c, ctl, st, slot, false);
+    const uint32_t flags = ctl.flags;
+    uint32_t pending = st.pending;
+    float pre_mem = st.pre_mem, master_mem = st.master_mem, pre_tgt = st.pre_tgt, master_tgt = st.master_tgt;
+    const float ctl_pre_target = ctl.pre_target, ctl_master_target = ctl.master_target, ctl_pre_coef = ctl.pre_coef, ctl_master_coef = ctl.master_coef;
+    // the Dense's lanes: a lane per (stream, frame of the tile)
+    const int dj = lane >> 4, df = lane & 15;
+    const uint32_t fdj = a.ctl[s0 + dj < (int)a.n_streams ? s0 + dj : (int)a.n_streams - 1].flags;
+    // the PARAM smoothers (LinearValueSmoother, ValueSmoother.hpp:166-241; run() :634-640) of a conditioned model: lane 48 + 2 j + i owns
+    // PARAM(i + 1) of stream j — target changes and the first-run snap here (param_targets()' arithmetic), then a value per frame
+    static_assert(kP4Helpers == 1, "the PARAM lanes' state is not handed from helper to helper");
+    const bool plane = kCond && lane >= kP4ChainLanes && lane < kP4ChainLanes + 2 * kP4Streams;
+    const int jp = plane ? (lane - kP4ChainLanes) >> 1 : 0, ip = lane & 1;
+    const bool there_p = s0 + jp < (int)a.n_streams;
+    const int sp = there_p ? s0 + jp : (int)a.n_streams - 1;
+    float pm = 0.f, pt = 0.f, ps = 0.f, p_nt = 0.f, p_den = 1.f;
+    uint32_t p_flags = 0, p_pending = 0;
+    if constexpr (kCond) {
+        pm = a.st[sp].p_mem[ip]; pt = a.st[sp].p_tgt[ip]; ps = a.st[sp].p_step[ip];
+        p_nt = a.ctl[sp].p_target[ip]; p_den = a.ctl[sp].p_den;
+        p_flags = a.ctl[sp].flags; p_pending = a.st[sp].pending;
+    }
+    // ---- ... and now it is put where it belongs
+    if (kP4Helpers == 1 && n == 256) {
         reinterpret_cast<float4*>(rows)[lane] = r0;
         reinterpret_cast<float4*>(rows + n)[lane] = r1;
         reinterpret_cast<float4*>(rows + 2 * n)[lane] = r2;
         reinterpret_cast<float4*>(rows + 3 * n)[lane] = r3;
     } else if (kP4Helpers == 1 && n < 256) {
-        const int have4 = ((int)a.n_streams - s0 < kP4Streams ? (int)a.n_streams - s0 : kP4Streams) * (n / 4);      // the 16-byte words that exist
-        const float4* g4 = reinterpret_cast<const float4*>(a.in + (size_t)s0 * n);
         float4* l4 = reinterpret_cast<float4*>(rows);
         const int i0 = lane, i1 = kWave + lane, i2 = 2 * kWave + lane, i3 = 3 * kWave + lane;
-        const float4 r0 = g4[i0 < have4 ? i0 : 0];
-        const float4 r1 = g4[i1 < have4 ? i1 : 0];
-        const float4 r2 = g4[i2 < have4 ? i2 : 0];
-        const float4 r3 = g4[i3 < have4 ? i3 : 0];
         if (i0 < n) l4[i0] = r0;
         if (i1 < n) l4[i1] = r1;
         if (i2 < n) l4[i2] = r2;
@@ -1299,26 +1335,18 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
             for (int i = lane; i < n / 4; i += kWave) dst[i] = src[i];
         }
     }
-    if (hq == 0) {
-        const float* wd_nat = a.wpack + (size_t)Cell::PACK * kWave;         // [H] Dense weights then bias
-        for (int i = lane; i < H + 1; i += kWave) wdl[i] = wd_nat[i];
-    }
-    ChainPass c;
-    chain_load(c, ctl, st, slot, false);
-    const uint32_t flags = ctl.flags;
+    if (hq == 0 && lane < H + 1) wdl[lane] = wdv;
     // this lane's stream: disabled = a raw copy, nothing advances but the latches (:612-619); model out of circuit = the chain alone (:631-632)
     const bool live = there && (flags & CTL_ENABLED) != 0;
     const bool netj = live && (flags & CTL_NET_ON) != 0;
-    uint32_t pending = st.pending;
-    float pre_mem = st.pre_mem, master_mem = st.master_mem, pre_tgt = st.pre_tgt, master_tgt = st.master_tgt;
     if (pending & PEND_ACTIVATE) { pre_mem = pre_tgt; master_mem = master_tgt; pending &= ~PEND_ACTIVATE; }     // activate(): :341-342
-    pre_tgt = ctl.pre_target;
-    if (live) master_tgt = ctl.master_target;
+    pre_tgt = ctl_pre_target;
+    if (live) master_tgt = ctl_master_target;
     const int Kpj = (flags & CTL_EQ_PRE) ? 6 : 1, Kqj = (flags & CTL_EQ_POST) ? 6 : 1;
     c.K = isQ ? Kqj : Kpj;
     c.gain_lane = isQ ? Kqj - 1 : 0;
     c.active = stage == 0 ? (flags & (isQ ? CTL_DC_ON : CTL_LPF_ON)) != 0 : ((flags & CTL_EQ_BANDPASS) ? slot == BQ_MID : true);
-    c.g.arm(isQ ? master_mem : pre_mem, isQ ? master_tgt : pre_tgt, isQ ? ctl.master_coef : ctl.pre_coef);
+    c.g.arm(isQ ? master_mem : pre_mem, isQ ? master_tgt : pre_tgt, isQ ? ctl_master_coef : ctl_pre_coef);
     const bool run = lane < kP4ChainLanes && stage < c.K && live;
     const double z1o = c.z1, z2o = c.z2;
     ExpRamp g = c.g;
@@ -1329,28 +1357,16 @@ __device__ __forceinline__ void stream_body_pipe4(const LaunchArgs& a, float* sm
     const bool plain = __builtin_amdgcn_ballot_w64(fussy) == 0;
     const int m0 = isQ ? 2 * (d1 + 1) : 0;
     float* myrow = rows + j * n;
-    // the Dense's lanes: a lane per (stream, frame of the tile)
-    const int dj = lane >> 4, df = lane & 15;
     const float* hdj = hh + dj * kRing * HS;
     float* drow = rows + dj * n;
-    // the PARAM smoothers (LinearValueSmoother, ValueSmoother.hpp:166-241; run() :634-640) of a conditioned model: lane 48 + 2 j + i owns
-    // PARAM(i + 1) of stream j — target changes and the first-run snap here (param_targets()' arithmetic), then a value per frame
-    static_assert(kP4Helpers == 1, "the PARAM lanes' state is not handed from helper to helper");
-    const bool plane = kCond && lane >= kP4ChainLanes && lane < kP4ChainLanes + 2 * kP4Streams;
-    const int jp = plane ? (lane - kP4ChainLanes) >> 1 : 0, ip = lane & 1;
-    const bool there_p = s0 + jp < (int)a.n_streams;
-    const int sp = there_p ? s0 + jp : (int)a.n_streams - 1;
-    const bool net_p = plane && there_p && (a.ctl[sp].flags & (CTL_ENABLED | CTL_NET_ON)) == (CTL_ENABLED | CTL_NET_ON);
-    float pm = 0.f, pt = 0.f, ps = 0.f;
+    const bool net_p = plane && there_p && (p_flags & (CTL_ENABLED | CTL_NET_ON)) == (CTL_ENABLED | CTL_NET_ON);
     if constexpr (kCond) {
-        pm = a.st[sp].p_mem[ip]; pt = a.st[sp].p_tgt[ip]; ps = a.st[sp].p_step[ip];
-        const float nt = a.ctl[sp].p_target[ip];
-        if (__builtin_fabsf(pt - nt) >= FLT_EPSILON) { pt = nt; ps = (pt - pm) / a.ctl[sp].p_den; }      // setTargetValue (:209-216)
-        if (a.st[sp].pending & PEND_PARAM_FIRST) pm = pt;                                                // paramFirstRun (:636-640)
+        if (__builtin_fabsf(pt - p_nt) >= FLT_EPSILON) { pt = p_nt; ps = (pt - pm) / p_den; }      // setTargetValue (:209-216)
+        if (p_pending & PEND_PARAM_FIRST) pm = pt;                                                // paramFirstRun (:636-640)
     }
     const bool pstep = net_p && ip < I - 1;                   // this PARAM is a model input: a smoothed value per frame
     float* pdst = prow + (jp * 2 + ip) * n;
-    const bool netd = s0 + dj < (int)a.n_streams && (a.ctl[s0 + dj < (int)a.n_streams ? s0 + dj : (int)a.n_streams - 1].flags & (CTL_ENABLED | CTL_NET_ON)) == (CTL_ENABLED | CTL_NET_ON);
+    const bool netd = s0 + dj < (int)a.n_streams && (fdj & (CTL_ENABLED | CTL_NET_ON)) == (CTL_ENABLED | CTL_NET_ON);
     if (hq == 0 && lane < 8) prog[lane] = 0;
     P4_STAMP(1);                                              // (the helper's loads are issued)
     __syncthreads();

@@ -1811,12 +1811,20 @@ __global__ void k_adopt_dsp(StreamState* dst, const StreamState* src)
 static const KernelEntry kTable[] = {
     // the 18 (cell, hidden) pairs of variant/generate_variant_hpp.py:4-6; input size is a run-time argument
     // (k_*_pipe4 where it measured ahead of k_*_pipe at a full pool of 1024 streams, profiles/r06_pipe4_cells.txt: LSTM-8 / 12 / 16 by 14 - 19 %,
-    // GRU-8 / 12 / 16 by 9 - 14 %, LSTM-32 by 3 %; LSTM-20 / 24 and GRU-20 / 24 / 32 measured 1 - 13 % behind and keep the three-wave pipeline.
+    // GRU-8 / 12 / 16 by 9 - 14 %, LSTM-32 by 3 %; re-measured on the round's final kernel: GRU-24 by 6 %, LSTM-20 by 1 - 2 %; LSTM-24 and
+    // GRU-20 / 32 measure 1 - 10 % behind and keep the three-wave pipeline.
     // A CONDITIONED model — PARAM1 / PARAM2 as inputs — runs k_*_pipe4<H, true> at every cell up to 32: 9 - 25 % ahead, same file)
-    AIDAX_LSTM_P4(8), AIDAX_LSTM_P4(12), AIDAX_LSTM_P4(16), AIDAX_LSTM_P4C(20), AIDAX_LSTM_P4C(24),
+#ifdef AIDAX_P4_ALL_CELLS      // (measurement build, scratch/r06_pipe4_cells.py: the plain models of every cell up to 32 on k_*_pipe4)
+    AIDAX_LSTM_P4(8), AIDAX_LSTM_P4(12), AIDAX_LSTM_P4(16), AIDAX_LSTM_P4(20), AIDAX_LSTM_P4(24),
     AIDAX_LSTM_P4(32), AIDAX_LSTM(40), AIDAX_LSTM_WIDE(64, k_nn<LstmCell<64>>), AIDAX_LSTM_WIDE(80, nullptr),
-    AIDAX_GRU_P4(8), AIDAX_GRU_P4(12), AIDAX_GRU_P4(16), AIDAX_GRU_P4C(20), AIDAX_GRU_P4C(24),
+    AIDAX_GRU_P4(8), AIDAX_GRU_P4(12), AIDAX_GRU_P4(16), AIDAX_GRU_P4(20), AIDAX_GRU_P4(24),
+    AIDAX_GRU_P4(32), AIDAX_GRU(40), AIDAX_GRU(64), AIDAX_GRU(80),
+#else
+    AIDAX_LSTM_P4(8), AIDAX_LSTM_P4(12), AIDAX_LSTM_P4(16), AIDAX_LSTM_P4(20), AIDAX_LSTM_P4C(24),
+    AIDAX_LSTM_P4(32), AIDAX_LSTM(40), AIDAX_LSTM_WIDE(64, k_nn<LstmCell<64>>), AIDAX_LSTM_WIDE(80, nullptr),
+    AIDAX_GRU_P4(8), AIDAX_GRU_P4(12), AIDAX_GRU_P4(16), AIDAX_GRU_P4C(20), AIDAX_GRU_P4(24),
     AIDAX_GRU_P4C(32), AIDAX_GRU(40), AIDAX_GRU(64), AIDAX_GRU(80),
+#endif
 };
 
 const KernelEntry* find_kernel(int cell, int hidden)

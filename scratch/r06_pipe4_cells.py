@@ -24,12 +24,13 @@ for _ in range(N): pool.process_device(x.data_ptr(), y.data_ptr(), n, st.cuda_st
 e1.record(st); torch.cuda.synchronize()
 print(pool.kernel_name, round(e0.elapsed_time(e1) / N * 1e3, 2))
 '''
-env0 = dict(os.environ, AIDAX_LIB=os.path.join(ROOT, "aidadsp-lv2_amd", "lib", "hooks", "libaidax_hip.so"))
+env0 = dict(os.environ, AIDAX_LIB=os.environ.get("CELLS_LIB") or os.path.join(ROOT, "aidadsp-lv2_amd", "lib", "hooks", "libaidax_hip.so"))      # CELLS_LIB: a measurement build (-DAIDAX_P4_ALL_CELLS: every cell up to 32 has the kernel)
 S = int(os.environ.get("STREAMS", "1024"))
 I = os.environ.get("INPUTS", "1")          # 2 / 3: conditioned models (PARAM1 / PARAM2 as model inputs)
 SMALL = os.environ.get("SMALL") == "1"     # only the cells k_*_pipe4 is built for
+MID = os.environ.get("MID") == "1"         # only the cells whose plain models keep k_*_pipe
 print(f"# {S} streams, input_size {I}, us per block; k_*_pipe (AIDAX_PIPE4=0) | k_*_pipe4 (default)   at 256 / 64 frames")
-for kind, hs in ((("lstm", (8, 12, 16, 32)), ("gru", (8, 12, 16))) if SMALL else (("lstm", (8, 12, 16, 20, 24, 32)), ("gru", (8, 12, 16, 20, 24, 32))) if I != "1" else (("lstm", (8, 12, 16, 20, 24, 32, 40)), ("gru", (8, 12, 16, 20, 24, 32, 40, 64)))):
+for kind, hs in ((("lstm", (20, 24)), ("gru", (20, 24, 32))) if MID else (("lstm", (8, 12, 16, 32)), ("gru", (8, 12, 16))) if SMALL else (("lstm", (8, 12, 16, 20, 24, 32)), ("gru", (8, 12, 16, 20, 24, 32))) if I != "1" else (("lstm", (8, 12, 16, 20, 24, 32, 40)), ("gru", (8, 12, 16, 20, 24, 32, 40, 64)))):
     for H in hs:
         row = []
         for n in (256, 64):

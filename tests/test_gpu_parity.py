@@ -1674,7 +1674,7 @@ def test_four_streams_per_workgroup_pipeline_is_bit_identical_to_the_three_wave_
     assert np.array_equal(a, b)
 
 
-_P4_PLAIN = [("lstm", 8), ("lstm", 12), ("lstm", 16), ("gru", 8), ("gru", 12), ("gru", 16)]
+_P4_PLAIN = [("lstm", 8), ("lstm", 12), ("lstm", 16), ("lstm", 20), ("gru", 8), ("gru", 12), ("gru", 16), ("gru", 24)]
 _P4_CONDITIONED = [("lstm", 12, 2), ("lstm", 16, 3), ("gru", 8, 3), ("gru", 12, 2), ("lstm", 32, 2), ("lstm", 32, 3),
                    ("lstm", 20, 3), ("lstm", 24, 2), ("gru", 20, 2), ("gru", 24, 3), ("gru", 32, 3)]
 

@@ -176,3 +176,17 @@ def test_the_rccl_branch_runs_at_world_size_one():
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, "bench_1rank_rccl.json"), "w") as f:
             f.write(lines[0] + "\n")
+
+
+def test_bench_matches_a_profile_row_to_the_pool_s_kernel_name():
+    """bench.py reads its kernel's rows out of rocprofv3 tables by the name the pool reports (`k_lstm_pipe4<32>`); the instantiation in the
+    table may carry further template arguments behind the quoted ones (`k_lstm_pipe4<32, false>` since the conditioned models have a kernel
+    of their own) — a matcher that missed it left `roofline.traffic` null for a whole evidence run."""
+    import importlib
+    bench = importlib.import_module("bench")
+    rows = ["void aidax::k_lstm_pipe4<32, false>(aidax::LaunchArgs)", "void aidax::k_lstm_pipe4<32>(aidax::LaunchArgs)",
+            "void aidax::k_gru_gs<4, 4, 6>(aidax::LaunchArgs, aidax::MfmaDesc)", "void aidax::k_conv_st<aidax::StGeoA, 256, true>(aidax::LaunchArgs, aidax::ConvDesc)"]
+    assert bench._kernel_matches("k_lstm_pipe4<32>", rows[0]) and bench._kernel_matches("k_lstm_pipe4<32>", rows[1])
+    assert not bench._kernel_matches("k_lstm_pipe<32>", rows[0]) and not bench._kernel_matches("k_lstm_pipe4<3>", rows[0])
+    assert not bench._kernel_matches("k_lstm_pipe4<16>", rows[0])
+    assert bench._kernel_matches("k_gru_gs", rows[2]) and bench._kernel_matches("k_conv_st", rows[3]) and not bench._kernel_matches("k_conv_ms", rows[3])
